@@ -1,0 +1,243 @@
+"""Generate the golden fixtures under tests/golden/ from the reference itself.
+
+Runs ONLY in the build container (needs /root/reference).  It imports the
+reference modules that import unmodified on CPU — ``utils``, ``dataset``,
+``trainer`` — and records their outputs on small seeded inputs.  ``model.py``
+is NOT imported: it needs DGL, which the image lacks, and no stand-in for it is
+written (see oracle/oracle.py header).  Where a reference trainer needs a model
+object, a small hand-written one defined in this file is passed in; it is an
+*input* to the reference code and is recorded with the outputs.
+
+Outputs are data only (inputs + expected outputs): .npz arrays and toy datasets
+in the reference's own text format.  Usage:  python oracle/gen_golden.py
+"""
+import io
+import os
+import random
+import sys
+import contextlib
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
+
+
+def write_lists(path, data):
+    with open(path, 'w') as f:
+        for u, items in enumerate(data):
+            f.write(' '.join([str(u)] + [str(i) for i in items]) + '\n')
+
+
+def make_toy(name, n_users, n_items, seed, quirks):
+    """Seeded toy split in the reference text format (dataset.py:154-164)."""
+    rng = np.random.RandomState(seed)
+    pop = 1. / np.arange(1, n_items + 1) ** 0.8
+    pop /= pop.sum()
+    train, val, test = [], [], []
+    for u in range(n_users):
+        n = int(rng.randint(4, 12))
+        items = rng.choice(n_items - 2 if quirks else n_items, size=n, replace=False, p=None if not quirks else None)
+        items = [int(i) for i in items]
+        n_tr = max(1, int(n * 0.7))
+        n_te = max(1, int(n * 0.2))
+        train.append(items[:n_tr]); val.append(items[n_tr:n - n_te]); test.append(items[n - n_te:])
+    if quirks:
+        # users with an empty train list / empty val / empty test list
+        train[3] = []; train[17] = []; val[5] = []; test[7] = []; test[3] = []
+        # duplicate (user, item) pairs in train -> adjacency value 2
+        train[0] = train[0] + [train[0][0]]
+        train[9] = train[9] + [train[9][1], train[9][1]]
+        # item n_items-2 has train degree exactly 1; item n_items-1 appears only in test
+        train[11] = train[11] + [n_items - 2]
+        test[12] = test[12] + [n_items - 1]
+    d = os.path.join(OUT, name)
+    os.makedirs(d, exist_ok=True)
+    write_lists(os.path.join(d, 'train.txt'), train)
+    write_lists(os.path.join(d, 'val.txt'), val)
+    write_lists(os.path.join(d, 'test.txt'), test)
+    return d
+
+
+class RecordingModel(torch.nn.Module):
+    """Hand-written model object handed to the reference trainers (an input).
+
+    ``predict`` returns rows of a fixed score matrix; ``bpr_forward`` gathers
+    rows of a fixed [n_users + n_items, d] parameter and records its arguments.
+    """
+
+    def __init__(self, n_users, n_items, d, seed, template=False):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.name = 'RecordingModel'
+        self.trainable = True
+        self.n_users, self.n_items = n_users, n_items
+        self.rep = torch.nn.Parameter(torch.randn(n_users + n_items, d, generator=g) * 0.3)
+        self.scores = torch.randn(n_users, n_items, generator=g)
+        # a few exact ties to exercise tie handling downstream
+        self.scores[1, 4] = self.scores[1, 2]
+        self.calls = []
+        if template:
+            self.embedding = torch.nn.Embedding(n_users + n_items + 2, d)
+            with torch.no_grad():
+                self.embedding.weight.copy_(torch.randn(n_users + n_items + 2, d, generator=g) * 0.3)
+            self.w = torch.nn.Parameter(torch.rand(d, generator=g) + 0.5)
+            self.user_map = {u: u for u in range(n_users)}
+            self.item_map = {i: i for i in range(n_items)}
+            self.anneal_calls = 0
+
+    def predict(self, users):
+        return self.scores[users].clone()
+
+    def bpr_forward(self, users, pos_items, neg_items):
+        u, p, n = self.rep[users], self.rep[self.n_users + pos_items], self.rep[self.n_users + neg_items]
+        l2 = torch.norm(u, p=2, dim=1) ** 2 + torch.norm(p, p=2, dim=1) ** 2 + torch.norm(n, p=2, dim=1) ** 2
+        self.calls.append(dict(users=users.numpy().copy(), pos=pos_items.numpy().copy(),
+                               neg=neg_items.numpy().copy()))
+        return u, p, n, l2
+
+    def feat_mat_anneal(self):
+        self.anneal_calls += 1
+
+
+def main():
+    sys.path.insert(0, REF)
+    with contextlib.redirect_stdout(io.StringIO()):
+        import utils as ref_utils          # noqa: E402  (reference, unmodified)
+        import dataset as ref_dataset      # noqa: E402
+        import trainer as ref_trainer      # noqa: E402
+    os.makedirs(OUT, exist_ok=True)
+    quiet = contextlib.redirect_stdout(io.StringIO())
+
+    toys = {'toy_a': make_toy('toy_a', 30, 20, 11, quirks=False),
+            'toy_b': make_toy('toy_b', 300, 200, 12, quirks=True)}
+
+    for name, path in toys.items():
+        g = {}
+        with quiet:
+            ds = ref_dataset.get_dataset({'name': 'ProcessedDataset', 'path': path, 'device': 'cpu'})
+        g['n_users'], g['n_items'] = ds.n_users, ds.n_items
+        g['train_array'] = np.array(ds.train_array, dtype=np.int64).reshape(-1, 2)
+        g['len'] = len(ds)
+
+        # utils.generate_daj_mat / get_sparse_tensor  (utils.py:32-49)
+        adj = ref_utils.generate_daj_mat(ds)
+        g['adj_indptr'], g['adj_indices'], g['adj_data'] = adj.indptr, adj.indices, adj.data
+        g['adj_has_sorted_indices'] = adj.has_sorted_indices
+        sp = ref_utils.get_sparse_tensor(adj, 'cpu')
+        g['adj_coo_indices'] = sp.indices().numpy()
+        g['adj_coo_values'] = sp.values().numpy()
+
+        # utils.graph_rank_nodes  (utils.py:94-123)
+        for metric in ('degree', 'sort'):
+            ru, ri = ref_utils.graph_rank_nodes(ds, metric)
+            g['rank_%s_users' % metric], g['rank_%s_items' % metric] = ru, ri
+
+        # AuxiliaryDataset re-indexing with partial maps  (dataset.py:258-273)
+        ru, ri = ref_utils.graph_rank_nodes(ds, 'degree')
+        user_map = {int(u): j for j, u in enumerate(ru[:ds.n_users // 2])}
+        item_map = {int(i): j for j, i in enumerate(ri[:ds.n_items // 2])}
+        aux = ref_dataset.AuxiliaryDataset(ds, user_map, item_map)
+        g['aux_user_keys'] = np.array(list(user_map.keys()), dtype=np.int64)
+        g['aux_item_keys'] = np.array(list(item_map.keys()), dtype=np.int64)
+        g['aux_len'] = len(aux)
+        g['aux_rowlen'] = np.array([len(x) for x in aux.train_data], dtype=np.int64)
+        g['aux_flat'] = np.array([i for x in aux.train_data for i in x], dtype=np.int64)
+
+        # sampler semantics (dataset.py:119-131): shape/dtype and membership facts
+        random.seed(5); np.random.seed(5)
+        samples = np.stack([ds[0] for _ in range(400)], axis=0)
+        g['sample_shape'] = np.array(samples.shape)
+        g['samples'] = samples
+
+        # BasicTrainer.eval + calculate_metrics  (trainer.py:109-177)
+        model = RecordingModel(ds.n_users, ds.n_items, 8, seed=21)
+        cfg = {'name': 'BasicTrainer', 'dataset': ds, 'model': model, 'topks': [5, 20] if ds.n_items > 20 else [5, 10],
+               'device': 'cpu', 'n_epochs': 0, 'test_batch_size': 7}
+        with quiet:
+            tr = ref_trainer.BasicTrainer(cfg)
+        g['eval_scores'] = model.scores.numpy()
+        g['eval_topks'] = np.array(cfg['topks'])
+        rec = {}
+        orig = tr.calculate_metrics
+
+        def spy(eval_data, rec_items, _rec=rec):
+            _rec['items'] = rec_items.copy()
+            return orig(eval_data, rec_items)
+        tr.calculate_metrics = spy
+        banned = np.arange(ds.n_items // 2, ds.n_items)
+        for tag, stage, ban in (('train', 'train', None), ('val', 'val', None), ('test', 'test', None),
+                                ('testban', 'test', banned)):
+            _, metrics = tr.eval(stage, banned_items=ban)
+            g['eval_%s_rec' % tag] = rec['items']
+            for m in metrics:
+                for k in metrics[m]:
+                    g['eval_%s_%s_%d' % (tag, m, k)] = np.float64(metrics[m][k])
+        g['eval_banned'] = banned
+
+        # calculate_metrics on hand-made inputs (k > |eval|, empty eval lists)
+        rng = np.random.RandomState(3)
+        hm_rec = rng.randint(0, ds.n_items, size=(ds.n_users, max(cfg['topks'])))
+        metrics = orig(ds.test_data, hm_rec)
+        g['hm_rec'] = hm_rec
+        for m in metrics:
+            for k in metrics[m]:
+                g['hm_%s_%d' % (m, k)] = np.float64(metrics[m][k])
+
+        # BPRTrainer.train_one_epoch: loss arithmetic + one Adam step (trainer.py:222-248)
+        torch.manual_seed(7); random.seed(7); np.random.seed(7)
+        model = RecordingModel(ds.n_users, ds.n_items, 8, seed=22)
+        rep0 = model.rep.detach().numpy().copy()
+        cfg = {'name': 'BPRTrainer', 'dataset': ds, 'model': model, 'topks': [5], 'device': 'cpu', 'n_epochs': 1,
+               'test_batch_size': 7, 'optimizer': 'Adam', 'lr': 1e-2, 'l2_reg': 1e-2,
+               'batch_size': len(ds) + 5, 'dataloader_num_workers': 0}
+        with quiet:
+            tr = ref_trainer.BPRTrainer(cfg)
+        loss = tr.train_one_epoch()
+        assert len(model.calls) == 1
+        g['bpr_rep0'] = rep0
+        g['bpr_users'], g['bpr_pos'], g['bpr_neg'] = (model.calls[0][k] for k in ('users', 'pos', 'neg'))
+        g['bpr_loss'] = np.float64(loss)
+        g['bpr_l2_reg'], g['bpr_lr'] = cfg['l2_reg'], cfg['lr']
+        g['bpr_rep1'] = model.rep.detach().numpy().copy()
+
+        # IGCNTrainer.train_one_epoch: main + auxiliary loss (trainer.py:281-320)
+        torch.manual_seed(8); random.seed(8); np.random.seed(8)
+        model = RecordingModel(ds.n_users, ds.n_items, 8, seed=23, template=True)
+        rep0 = model.rep.detach().numpy().copy()
+        emb0 = model.embedding.weight.detach().numpy().copy()
+        w0 = model.w.detach().numpy().copy()
+        cfg = {'name': 'IGCNTrainer', 'dataset': ds, 'model': model, 'topks': [5], 'device': 'cpu', 'n_epochs': 1,
+               'test_batch_size': 7, 'optimizer': 'Adam', 'lr': 1e-2, 'l2_reg': 1e-3, 'aux_reg': 0.1,
+               'batch_size': len(ds) + 5, 'dataloader_num_workers': 0}
+        with quiet:
+            tr = ref_trainer.IGCNTrainer(cfg)
+        # record the auxiliary batch the reference draws (second DataLoader)
+        aux_batches = []
+        orig_aux = tr.aux_dataloader
+
+        class Tap:
+            def __iter__(self_inner):
+                for b in orig_aux:
+                    aux_batches.append(b.numpy().copy())
+                    yield b
+        tr.aux_dataloader = Tap()
+        loss = tr.train_one_epoch()
+        assert len(model.calls) == 1 and len(aux_batches) == 1 and model.anneal_calls == 1
+        g['igcn_rep0'], g['igcn_emb0'], g['igcn_w0'] = rep0, emb0, w0
+        g['igcn_users'], g['igcn_pos'], g['igcn_neg'] = (model.calls[0][k] for k in ('users', 'pos', 'neg'))
+        g['igcn_aux'] = aux_batches[0][:, 0, :]
+        g['igcn_loss'] = np.float64(loss)
+        g['igcn_l2_reg'], g['igcn_aux_reg'], g['igcn_lr'] = cfg['l2_reg'], cfg['aux_reg'], cfg['lr']
+        g['igcn_rep1'] = model.rep.detach().numpy().copy()
+        g['igcn_emb1'] = model.embedding.weight.detach().numpy().copy()
+        g['igcn_w1'] = model.w.detach().numpy().copy()
+
+        np.savez_compressed(os.path.join(OUT, name + '.npz'), **g)
+        print('wrote', name, 'n_users', ds.n_users, 'n_items', ds.n_items, 'train pairs', len(ds))
+
+
+if __name__ == '__main__':
+    main()

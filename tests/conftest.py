@@ -1,0 +1,22 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run on the GPU box with -m gpu)')
+
+
+@pytest.fixture(scope='session', params=['toy_a', 'toy_b'])
+def golden(request):
+    g = dict(np.load(os.path.join(GOLDEN, request.param + '.npz')))
+    g['name'] = request.param
+    g['path'] = os.path.join(GOLDEN, request.param)
+    return g
