@@ -1,0 +1,49 @@
+"""Builds libigcn_hip.so (gfx950) in-tree with hipcc.  No JIT cache: the .so sits
+next to the package so that it travels to the GPU box with the source tree."""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, 'csrc')
+LIB = os.path.join(PKG, 'libigcn_hip.so')
+SOURCES = [f for f in ('spmm.hip', 'bpr.hip', 'score_topk.hip', 'sampler.hip')
+           if os.path.exists(os.path.join(CSRC, f))]
+FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-Wall', '-Wno-unused-function',
+         '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
+
+
+def _newer(src_list, out):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(s) > t for s in src_list)
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    headers.append(os.path.join(ROOT, 'include', 'igcn_hip.h'))
+    objs = []
+    for name in SOURCES:
+        src = os.path.join(CSRC, name)
+        if not os.path.exists(src):
+            raise FileNotFoundError(src)
+        obj = os.path.join(CSRC, name.replace('.hip', '.o'))
+        if force or _newer([src] + headers, obj):
+            cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(obj)
+    if force or _newer(objs, LIB):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

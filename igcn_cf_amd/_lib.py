@@ -1,0 +1,103 @@
+"""ctypes binding of libigcn_hip.so (C ABI declared in include/igcn_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a
+symbol is absent, importing an op raises immediately.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libigcn_hip.so')
+
+MAX_ADDS = 8
+MAX_TOPK = 128
+
+c_i64_p = C.POINTER(C.c_int64)
+vp = C.c_void_p
+
+ROW_SEGMENT_DTYPE = np.dtype([('start', '<i8'), ('len', '<i4'), ('slot', '<i4')])
+LONG_ROW_DTYPE = np.dtype([('row', '<i4'), ('first_slot', '<i4'), ('n_slots', '<i4'), ('reserved', '<i4')])
+
+# name -> (restype, argtypes); every symbol of include/igcn_hip.h
+SIGNATURES = {
+    'igcn_abi_version': (C.c_int, []),
+    'igcn_error_string': (C.c_char_p, [C.c_int]),
+    'igcn_spmm_plan_count_host': (C.c_int, [vp, C.c_int64, C.c_int32, C.c_int32, c_i64_p, c_i64_p]),
+    'igcn_spmm_plan_fill_host': (C.c_int, [vp, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int64, vp, C.c_int64]),
+    'igcn_spmm_csr_f32': (C.c_int, [vp, vp, vp, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
+                                    C.c_float, C.POINTER(vp), C.c_int32, C.c_float, vp, vp,
+                                    vp, C.c_int64, vp, C.c_int64, vp, C.c_int32,
+                                    vp, C.c_uint64, C.c_float, vp]),
+    'igcn_csr_row_pow_f32': (C.c_int, [vp, vp, C.c_float, vp, vp, C.c_int64, vp]),
+    'igcn_bpr_fwd_f32': (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, vp, C.c_int64, vp, vp, vp,
+                                   C.c_int64, C.c_int32, vp, vp, vp, vp]),
+    'igcn_bpr_bwd_f32': (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, vp, C.c_int64, vp, vp, vp,
+                                   C.c_int64, C.c_int32, vp, vp, vp,
+                                   vp, vp, vp, vp, vp, vp, vp, vp]),
+    'igcn_score_topk_workspace_bytes': (C.c_int64, [C.c_int64, C.c_int64, C.c_int32]),
+    'igcn_score_topk_f32': (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32,
+                                      vp, vp, vp, C.c_int32, vp, vp, vp, vp]),
+    'igcn_hit_matrix': (C.c_int, [vp, C.c_int64, C.c_int32, vp, vp, vp, vp]),
+    'igcn_bpr_sample': (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, vp, vp]),
+}
+
+_handle = None
+_bound = {}
+
+
+class IgcnError(RuntimeError):
+    pass
+
+
+def handle():
+    """The loaded shared library; raises if it is missing (no fallback)."""
+    global _handle
+    if _handle is None:
+        if not os.path.exists(LIB_PATH):
+            raise IgcnError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                            '(hipcc --offload-arch=gfx950); there is no CPU fallback' % LIB_PATH)
+        _handle = C.CDLL(LIB_PATH)
+    return _handle
+
+
+class _Lib:
+    """Attribute access binds the symbol with its declared signature on first use
+    and raises IgcnError when the library does not export it."""
+
+    def __getattr__(self, name):
+        fn = _bound.get(name)
+        if fn is None:
+            if name not in SIGNATURES:
+                raise AttributeError(name)
+            try:
+                fn = getattr(handle(), name)
+            except AttributeError:
+                raise IgcnError('libigcn_hip.so does not export %s; rebuild it' % name)
+            fn.restype, fn.argtypes = SIGNATURES[name]
+            _bound[name] = fn
+        return fn
+
+
+_LIB = _Lib()
+
+
+def lib():
+    return _LIB
+
+
+def check(code, what):
+    if code != 0:
+        msg = lib().igcn_error_string(int(code))
+        raise IgcnError('%s failed: %s (code %d)' % (what, msg.decode() if msg else '?', code))
+
+
+def ptr(t):
+    """Raw device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,54 @@
+// Shared device/host helpers for libigcn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "igcn_hip.h"
+
+namespace igcn {
+
+constexpr int kWave = 64;      // CDNA wavefront
+constexpr int kBlock = 256;    // 4 waves per workgroup
+
+inline int launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? IGCN_OK : static_cast<int>(e);
+}
+
+// Number of CUs of the current device (256 on MI355X); cached.
+inline int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
+            n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// 32-bit finaliser (lowbias32-style); used as a counter-based RNG: the value
+// depends only on (seed, counter), so a matrix and its transposed view agree.
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x21f0aaadu;
+    x ^= x >> 15; x *= 0x735a2d97u;
+    x ^= x >> 15;
+    return x;
+}
+__host__ __device__ __forceinline__ uint32_t hash_counter(uint64_t counter, uint32_t s0, uint32_t s1) {
+    uint32_t lo = static_cast<uint32_t>(counter), hi = static_cast<uint32_t>(counter >> 32);
+    uint32_t h = mix32(lo ^ s0);
+    h = mix32(h + (hi ^ s1) * 0x9e3779b9u + 0x85ebca6bu);
+    return h;
+}
+
+__device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void f4_fma(float4 &a, float w, const float4 &x) {
+    a.x = fmaf(w, x.x, a.x); a.y = fmaf(w, x.y, a.y); a.z = fmaf(w, x.z, a.z); a.w = fmaf(w, x.w, a.w);
+}
+__device__ __forceinline__ void f4_add(float4 &a, const float4 &x) { a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w; }
+__device__ __forceinline__ float4 f4_shfl_xor(const float4 &a, int m) {
+    return make_float4(__shfl_xor(a.x, m), __shfl_xor(a.y, m), __shfl_xor(a.z, m), __shfl_xor(a.w, m));
+}
+
+}  // namespace igcn

@@ -1,0 +1,400 @@
+// CSR SpMM for embedding propagation on MI355X (gfx950):  Y = epilogue(M @ X).
+//
+// Replaces dgl.ops.gspmm(g,'mul','sum',X,w) of the reference (model.py:102,
+// :430, :442) together with the per-call graph rebuild (model.py:99-100), the
+// layer mean (model.py:104-105), the sparse dropout (model.py:263-275 via :435)
+// and the row-constant feature values (model.py:374-377).
+//
+// Mapping to the hardware (HBM / Infinity-Cache bound, no MFMA: there is no
+// dense contraction here):
+//   * one 64-lane wave owns one output row at a time; the wave is cut into
+//     G = 64/LPR lane groups, LPR = d/4 lanes each, and every lane moves one
+//     float4, so ONE gather instruction fetches G whole source rows as G fully
+//     coalesced d*4-byte requests (d=64: 4 rows x 256 B = 1 KiB per instruction,
+//     the widest access the memory pipeline has);
+//   * col/val of up to 64 nonzeros are read with one coalesced load per array
+//     and handed to the groups through the cross-lane network (ds_bpermute), so
+//     the index stream is read once, as whole lines;
+//   * 4 gather instructions (4*G source rows) are kept in flight per wave before
+//     the first FMA; with 8 waves per SIMD that is >64 KiB in flight per CU;
+//   * rows longer than `long_threshold` nonzeros (power-law item rows) are not
+//     processed as rows: the host plan cuts them into row segments that are
+//     scheduled like ordinary rows ("virtual rows" after the real ones), write
+//     partial sums, and a second tiny kernel adds the partials in a fixed order
+//     — results are bitwise reproducible, no float atomics;
+//   * persistent grid: 8 workgroups of 4 waves per CU, wave-strided over the
+//     virtual rows, so neighbouring waves stream neighbouring col/val lines.
+#include "common.h"
+
+namespace igcn {
+
+struct SpmmEpilogue {
+    const float *add[IGCN_MAX_ADDS];
+    int n_adds;
+    float out_scale;
+    float add_scale;
+    const float *row_scale;
+    const float *col_scale;
+};
+
+struct SpmmDropout {
+    const int32_t *edge_id;
+    uint32_t s0, s1;
+    uint32_t keep_below;   // keep iff hash < keep_below
+    float keep_prob;
+};
+
+template <int LPR, bool DROPOUT>
+__global__ __launch_bounds__(kBlock) void spmm_csr_rows_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
+    const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy,
+    int64_t n_rows, int d, SpmmEpilogue ep, SpmmDropout dr,
+    const igcn_row_segment *__restrict__ segments, int64_t n_segments,
+    float *__restrict__ partial, int long_threshold)
+{
+    constexpr int G = kWave / LPR;           // source rows per gather instruction
+    const int lane = threadIdx.x & (kWave - 1);
+    const int g = lane / LPR;
+    const int t = lane % LPR;
+    const bool lane_on = (4 * t) < d;
+    const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)));
+    const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
+    const int64_t n_virtual = n_rows + n_segments;
+
+    for (int64_t v = wave0; v < n_virtual; v += n_waves) {
+        int64_t start, end, dst;
+        bool to_partial;
+        if (v < n_rows) {
+            start = rowptr[v];
+            end = rowptr[v + 1];
+            if (n_segments > 0 && end - start > long_threshold) continue;   // handled as segments
+            dst = v;
+            to_partial = false;
+        } else {
+            const igcn_row_segment s = segments[v - n_rows];
+            start = s.start;
+            end = s.start + s.len;
+            dst = s.slot;
+            to_partial = true;
+        }
+
+        float4 acc = f4_zero();
+        for (int64_t base = start; base < end; base += kWave) {
+            const int64_t rem = end - base;
+            const int cnt = rem < kWave ? (int)rem : kWave;     // wave-uniform
+            int c = 0;
+            float w = 0.f;
+            if (lane < cnt) {
+                const int64_t p = base + lane;
+                c = col[p];
+                w = val ? val[p] : 1.f;
+                if (ep.col_scale) w *= ep.col_scale[c];
+                if (DROPOUT) {
+                    const uint64_t e = dr.edge_id ? (uint64_t)(uint32_t)dr.edge_id[p] : (uint64_t)p;
+                    w = hash_counter(e, dr.s0, dr.s1) < dr.keep_below ? w / dr.keep_prob : 0.f;
+                }
+            }
+            int k = 0;
+            // main: 4 gather instructions in flight
+            for (; k + 4 * G <= cnt; k += 4 * G) {
+                int c0 = __shfl(c, k + g), c1 = __shfl(c, k + G + g), c2 = __shfl(c, k + 2 * G + g), c3 = __shfl(c, k + 3 * G + g);
+                float w0 = __shfl(w, k + g), w1 = __shfl(w, k + G + g), w2 = __shfl(w, k + 2 * G + g), w3 = __shfl(w, k + 3 * G + g);
+                float4 x0 = f4_zero(), x1 = f4_zero(), x2 = f4_zero(), x3 = f4_zero();
+                if (lane_on) {
+                    x0 = *reinterpret_cast<const float4 *>(x + (int64_t)c0 * ldx + 4 * t);
+                    x1 = *reinterpret_cast<const float4 *>(x + (int64_t)c1 * ldx + 4 * t);
+                    x2 = *reinterpret_cast<const float4 *>(x + (int64_t)c2 * ldx + 4 * t);
+                    x3 = *reinterpret_cast<const float4 *>(x + (int64_t)c3 * ldx + 4 * t);
+                }
+                f4_fma(acc, w0, x0); f4_fma(acc, w1, x1); f4_fma(acc, w2, x2); f4_fma(acc, w3, x3);
+            }
+            // tail: one gather instruction per step, groups past the end masked off
+            for (; k < cnt; k += G) {
+                const int src = k + g;
+                const int cc = __shfl(c, src);
+                const float ww = __shfl(w, src);
+                if (lane_on && src < cnt) {
+                    const float4 xv = *reinterpret_cast<const float4 *>(x + (int64_t)cc * ldx + 4 * t);
+                    f4_fma(acc, ww, xv);
+                }
+            }
+        }
+        // fold the G groups (fixed order -> deterministic)
+#pragma unroll
+        for (int off = LPR; off < kWave; off <<= 1) f4_add(acc, f4_shfl_xor(acc, off));
+
+        if (g == 0 && lane_on) {
+            if (to_partial) {
+                *reinterpret_cast<float4 *>(partial + dst * (int64_t)d + 4 * t) = acc;
+            } else {
+                float4 r = make_float4(acc.x * ep.out_scale, acc.y * ep.out_scale, acc.z * ep.out_scale, acc.w * ep.out_scale);
+                if (ep.n_adds > 0) {
+                    float4 s = f4_zero();
+                    for (int i = 0; i < ep.n_adds; ++i)
+                        f4_add(s, *reinterpret_cast<const float4 *>(ep.add[i] + dst * ldy + 4 * t));
+                    f4_fma(r, ep.add_scale, s);
+                }
+                if (ep.row_scale) {
+                    const float rs = ep.row_scale[dst];
+                    r.x *= rs; r.y *= rs; r.z *= rs; r.w *= rs;
+                }
+                *reinterpret_cast<float4 *>(y + dst * ldy + 4 * t) = r;
+            }
+        }
+    }
+}
+
+// Adds the partial sums of each long row in slot order, applies the epilogue.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void spmm_long_rows_reduce_kernel(
+    const igcn_long_row *__restrict__ long_rows, int64_t n_long, const float *__restrict__ partial,
+    float *__restrict__ y, int64_t ldy, int d, SpmmEpilogue ep)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (wave >= n_long || lane >= LPR || 4 * lane >= d) return;
+    const igcn_long_row lr = long_rows[wave];
+    float4 acc = f4_zero();
+    for (int s = 0; s < lr.n_slots; ++s)
+        f4_add(acc, *reinterpret_cast<const float4 *>(partial + (int64_t)(lr.first_slot + s) * d + 4 * lane));
+    const int64_t dst = lr.row;
+    float4 r = make_float4(acc.x * ep.out_scale, acc.y * ep.out_scale, acc.z * ep.out_scale, acc.w * ep.out_scale);
+    if (ep.n_adds > 0) {
+        float4 s = f4_zero();
+        for (int i = 0; i < ep.n_adds; ++i)
+            f4_add(s, *reinterpret_cast<const float4 *>(ep.add[i] + dst * ldy + 4 * lane));
+        f4_fma(r, ep.add_scale, s);
+    }
+    if (ep.row_scale) {
+        const float rs = ep.row_scale[dst];
+        r.x *= rs; r.y *= rs; r.z *= rs; r.w *= rs;
+    }
+    *reinterpret_cast<float4 *>(y + dst * ldy + 4 * lane) = r;
+}
+
+// Any d (not a multiple of 4, or misaligned leading dimensions): one wave per
+// row, lane j owns columns j, j+64, ...; slow path, used for odd shapes only.
+__global__ __launch_bounds__(kBlock) void spmm_csr_scalar_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
+    const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy,
+    int64_t n_rows, int d, SpmmEpilogue ep, SpmmDropout dr, bool dropout)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
+    for (int64_t r = wave0; r < n_rows; r += n_waves) {
+        const int64_t start = rowptr[r], end = rowptr[r + 1];
+        for (int j0 = 0; j0 < d; j0 += kWave) {
+            const int j = j0 + lane;
+            float acc = 0.f;
+            for (int64_t p = start; p < end; ++p) {
+                float w = val ? val[p] : 1.f;
+                if (ep.col_scale) w *= ep.col_scale[col[p]];
+                if (dropout) {
+                    const uint64_t e = dr.edge_id ? (uint64_t)(uint32_t)dr.edge_id[p] : (uint64_t)p;
+                    w = hash_counter(e, dr.s0, dr.s1) < dr.keep_below ? w / dr.keep_prob : 0.f;
+                }
+                if (j < d) acc = fmaf(w, x[(int64_t)col[p] * ldx + j], acc);
+            }
+            if (j < d) {
+                float rr = acc * ep.out_scale;
+                float s = 0.f;
+                for (int i = 0; i < ep.n_adds; ++i) s += ep.add[i][r * ldy + j];
+                if (ep.n_adds > 0) rr = fmaf(ep.add_scale, s, rr);
+                if (ep.row_scale) rr *= ep.row_scale[r];
+                y[r * ldy + j] = rr;
+            }
+        }
+    }
+}
+
+__global__ void csr_row_pow_kernel(const int64_t *__restrict__ rowptr, const float *__restrict__ row_sum,
+                                   float exponent, float *__restrict__ val_out, float *__restrict__ row_scale_out,
+                                   int64_t n_rows)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave0 = (int64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x / kWave);
+    for (int64_t r = wave0; r < n_rows; r += n_waves) {
+        const float v = powf(row_sum[r], exponent);
+        if (row_scale_out && lane == 0) row_scale_out[r] = v;
+        if (val_out)
+            for (int64_t p = rowptr[r] + lane; p < rowptr[r + 1]; p += kWave) val_out[p] = v;
+    }
+}
+
+template <int LPR>
+static int launch_rows(bool dropout, dim3 grid, hipStream_t st,
+                       const int64_t *rowptr, const int32_t *col, const float *val, const float *x, int64_t ldx,
+                       float *y, int64_t ldy, int64_t n_rows, int d, const SpmmEpilogue &ep, const SpmmDropout &dr,
+                       const igcn_row_segment *segments, int64_t n_segments, float *partial, int long_threshold,
+                       const igcn_long_row *long_rows, int64_t n_long)
+{
+    if (dropout)
+        hipLaunchKernelGGL((spmm_csr_rows_kernel<LPR, true>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
+                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold);
+    else
+        hipLaunchKernelGGL((spmm_csr_rows_kernel<LPR, false>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
+                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold);
+    int rc = launch_status();
+    if (rc != IGCN_OK) return rc;
+    if (n_long > 0) {
+        const int64_t blocks = (n_long + (kBlock / kWave) - 1) / (kBlock / kWave);
+        hipLaunchKernelGGL((spmm_long_rows_reduce_kernel<LPR>), dim3((unsigned)blocks), dim3(kBlock), 0, st,
+                           long_rows, n_long, partial, y, ldy, d, ep);
+        rc = launch_status();
+    }
+    return rc;
+}
+
+}  // namespace igcn
+
+using namespace igcn;
+
+extern "C" int igcn_spmm_plan_count_host(const int64_t *rowptr_host, int64_t n_rows, int32_t long_threshold,
+                                         int32_t segment_len, int64_t *n_long_rows, int64_t *n_segments)
+{
+    if (!rowptr_host || !n_long_rows || !n_segments) return IGCN_E_NULL;
+    if (n_rows < 0) return IGCN_E_SHAPE;
+    if (long_threshold < 1 || segment_len < 1 || segment_len > long_threshold) return IGCN_E_RANGE;
+    int64_t nl = 0, ns = 0;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int64_t deg = rowptr_host[r + 1] - rowptr_host[r];
+        if (deg < 0) return IGCN_E_SHAPE;
+        if (deg > long_threshold) { ++nl; ns += (deg + segment_len - 1) / segment_len; }
+    }
+    *n_long_rows = nl;
+    *n_segments = ns;
+    return IGCN_OK;
+}
+
+extern "C" int igcn_spmm_plan_fill_host(const int64_t *rowptr_host, int64_t n_rows, int32_t long_threshold,
+                                        int32_t segment_len, igcn_long_row *long_rows_host, int64_t n_long_rows,
+                                        igcn_row_segment *segments_host, int64_t n_segments)
+{
+    if (!rowptr_host) return IGCN_E_NULL;
+    if ((n_long_rows > 0 && !long_rows_host) || (n_segments > 0 && !segments_host)) return IGCN_E_NULL;
+    if (long_threshold < 1 || segment_len < 1 || segment_len > long_threshold) return IGCN_E_RANGE;
+    if (n_rows >= (int64_t)1 << 31) return IGCN_E_SHAPE;
+    int64_t il = 0, is = 0;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int64_t s = rowptr_host[r], e = rowptr_host[r + 1];
+        if (e - s <= long_threshold) continue;
+        const int64_t n = (e - s + segment_len - 1) / segment_len;
+        if (il >= n_long_rows || is + n > n_segments || is + n >= (int64_t)1 << 31) return IGCN_E_SHAPE;
+        long_rows_host[il].row = (int32_t)r;
+        long_rows_host[il].first_slot = (int32_t)is;
+        long_rows_host[il].n_slots = (int32_t)n;
+        long_rows_host[il].reserved = 0;
+        ++il;
+        for (int64_t p = s; p < e; p += segment_len, ++is) {
+            segments_host[is].start = p;
+            segments_host[is].len = (int32_t)((e - p) < segment_len ? (e - p) : segment_len);
+            segments_host[is].slot = (int32_t)is;
+        }
+    }
+    return (il == n_long_rows && is == n_segments) ? IGCN_OK : IGCN_E_SHAPE;
+}
+
+extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val,
+                                 const float *x, int64_t ldx, float *y, int64_t ldy,
+                                 int64_t n_rows, int64_t n_cols, int32_t d,
+                                 float out_scale, const float *const *adds_host, int32_t n_adds,
+                                 float add_scale, const float *row_scale, const float *col_scale,
+                                 const igcn_long_row *long_rows, int64_t n_long_rows,
+                                 const igcn_row_segment *segments, int64_t n_segments,
+                                 float *partial, int32_t long_threshold,
+                                 const int32_t *edge_id, uint64_t seed, float keep_prob, void *stream)
+{
+    if (!rowptr || !x || !y) return IGCN_E_NULL;
+    if (n_rows < 0 || n_cols < 0 || d < 1 || d > 256 || ldx < d || ldy < d) return IGCN_E_SHAPE;
+    if (n_rows >= ((int64_t)1 << 31) || n_cols >= ((int64_t)1 << 31)) return IGCN_E_SHAPE;
+    if (n_adds < 0 || n_adds > IGCN_MAX_ADDS || (n_adds > 0 && !adds_host)) return IGCN_E_RANGE;
+    if (!(keep_prob > 0.f)) return IGCN_E_RANGE;
+    if ((n_long_rows > 0 || n_segments > 0) && (!long_rows || !segments || !partial || n_long_rows < 1 || n_segments < 1))
+        return IGCN_E_NULL;
+    if (n_segments > 0 && long_threshold < 1) return IGCN_E_RANGE;
+    if (x == y) return IGCN_E_RANGE;     // in-place propagation would read rows being written
+    if (n_rows == 0) return IGCN_OK;
+    if (!col) return IGCN_E_NULL;
+
+    SpmmEpilogue ep{};
+    ep.n_adds = n_adds;
+    for (int i = 0; i < n_adds; ++i) {
+        if (!adds_host[i]) return IGCN_E_NULL;
+        ep.add[i] = adds_host[i];
+    }
+    ep.out_scale = out_scale;
+    ep.add_scale = add_scale;
+    ep.row_scale = row_scale;
+    ep.col_scale = col_scale;
+
+    const bool dropout = keep_prob < 1.f;
+    SpmmDropout dr{};
+    dr.edge_id = edge_id;
+    dr.s0 = (uint32_t)seed;
+    dr.s1 = (uint32_t)(seed >> 32);
+    double kb = (double)keep_prob * 4294967296.0;
+    dr.keep_below = kb >= 4294967295.0 ? 4294967295u : (uint32_t)kb;
+    dr.keep_prob = keep_prob;
+
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int waves_per_block = kBlock / kWave;
+    const int64_t n_virtual = n_rows + n_segments;
+    int64_t blocks = (n_virtual + waves_per_block - 1) / waves_per_block;
+    const int64_t max_blocks = (int64_t)cu_count() * 8;
+    if (blocks > max_blocks) blocks = max_blocks;
+    dim3 grid((unsigned)blocks);
+
+    bool vec = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) &&
+               ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 == 0);
+    for (int i = 0; i < n_adds && vec; ++i) vec = reinterpret_cast<uintptr_t>(ep.add[i]) % 16 == 0;
+    if (n_segments > 0 && (reinterpret_cast<uintptr_t>(partial) % 16 != 0)) return IGCN_E_ALIGN;
+    if (!vec) {
+        if (n_segments > 0) return IGCN_E_ALIGN;   // the plan's partial layout needs the vector path
+        hipLaunchKernelGGL(spmm_csr_scalar_kernel, grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
+                           n_rows, (int)d, ep, dr, dropout);
+        return launch_status();
+    }
+#define IGCN_SPMM_CASE(L)                                                                                         \
+    return launch_rows<L>(dropout, grid, st, rowptr, col, val, x, ldx, y, ldy, n_rows, (int)d, ep, dr, segments,  \
+                          n_segments, partial, (int)long_threshold, long_rows, n_long_rows)
+    const int q = d / 4;
+    if (q <= 1) IGCN_SPMM_CASE(1);
+    if (q <= 2) IGCN_SPMM_CASE(2);
+    if (q <= 4) IGCN_SPMM_CASE(4);
+    if (q <= 8) IGCN_SPMM_CASE(8);
+    if (q <= 16) IGCN_SPMM_CASE(16);
+    if (q <= 32) IGCN_SPMM_CASE(32);
+    IGCN_SPMM_CASE(64);
+#undef IGCN_SPMM_CASE
+}
+
+extern "C" int igcn_csr_row_pow_f32(const int64_t *rowptr, const float *row_sum, float exponent,
+                                    float *val_out, float *row_scale_out, int64_t n_rows, void *stream)
+{
+    if (!rowptr || !row_sum || (!val_out && !row_scale_out)) return IGCN_E_NULL;
+    if (n_rows < 0) return IGCN_E_SHAPE;
+    if (n_rows == 0) return IGCN_OK;
+    int64_t blocks = (n_rows + 3) / 4;
+    const int64_t max_blocks = (int64_t)cu_count() * 8;
+    if (blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL(csr_row_pow_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       rowptr, row_sum, exponent, val_out, row_scale_out, n_rows);
+    return launch_status();
+}
+
+extern "C" int igcn_abi_version(void) { return IGCN_ABI_VERSION; }
+
+extern "C" const char *igcn_error_string(int code)
+{
+    switch (code) {
+    case IGCN_OK: return "ok";
+    case IGCN_E_NULL: return "a required pointer is NULL";
+    case IGCN_E_SHAPE: return "invalid size or leading dimension";
+    case IGCN_E_ALIGN: return "pointer or stride not 16-byte aligned";
+    case IGCN_E_RANGE: return "scalar argument out of range";
+    case IGCN_E_NO_DEVICE: return "no HIP device";
+    default: return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "unknown igcn error";
+    }
+}

@@ -1,0 +1,286 @@
+"""Datasets for the propagation + scoring path.
+
+Mirrors the reference's dataset contract (dataset.py:10-14 get_dataset,
+:47-64 BasicDataset attributes, :116-131 sampler, :140-164 ProcessedDataset
+text format, :258-273 AuxiliaryDataset) with CSR arrays as the primary storage
+so the lists can be handed to the device kernels without Python loops.
+The raw-dump preprocessors (dataset.py:167-255) are out of scope.
+"""
+import os
+import random
+import sys
+
+import numpy as np
+
+
+def get_dataset(config):
+    """Factory by class name, as the reference's get_dataset (dataset.py:10-14)."""
+    config = config.copy()
+    cls = getattr(sys.modules[__name__], config['name'])
+    return cls(config)
+
+
+def lists_to_csr(lists, sort=False):
+    lens = np.fromiter((len(x) for x in lists), dtype=np.int64, count=len(lists))
+    rowptr = np.zeros(len(lists) + 1, dtype=np.int64)
+    np.cumsum(lens, out=rowptr[1:])
+    col = np.fromiter((i for x in lists for i in x), dtype=np.int64, count=int(rowptr[-1]))
+    if sort and col.size:
+        row = np.repeat(np.arange(len(lists), dtype=np.int64), lens)
+        order = np.lexsort((col, row))
+        col = col[order]
+    return rowptr, col
+
+
+def csr_to_lists(rowptr, col):
+    col = col.tolist()
+    return [col[rowptr[u]:rowptr[u + 1]] for u in range(len(rowptr) - 1)]
+
+
+class BasicDataset:
+    """Attribute contract of the reference's BasicDataset (dataset.py:47-64)."""
+
+    def __init__(self, dataset_config):
+        self.config = dataset_config
+        self.name = dataset_config['name']
+        self.device = dataset_config.get('device', 'cpu')
+        self.negative_sample_ratio = dataset_config.get('neg_ratio', 1)
+        self.n_users = 0
+        self.n_items = 0
+        self.train_data = None
+        self.val_data = None
+        self.test_data = None
+        self.train_array = None
+        self._csr = {}
+
+    # ---- list views <-> CSR views ------------------------------------------------
+    def csr(self, which, sort=True):
+        """(rowptr int64, col int64) of train/val/test lists; `sort` orders each
+        user's items ascending (what the device membership tests expect)."""
+        key = (which, sort)
+        if key not in self._csr:
+            self._csr[key] = lists_to_csr(getattr(self, which + '_data'), sort=sort)
+        return self._csr[key]
+
+    def invalidate(self):
+        """Call after mutating train/val/test lists in place (inductive_eval does)."""
+        self._csr = {}
+
+    def _finish(self):
+        rowptr, col = lists_to_csr(self.train_data)
+        users = np.repeat(np.arange(self.n_users, dtype=np.int64), np.diff(rowptr))
+        self.train_array = np.stack([users, col], axis=1)
+
+    def __len__(self):
+        return len(self.train_array)
+
+    def __getitem__(self, index):
+        """One BPR draw, same procedure as dataset.py:119-131 (index ignored)."""
+        user = random.randint(0, self.n_users - 1)
+        while not self.train_data[user]:
+            user = random.randint(0, self.n_users - 1)
+        pos_item = np.random.choice(self.train_data[user])
+        out = [[user, pos_item] for _ in range(self.negative_sample_ratio)]
+        for idx in range(self.negative_sample_ratio):
+            neg_item = random.randint(0, self.n_items - 1)
+            while neg_item in self.train_data[user]:
+                neg_item = random.randint(0, self.n_items - 1)
+            out[idx].append(neg_item)
+        return np.array(out, dtype=np.int64)
+
+    def sample_batch_host(self, batch_size, rng):
+        """Vectorised host sampler with the distribution of __getitem__:
+        uniform non-empty user, uniform positive, rejection-sampled negative.
+        Returns int64 [batch, 3]."""
+        rowptr, col = self.csr('train', sort=True)
+        lens = np.diff(rowptr)
+        nonempty = np.flatnonzero(lens > 0)
+        users = nonempty[rng.integers(0, nonempty.size, size=batch_size)]
+        pos = col[rowptr[users] + (rng.random(batch_size) * lens[users]).astype(np.int64)]
+        neg = rng.integers(0, self.n_items, size=batch_size)
+        key = users * np.int64(self.n_items)
+        allkeys = np.repeat(np.arange(self.n_users, dtype=np.int64), lens) * np.int64(self.n_items) + col
+        todo = np.arange(batch_size)
+        while todo.size:
+            k = key[todo] + neg[todo]
+            pos_in = np.searchsorted(allkeys, k)
+            hit = (pos_in < allkeys.size) & (allkeys[np.minimum(pos_in, allkeys.size - 1)] == k)
+            todo = todo[hit]
+            neg[todo] = rng.integers(0, self.n_items, size=todo.size)
+        return np.stack([users, pos, neg], axis=1).astype(np.int64)
+
+    def output_dataset(self, path):
+        """Writes train/val/test.txt in the reference format (dataset.py:40-44, :133-137)."""
+        os.makedirs(path, exist_ok=True)
+        for name in ('train', 'val', 'test'):
+            with open(os.path.join(path, name + '.txt'), 'w') as f:
+                for user, items in enumerate(getattr(self, name + '_data')):
+                    f.write(' '.join([str(user)] + [str(i) for i in items]) + '\n')
+
+
+class ProcessedDataset(BasicDataset):
+    """Reader of the reference's processed text format (dataset.py:140-164):
+    one line per user, 'user item item ...'; n_items = max id + 1 over all files."""
+
+    def __init__(self, dataset_config):
+        super().__init__(dataset_config)
+        self.train_data = self.read_data(os.path.join(dataset_config['path'], 'train.txt'))
+        self.val_data = self.read_data(os.path.join(dataset_config['path'], 'val.txt'))
+        self.test_data = self.read_data(os.path.join(dataset_config['path'], 'test.txt'))
+        assert len(self.train_data) == len(self.val_data)
+        assert len(self.train_data) == len(self.test_data)
+        self.n_users = len(self.train_data)
+        self._finish()
+
+    def read_data(self, file_path):
+        data = []
+        with open(file_path, 'r') as f:
+            lines = f.read().strip().split('\n')
+        for line in lines:
+            items = [int(item) for item in line.split(' ')[1:]]
+            if items:
+                self.n_items = max(self.n_items, max(items) + 1)
+            data.append(items)
+        return data
+
+
+class SyntheticDataset(BasicDataset):
+    """Seeded synthetic implicit-feedback split with the shape of the paper's
+    datasets: per-user interaction counts ~ max(min_inter,
+    LogNormal), items drawn from a Zipf-Mandelbrot popularity over a random
+    permutation (zipf_q = 0 gives the pure Zipf stress case, zipf_a = 0 the
+    uniform one), de-duplicated per user, split 70/10/20 per user in draw order
+    as dataset.py:94-114 does."""
+
+    PRESETS = {
+        'gowalla': dict(n_users=29858, n_items=40988, n_inter=1027464),
+        'yelp': dict(n_users=75173, n_items=42706, n_inter=1931173),
+        'amazon': dict(n_users=109730, n_items=96421, n_inter=3181759),
+    }
+
+    def __init__(self, dataset_config):
+        super().__init__(dataset_config)
+        cfg = dict(self.PRESETS.get(dataset_config.get('preset', ''), {}))
+        cfg.update({k: dataset_config[k] for k in ('n_users', 'n_items', 'n_inter') if k in dataset_config})
+        self.n_users, self.n_items = int(cfg['n_users']), int(cfg['n_items'])
+        n_inter = int(cfg['n_inter'])
+        seed = dataset_config.get('seed', 2021)
+        min_inter = dataset_config.get('min_inter', 10)
+        zipf_a = dataset_config.get('zipf_a', 1.0)
+        zipf_q = dataset_config.get('zipf_q', 150.0)
+        split = dataset_config.get('split_ratio', [0.7, 0.1, 0.2])
+        rng = np.random.default_rng(seed)
+
+        # per-user counts: max(min_inter, lognormal), scale found by bisection on the total
+        z = rng.standard_normal(self.n_users)
+        lo, hi = -5., 12.
+        for _ in range(60):
+            mu = 0.5 * (lo + hi)
+            cnt = np.maximum(min_inter, np.rint(np.exp(mu + z))).astype(np.int64)
+            if cnt.sum() > n_inter:
+                hi = mu
+            else:
+                lo = mu
+        cnt = np.minimum(cnt, self.n_items // 2)
+        # popularity over a random permutation of the items
+        rank = np.arange(1, self.n_items + 1, dtype=np.float64)
+        p = 1. / np.power(rank + zipf_q, zipf_a)
+        cdf = np.cumsum(p / p.sum())
+        perm = rng.permutation(self.n_items)
+
+        users = np.repeat(np.arange(self.n_users, dtype=np.int64), cnt)
+        items = perm[np.minimum(np.searchsorted(cdf, rng.random(users.size)), self.n_items - 1)]
+        # de-duplicate per user, keeping draw order (first occurrence)
+        key = users * np.int64(self.n_items) + items
+        _, first = np.unique(key, return_index=True)
+        first.sort()
+        users, items = users[first], items[first]
+        cnt = np.bincount(users, minlength=self.n_users)
+        rowptr = np.zeros(self.n_users + 1, dtype=np.int64)
+        np.cumsum(cnt, out=rowptr[1:])
+        n_train = (cnt * split[0]).astype(np.int64)
+        n_test = (cnt * split[2]).astype(np.int64)
+        pos_in_user = np.arange(users.size, dtype=np.int64) - rowptr[users]
+        is_train = pos_in_user < n_train[users]
+        is_test = pos_in_user >= (cnt - n_test)[users]
+        is_test &= n_test[users] > 0
+        is_val = ~is_train & ~is_test
+        self._csr = {}
+        for name, m in (('train', is_train), ('val', is_val), ('test', is_test)):
+            c = np.bincount(users[m], minlength=self.n_users)
+            rp = np.zeros(self.n_users + 1, dtype=np.int64)
+            np.cumsum(c, out=rp[1:])
+            self._csr[(name, False)] = (rp, items[m].astype(np.int64))
+        self._lists = {}
+        rp, col = self._csr[('train', False)]
+        self.train_array = np.stack([np.repeat(np.arange(self.n_users, dtype=np.int64), np.diff(rp)), col], axis=1)
+
+    # lists are materialised lazily: the device path only needs the CSR views
+    def _get_list(self, name):
+        if name not in self._lists:
+            self._lists[name] = csr_to_lists(*self._csr[(name, False)])
+        return self._lists[name]
+
+    train_data = property(lambda self: self._get_list('train'), lambda self, v: self._set_list('train', v))
+    val_data = property(lambda self: self._get_list('val'), lambda self, v: self._set_list('val', v))
+    test_data = property(lambda self: self._get_list('test'), lambda self, v: self._set_list('test', v))
+
+    def _set_list(self, name, value):
+        if value is None:
+            return
+        self._lists[name] = value
+        for k in [k for k in self._csr if k[0] == name]:
+            del self._csr[k]
+
+    def csr(self, which, sort=True):
+        key = (which, sort)
+        if key not in self._csr:
+            if (which, False) in self._csr and which not in self._lists:
+                rp, col = self._csr[(which, False)]
+                row = np.repeat(np.arange(self.n_users, dtype=np.int64), np.diff(rp))
+                self._csr[key] = (rp, col[np.lexsort((col, row))])
+            else:
+                self._csr[key] = lists_to_csr(self._get_list(which), sort=sort)
+        return self._csr[key]
+
+    def invalidate(self):
+        for k in [k for k in self._csr if k[0] in self._lists]:
+            del self._csr[k]
+
+
+class AuxiliaryDataset(BasicDataset):
+    """Train lists re-indexed into template-id space for the INMO auxiliary
+    loss (dataset.py:258-273).  user_map / item_map: dict or None (= identity)."""
+
+    def __init__(self, dataset, user_map, item_map):
+        super().__init__({'name': 'AuxiliaryDataset', 'device': dataset.device})
+        self.n_users = dataset.n_users if user_map is None else len(user_map)
+        self.n_items = dataset.n_items if item_map is None else len(item_map)
+        self.negative_sample_ratio = 1
+        self.length = len(dataset)
+        rowptr, col = dataset.csr('train', sort=False)
+        users = np.repeat(np.arange(dataset.n_users, dtype=np.int64), np.diff(rowptr))
+        u_lut = np.arange(dataset.n_users, dtype=np.int64)
+        i_lut = np.arange(dataset.n_items, dtype=np.int64)
+        if user_map is not None:
+            u_lut = np.full(dataset.n_users, -1, dtype=np.int64)
+            for k, v in user_map.items():
+                if k < dataset.n_users:
+                    u_lut[k] = v
+        if item_map is not None:
+            i_lut = np.full(dataset.n_items, -1, dtype=np.int64)
+            for k, v in item_map.items():
+                if k < dataset.n_items:
+                    i_lut[k] = v
+        tu, ti = u_lut[users], i_lut[col]
+        keep = (tu >= 0) & (ti >= 0)
+        tu, ti = tu[keep], ti[keep]
+        order = np.argsort(tu, kind='stable')          # original users ascending within a template user
+        tu, ti = tu[order], ti[order]
+        rp = np.zeros(self.n_users + 1, dtype=np.int64)
+        np.cumsum(np.bincount(tu, minlength=self.n_users), out=rp[1:])
+        self.train_data = csr_to_lists(rp, ti)
+        self.train_array = np.stack([tu, ti], axis=1)
+
+    def __len__(self):
+        return self.length

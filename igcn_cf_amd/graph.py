@@ -1,0 +1,188 @@
+"""Host-side graph construction and the device CSR container.
+
+Counterpart of the reference's utils.get_sparse_tensor / generate_daj_mat
+(utils.py:32-49), LightGCN.generate_graph (model.py:85-94) and
+IGCN.generate_feat (model.py:386-421).  The reference keeps a coalesced COO
+tensor and rebuilds a DGL graph from it on every get_rep call
+(model.py:99-100); here the matrix is converted ONCE into CSR resident in HBM,
+together with the long-row schedule the SpMM kernel uses.
+
+Everything here is vectorised numpy on the host; nothing is per-step.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+LONG_THRESHOLD = 1024      # rows with more nonzeros are cut into segments
+SEGMENT_LEN = 512
+
+
+def coo_to_csr_host(row, col, val, shape):
+    """Row-major sorted CSR with duplicate entries summed (the result of the
+    reference's coo_matrix(...).tocsr() + coalesce(), utils.py:32-38, :46-48).
+    Returns (rowptr int64, col int32, val float32)."""
+    row = np.asarray(row, dtype=np.int64)
+    col = np.asarray(col, dtype=np.int64)
+    val = np.asarray(val, dtype=np.float32)
+    n_rows, n_cols = int(shape[0]), int(shape[1])
+    if row.size:
+        key = row * np.int64(n_cols) + col
+        order = np.argsort(key, kind='stable')
+        key = key[order]
+        first = np.empty(key.shape, dtype=bool)
+        first[0] = True
+        np.not_equal(key[1:], key[:-1], out=first[1:])
+        starts = np.flatnonzero(first)
+        val = np.add.reduceat(val[order], starts).astype(np.float32)
+        key = key[starts]
+        row, col = key // n_cols, key % n_cols
+    rowptr = np.zeros(n_rows + 1, dtype=np.int64)
+    np.cumsum(np.bincount(row, minlength=n_rows), out=rowptr[1:])
+    return rowptr, col.astype(np.int32), val
+
+
+def adjacency_host(train_array, n_users, n_items):
+    """A = [[0, R], [R^T, 0]] as host CSR.  utils.py:41-49."""
+    ta = np.asarray(train_array, dtype=np.int64).reshape(-1, 2)
+    users, items = ta[:, 0], ta[:, 1] + n_users
+    row = np.concatenate([users, items])
+    col = np.concatenate([items, users])
+    n = n_users + n_items
+    return coo_to_csr_host(row, col, np.ones(row.shape, dtype=np.float32), (n, n))
+
+
+def normalized_adjacency_host(train_array, n_users, n_items):
+    """A_hat = D^-1/2 A D^-1/2, deg = max(1, rowsum), float32 in the reference's
+    operation order (d_mat.dot(adj).dot(d_mat)).  model.py:85-94."""
+    rowptr, col, val = adjacency_host(train_array, n_users, n_items)
+    n = n_users + n_items
+    row = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr))
+    degree = np.zeros(n, dtype=np.float32)
+    np.add.at(degree, row, val)
+    degree = np.maximum(np.float32(1.), degree).astype(np.float32)
+    d_inv = np.power(degree, np.float32(-0.5)).astype(np.float32)
+    val = ((d_inv[row] * val).astype(np.float32) * d_inv[col]).astype(np.float32)
+    return rowptr, col, val
+
+
+def transpose_host(rowptr, col, n_cols):
+    """CSR of M^T plus, for every entry of M^T, the position of the same entry in
+    M (edge id) so that both views drop the same edges under dropout."""
+    n_rows = rowptr.shape[0] - 1
+    row = np.repeat(np.arange(n_rows, dtype=np.int64), np.diff(rowptr))
+    order = np.argsort(col.astype(np.int64) * np.int64(n_rows) + row, kind='stable')
+    t_rowptr = np.zeros(n_cols + 1, dtype=np.int64)
+    np.cumsum(np.bincount(col, minlength=n_cols), out=t_rowptr[1:])
+    return t_rowptr, row[order].astype(np.int32), order.astype(np.int32)
+
+
+def feature_matrix_host(train_array, n_users, n_items, user_map=None, item_map=None):
+    """INMO template feature matrix F (binary structure) and row_sum.  model.py:386-421.
+
+    user_map / item_map: dict original id -> template id, or None for "every
+    node is a template" (feature_ratio = 1., model.py:392-394).
+    Returns (rowptr, col, row_sum float32, shape)."""
+    ta = np.asarray(train_array, dtype=np.int64).reshape(-1, 2)
+    users, items = ta[:, 0], ta[:, 1]
+    if user_map is None:
+        u_lut = np.arange(n_users, dtype=np.int64)
+        user_dim = n_users
+    else:
+        u_lut = np.full(n_users, -1, dtype=np.int64)
+        if len(user_map):
+            k = np.fromiter(user_map.keys(), dtype=np.int64, count=len(user_map))
+            v = np.fromiter(user_map.values(), dtype=np.int64, count=len(user_map))
+            keep = k < n_users
+            u_lut[k[keep]] = v[keep]
+        user_dim = len(user_map)
+    if item_map is None:
+        i_lut = np.arange(n_items, dtype=np.int64)
+        item_dim = n_items
+    else:
+        i_lut = np.full(n_items, -1, dtype=np.int64)
+        if len(item_map):
+            k = np.fromiter(item_map.keys(), dtype=np.int64, count=len(item_map))
+            v = np.fromiter(item_map.values(), dtype=np.int64, count=len(item_map))
+            keep = k < n_items
+            i_lut[k[keep]] = v[keep]
+        item_dim = len(item_map)
+    it, ut = i_lut[items], u_lut[users]
+    m_i, m_u = it >= 0, ut >= 0
+    row = np.concatenate([users[m_i], n_users + items[m_u],
+                          np.arange(n_users, dtype=np.int64), n_users + np.arange(n_items, dtype=np.int64)])
+    col = np.concatenate([user_dim + it[m_i], ut[m_u],
+                          np.full(n_users, user_dim + item_dim, dtype=np.int64),
+                          np.full(n_items, user_dim + item_dim + 1, dtype=np.int64)])
+    shape = (n_users + n_items, user_dim + item_dim + 2)
+    rowptr, col, val = coo_to_csr_host(row, col, np.ones(row.shape, dtype=np.float32), shape)
+    row_sum = np.add.reduceat(val, rowptr[:-1]).astype(np.float32)   # every row has its global column
+    return rowptr, col, row_sum, shape
+
+
+class CsrMatrix:
+    """A CSR matrix resident in HBM with the SpMM long-row schedule.
+
+    rowptr int64 [n_rows+1], col int32 [nnz], val float32 [nnz] or None (all
+    ones), edge_id int32 [nnz] or None."""
+
+    def __init__(self, rowptr, col, val, shape, device, edge_id=None,
+                 long_threshold=LONG_THRESHOLD, segment_len=SEGMENT_LEN):
+        rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        self.shape = (int(shape[0]), int(shape[1]))
+        if rowptr.shape[0] != self.shape[0] + 1 or rowptr[0] != 0 or rowptr[-1] != col.shape[0]:
+            raise ValueError('inconsistent CSR arrays')
+        if col.size and (col.min() < 0 or col.max() >= self.shape[1]):
+            raise ValueError('column index out of range')
+        self.nnz = int(col.shape[0])
+        self.device = torch.device(device)
+        self.rowptr_host = rowptr
+        self.rowptr = torch.from_numpy(rowptr).to(self.device)
+        self.col = torch.from_numpy(col).to(self.device)
+        self.val = None if val is None else torch.from_numpy(np.ascontiguousarray(val, dtype=np.float32)).to(self.device)
+        self.edge_id = None if edge_id is None else \
+            torch.from_numpy(np.ascontiguousarray(edge_id, dtype=np.int32)).to(self.device)
+        self.long_threshold = int(long_threshold)
+        self.segment_len = int(segment_len)
+        self._build_plan()
+        self._partial = {}
+
+    def _build_plan(self):
+        L = _lib.lib()
+        n_long, n_seg = C.c_int64(0), C.c_int64(0)
+        _lib.check(L.igcn_spmm_plan_count_host(self.rowptr_host.ctypes.data, self.shape[0], self.long_threshold,
+                                               self.segment_len, C.byref(n_long), C.byref(n_seg)), 'spmm_plan_count')
+        self.n_long, self.n_segments = int(n_long.value), int(n_seg.value)
+        self.long_rows = self.segments = None
+        if self.n_long:
+            lr = np.zeros(self.n_long, dtype=_lib.LONG_ROW_DTYPE)
+            sg = np.zeros(self.n_segments, dtype=_lib.ROW_SEGMENT_DTYPE)
+            _lib.check(L.igcn_spmm_plan_fill_host(self.rowptr_host.ctypes.data, self.shape[0], self.long_threshold,
+                                                  self.segment_len, lr.ctypes.data, self.n_long,
+                                                  sg.ctypes.data, self.n_segments), 'spmm_plan_fill')
+            self.long_rows = torch.from_numpy(lr.view(np.uint8)).to(self.device)
+            self.segments = torch.from_numpy(sg.view(np.uint8)).to(self.device)
+
+    def partial(self, d):
+        """Workspace for the partial sums of long-row segments (n_segments x d)."""
+        if not self.n_segments:
+            return None
+        buf = self._partial.get(d)
+        if buf is None:
+            buf = torch.empty(self.n_segments * d, dtype=torch.float32, device=self.device)
+            self._partial[d] = buf
+        return buf
+
+    @classmethod
+    def transposed(cls, rowptr, col, shape, device, **kw):
+        t_rowptr, t_col, edge_id = transpose_host(np.asarray(rowptr), np.asarray(col), int(shape[1]))
+        return cls(t_rowptr, t_col, None, (shape[1], shape[0]), device, edge_id=edge_id, **kw)
+
+    def to_torch_coo(self):
+        """Coalesced torch COO view (what the reference's norm_adj / feat_mat are)."""
+        row = torch.repeat_interleave(torch.arange(self.shape[0], device=self.device), self.rowptr[1:] - self.rowptr[:-1])
+        val = self.val if self.val is not None else torch.ones(self.nnz, device=self.device)
+        return torch.sparse_coo_tensor(torch.stack([row, self.col.long()]), val, self.shape).coalesce()

@@ -1,0 +1,184 @@
+/*
+ * igcn_hip.h — C ABI of libigcn_hip.so: the MI355X (gfx950) kernels behind the
+ * INMO / LightGCN propagation + scoring path.
+ *
+ * The reference (WuYunfan/igcn_cf) has no FFI: its hot path reaches the device
+ * through three library calls.  Each entry point below names the reference
+ * call site it replaces (file:line in the reference tree).
+ *
+ * Conventions
+ *   - every pointer is a raw DEVICE pointer unless the name ends in _host;
+ *   - the caller owns all memory; the library allocates and frees nothing;
+ *   - all launches go to the caller's `stream` (a hipStream_t passed as void*,
+ *     NULL = the default stream); no call synchronises;
+ *   - every function returns 0 on success, a negative IGCN_E_* on a bad
+ *     argument, or a positive hipError_t from the launch.
+ */
+#ifndef IGCN_HIP_H
+#define IGCN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IGCN_ABI_VERSION 1
+
+#define IGCN_OK            0
+#define IGCN_E_NULL       -1   /* a required pointer is NULL               */
+#define IGCN_E_SHAPE      -2   /* a size / leading dimension is invalid    */
+#define IGCN_E_ALIGN      -3   /* a pointer / stride misses its alignment  */
+#define IGCN_E_RANGE      -4   /* a scalar argument is out of range        */
+#define IGCN_E_NO_DEVICE  -5   /* no HIP device is available               */
+
+#define IGCN_MAX_ADDS      8   /* epilogue addends of igcn_spmm_csr_f32     */
+#define IGCN_MAX_TOPK    128   /* k of igcn_score_topk_f32                  */
+
+int         igcn_abi_version(void);
+const char *igcn_error_string(int code);
+
+/* One piece of a long CSR row (a "row segment"): nonzeros [start, start+len)
+ * of row `row`, whose partial sum goes to partial[slot].  Built once per graph
+ * by igcn_spmm_plan_fill_host. */
+typedef struct igcn_row_segment {
+    int64_t start;
+    int32_t len;
+    int32_t slot;
+} igcn_row_segment;
+
+/* One long row: its partial sums are partial[first_slot .. first_slot+n_slots). */
+typedef struct igcn_long_row {
+    int32_t row;
+    int32_t first_slot;
+    int32_t n_slots;
+    int32_t reserved;
+} igcn_long_row;
+
+/* Host-side schedule for rows longer than `long_threshold` nonzeros (power-law
+ * item rows): each is cut into segments of at most `segment_len` nonzeros.
+ * Replaces the per-call graph object the reference rebuilds in
+ * model.py:99-100 / :428-429 / :439-440 (dgl.graph((column,row))).
+ * _count returns the sizes; _fill writes the two arrays (host memory). */
+int igcn_spmm_plan_count_host(const int64_t *rowptr_host, int64_t n_rows,
+                              int32_t long_threshold, int32_t segment_len,
+                              int64_t *n_long_rows, int64_t *n_segments);
+int igcn_spmm_plan_fill_host(const int64_t *rowptr_host, int64_t n_rows,
+                             int32_t long_threshold, int32_t segment_len,
+                             igcn_long_row *long_rows_host, int64_t n_long_rows,
+                             igcn_row_segment *segments_host, int64_t n_segments);
+
+/* Y = epilogue( M @ X ) for a CSR matrix M (n_rows x n_cols), X [n_cols, d]
+ * fp32 row-major with leading dimension ldx, Y [n_rows, d] with ldy.
+ *
+ *   acc[r]  = sum_{p in rowptr[r]..rowptr[r+1]}  w_p * X[col[p]]
+ *   w_p     = (val ? val[p] : 1) * (col_scale ? col_scale[col[p]] : 1) * drop_p
+ *   drop_p  = keep_prob >= 1 ? 1
+ *           : (hash(seed, edge_id ? edge_id[p] : p) keeps) ? 1/keep_prob : 0
+ *   Y[r]    = (out_scale * acc[r] + add_scale * sum_i adds[i][r])
+ *             * (row_scale ? row_scale[r] : 1)
+ *
+ * Replaces dgl.ops.gspmm(g,'mul','sum',X,w) at model.py:102, :430, :442, the
+ * layer mean of model.py:104-105 / :444-445 (adds + scales on the last layer),
+ * NGCF.dropout_sp_mat as used at model.py:435 (drop_p, no structure rebuild)
+ * and the row-constant values of IGCN.update_feat_mat, model.py:374-377
+ * (val == NULL, row_scale = row_sum^exponent; the transposed view used by the
+ * backward pass takes the same vector as col_scale).
+ *
+ * rowptr int64 [n_rows+1]; col int32 [nnz]; val fp32 [nnz] or NULL;
+ * adds_host: HOST array of n_adds device pointers, each [n_rows, d] with ldy;
+ * long rows (may be NULL / 0 when the matrix has none): long_rows / segments
+ * as produced by igcn_spmm_plan_fill_host, copied to the device, and `partial`
+ * a device workspace of n_segments * d floats;
+ * edge_id int32 [nnz] or NULL (used when M is a transposed view, so that both
+ * views drop the same edges). */
+int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val,
+                      const float *x, int64_t ldx, float *y, int64_t ldy,
+                      int64_t n_rows, int64_t n_cols, int32_t d,
+                      float out_scale, const float *const *adds_host, int32_t n_adds,
+                      float add_scale, const float *row_scale, const float *col_scale,
+                      const igcn_long_row *long_rows, int64_t n_long_rows,
+                      const igcn_row_segment *segments, int64_t n_segments,
+                      float *partial, int32_t long_threshold,
+                      const int32_t *edge_id, uint64_t seed, float keep_prob,
+                      void *stream);
+
+/* out[e] = row_sum[row(e)] ^ exponent for every stored entry of a CSR matrix:
+ * IGCN.update_feat_mat, model.py:374-377, as explicit values (the propagation
+ * path itself uses row_scale instead and never materialises them). */
+int igcn_csr_row_pow_f32(const int64_t *rowptr, const float *row_sum, float exponent,
+                         float *val_out, float *row_scale_out, int64_t n_rows, void *stream);
+
+/* Fused BPR triplet scoring, forward:  trainer.py:238-243 (+ :306-311 with w),
+ * model.py:110-116 / :295-299 / :62-67 (gathers and squared norms).
+ *   pos_b = sum_j U[u_b,j] P[p_b,j] w_j ,  neg_b likewise with N[n_b]
+ *   loss_out[0] = (1/B) sum_b softplus(neg_b - pos_b)
+ *   loss_out[1] = (1/B) sum_b (|L_u[u_b]|^2 + |L_p[p_b]|^2 + |L_n[n_b]|^2)
+ * U/P/N are the tables the scores gather from (the caller applies row offsets
+ * such as "+ n_users" to the base pointers), leading dimension ld;
+ * l2_* are the tables the L2 term gathers from (may equal the score tables;
+ * all three NULL skips the term and loss_out[1] = 0); w is NULL or [d].
+ * work: device scratch of 3*B floats; work[0..B) holds sigmoid(neg_b - pos_b)
+ * afterwards and must be passed unchanged to igcn_bpr_bwd_f32.
+ * The two sums are reduced in a fixed order (bitwise reproducible). */
+int igcn_bpr_fwd_f32(const float *u_tab, const float *p_tab, const float *n_tab, int64_t ld,
+                     const float *l2_u_tab, const float *l2_p_tab, const float *l2_n_tab, int64_t ld_l2,
+                     const int64_t *users, const int64_t *pos, const int64_t *neg,
+                     int64_t batch, int32_t d, const float *w,
+                     float *loss_out, float *work, void *stream);
+
+/* Backward of igcn_bpr_fwd_f32: accumulates (float atomic add, 256-byte row
+ * segments) row-sparse gradients into dense gradient tables laid out like the
+ * forward tables (same leading dimensions and base offsets).
+ *   g_out: DEVICE pointer to 2 floats, d total / d loss_out[0..1].
+ * gw_out [d] (NULL if w is NULL) accumulates d/dw.  Gradient tables for the L2
+ * term may be NULL when the l2 tables are NULL. */
+int igcn_bpr_bwd_f32(const float *u_tab, const float *p_tab, const float *n_tab, int64_t ld,
+                     const float *l2_u_tab, const float *l2_p_tab, const float *l2_n_tab, int64_t ld_l2,
+                     const int64_t *users, const int64_t *pos, const int64_t *neg,
+                     int64_t batch, int32_t d, const float *w, const float *work,
+                     const float *g_out,
+                     float *gu_tab, float *gp_tab, float *gn_tab,
+                     float *gl2_u_tab, float *gl2_p_tab, float *gl2_n_tab,
+                     float *gw_out, void *stream);
+
+/* Fused score + mask + top-k:  torch.mm at model.py:122 / :71, the -inf masking
+ * of trainer.py:149-161 and torch.topk at trainer.py:163, without ever
+ * materialising the [B, n_items] score matrix.
+ *   score[b,i] = <user_rows[user_ids[b]], item_rows[i]>   (exact fp32 MFMA chain)
+ *   masked (treated as -inf): items in excl_col[excl_rowptr[u]..excl_rowptr[u+1])
+ *   with u = user_ids[b] (sorted ascending per user), and items with
+ *   banned[i] != 0.
+ *   out_idx[b, 0..k) = the k best item ids, best first; ties -> lower id first;
+ *   out_val[b, 0..k) = their scores (-inf for masked fill-ins).
+ * user_ids int64 [B] or NULL (then row b of user_rows is user b);
+ * excl_rowptr int64 / excl_col int32 may be NULL; banned uint8 [n_items] or NULL.
+ * d <= 128, d % 4 == 0; k <= IGCN_MAX_TOPK and k <= n_items.
+ * workspace: igcn_score_topk_workspace_bytes(B, n_items, k) bytes (partial
+ * lists of the item-range splits that fill the chip when B is small). */
+int64_t igcn_score_topk_workspace_bytes(int64_t batch, int64_t n_items, int32_t k);
+int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
+                        const float *item_rows, int64_t ldi, int64_t n_items, int32_t d,
+                        const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned,
+                        int32_t k, int64_t *out_idx, float *out_val,
+                        void *workspace, void *stream);
+
+/* hit[u, j] = 1 if rec[u, j] is in eval_col[eval_rowptr[u]..eval_rowptr[u+1])
+ * (sorted ascending), else 0: the membership loop of trainer.py:111-115. */
+int igcn_hit_matrix(const int64_t *rec, int64_t n_users, int32_t k,
+                    const int64_t *eval_rowptr, const int32_t *eval_col,
+                    float *hit, void *stream);
+
+/* Device-side BPR negative sampler (dataset.py:119-131): for each of `batch`
+ * draws, a uniform user with a non-empty train list, a uniform positive from
+ * it, and a uniform negative item rejected while it is in the list.
+ * train_rowptr int64 / train_col int32 sorted per user; nonempty_users int32
+ * [n_nonempty]; out [batch, 3] int64 (user, pos, neg). */
+int igcn_bpr_sample(const int64_t *train_rowptr, const int32_t *train_col,
+                    const int32_t *nonempty_users, int64_t n_nonempty, int64_t n_items,
+                    int64_t batch, uint64_t seed, int64_t *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IGCN_HIP_H */

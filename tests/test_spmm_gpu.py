@@ -1,0 +1,183 @@
+"""HIP CSR SpMM (through the C ABI) against the CPU oracle.  Tolerance: 1e-4
+relative to the output's magnitude (BASELINE.json north_star), fp32."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def _random_csr(rng, n_rows, n_cols, degs):
+    degs = np.minimum(np.asarray(degs, dtype=np.int64), n_cols)
+    rowptr = np.zeros(n_rows + 1, dtype=np.int64)
+    np.cumsum(degs, out=rowptr[1:])
+    col = np.concatenate([np.sort(rng.choice(n_cols, size=int(k), replace=False)) for k in degs] + [np.zeros(0, dtype=np.int64)])
+    val = rng.standard_normal(col.shape[0]).astype(np.float32)
+    return rowptr, col.astype(np.int32), val
+
+
+def _oracle(rowptr, col, val, x, n_rows):
+    row = np.repeat(np.arange(n_rows, dtype=np.int64), np.diff(rowptr))
+    return O.spmm_coo_f64(row, col.astype(np.int64), val if val is not None else np.ones(col.shape[0], np.float32), x, n_rows)
+
+
+@pytest.mark.parametrize('d', [4, 8, 16, 32, 64, 128, 192, 256, 6, 63])
+def test_spmm_random_shapes(d):
+    from igcn_cf_amd.graph import CsrMatrix
+    from igcn_cf_amd.ops import spmm
+    rng = np.random.default_rng(d)
+    n_rows, n_cols = 517, 403
+    degs = rng.integers(0, 40, size=n_rows)
+    degs[:7] = [0, 1, 2, 63, 64, 65, 200]          # empty row, lengths around the 64-wide chunk
+    rowptr, col, val = _random_csr(rng, n_rows, n_cols, degs)
+    x = rng.standard_normal((n_cols, d)).astype(np.float32)
+    csr = CsrMatrix(rowptr, col, val, (n_rows, n_cols), 'cuda')
+    y = spmm(csr, torch.from_numpy(x).cuda()).cpu().numpy()
+    assert _rel_err(y, _oracle(rowptr, col, val, x, n_rows)) < TOL
+    assert np.all(y[0] == 0)                        # empty row writes zeros
+
+
+@pytest.mark.parametrize('d', [64, 128, 32])
+def test_spmm_long_rows_segments(d):
+    """Rows above the long-row threshold go through the segment + reduce path."""
+    from igcn_cf_amd.graph import CsrMatrix
+    from igcn_cf_amd.ops import spmm
+    rng = np.random.default_rng(7)
+    n_rows, n_cols = 300, 5000
+    degs = rng.integers(0, 30, size=n_rows)
+    degs[[3, 50, 299]] = [4999, 1025, 2048]
+    degs[10] = 1024                                  # exactly at the threshold: ordinary row
+    rowptr, col, val = _random_csr(rng, n_rows, n_cols, degs)
+    x = rng.standard_normal((n_cols, d)).astype(np.float32)
+    xt = torch.from_numpy(x).cuda()
+    csr = CsrMatrix(rowptr, col, val, (n_rows, n_cols), 'cuda')
+    assert csr.n_long == 3 and csr.n_segments == 10 + 3 + 4
+    ref = _oracle(rowptr, col, val, x, n_rows)
+    y = spmm(csr, xt).cpu().numpy()
+    assert _rel_err(y, ref) < TOL
+    # a different cut of the same rows gives the same result within rounding, and reruns are bitwise equal
+    csr2 = CsrMatrix(rowptr, col, val, (n_rows, n_cols), 'cuda', long_threshold=64, segment_len=64)
+    y2 = spmm(csr2, xt).cpu().numpy()
+    assert _rel_err(y2, ref) < TOL
+    assert np.array_equal(spmm(csr2, xt).cpu().numpy(), y2)
+
+
+def test_spmm_epilogue_and_scales():
+    from igcn_cf_amd.graph import CsrMatrix
+    from igcn_cf_amd.ops import spmm
+    rng = np.random.default_rng(3)
+    n, d = 700, 64
+    degs = rng.integers(0, 50, size=n)
+    degs[5] = 1500
+    rowptr, col, val = _random_csr(rng, n, n, degs)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    adds = [rng.standard_normal((n, d)).astype(np.float32) for _ in range(3)]
+    rs = rng.random(n).astype(np.float32) + 0.5
+    cs = rng.random(n).astype(np.float32) + 0.5
+    csr = CsrMatrix(rowptr, col, val, (n, n), 'cuda')
+    y = spmm(csr, torch.from_numpy(x).cuda(), adds=[torch.from_numpy(a).cuda() for a in adds], out_scale=0.25,
+             add_scale=0.5, row_scale=torch.from_numpy(rs).cuda(), col_scale=torch.from_numpy(cs).cuda()).cpu().numpy()
+    ref = (0.25 * _oracle(rowptr, col, val * cs[col], x, n) + 0.5 * sum(a.astype(np.float64) for a in adds)) * rs[:, None]
+    assert _rel_err(y, ref) < TOL
+    # val == NULL means all ones
+    csr1 = CsrMatrix(rowptr, col, None, (n, n), 'cuda')
+    y1 = spmm(csr1, torch.from_numpy(x).cuda()).cpu().numpy()
+    assert _rel_err(y1, _oracle(rowptr, col, None, x, n)) < TOL
+
+
+def test_spmm_rectangular_and_strided():
+    from igcn_cf_amd.graph import CsrMatrix
+    from igcn_cf_amd.ops import spmm
+    rng = np.random.default_rng(4)
+    n_rows, n_cols, d = 333, 1200, 64
+    rowptr, col, val = _random_csr(rng, n_rows, n_cols, rng.integers(0, 25, size=n_rows))
+    big = rng.standard_normal((n_cols + 10, 2 * d)).astype(np.float32)
+    xt = torch.from_numpy(big).cuda()[:, d:]          # leading dimension 2d, offset d
+    csr = CsrMatrix(rowptr, col, val, (n_rows, n_cols), 'cuda')
+    y = spmm(csr, xt).cpu().numpy()
+    assert _rel_err(y, _oracle(rowptr, col, val, big[:n_cols, d:], n_rows)) < TOL
+
+
+def test_spmm_dropout_statistics_and_transpose_consistency():
+    """Dropout as a per-edge mask from (seed, edge id): keep-rate ~ 1-p, kept values
+    scaled by 1/(1-p) (model.py:263-275), and M / M^T drop the same edges."""
+    from igcn_cf_amd.graph import CsrMatrix
+    from igcn_cf_amd.ops import spmm
+    rng = np.random.default_rng(5)
+    n_rows, n_cols, d = 2000, 1500, 4
+    rowptr, col, _ = _random_csr(rng, n_rows, n_cols, rng.integers(5, 60, size=n_rows))
+    nnz = col.shape[0]
+    p = 0.3
+    csr = CsrMatrix(rowptr, col, None, (n_rows, n_cols), 'cuda')
+    csr_t = CsrMatrix.transposed(rowptr, col, (n_rows, n_cols), 'cuda')
+    ones = torch.ones((n_cols, d), device='cuda')
+    y = spmm(csr, ones, keep_prob=1 - p, seed=1234).cpu().numpy()[:, 0]
+    kept = y * (1 - p)                                   # number of kept edges per row
+    assert np.allclose(kept, np.rint(kept), atol=1e-3)
+    rate = kept.sum() / nnz
+    assert abs(rate - (1 - p)) < 4 * np.sqrt(p * (1 - p) / nnz)
+    # different seed -> different mask; same seed -> identical
+    y2 = spmm(csr, ones, keep_prob=1 - p, seed=1235).cpu().numpy()[:, 0]
+    assert not np.array_equal(y, y2)
+    assert np.array_equal(y, spmm(csr, ones, keep_prob=1 - p, seed=1234).cpu().numpy()[:, 0])
+    # <M_d x, z> == <x, M_d^T z> with the same seed
+    x = torch.from_numpy(rng.standard_normal((n_cols, d)).astype(np.float32)).cuda()
+    z = torch.from_numpy(rng.standard_normal((n_rows, d)).astype(np.float32)).cuda()
+    lhs = (spmm(csr, x, keep_prob=1 - p, seed=99).double() * z.double()).sum().item()
+    rhs = (x.double() * spmm(csr_t, z, keep_prob=1 - p, seed=99).double()).sum().item()
+    assert abs(lhs - rhs) < 1e-4 * max(1., abs(lhs))
+
+
+def test_propagate_matches_oracle_on_golden_toys(golden):
+    from igcn_cf_amd.graph import CsrMatrix, normalized_adjacency_host
+    from igcn_cf_amd.ops import propagate_mean
+    nu, ni = int(golden['n_users']), int(golden['n_items'])
+    adj = O.lightgcn_norm_adj(golden['train_array'], nu, ni)
+    rowptr, col, val = normalized_adjacency_host(golden['train_array'], nu, ni)
+    np.testing.assert_array_equal(col, adj[1])
+    np.testing.assert_array_equal(val, adj[2])           # A_hat values bit-exact with the restated model.py:85-94
+    rng = np.random.default_rng(0)
+    for d in (64, 128):
+        emb = (rng.standard_normal((nu + ni, d)) * 0.1).astype(np.float32)
+        csr = CsrMatrix(rowptr, col, val, (nu + ni, nu + ni), 'cuda')
+        rep = propagate_mean(csr, torch.from_numpy(emb).cuda(), 3).cpu().numpy()
+        assert _rel_err(rep, O.lightgcn_get_rep(adj, emb, 3)) < TOL
+
+
+def test_propagate_backward_is_adjoint():
+    """Linearity + adjointness at full Amazon-book-like size (size-independent
+    properties): <P x, z> == <x, P^T z> for P = mean of powers of A_hat."""
+    from igcn_cf_amd.dataset import SyntheticDataset
+    from igcn_cf_amd.graph import CsrMatrix, normalized_adjacency_host
+    from igcn_cf_amd.ops import propagate_mean, propagate_mean_backward
+    ds = SyntheticDataset({'name': 'SyntheticDataset', 'preset': 'amazon'})
+    n = ds.n_users + ds.n_items
+    rowptr, col, val = normalized_adjacency_host(ds.train_array, ds.n_users, ds.n_items)
+    csr = CsrMatrix(rowptr, col, val, (n, n), 'cuda')
+    g = torch.Generator(device='cuda').manual_seed(1)
+    x = torch.randn(n, 64, device='cuda', generator=g) * 0.1
+    z = torch.randn(n, 64, device='cuda', generator=g)
+    px = propagate_mean(csr, x, 3)
+    ptz = propagate_mean_backward(csr, z, 3)
+    lhs, rhs = (px.double() * z.double()).sum().item(), (x.double() * ptz.double()).sum().item()
+    assert abs(lhs - rhs) < 1e-5 * max(1., abs(lhs))
+    # linearity
+    x2 = torch.randn(n, 64, device='cuda', generator=g) * 0.1
+    lin = propagate_mean(csr, 2 * x + x2, 3) - (2 * px + propagate_mean(csr, x2, 3))
+    assert lin.abs().max().item() < 1e-5
+    # against a float64 torch sparse chain on the device (independent arithmetic)
+    a = csr.to_torch_coo().double()
+    x64 = x.double()
+    l1 = torch.sparse.mm(a, x64); l2 = torch.sparse.mm(a, l1); l3 = torch.sparse.mm(a, l2)
+    ref = (x64 + l1 + l2 + l3) / 4
+    assert ((px.double() - ref).abs().max() / ref.abs().max()).item() < TOL
