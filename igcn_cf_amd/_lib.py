@@ -12,7 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libigcn_hip.so')
 
 MAX_ADDS = 8
-MAX_TOPK = 128
+MAX_TOPK = 64
 
 c_i64_p = C.POINTER(C.c_int64)
 vp = C.c_void_p
@@ -36,7 +36,7 @@ SIGNATURES = {
     'igcn_bpr_bwd_f32': (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, vp, C.c_int64, vp, vp, vp,
                                    C.c_int64, C.c_int32, vp, vp, vp,
                                    vp, vp, vp, vp, vp, vp, vp, vp]),
-    'igcn_score_topk_workspace_bytes': (C.c_int64, [C.c_int64, C.c_int64, C.c_int32]),
+    'igcn_score_topk_workspace_bytes': (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     'igcn_score_topk_f32': (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32,
                                       vp, vp, vp, C.c_int32, vp, vp, vp, vp]),
     'igcn_hit_matrix': (C.c_int, [vp, C.c_int64, C.c_int32, vp, vp, vp, vp]),

@@ -1,0 +1,155 @@
+// Fused BPR triplet scoring for MI355X (gfx950): gather + dot + softplus + L2,
+// forward and backward.  Replaces trainer.py:238-243 / :306-311 and the row
+// gathers + squared norms of model.py:110-116, :295-299, :62-67.
+//
+// This is 3*B row gathers of d floats (B = 2048, d = 64: 1.5 MB) — latency
+// bound, nowhere near a GEMM, so no MFMA: one wave per triplet, each row read
+// as one coalesced d*4-byte request, wave-level shuffles for the dots, a fixed
+// order second stage for the two batch means (bitwise reproducible), and in
+// the backward pass one 256-byte float-atomic row segment per gradient row
+// (the shape the memory-side atomic units run at full rate).
+#include "common.h"
+
+namespace igcn {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(kBlock) void bpr_fwd_kernel(
+    const float *__restrict__ u_tab, const float *__restrict__ p_tab, const float *__restrict__ n_tab, int64_t ld,
+    const float *__restrict__ l2u, const float *__restrict__ l2p, const float *__restrict__ l2n, int64_t ld2,
+    const int64_t *__restrict__ users, const int64_t *__restrict__ pos, const int64_t *__restrict__ neg,
+    int64_t batch, int d, const float *__restrict__ w, float *__restrict__ work)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t b = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (b >= batch) return;
+    const int64_t iu = users[b], ip = pos[b], in = neg[b];
+    float ps = 0.f, ns = 0.f, l2 = 0.f;
+    for (int j = lane; j < d; j += kWave) {
+        const float u = u_tab[iu * ld + j], p = p_tab[ip * ld + j], n = n_tab[in * ld + j];
+        const float uw = w ? u * w[j] : u;
+        ps = fmaf(uw, p, ps);
+        ns = fmaf(uw, n, ns);
+        if (l2u) {
+            const float a = l2u[iu * ld2 + j], c = l2p[ip * ld2 + j], e = l2n[in * ld2 + j];
+            l2 = fmaf(a, a, l2); l2 = fmaf(c, c, l2); l2 = fmaf(e, e, l2);
+        }
+    }
+    ps = wave_sum(ps); ns = wave_sum(ns); l2 = wave_sum(l2);
+    if (lane == 0) {
+        const float x = ns - ps;
+        // softplus(x), beta=1, threshold=20 (torch.nn.functional.softplus)
+        const float sp = x > 20.f ? x : log1pf(expf(x));
+        work[b] = 1.f / (1.f + expf(-x));
+        work[batch + b] = sp;
+        work[2 * batch + b] = l2;
+    }
+}
+
+// loss_out[0] = mean(work[B..2B)), loss_out[1] = mean(work[2B..3B)); one block, fixed order.
+__global__ __launch_bounds__(kBlock) void bpr_reduce_kernel(const float *__restrict__ work, int64_t batch,
+                                                            float *__restrict__ loss_out)
+{
+    __shared__ float sm[2][kBlock];
+    float a = 0.f, c = 0.f;
+    for (int64_t i = threadIdx.x; i < batch; i += kBlock) { a += work[batch + i]; c += work[2 * batch + i]; }
+    sm[0][threadIdx.x] = a; sm[1][threadIdx.x] = c;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { sm[0][threadIdx.x] += sm[0][threadIdx.x + s]; sm[1][threadIdx.x] += sm[1][threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { loss_out[0] = sm[0][0] / (float)batch; loss_out[1] = sm[1][0] / (float)batch; }
+}
+
+__global__ __launch_bounds__(kBlock) void bpr_bwd_kernel(
+    const float *__restrict__ u_tab, const float *__restrict__ p_tab, const float *__restrict__ n_tab, int64_t ld,
+    const float *__restrict__ l2u, const float *__restrict__ l2p, const float *__restrict__ l2n, int64_t ld2,
+    const int64_t *__restrict__ users, const int64_t *__restrict__ pos, const int64_t *__restrict__ neg,
+    int64_t batch, int d, const float *__restrict__ w, const float *__restrict__ work, const float *__restrict__ g_out,
+    float *__restrict__ gu, float *__restrict__ gp, float *__restrict__ gn,
+    float *__restrict__ g2u, float *__restrict__ g2p, float *__restrict__ g2n, float *__restrict__ gw)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t b = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (b >= batch) return;
+    const int64_t iu = users[b], ip = pos[b], in = neg[b];
+    const float inv_b = 1.f / (float)batch;
+    const float c = g_out[0] * work[b] * inv_b;       // d loss / d (neg_b - pos_b)
+    const float c2 = 2.f * g_out[1] * inv_b;
+    for (int j = lane; j < d; j += kWave) {
+        const float u = u_tab[iu * ld + j], p = p_tab[ip * ld + j], n = n_tab[in * ld + j];
+        const float wj = w ? w[j] : 1.f;
+        atomicAdd(gu + iu * ld + j, c * (n - p) * wj);
+        atomicAdd(gp + ip * ld + j, -c * u * wj);
+        atomicAdd(gn + in * ld + j, c * u * wj);
+        if (gw) atomicAdd(gw + j, c * u * (n - p));
+        if (l2u && g2u) {
+            atomicAdd(g2u + iu * ld2 + j, c2 * l2u[iu * ld2 + j]);
+            atomicAdd(g2p + ip * ld2 + j, c2 * l2p[ip * ld2 + j]);
+            atomicAdd(g2n + in * ld2 + j, c2 * l2n[in * ld2 + j]);
+        }
+    }
+}
+
+}  // namespace igcn
+
+using namespace igcn;
+
+static int bpr_check(const float *u, const float *p, const float *n, int64_t ld,
+                     const float *a, const float *b, const float *c, int64_t ld2,
+                     const int64_t *users, const int64_t *pos, const int64_t *neg, int64_t batch, int32_t d)
+{
+    if (!u || !p || !n || !users || !pos || !neg) return IGCN_E_NULL;
+    const int n_l2 = (a != nullptr) + (b != nullptr) + (c != nullptr);
+    if (n_l2 != 0 && n_l2 != 3) return IGCN_E_NULL;
+    if (batch < 0 || d < 1 || ld < d || (n_l2 == 3 && ld2 < d)) return IGCN_E_SHAPE;
+    return IGCN_OK;
+}
+
+extern "C" int igcn_bpr_fwd_f32(const float *u_tab, const float *p_tab, const float *n_tab, int64_t ld,
+                                const float *l2_u_tab, const float *l2_p_tab, const float *l2_n_tab, int64_t ld_l2,
+                                const int64_t *users, const int64_t *pos, const int64_t *neg,
+                                int64_t batch, int32_t d, const float *w,
+                                float *loss_out, float *work, void *stream)
+{
+    int rc = bpr_check(u_tab, p_tab, n_tab, ld, l2_u_tab, l2_p_tab, l2_n_tab, ld_l2, users, pos, neg, batch, d);
+    if (rc != IGCN_OK) return rc;
+    if (!loss_out || !work) return IGCN_E_NULL;
+    if (batch == 0) return IGCN_E_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t blocks = (batch + 3) / 4;
+    hipLaunchKernelGGL(bpr_fwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, u_tab, p_tab, n_tab, ld,
+                       l2_u_tab, l2_p_tab, l2_n_tab, ld_l2, users, pos, neg, batch, (int)d, w, work);
+    rc = launch_status();
+    if (rc != IGCN_OK) return rc;
+    hipLaunchKernelGGL(bpr_reduce_kernel, dim3(1), dim3(kBlock), 0, st, work, batch, loss_out);
+    return launch_status();
+}
+
+extern "C" int igcn_bpr_bwd_f32(const float *u_tab, const float *p_tab, const float *n_tab, int64_t ld,
+                                const float *l2_u_tab, const float *l2_p_tab, const float *l2_n_tab, int64_t ld_l2,
+                                const int64_t *users, const int64_t *pos, const int64_t *neg,
+                                int64_t batch, int32_t d, const float *w, const float *work, const float *g_out,
+                                float *gu_tab, float *gp_tab, float *gn_tab,
+                                float *gl2_u_tab, float *gl2_p_tab, float *gl2_n_tab,
+                                float *gw_out, void *stream)
+{
+    int rc = bpr_check(u_tab, p_tab, n_tab, ld, l2_u_tab, l2_p_tab, l2_n_tab, ld_l2, users, pos, neg, batch, d);
+    if (rc != IGCN_OK) return rc;
+    if (!work || !g_out || !gu_tab || !gp_tab || !gn_tab) return IGCN_E_NULL;
+    const int n_g2 = (gl2_u_tab != nullptr) + (gl2_p_tab != nullptr) + (gl2_n_tab != nullptr);
+    if (n_g2 != 0 && n_g2 != 3) return IGCN_E_NULL;
+    if (n_g2 == 3 && !l2_u_tab) return IGCN_E_NULL;
+    if (gw_out && !w) return IGCN_E_NULL;
+    if (batch == 0) return IGCN_E_SHAPE;
+    const int64_t blocks = (batch + 3) / 4;
+    hipLaunchKernelGGL(bpr_bwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       u_tab, p_tab, n_tab, ld, l2_u_tab, l2_p_tab, l2_n_tab, ld_l2, users, pos, neg, batch, (int)d, w,
+                       work, g_out, gu_tab, gp_tab, gn_tab, gl2_u_tab, gl2_p_tab, gl2_n_tab, gw_out);
+    return launch_status();
+}

@@ -1,0 +1,180 @@
+"""Row-sharded propagation across the GPUs of one node (one process per GPU,
+torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).
+
+Not in the reference (single process, single device — SURVEY.md section 2.1); this is
+the scheme BASELINE.json's north_star asks for at Amazon-book scale and above:
+
+* the user set and the item set are each cut into P equal contiguous blocks
+  (padded); rank r owns user block r and item block r: those rows of A_hat as
+  local CSR (global, padded column ids), of the embeddings and of the outputs;
+* every layer input X_l is replicated (the all-gather target); a rank computes
+  its own rows of X_{l+1} straight into its slot of the next replicated buffer
+  and the slots are exchanged with an in-place all-gather;
+* the graph is bipartite: user rows read only item embeddings and vice versa.
+  Each layer is therefore two half-steps, and the order of the halves alternates
+  from layer to layer (users,items / items,users / ...), so that every
+  all-gather runs under the SpMM of the other half — no half-step ever waits
+  for a collective that was issued immediately before it;
+* the layer mean is the epilogue of the last local SpMM, on owned rows only.
+
+`spmm_fn` is the local product; the product path uses the HIP kernel
+(ops.spmm).  The CPU tests inject a checker implementation to exercise the
+partitioning / exchange logic under gloo with world_size 2.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .graph import normalized_adjacency_host
+
+
+def block_size(n, world):
+    return (n + world - 1) // world
+
+
+class ShardLayout:
+    """Padded global layout [P*bu user rows ; P*bi item rows]."""
+
+    def __init__(self, n_users, n_items, world):
+        self.n_users, self.n_items, self.world = n_users, n_items, world
+        self.bu, self.bi = block_size(n_users, world), block_size(n_items, world)
+        self.pu, self.pi = self.bu * world, self.bi * world          # padded section sizes
+        self.n_pad = self.pu + self.pi
+
+    def pad_index(self, node):
+        """global node id (users first, then items) -> row in the padded layout."""
+        node = np.asarray(node, dtype=np.int64)
+        return np.where(node < self.n_users, node, node - self.n_users + self.pu)
+
+    def user_rows(self, rank):
+        lo = rank * self.bu
+        return lo, min(lo + self.bu, self.n_users)
+
+    def item_rows(self, rank):
+        lo = rank * self.bi
+        return lo, min(lo + self.bi, self.n_items)
+
+
+def local_blocks_host(rowptr, col, val, layout, rank):
+    """Rows of the global CSR owned by `rank`, as two CSR blocks (user rows,
+    item rows) of exactly bu / bi rows (padding rows empty), padded column ids."""
+    out = []
+    for (lo, hi), nb, base in ((layout.user_rows(rank), layout.bu, 0),
+                               (layout.item_rows(rank), layout.bi, layout.n_users)):
+        s, e = rowptr[base + lo], rowptr[base + max(hi, lo)]
+        rp = np.full(nb + 1, e - s, dtype=np.int64)
+        rp[:max(hi - lo, 0) + 1] = rowptr[base + lo: base + max(hi, lo) + 1] - s
+        out.append((rp, layout.pad_index(col[s:e]).astype(np.int32), val[s:e].copy()))
+    return out
+
+
+class RowShardedPropagator:
+    def __init__(self, train_array, n_users, n_items, n_layers, rank, world, device, group=None,
+                 spmm_fn=None, csr_factory=None, adjacency=None):
+        self.layout = ShardLayout(n_users, n_items, world)
+        self.n_layers, self.rank, self.world, self.group = n_layers, rank, world, group
+        self.device = torch.device(device)
+        if spmm_fn is None:
+            from . import ops
+            spmm_fn = ops.spmm
+        if csr_factory is None:
+            from .graph import CsrMatrix
+            csr_factory = lambda rp, c, v, shape: CsrMatrix(rp, c, v, shape, self.device)
+        self.spmm = spmm_fn
+        rowptr, col, val = adjacency if adjacency is not None else normalized_adjacency_host(train_array, n_users, n_items)
+        (urp, ucol, uval), (irp, icol, ival) = local_blocks_host(rowptr, col, val, self.layout, rank)
+        L = self.layout
+        self.local_nnz = int(urp[-1] + irp[-1])
+        self.global_nnz = int(rowptr[-1])
+        self.csr_u = csr_factory(urp, ucol, uval, (L.bu, L.n_pad))
+        self.csr_i = csr_factory(irp, icol, ival, (L.bi, L.n_pad))
+        self._bufs = None
+
+    # ---- buffers -----------------------------------------------------------------
+    def _buffers(self, d):
+        if self._bufs is None or self._bufs[0].shape[1] != d:
+            L = self.layout
+            self._bufs = [torch.zeros((L.n_pad, d), dtype=torch.float32, device=self.device)
+                          for _ in range(max(self.n_layers, 1))]
+            self._rep_u = torch.empty((L.bu, d), dtype=torch.float32, device=self.device)
+            self._rep_i = torch.empty((L.bi, d), dtype=torch.float32, device=self.device)
+        return self._bufs
+
+    def _slot(self, buf, part):
+        L = self.layout
+        if part == 'u':
+            return buf[self.rank * L.bu:(self.rank + 1) * L.bu]
+        return buf[L.pu + self.rank * L.bi: L.pu + (self.rank + 1) * L.bi]
+
+    def _section(self, buf, part):
+        L = self.layout
+        return buf[:L.pu] if part == 'u' else buf[L.pu:]
+
+    def _allgather(self, buf, part):
+        if self.world == 1:
+            return None
+        return dist.all_gather_into_tensor(self._section(buf, part), self._slot(buf, part), group=self.group,
+                                           async_op=True)
+
+    def load_local_embedding(self, emb_u_local, emb_i_local):
+        """Owned rows of the layer-0 embeddings -> slot of X_0, then exchange X_0."""
+        d = emb_u_local.shape[1]
+        x0 = self._buffers(d)[0]
+        su, si = self._slot(x0, 'u'), self._slot(x0, 'i')
+        su.zero_(); si.zero_()
+        su[:emb_u_local.shape[0]].copy_(emb_u_local)
+        si[:emb_i_local.shape[0]].copy_(emb_i_local)
+        for w in (self._allgather(x0, 'u'), self._allgather(x0, 'i')):
+            if w is not None:
+                w.wait()
+        return x0
+
+    # ---- the sharded K-layer pass -------------------------------------------------
+    def propagate(self, x0=None):
+        """mean(X_0..X_K) on the owned rows: (rep_users [bu, d], rep_items [bi, d]).
+        `x0`: replicated padded layer-0 buffer (default: the one filled by
+        load_local_embedding)."""
+        bufs = self._buffers(x0.shape[1] if x0 is not None else self._bufs[0].shape[1])
+        if x0 is not None and x0.data_ptr() != bufs[0].data_ptr():
+            bufs[0].copy_(x0)
+        K = self.n_layers
+        s = 1.0 / (K + 1)
+        if K == 0:
+            return self._slot(bufs[0], 'u').clone(), self._slot(bufs[0], 'i').clone()
+        pending = {}                                     # (layer, part) -> in-flight all-gather
+        csr = {'u': self.csr_u, 'i': self.csr_i}
+        rep = {'u': self._rep_u, 'i': self._rep_i}
+        for l in range(K):
+            last = l == K - 1
+            src = bufs[l]
+            order = ('u', 'i') if l % 2 == 0 else ('i', 'u')
+            for part in order:
+                other = 'i' if part == 'u' else 'u'
+                w = pending.pop((l, other), None)        # this half reads X_l[other], replicated
+                if w is not None:
+                    w.wait()
+                if last:
+                    adds = [self._slot(bufs[j], part) for j in range(K)]
+                    self.spmm(csr[part], src, out=rep[part], adds=adds, out_scale=s, add_scale=s)
+                else:
+                    dst = bufs[l + 1]
+                    self.spmm(csr[part], src, out=self._slot(dst, part))
+                    pending[(l + 1, part)] = self._allgather(dst, part)
+        for w in pending.values():                        # nothing should be left; be safe
+            if w is not None:
+                w.wait()
+        return rep['u'], rep['i']
+
+    def gather_full_rep(self, rep_u, rep_i):
+        """Replicated [n_users + n_items, d] from the owned blocks (used once per
+        evaluation: scoring shards by user and needs every item row)."""
+        L = self.layout
+        d = rep_u.shape[1]
+        full_u = torch.empty((L.pu, d), dtype=torch.float32, device=self.device)
+        full_i = torch.empty((L.pi, d), dtype=torch.float32, device=self.device)
+        if self.world == 1:
+            full_u.copy_(rep_u); full_i.copy_(rep_i)
+        else:
+            dist.all_gather_into_tensor(full_u, rep_u.contiguous(), group=self.group)
+            dist.all_gather_into_tensor(full_i, rep_i.contiguous(), group=self.group)
+        return torch.cat([full_u[:L.n_users], full_i[:L.n_items]], dim=0)

@@ -122,6 +122,28 @@ def feature_matrix_host(train_array, n_users, n_items, user_map=None, item_map=N
     return rowptr, col, row_sum, shape
 
 
+def graph_rank_nodes(dataset, ranking_metric):
+    """Template ranking for feature_ratio < 1 (utils.py:94-123): 'degree' = row sums
+    of A, 'sort' / 'greedy' = column sums of the row-L1-normalised A.  Returns
+    (ranked_users, ranked_items), best first, as the reference's argsort()[::-1]."""
+    n_users, n_items = dataset.n_users, dataset.n_items
+    rowptr, col, val = adjacency_host(dataset.train_array, n_users, n_items)
+    n = n_users + n_items
+    row = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr))
+    if ranking_metric == 'degree':
+        metric = np.zeros(n, dtype=np.float32)
+        np.add.at(metric, row, val)
+    elif ranking_metric in ('sort', 'greedy'):
+        rs = np.zeros(n, dtype=np.float32)
+        np.add.at(rs, row, np.abs(val))
+        rs[rs == 0] = 1.
+        metric = np.zeros(n, dtype=np.float32)
+        np.add.at(metric, col, (val / rs[row]).astype(np.float32))
+    else:
+        raise ValueError("ranking_metric %r not supported (use 'degree' or 'sort')" % (ranking_metric,))
+    return np.argsort(metric[:n_users])[::-1].copy(), np.argsort(metric[n_users:])[::-1].copy()
+
+
 class CsrMatrix:
     """A CSR matrix resident in HBM with the SpMM long-row schedule.
 
@@ -129,7 +151,7 @@ class CsrMatrix:
     ones), edge_id int32 [nnz] or None."""
 
     def __init__(self, rowptr, col, val, shape, device, edge_id=None,
-                 long_threshold=LONG_THRESHOLD, segment_len=SEGMENT_LEN):
+                 long_threshold=LONG_THRESHOLD, segment_len=SEGMENT_LEN, keep_host=False):
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
         col = np.ascontiguousarray(col, dtype=np.int32)
         self.shape = (int(shape[0]), int(shape[1]))
@@ -149,6 +171,17 @@ class CsrMatrix:
         self.segment_len = int(segment_len)
         self._build_plan()
         self._partial = {}
+        self._col_host = col if keep_host else None
+        self._transposed = None
+
+    def transposed_view(self):
+        """CSR of M^T (values all ones) sharing edge ids with M; built on first use."""
+        if self._transposed is None:
+            col = self._col_host if self._col_host is not None else self.col.cpu().numpy()
+            self._transposed = CsrMatrix.transposed(self.rowptr_host, col, self.shape, self.device,
+                                                    long_threshold=self.long_threshold, segment_len=self.segment_len)
+            self._col_host = None
+        return self._transposed
 
     def _build_plan(self):
         L = _lib.lib()

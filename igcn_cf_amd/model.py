@@ -1,0 +1,308 @@
+"""MF / LightGCN / IGCN (INMO-LightGCN) / IMF (INMO-MF) on the HIP kernels.
+
+Host-side mirror of the reference's model contract (model.py:16-21 get_model,
+:31-49 BasicModel, :52-72 MF, :75-123 LightGCN, :354-466 IGCN, :536-543 IMF):
+same class names, constructor config keys, attributes, method names, argument
+meaning and checkpoint keys, so the reference's run scripts and trainers read
+the same against this package.  What differs is what runs underneath:
+
+* the normalised adjacency / template feature matrix are CSR in HBM
+  (graph.CsrMatrix) built once, not a COO tensor turned into a DGL graph on
+  every call (model.py:99-100, :428-429, :439-440);
+* get_rep() is K launches of the hand-written SpMM with the layer mean fused
+  into the last one; in eval mode the result is cached until the parameters or
+  the graph change (the reference recomputes it for every 512-user batch,
+  model.py:119 — identical results, dropout is off in eval, model.py:264-265);
+* bpr_loss_terms() / recommend() are the fused kernels the trainers use;
+  bpr_forward() / predict() keep the reference's signatures for callers that
+  want gathered rows or a dense score block.
+
+Baseline models outside the hot path (NGCF, IDCF, IMCGAE, MultiVAE, NeuMF,
+ItemKNN, Popularity) are out of scope.
+"""
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.init import normal_
+
+from . import _lib, ops
+from .graph import (CsrMatrix, feature_matrix_host, graph_rank_nodes, normalized_adjacency_host)
+
+
+def get_model(config, dataset):
+    """Factory by class name (model.py:16-21)."""
+    config = config.copy()
+    config['dataset'] = dataset
+    cls = getattr(sys.modules[__name__], config['name'])
+    return cls(config)
+
+
+class BasicModel(nn.Module):
+    def __init__(self, model_config):
+        super().__init__()
+        self.config = model_config
+        self.name = model_config['name']
+        self.device = torch.device(model_config['device'])
+        if self.device.type != 'cuda':
+            raise _lib.IgcnError('%s runs on the MI355X HIP kernels only; device must be cuda' % self.name)
+        self.n_users = model_config['dataset'].n_users
+        self.n_items = model_config['dataset'].n_items
+        self.trainable = True
+        self._rep_cache = None
+
+    def predict(self, users):
+        raise NotImplementedError
+
+    def save(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load(self, path):
+        self.load_state_dict(torch.load(path, map_location=self.device))
+
+    # ---- fused entry points used by the trainers -------------------------------
+    def score_tables(self):
+        """(user_rows [>=n_users, d], item_rows [n_items, d]) for scoring."""
+        rep = self.get_rep()
+        return rep, rep[self.n_users:]
+
+    def recommend(self, users, k, excl_rowptr=None, excl_col=None, banned=None):
+        """Top-k item ids per user (best first), masked by the exclusion CSR and the
+        banned mask: predict -> mask -> topk of trainer.py:147-163, fused."""
+        user_rows, item_rows = self.score_tables()
+        idx, _ = ops.score_topk(user_rows, item_rows, k, user_ids=users.contiguous(), excl_rowptr=excl_rowptr,
+                                excl_col=excl_col, banned=banned)
+        return idx
+
+    def _cached_rep(self, key, compute):
+        if self.training or torch.is_grad_enabled():
+            return compute()
+        if self._rep_cache is None or self._rep_cache[0] != key:
+            self._rep_cache = (key, compute())
+        return self._rep_cache[1]
+
+
+class MF(BasicModel):
+    """model.py:52-72."""
+
+    def __init__(self, model_config):
+        super().__init__(model_config)
+        self.embedding_size = model_config['embedding_size']
+        self.user_embedding = nn.Embedding(self.n_users, self.embedding_size)
+        self.item_embedding = nn.Embedding(self.n_items, self.embedding_size)
+        normal_(self.user_embedding.weight, std=0.1)
+        normal_(self.item_embedding.weight, std=0.1)
+        self.to(device=self.device)
+
+    def bpr_forward(self, users, pos_items, neg_items):
+        users_e = self.user_embedding(users)
+        pos_items_e, neg_items_e = self.item_embedding(pos_items), self.item_embedding(neg_items)
+        l2_norm_sq = torch.norm(users_e, p=2, dim=1) ** 2 + torch.norm(pos_items_e, p=2, dim=1) ** 2 \
+            + torch.norm(neg_items_e, p=2, dim=1) ** 2
+        return users_e, pos_items_e, neg_items_e, l2_norm_sq
+
+    def bpr_loss_terms(self, users, pos_items, neg_items):
+        u, i = self.user_embedding.weight, self.item_embedding.weight
+        return ops.bpr_loss_terms(u, i, u, i, None, users, pos_items, neg_items)
+
+    def score_tables(self):
+        return self.user_embedding.weight.detach(), self.item_embedding.weight.detach()
+
+    def predict(self, users):
+        user_e = self.user_embedding(users)
+        return torch.mm(user_e, self.item_embedding.weight.t())
+
+
+class LightGCN(BasicModel):
+    """model.py:75-123."""
+
+    def __init__(self, model_config):
+        super().__init__(model_config)
+        self.embedding_size = model_config['embedding_size']
+        self.n_layers = model_config['n_layers']
+        self.embedding = nn.Embedding(self.n_users + self.n_items, self.embedding_size)
+        self.norm_adj = self.generate_graph(model_config['dataset'])
+        normal_(self.embedding.weight, std=0.1)
+        self.to(device=self.device)
+
+    def generate_graph(self, dataset):
+        """A_hat = D^-1/2 A D^-1/2 as device CSR (model.py:85-94)."""
+        n = dataset.n_users + dataset.n_items
+        rowptr, col, val = normalized_adjacency_host(dataset.train_array, dataset.n_users, dataset.n_items)
+        return CsrMatrix(rowptr, col, val, (n, n), self.device)
+
+    def get_rep(self):
+        w = self.embedding.weight
+        key = (w._version, id(self.norm_adj), w.data_ptr())
+        # A_hat is symmetric, so the same CSR serves the backward pass
+        return self._cached_rep(key, lambda: ops.PropagateFn.apply(w, self.norm_adj, self.norm_adj, self.n_layers))
+
+    def bpr_forward(self, users, pos_items, neg_items):
+        rep = self.get_rep()
+        users_e = self.embedding(users)
+        pos_items_e, neg_items_e = self.embedding(self.n_users + pos_items), self.embedding(self.n_users + neg_items)
+        l2_norm_sq = torch.norm(users_e, p=2, dim=1) ** 2 + torch.norm(pos_items_e, p=2, dim=1) ** 2 \
+            + torch.norm(neg_items_e, p=2, dim=1) ** 2
+        users_r = rep[users, :]
+        pos_items_r, neg_items_r = rep[self.n_users + pos_items, :], rep[self.n_users + neg_items, :]
+        return users_r, pos_items_r, neg_items_r, l2_norm_sq
+
+    def bpr_loss_terms(self, users, pos_items, neg_items):
+        rep, e = self.get_rep(), self.embedding.weight
+        return ops.bpr_loss_terms(rep, rep, e, e, None, users, pos_items, neg_items, self.n_users, self.n_users)
+
+    def predict(self, users):
+        rep = self.get_rep()
+        return torch.mm(rep[users, :], rep[self.n_users:, :].t())
+
+
+class IGCN(BasicModel):
+    """INMO-LightGCN, model.py:354-466."""
+
+    def __init__(self, model_config):
+        super().__init__(model_config)
+        self.embedding_size = model_config['embedding_size']
+        self.n_layers = model_config['n_layers']
+        self.dropout = model_config['dropout']
+        self.feature_ratio = model_config['feature_ratio']
+        self.norm_adj = self.generate_graph(model_config['dataset'])
+        self.alpha = 1.
+        self.delta = model_config.get('delta', 0.99)
+        self.feat_mat, self.user_map, self.item_map, self.row_sum = \
+            self.generate_feat(model_config['dataset'], ranking_metric=model_config.get('ranking_metric', 'sort'))
+        self.update_feat_mat()
+
+        self.embedding = nn.Embedding(self.feat_mat.shape[1], self.embedding_size)
+        self.w = nn.Parameter(torch.ones([self.embedding_size], dtype=torch.float32, device=self.device))
+        normal_(self.embedding.weight, std=0.1)
+        self.to(device=self.device)
+        self._drop_calls = 0
+
+    # feat_mat may be re-assigned on a live model (run/dropui/igcn_dropui.py:28-32)
+    @property
+    def feat_mat(self):
+        return self._feat_mat
+
+    @feat_mat.setter
+    def feat_mat(self, value):
+        self._feat_mat = value
+        self._feat_scale = None
+        self._rep_cache = None
+
+    def update_feat_mat(self):
+        """Edge value = row_sum[row]^((alpha-1)/2 - 0.5) (model.py:374-377), kept as
+        one scale per ROW — the kernel applies it in its epilogue, the matrix
+        structure is never rebuilt."""
+        n_rows = self.feat_mat.shape[0]
+        scale = torch.empty(n_rows, dtype=torch.float32, device=self.device)
+        expo = (self.alpha - 1.) / 2. - 0.5
+        _lib.check(_lib.lib().igcn_csr_row_pow_f32(self.feat_mat.rowptr.data_ptr(), self.row_sum.data_ptr(), expo,
+                                                   None, scale.data_ptr(), n_rows, _lib.current_stream()),
+                   'igcn_csr_row_pow_f32')
+        self._feat_scale = scale
+        self._rep_cache = None
+
+    def feat_mat_anneal(self):
+        self.alpha *= self.delta
+        self.update_feat_mat()
+
+    def feat_values(self):
+        """Explicit per-edge values of the feature matrix (what the reference stores)."""
+        val = torch.empty(self.feat_mat.nnz, dtype=torch.float32, device=self.device)
+        expo = (self.alpha - 1.) / 2. - 0.5
+        _lib.check(_lib.lib().igcn_csr_row_pow_f32(self.feat_mat.rowptr.data_ptr(), self.row_sum.data_ptr(), expo,
+                                                   val.data_ptr(), None, self.feat_mat.shape[0],
+                                                   _lib.current_stream()), 'igcn_csr_row_pow_f32')
+        return val
+
+    def generate_graph(self, dataset):
+        return LightGCN.generate_graph(self, dataset)
+
+    def generate_feat(self, dataset, is_updating=False, ranking_metric=None):
+        """Template feature matrix (model.py:386-421); returns
+        (feat CsrMatrix, user_map, item_map, row_sum tensor)."""
+        if not is_updating:
+            if self.feature_ratio < 1.:
+                ranked_users, ranked_items = graph_rank_nodes(dataset, ranking_metric)
+                core_users = ranked_users[:int(self.n_users * self.feature_ratio)]
+                core_items = ranked_items[:int(self.n_items * self.feature_ratio)]
+            else:
+                core_users = np.arange(self.n_users, dtype=np.int64)
+                core_items = np.arange(self.n_items, dtype=np.int64)
+            user_map = {int(u): idx for idx, u in enumerate(core_users)}
+            item_map = {int(i): idx for idx, i in enumerate(core_items)}
+        else:
+            user_map, item_map = self.user_map, self.item_map
+        rowptr, col, row_sum, shape = feature_matrix_host(dataset.train_array, self.n_users, self.n_items,
+                                                          user_map, item_map)
+        feat = CsrMatrix(rowptr, col, None, shape, self.device, keep_host=True)
+        return feat, user_map, item_map, torch.from_numpy(row_sum).to(self.device)
+
+    def inductive_rep_layer(self, feat_mat, keep_prob=1., seed=0):
+        """X0 = dropout(F) @ T (model.py:423-432; no padding tensor is needed)."""
+        if self._feat_scale is None:
+            self.update_feat_mat()
+        return ops.FeatureLayerFn.apply(self.embedding.weight, feat_mat, feat_mat.transposed_view(),
+                                        self._feat_scale, keep_prob, seed)
+
+    def _dropout_args(self):
+        """NGCF.dropout_sp_mat (model.py:263-275): train mode only; the mask is a
+        hash of (seed, edge id) drawn per call from torch's CPU generator."""
+        if not self.training or self.dropout <= 0.:
+            return 1., 0
+        return 1. - self.dropout, int(torch.randint(0, 2 ** 62, (1,)).item())
+
+    def _compute_rep(self):
+        keep_prob, seed = self._dropout_args()
+        x0 = self.inductive_rep_layer(self.feat_mat, keep_prob, seed)
+        return ops.PropagateFn.apply(x0, self.norm_adj, self.norm_adj, self.n_layers)
+
+    def get_rep(self):
+        w = self.embedding.weight
+        key = (w._version, id(self.norm_adj), id(self.feat_mat), id(self._feat_scale), w.data_ptr())
+        return self._cached_rep(key, self._compute_rep)
+
+    def bpr_forward(self, users, pos_items, neg_items):
+        rep = self.get_rep()
+        users_r = rep[users, :]
+        pos_items_r, neg_items_r = rep[self.n_users + pos_items, :], rep[self.n_users + neg_items, :]
+        l2_norm_sq = torch.norm(users_r, p=2, dim=1) ** 2 + torch.norm(pos_items_r, p=2, dim=1) ** 2 \
+            + torch.norm(neg_items_r, p=2, dim=1) ** 2
+        return users_r, pos_items_r, neg_items_r, l2_norm_sq
+
+    def bpr_loss_terms(self, users, pos_items, neg_items):
+        rep = self.get_rep()
+        return ops.bpr_loss_terms(rep, rep, rep, rep, None, users, pos_items, neg_items, self.n_users, self.n_users)
+
+    def aux_loss(self, users, pos_items, neg_items):
+        """Self-enhanced auxiliary BPR loss on the raw template rows, weighted by w
+        (trainer.py:304-311)."""
+        e = self.embedding.weight
+        off = len(self.user_map)
+        return ops.bpr_loss_terms(e, e, None, None, self.w, users, pos_items, neg_items, off, 0)[0]
+
+    def predict(self, users):
+        return LightGCN.predict(self, users)
+
+    def save(self, path):
+        params = {'sate_dict': self.state_dict(), 'user_map': self.user_map,
+                  'item_map': self.item_map, 'alpha': self.alpha}
+        torch.save(params, path)
+
+    def load(self, path):
+        params = torch.load(path, map_location=self.device, weights_only=False)
+        self.load_state_dict(params['sate_dict'])
+        self.user_map = params['user_map']
+        self.item_map = params['item_map']
+        self.alpha = params['alpha']
+        self.feat_mat, _, _, self.row_sum = self.generate_feat(self.config['dataset'], is_updating=True)
+        self.update_feat_mat()
+
+
+class IMF(IGCN):
+    """INMO-MF, model.py:536-543: the template layer without propagation."""
+
+    def _compute_rep(self):
+        keep_prob, seed = self._dropout_args()
+        return self.inductive_rep_layer(self.feat_mat, keep_prob, seed)

@@ -121,3 +121,154 @@ class FeatureLayerFn(torch.autograd.Function):
     def backward(ctx, grad):
         return spmm(ctx.feat_t, grad.contiguous(), col_scale=ctx.row_scale, keep_prob=ctx.keep_prob,
                     seed=ctx.seed), None, None, None, None, None
+
+
+def _require_i64(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
+        raise _lib.IgcnError('%s must be a contiguous int64 tensor on the GPU' % name)
+
+
+def _row_view(t, offset):
+    """Base pointer of table `t` shifted by `offset` rows (e.g. '+ n_users')."""
+    return t.data_ptr() + offset * t.stride(0) * 4
+
+
+class BprLossFn(torch.autograd.Function):
+    """Fused BPR triplet scoring (igcn_bpr_fwd_f32 / igcn_bpr_bwd_f32).
+
+    forward(u_tab, p_tab, l2u_tab | None, l2p_tab | None, w | None, users, pos, neg,
+            item_offset, l2_item_offset) -> tensor [2] = (mean softplus(neg - pos), mean l2_norm_sq)
+
+    u_tab / p_tab: tables the user / item rows of the scores are gathered from;
+    the same tensor may be passed for both (stacked [users; items] layout of
+    LightGCN / IGCN, model.py:110-115, :295-298) with item_offset = n_users
+    (len(user_map) for the auxiliary loss, trainer.py:306-308).  l2 tables: where
+    the squared-norm term gathers from (raw embeddings for LightGCN / MF,
+    propagated rows for IGCN).  A tensor passed several times gets ONE dense
+    gradient buffer.
+    """
+
+    @staticmethod
+    def forward(ctx, u_tab, p_tab, l2u_tab, l2p_tab, w, users, pos, neg, item_offset, l2_item_offset):
+        has_l2 = l2u_tab is not None
+        tabs = [u_tab, p_tab] + ([l2u_tab, l2p_tab] if has_l2 else [])
+        for t in tabs:
+            _require_gpu_f32(t, 'table')
+            if not t.is_contiguous():
+                raise _lib.IgcnError('BPR tables must be contiguous')
+        for t, n in ((users, 'users'), (pos, 'pos_items'), (neg, 'neg_items')):
+            _require_i64(t, n)
+        d = u_tab.shape[1]
+        if any(t.shape[1] != d for t in tabs) or (w is not None and w.numel() != d):
+            raise _lib.IgcnError('BPR tables / w differ in width')
+        B = users.numel()
+        out = torch.empty(2, dtype=torch.float32, device=u_tab.device)
+        work = torch.empty(3 * B, dtype=torch.float32, device=u_tab.device)
+        p_ptr = _row_view(p_tab, item_offset)
+        l2u_ptr = l2u_tab.data_ptr() if has_l2 else None
+        l2p_ptr = _row_view(l2p_tab, l2_item_offset) if has_l2 else None
+        _lib.check(_lib.lib().igcn_bpr_fwd_f32(
+            u_tab.data_ptr(), p_ptr, p_ptr, d, l2u_ptr, l2p_ptr, l2p_ptr, d,
+            users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B, d,
+            _lib.ptr(w), out.data_ptr(), work.data_ptr(), _lib.current_stream()), 'igcn_bpr_fwd_f32')
+        ctx.tabs = (u_tab.detach(), p_tab.detach(), l2u_tab.detach() if has_l2 else None,
+                    l2p_tab.detach() if has_l2 else None, w.detach() if w is not None else None)
+        ctx.idx = (users, pos, neg, work)
+        ctx.item_offset, ctx.l2_item_offset = item_offset, l2_item_offset
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        u_tab, p_tab, l2u_tab, l2p_tab, w = ctx.tabs
+        users, pos, neg, work = ctx.idx
+        has_l2, has_w = l2u_tab is not None, w is not None
+        bufs = {}
+
+        def buf_for(t):
+            key = (t.data_ptr(), tuple(t.shape))
+            if key not in bufs:
+                bufs[key] = torch.zeros_like(t)
+            return bufs[key]
+        gu, gp = buf_for(u_tab), buf_for(p_tab)
+        g2u = buf_for(l2u_tab) if has_l2 else None
+        g2p = buf_for(l2p_tab) if has_l2 else None
+        gw = torch.zeros_like(w) if has_w else None
+        g = g_out.contiguous().float()
+        B, d = users.numel(), u_tab.shape[1]
+        p_ptr, gp_ptr = _row_view(p_tab, ctx.item_offset), _row_view(gp, ctx.item_offset)
+        l2p_ptr = _row_view(l2p_tab, ctx.l2_item_offset) if has_l2 else None
+        g2p_ptr = _row_view(g2p, ctx.l2_item_offset) if has_l2 else None
+        _lib.check(_lib.lib().igcn_bpr_bwd_f32(
+            u_tab.data_ptr(), p_ptr, p_ptr, d,
+            l2u_tab.data_ptr() if has_l2 else None, l2p_ptr, l2p_ptr, d,
+            users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B, d, _lib.ptr(w),
+            work.data_ptr(), g.data_ptr(), gu.data_ptr(), gp_ptr, gp_ptr,
+            g2u.data_ptr() if has_l2 else None, g2p_ptr, g2p_ptr,
+            _lib.ptr(gw), _lib.current_stream()), 'igcn_bpr_bwd_f32')
+        seen = set()
+
+        def once(bf):
+            if bf is None or id(bf) in seen:
+                return None
+            seen.add(id(bf))
+            return bf
+        return once(gu), once(gp), once(g2u), once(g2p), gw, None, None, None, None, None
+
+
+def bpr_loss_terms(u_tab, p_tab, l2u_tab, l2p_tab, w, users, pos, neg, item_offset=0, l2_item_offset=0):
+    return BprLossFn.apply(u_tab, p_tab, l2u_tab, l2p_tab, w, users, pos, neg, item_offset, l2_item_offset)
+
+
+def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_col=None, banned=None, batch=None):
+    """Top-k item ids (best first) and scores for each user row; masked items are
+    never returned unless fewer than k unmasked items exist (igcn_score_topk_f32)."""
+    _require_gpu_f32(user_rows, 'user_rows')
+    _require_gpu_f32(item_rows, 'item_rows')
+    if user_ids is not None:
+        _require_i64(user_ids, 'user_ids')
+        B = user_ids.numel()
+    else:
+        B = user_rows.shape[0] if batch is None else batch
+    n_items, d = item_rows.shape
+    if user_rows.shape[1] != d:
+        raise _lib.IgcnError('user and item rows differ in width')
+    if excl_rowptr is not None:
+        _require_i64(excl_rowptr, 'excl_rowptr')
+        if excl_col.dtype != torch.int32 or not excl_col.is_cuda:
+            raise _lib.IgcnError('excl_col must be int32 on the GPU')
+    if banned is not None and (banned.dtype != torch.uint8 or banned.numel() != n_items or not banned.is_cuda):
+        raise _lib.IgcnError('banned must be uint8 [n_items] on the GPU')
+    L = _lib.lib()
+    ws_bytes = L.igcn_score_topk_workspace_bytes(B, n_items, d, k)
+    if ws_bytes < 0:
+        raise _lib.IgcnError('unsupported top-k shape: batch=%d n_items=%d d=%d k=%d (need d%%4==0, d<=128, '
+                             'k<=%d, k<=n_items)' % (B, n_items, d, k, _lib.MAX_TOPK))
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=item_rows.device)
+    out_idx = torch.empty((B, k), dtype=torch.int64, device=item_rows.device)
+    out_val = torch.empty((B, k), dtype=torch.float32, device=item_rows.device)
+    _lib.check(L.igcn_score_topk_f32(
+        user_rows.data_ptr(), user_rows.stride(0), _lib.ptr(user_ids), B,
+        item_rows.data_ptr(), item_rows.stride(0), n_items, d,
+        _lib.ptr(excl_rowptr), _lib.ptr(excl_col), _lib.ptr(banned), k,
+        out_idx.data_ptr(), out_val.data_ptr(), ws.data_ptr(), _lib.current_stream()), 'igcn_score_topk_f32')
+    return out_idx, out_val
+
+
+def hit_matrix(rec, eval_rowptr, eval_col):
+    """float32 [U, k] of 0/1: rec[u, j] in eval list of u (sorted CSR)."""
+    _require_i64(rec, 'rec')
+    _require_i64(eval_rowptr, 'eval_rowptr')
+    hit = torch.empty(rec.shape, dtype=torch.float32, device=rec.device)
+    _lib.check(_lib.lib().igcn_hit_matrix(rec.data_ptr(), rec.shape[0], rec.shape[1], eval_rowptr.data_ptr(),
+                                          eval_col.data_ptr(), hit.data_ptr(), _lib.current_stream()), 'igcn_hit_matrix')
+    return hit
+
+
+def bpr_sample(train_rowptr, train_col, nonempty_users, n_items, batch, seed):
+    """int64 [batch, 3] (user, pos, neg) drawn on the device (igcn_bpr_sample)."""
+    _require_i64(train_rowptr, 'train_rowptr')
+    out = torch.empty((batch, 3), dtype=torch.int64, device=train_rowptr.device)
+    _lib.check(_lib.lib().igcn_bpr_sample(train_rowptr.data_ptr(), train_col.data_ptr(), nonempty_users.data_ptr(),
+                                          nonempty_users.numel(), n_items, batch, int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                          out.data_ptr(), _lib.current_stream()), 'igcn_bpr_sample')
+    return out

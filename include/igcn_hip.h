@@ -33,7 +33,7 @@ extern "C" {
 #define IGCN_E_NO_DEVICE  -5   /* no HIP device is available               */
 
 #define IGCN_MAX_ADDS      8   /* epilogue addends of igcn_spmm_csr_f32     */
-#define IGCN_MAX_TOPK    128   /* k of igcn_score_topk_f32                  */
+#define IGCN_MAX_TOPK     64   /* k of igcn_score_topk_f32                  */
 
 int         igcn_abi_version(void);
 const char *igcn_error_string(int code);
@@ -154,9 +154,9 @@ int igcn_bpr_bwd_f32(const float *u_tab, const float *p_tab, const float *n_tab,
  * user_ids int64 [B] or NULL (then row b of user_rows is user b);
  * excl_rowptr int64 / excl_col int32 may be NULL; banned uint8 [n_items] or NULL.
  * d <= 128, d % 4 == 0; k <= IGCN_MAX_TOPK and k <= n_items.
- * workspace: igcn_score_topk_workspace_bytes(B, n_items, k) bytes (partial
+ * workspace: igcn_score_topk_workspace_bytes(B, n_items, d, k) bytes (partial
  * lists of the item-range splits that fill the chip when B is small). */
-int64_t igcn_score_topk_workspace_bytes(int64_t batch, int64_t n_items, int32_t k);
+int64_t igcn_score_topk_workspace_bytes(int64_t batch, int64_t n_items, int32_t d, int32_t k);
 int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
                         const float *item_rows, int64_t ldi, int64_t n_items, int32_t d,
                         const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned,

@@ -1,0 +1,213 @@
+"""CPU-only tests: the C-ABI library loads and exports every declared symbol, the host
+logic (graph builders, datasets, configs, metric reductions) matches the oracle and the
+reference's golden vectors, and the ops fail loudly without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    from igcn_cf_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        g.build()
+    header = open(os.path.join(ROOT, 'include', 'igcn_hip.h')).read()
+    declared = set(re.findall(r'\b(igcn_[a-z0-9_]+)\s*\(', header))
+    declared -= {'igcn_row_segment', 'igcn_long_row'}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert getattr(_lib.lib(), name) is not None
+    assert _lib.lib().igcn_abi_version() == 1
+    assert _lib.lib().igcn_error_string(-1).decode().startswith('a required pointer')
+
+
+def test_spmm_plan_host_functions():
+    from igcn_cf_amd import _lib
+    L = _lib.lib()
+    degs = np.array([0, 5, 1024, 1025, 3000, 7, 512, 513], dtype=np.int64)
+    rowptr = np.zeros(len(degs) + 1, dtype=np.int64)
+    np.cumsum(degs, out=rowptr[1:])
+    nl, ns = C.c_int64(), C.c_int64()
+    assert L.igcn_spmm_plan_count_host(rowptr.ctypes.data, len(degs), 1024, 512, C.byref(nl), C.byref(ns)) == 0
+    assert (nl.value, ns.value) == (2, 3 + 6)
+    lr = np.zeros(nl.value, dtype=_lib.LONG_ROW_DTYPE)
+    sg = np.zeros(ns.value, dtype=_lib.ROW_SEGMENT_DTYPE)
+    assert L.igcn_spmm_plan_fill_host(rowptr.ctypes.data, len(degs), 1024, 512, lr.ctypes.data, nl.value,
+                                      sg.ctypes.data, ns.value) == 0
+    assert lr['row'].tolist() == [3, 4] and lr['first_slot'].tolist() == [0, 3] and lr['n_slots'].tolist() == [3, 6]
+    # the segments tile each long row exactly
+    for r, f, n in zip(lr['row'], lr['first_slot'], lr['n_slots']):
+        seg = sg[f:f + n]
+        assert seg['start'][0] == rowptr[r] and (seg['start'][-1] + seg['len'][-1]) == rowptr[r + 1]
+        assert np.all(seg['start'][1:] == seg['start'][:-1] + seg['len'][:-1]) and seg['len'].max() <= 512
+        assert seg['slot'].tolist() == list(range(f, f + n))
+    # error behaviour: NULL pointer, bad ranges
+    assert L.igcn_spmm_plan_count_host(None, 1, 1024, 512, C.byref(nl), C.byref(ns)) == -1
+    assert L.igcn_spmm_plan_count_host(rowptr.ctypes.data, len(degs), 16, 32, C.byref(nl), C.byref(ns)) == -4
+
+
+def test_ops_fail_loudly_without_gpu():
+    from igcn_cf_amd import _lib, ops
+    from igcn_cf_amd.model import get_model
+    x = torch.zeros(4, 4)
+    with pytest.raises(_lib.IgcnError):
+        ops.spmm(None, x)
+    with pytest.raises(_lib.IgcnError):
+        ops.score_topk(x, x, 2)
+
+    class DS:
+        n_users, n_items = 3, 3
+        train_array = np.zeros((0, 2), dtype=np.int64)
+    with pytest.raises(_lib.IgcnError):
+        get_model({'name': 'MF', 'embedding_size': 8, 'device': 'cpu'}, DS())
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, 'igcn_cf_amd')
+    for f in os.listdir(pkg):
+        if f.endswith('.py'):
+            src = open(os.path.join(pkg, f)).read()
+            assert 'oracle' not in src.replace('checker implementation', ''), f
+
+
+def test_graph_builders_match_oracle(golden):
+    from igcn_cf_amd import graph
+    nu, ni = int(golden['n_users']), int(golden['n_items'])
+    ta = golden['train_array']
+    rowptr, col, val = graph.adjacency_host(ta, nu, ni)
+    np.testing.assert_array_equal(rowptr, golden['adj_indptr'])        # reference utils.generate_daj_mat
+    np.testing.assert_array_equal(col, golden['adj_indices'])
+    np.testing.assert_array_equal(val, golden['adj_data'])
+    rowptr, col, val = graph.normalized_adjacency_host(ta, nu, ni)
+    orow, ocol, oval = O.lightgcn_norm_adj(ta, nu, ni)
+    np.testing.assert_array_equal(np.repeat(np.arange(nu + ni), np.diff(rowptr)), orow)
+    np.testing.assert_array_equal(col, ocol)
+    np.testing.assert_array_equal(val, oval)
+    # template feature matrix, full and partial maps
+    for um, im in ((None, None),
+                   ({int(u): j for j, u in enumerate(golden['aux_user_keys'])},
+                    {int(i): j for j, i in enumerate(golden['aux_item_keys'])})):
+        frp, fcol, row_sum, shape = graph.feature_matrix_host(ta, nu, ni, um, im)
+        r, c, v, rs, _, _, oshape = O.igcn_generate_feat(ta, nu, ni, um, im)
+        assert shape == oshape
+        np.testing.assert_array_equal(np.repeat(np.arange(shape[0]), np.diff(frp)), r)
+        np.testing.assert_array_equal(fcol, c)
+        np.testing.assert_array_equal(row_sum, rs)
+        # transpose carries edge ids that point back to the same entry
+        trp, tcol, eid = graph.transpose_host(frp, fcol, shape[1])
+        rows = np.repeat(np.arange(shape[0]), np.diff(frp))
+        np.testing.assert_array_equal(tcol, rows[eid])
+        np.testing.assert_array_equal(np.repeat(np.arange(shape[1]), np.diff(trp)), fcol[eid])
+        assert sorted(eid.tolist()) == list(range(len(fcol)))
+
+
+def test_rank_nodes_matches_reference(golden):
+    from igcn_cf_amd.graph import graph_rank_nodes
+
+    class DS:
+        n_users, n_items, train_array = int(golden['n_users']), int(golden['n_items']), golden['train_array']
+    for metric in ('degree', 'sort'):
+        ru, ri = graph_rank_nodes(DS(), metric)
+        np.testing.assert_array_equal(ru, golden['rank_%s_users' % metric])
+        np.testing.assert_array_equal(ri, golden['rank_%s_items' % metric])
+    with pytest.raises(ValueError):
+        graph_rank_nodes(DS(), 'page_rank')
+
+
+def test_processed_dataset_matches_reference(golden, tmp_path):
+    from igcn_cf_amd.dataset import AuxiliaryDataset, get_dataset
+    ds = get_dataset({'name': 'ProcessedDataset', 'path': golden['path'], 'device': 'cpu'})
+    assert (ds.n_users, ds.n_items, len(ds)) == (int(golden['n_users']), int(golden['n_items']), int(golden['len']))
+    np.testing.assert_array_equal(ds.train_array, golden['train_array'])
+    # write + re-read round trip in the reference text format
+    ds.output_dataset(str(tmp_path / 'out'))
+    ds2 = get_dataset({'name': 'ProcessedDataset', 'path': str(tmp_path / 'out'), 'device': 'cpu'})
+    assert ds2.train_data == ds.train_data and ds2.val_data == ds.val_data and ds2.test_data == ds.test_data
+    # auxiliary re-indexing equals the reference's AuxiliaryDataset
+    um = {int(u): j for j, u in enumerate(golden['aux_user_keys'])}
+    im = {int(i): j for j, i in enumerate(golden['aux_item_keys'])}
+    aux = AuxiliaryDataset(ds, um, im)
+    assert len(aux) == int(golden['aux_len'])
+    np.testing.assert_array_equal(np.array([len(x) for x in aux.train_data]), golden['aux_rowlen'])
+    np.testing.assert_array_equal(np.array([i for x in aux.train_data for i in x], dtype=np.int64), golden['aux_flat'])
+    # samplers: reference procedure (__getitem__) and the vectorised host one
+    item = ds[0]
+    assert item.shape == (1, 3) and item.dtype == np.int64
+    s = ds.sample_batch_host(2000, np.random.default_rng(0))
+    for u, p, n in s:
+        assert ds.train_data[u] and p in ds.train_data[u] and n not in ds.train_data[u]
+
+
+def test_synthetic_dataset_properties():
+    from igcn_cf_amd.dataset import SyntheticDataset
+    cfg = {'name': 'SyntheticDataset', 'n_users': 2000, 'n_items': 1500, 'n_inter': 60000, 'seed': 3}
+    a, b = SyntheticDataset(cfg), SyntheticDataset(cfg)
+    np.testing.assert_array_equal(a.train_array, b.train_array)                 # seeded
+    assert abs(len(a) / (0.7 * 60000) - 1) < 0.1
+    for u in (0, 17, 1999):
+        tr, va, te = a.train_data[u], a.val_data[u], a.test_data[u]
+        allu = tr + va + te
+        assert len(set(allu)) == len(allu) and len(tr) >= 5 and len(te) >= 1     # de-duplicated, 70/10/20
+    rp, col = a.csr('train', sort=True)
+    assert np.all(np.diff(col)[np.diff(np.repeat(np.arange(2000), np.diff(rp))) == 0] > 0)
+    # mutation protocol of inductive_eval: assign a list, CSR view follows
+    td = a.test_data.copy(); td[0] = []
+    a.test_data = td
+    assert a.csr('test')[0][1] == 0
+
+
+def test_config_schema_positions():
+    from igcn_cf_amd import config
+    for fn in (config.get_gowalla_config, config.get_yelp_config, config.get_amazon_config):
+        triples = fn('cuda')
+        assert [t[1]['name'] if t else None for t in triples] == \
+            ['MF', 'LightGCN', 'IGCN', None, None, None, 'IMF', None, None, None]
+        ds, m, t = triples[2]
+        assert {'name', 'path', 'device'} <= set(ds)
+        assert {'embedding_size', 'n_layers', 'dropout', 'feature_ratio', 'device'} <= set(m)
+        assert {'optimizer', 'lr', 'l2_reg', 'aux_reg', 'n_epochs', 'batch_size', 'dataloader_num_workers',
+                'test_batch_size', 'topks', 'device'} <= set(t)
+    assert config.get_amazon_config('cuda')[1][2]['l2_reg'] == 1e-5
+    assert config.get_synthetic_config('cuda', 'gowalla')[0][0]['name'] == 'SyntheticDataset'
+
+
+def test_metric_reductions_match_reference(golden):
+    """BasicTrainer._metrics_from_hits (the numpy part of calculate_metrics) on a hit matrix
+    built on the host == the reference's calculate_metrics values, bit for bit."""
+    from igcn_cf_amd.trainer import BasicTrainer
+    lists = {}
+    for name in ('train', 'val', 'test'):
+        lists[name], _ = O.read_data(os.path.join(golden['path'], name + '.txt'))
+    topks = [int(k) for k in golden['eval_topks']]
+    tr = BasicTrainer.__new__(BasicTrainer)
+    tr.topks = topks
+    for tag, stage in (('train', 'train'), ('val', 'val'), ('test', 'test'), ('testban', 'test')):
+        rec = golden['eval_%s_rec' % tag]
+        hit = np.array([[1. if rec[u, j] in lists[stage][u] else 0. for j in range(rec.shape[1])]
+                        for u in range(rec.shape[0])], dtype=np.float32)
+        m = tr._metrics_from_hits(hit, np.array([len(x) for x in lists[stage]], dtype=np.int32))
+        for name in m:
+            for k in m[name]:
+                assert m[name][k] == golden['eval_%s_%s_%d' % (tag, name, k)]
+
+
+def test_c_oracle_matches_numpy_oracle(golden):
+    from oracle import c_oracle as CO
+    from igcn_cf_amd.graph import normalized_adjacency_host
+    nu, ni = int(golden['n_users']), int(golden['n_items'])
+    rowptr, col, val = normalized_adjacency_host(golden['train_array'], nu, ni)
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal((nu + ni, 64)) * 0.1).astype(np.float32)
+    adj = O.lightgcn_norm_adj(golden['train_array'], nu, ni)
+    np.testing.assert_allclose(CO.propagate_mean(rowptr, col, val, x, 3), O.lightgcn_get_rep(adj, x, 3),
+                               rtol=1e-5, atol=1e-7)
+    idx, _ = CO.score_topk(x[:nu], x[nu:], 5)
+    np.testing.assert_array_equal(idx, O.eval_topk(x[:nu] @ x[nu:].T, None, None, k=5))
