@@ -1,0 +1,241 @@
+"""Benchmark of the propagation + scoring path (driver contract: one JSON line).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json: "propagation edges/sec + eval users/sec, Amazon-book
+dim=64"): LightGCN, 3 layers, d = 64, fp32, on the seeded Amazon-book-like
+synthetic split (109 730 users x 96 421 items, ~2.2 M train pairs); at N > 1 the
+graph is N x that size, row-sharded (igcn_cf_amd/dist.py) — weak scaling.
+
+A STEP is one K-layer propagation pass over the whole graph (LightGCN.get_rep,
+model.py:96-106 = 3 SpMM launches with the layer mean fused in the last; at N > 1
+plus the per-layer all-gathers).  Inputs are resident in HBM before the timed
+region.  value = edges/s = steps * n_layers * nnz(A_hat) / time (whole job).
+Also reported (outside `value`): full-evaluation users/s (propagate once + fused
+score/mask/top-20 over every user) and the full training step (sample + forward
++ BPR + backward + Adam).
+
+roofline: the dominant kernel is spmm_csr_rows_kernel<16,false>; `achieved` =
+algorithmic bytes per launch (nnz*(8+4d) + N*(4d+4)) / average
+launch duration measured with HIP events over the timed region.
+cpu_baseline (rank 0, N = 1): the C restatement of the path (oracle/oracle_c.c,
+kind "port") on all host cores, on the same graph, bounded to ~10-30 s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--preset', default='amazon')
+    ap.add_argument('--dim', type=int, default=64)
+    ap.add_argument('--layers', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the eval / train-step side measurements')
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs the MI355X (no CPU fallback for the product path)')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+
+    from igcn_cf_amd.dataset import SyntheticDataset
+    from igcn_cf_amd.graph import CsrMatrix, normalized_adjacency_host
+    from igcn_cf_amd import ops
+
+    base = SyntheticDataset.PRESETS[args.preset]
+    cfg = {'name': 'SyntheticDataset', 'n_users': base['n_users'] * world, 'n_items': base['n_items'] * world,
+           'n_inter': base['n_inter'] * world, 'seed': 2021, 'device': device}
+    ds = SyntheticDataset(cfg)
+    n = ds.n_users + ds.n_items
+    d, K = args.dim, args.layers
+    rowptr, col, val = normalized_adjacency_host(ds.train_array, ds.n_users, ds.n_items)
+    nnz = int(rowptr[-1])
+    gen = torch.Generator(device='cpu').manual_seed(2021)
+    emb_host = torch.randn(n, d, generator=gen) * 0.1                    # normal_(std=0.1), model.py:82
+
+    def barrier_sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if world == 1:
+        csr = CsrMatrix(rowptr, col, val, (n, n), device)
+        x0 = emb_host.to(device)
+        step = lambda: ops.propagate_mean(csr, x0, K)
+        launches_per_step = K
+    else:
+        from igcn_cf_amd.dist import RowShardedPropagator
+        prop = RowShardedPropagator(None, ds.n_users, ds.n_items, K, rank, world, device, adjacency=(rowptr, col, val))
+        L = prop.layout
+        (ulo, uhi), (ilo, ihi) = L.user_rows(rank), L.item_rows(rank)
+        eu = emb_host[ulo:uhi].to(device)
+        ei = emb_host[ds.n_users + ilo: ds.n_users + ihi].to(device)
+
+        def step():                                                       # exchange X_0, then the sharded pass
+            prop.load_local_embedding(eu, ei)
+            return prop.propagate()
+        launches_per_step = 2 * K
+
+    for _ in range(args.warmup):
+        step()
+    barrier_sync()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    barrier_sync()
+    wall = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    edges = args.steps * K * nnz
+    value = edges / wall
+    out = {
+        'metric': 'propagation edges/sec (3-layer LightGCN get_rep, Amazon-book-like, dim=64)',
+        'value': value, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': wall * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'LightGCN %d-layer d=%d propagation on synthetic %s-like x%d (users=%d items=%d nnz(A_hat)=%d)'
+                               % (K, d, args.preset, world, ds.n_users, ds.n_items, nnz),
+                   'parallelism': 'single GPU' if world == 1 else 'row-sharded x%d + RCCL all-gather per half-layer' % world},
+    }
+
+    # ---- roofline of the dominant kernel (per launch, this rank) ----------------------------------
+    if world == 1:
+        b_alg = nnz * (8 + 4 * d) + n * (4 * d + 4)
+        b_min = nnz * 8 + n * (8 * d + 4)
+        ms_launch = dev_ms / (args.steps * launches_per_step)
+        traffic = None
+        tp = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get('spmm_hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        ach = b_alg / ms_launch / 1e6
+        out['roofline'] = {'bound': 'hbm', 'kernel': 'spmm_csr_rows_kernel<16,false>', 'achieved': ach, 'peak': HBM_PEAK_GBPS,
+                           'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS, 'traffic': traffic,
+                           'algorithmic_bytes_per_launch': b_alg, 'compulsory_bytes_per_launch': b_min,
+                           'avg_launch_ms': ms_launch,
+                           'note': 'X (52.8 MB) fits the 256 MiB Infinity Cache: gathers are served on-die, so algorithmic '
+                                   'bytes/s may exceed the HBM peak; traffic = PMC-measured HBM bytes per launch'}
+
+    extras = {}
+    if world == 1 and not args.no_extras:
+        extras = side_measurements(ds, device, d, K)
+    out['extras'] = extras
+
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(rowptr, col, val, emb_host.numpy(), K, nnz, ds.n_users)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def side_measurements(ds, device, d, K):
+    """Full evaluation (users/s) and full training step (ms) on the same workload."""
+    from igcn_cf_amd.model import get_model
+    from igcn_cf_amd.trainer import get_trainer
+    torch.manual_seed(2021)
+    model = get_model({'name': 'LightGCN', 'embedding_size': d, 'n_layers': K, 'device': device}, ds)
+    trainer = get_trainer({'name': 'BPRTrainer', 'optimizer': 'Adam', 'lr': 1e-3, 'l2_reg': 1e-5, 'device': device,
+                           'n_epochs': 1, 'batch_size': 2048, 'dataloader_num_workers': 0, 'test_batch_size': 512,
+                           'topks': [20]}, ds, model)
+    res = {}
+    # training step: sample + forward + fused BPR + backward + Adam
+    model.train()
+    batches = [b for _, b in zip(range(30), trainer.sampler.epoch_batches(2048))]
+    for b in batches[:5]:
+        trainer.bpr_step(b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in batches[5:]:
+        trainer.bpr_step(b)
+    torch.cuda.synchronize()
+    res['train_step_ms'] = (time.perf_counter() - t0) * 1e3 / len(batches[5:])
+    res['train_step_edges_per_s_fwd_bwd'] = 2 * K * model.norm_adj.nnz / (res['train_step_ms'] / 1e3)
+    # evaluation: propagate once + fused score/mask/top-20 for every user (device part of trainer.eval)
+    model.eval()
+    trainer.recommend_all('test')
+    torch.cuda.synchronize()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        model._rep_cache = None
+        rec = trainer.recommend_all('test')
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    res['eval_users_per_s'] = ds.n_users / dt
+    res['eval_ms'] = dt * 1e3
+    res['eval_mfma_tflops'] = 2.0 * ds.n_users * ds.n_items * d / dt / 1e12
+    t0 = time.perf_counter()
+    _, metrics = trainer.eval('test')
+    res['eval_with_metrics_ms'] = (time.perf_counter() - t0) * 1e3
+    res['recall@20_random_init'] = float(metrics['Recall'][20])
+    return res
+
+
+def cpu_baseline(rowptr, col, val, x, K, nnz, n_users):
+    """The C restatement (oracle/oracle_c.c) on the host cores, same graph, bounded sample."""
+    from oracle import c_oracle as CO
+    threads = CO.num_threads()
+    CO.propagate_mean(rowptr, col, val, x, 1)                    # warm
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        CO.propagate_mean(rowptr, col, val, x, K)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt > 12.0 or reps >= 2000:
+            break
+    v = reps * K * nnz / dt
+    # eval side: users/s of the C restatement on a bounded user sample
+    n_sample = 256
+    U = x[:n_sample]
+    items = x[n_users:]
+    t0 = time.perf_counter()
+    CO.score_topk(U, items, 20)
+    ev = n_sample / (time.perf_counter() - t0)
+    return {'value': v, 'unit': 'edges/s', 'cores': threads, 'kind': 'port',
+            'sample': '%d full %d-layer passes of the same graph (%.1f s) with the OpenMP C restatement on %d threads; '
+                      'eval side: %d users x all items -> %.0f users/s' % (reps, K, dt, threads, n_sample, ev),
+            'eval_users_per_s': ev}
+
+
+if __name__ == '__main__':
+    main()

@@ -24,6 +24,7 @@
 //     — results are bitwise reproducible, no float atomics;
 //   * persistent grid: 8 workgroups of 4 waves per CU, wave-strided over the
 //     virtual rows, so neighbouring waves stream neighbouring col/val lines.
+#include <stdlib.h>
 #include "common.h"
 
 namespace igcn {
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rows_kernel(
     const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy,
     int64_t n_rows, int d, SpmmEpilogue ep, SpmmDropout dr,
     const igcn_row_segment *__restrict__ segments, int64_t n_segments,
-    float *__restrict__ partial, int long_threshold)
+    float *__restrict__ partial, int long_threshold, int seg_first)
 {
     constexpr int G = kWave / LPR;           // source rows per gather instruction
     const int lane = threadIdx.x & (kWave - 1);
@@ -61,7 +62,10 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rows_kernel(
     const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
     const int64_t n_virtual = n_rows + n_segments;
 
-    for (int64_t v = wave0; v < n_virtual; v += n_waves) {
+    for (int64_t vv = wave0; vv < n_virtual; vv += n_waves) {
+        // segments of long rows are scheduled FIRST (seg_first): the heaviest work
+        // items start at once and the launch ends on short rows
+        const int64_t v = seg_first ? (vv < n_segments ? n_rows + vv : vv - n_segments) : vv;
         int64_t start, end, dst;
         bool to_partial;
         if (v < n_rows) {
@@ -223,6 +227,18 @@ __global__ void csr_row_pow_kernel(const int64_t *__restrict__ rowptr, const flo
     }
 }
 
+// Developer tuning knobs (environment, read once): IGCN_SPMM_BLOCKS_PER_CU, IGCN_SPMM_SEG_FIRST.
+struct SpmmTuning { int blocks_per_cu; int seg_first; };
+static const SpmmTuning &tuning() {
+    static SpmmTuning t = [] {
+        SpmmTuning v{8, 1};
+        if (const char *e = getenv("IGCN_SPMM_BLOCKS_PER_CU")) { int x = atoi(e); if (x >= 1 && x <= 64) v.blocks_per_cu = x; }
+        if (const char *e = getenv("IGCN_SPMM_SEG_FIRST")) v.seg_first = atoi(e) != 0;
+        return v;
+    }();
+    return t;
+}
+
 template <int LPR>
 static int launch_rows(bool dropout, dim3 grid, hipStream_t st,
                        const int64_t *rowptr, const int32_t *col, const float *val, const float *x, int64_t ldx,
@@ -230,12 +246,13 @@ static int launch_rows(bool dropout, dim3 grid, hipStream_t st,
                        const igcn_row_segment *segments, int64_t n_segments, float *partial, int long_threshold,
                        const igcn_long_row *long_rows, int64_t n_long)
 {
+    const int seg_first = tuning().seg_first;
     if (dropout)
         hipLaunchKernelGGL((spmm_csr_rows_kernel<LPR, true>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
-                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold);
+                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, seg_first);
     else
         hipLaunchKernelGGL((spmm_csr_rows_kernel<LPR, false>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
-                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold);
+                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, seg_first);
     int rc = launch_status();
     if (rc != IGCN_OK) return rc;
     if (n_long > 0) {
@@ -342,7 +359,7 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
     const int waves_per_block = kBlock / kWave;
     const int64_t n_virtual = n_rows + n_segments;
     int64_t blocks = (n_virtual + waves_per_block - 1) / waves_per_block;
-    const int64_t max_blocks = (int64_t)cu_count() * 8;
+    const int64_t max_blocks = (int64_t)cu_count() * tuning().blocks_per_cu;
     if (blocks > max_blocks) blocks = max_blocks;
     dim3 grid((unsigned)blocks);
 

@@ -232,6 +232,8 @@ def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_co
     n_items, d = item_rows.shape
     if user_rows.shape[1] != d:
         raise _lib.IgcnError('user and item rows differ in width')
+    if excl_rowptr is not None and (excl_col is None or excl_col.numel() == 0):
+        excl_rowptr = excl_col = None                      # nothing is excluded
     if excl_rowptr is not None:
         _require_i64(excl_rowptr, 'excl_rowptr')
         if excl_col.dtype != torch.int32 or not excl_col.is_cuda:
