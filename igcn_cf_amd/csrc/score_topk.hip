@@ -22,13 +22,17 @@
 //     exclusion list with a cursor as the item sweep advances; banned items
 //     arrive as a 0/-inf bias staged with the tile;
 //   * top-k: one compare of the tile maximum against the user's current k-th
-//     best decides whether anything can enter; the rare insert replaces the
-//     worst entry of an unsorted k-slot list kept in LDS ([slot][lane], so lane
-//     l always hits bank l) and rescans for the new worst;
+//     best decides whether anything can enter.  Entries are 64-bit sortable keys
+//     (order-preserving image of the fp32 score << 32 | ~item id), kept per lane
+//     as a k-slot binary min-heap in LDS ([slot][lane]: lane l always hits its own
+//     bank pair); a rare insert replaces the root and sifts down, O(log k).  The
+//     wave handles "the first remaining candidate of every lane" per pass, so a
+//     tile costs about one pass however its candidates are spread over lanes;
 //   * when the batch has too few 32-user groups to fill 256 CUs, the item range
 //     is split across workgroups and a small kernel merges the partial lists.
 // Ties are broken towards the lower item id (torch.topk leaves them unspecified).
 #include <math.h>
+#include <stdlib.h>
 #include "common.h"
 
 namespace igcn {
@@ -61,8 +65,11 @@ static inline int topk_make_plan(int64_t batch, int64_t n_items, int32_t d, int3
     p->lds_bytes = topk_lds_bytes(p->waves, p->d_pad, k);
     const int64_t users_per_wg = 32 * p->waves;
     p->user_tiles = (batch + users_per_wg - 1) / users_per_wg;
-    const int64_t target = (int64_t)cu_count() * 2 * 4;              // ~4 rounds of 2 workgroups per CU
-    int64_t splits = (target + p->user_tiles - 1) / p->user_tiles;
+    // Item-range splits only when the user tiles alone cannot fill the chip (2 workgroups per CU):
+    // every split keeps its own k-entry lists, so splitting multiplies the insert work.
+    const int64_t slots = (int64_t)cu_count() * 2;
+    int64_t splits = p->user_tiles >= slots ? 1 : (2 * slots + p->user_tiles - 1) / p->user_tiles;
+    if (const char *e = getenv("IGCN_TOPK_SPLITS")) { int x = atoi(e); if (x >= 1) splits = x; }   // developer knob
     const int64_t max_by_items = n_items / 4096 > 1 ? n_items / 4096 : 1;
     if (splits > max_by_items) splits = max_by_items;
     if (splits > 64) splits = 64;
@@ -75,6 +82,19 @@ static inline int topk_make_plan(int64_t batch, int64_t n_items, int32_t d, int3
 }
 
 __device__ __forceinline__ int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// Sortable 64-bit key: larger key = ranks earlier (higher score, then lower item id).
+__device__ __forceinline__ unsigned long long make_key(float s, int item) {
+    unsigned int u = __float_as_uint(s);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);          // order-preserving map of fp32 to uint32
+    return ((unsigned long long)u << 32) | (unsigned int)(~item);
+}
+__device__ __forceinline__ float key_score(unsigned long long key) {
+    unsigned int u = (unsigned int)(key >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ int key_item(unsigned long long key) { return (int)~(unsigned int)key; }
 
 // (v, i) ranks before (w, j): higher score first, then lower item id
 __device__ __forceinline__ bool ranks_before(float v, int i, float w, int j) { return v > w || (v == w && i < j); }
@@ -95,8 +115,7 @@ __global__ __launch_bounds__(WAVES * kWave) void score_topk_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float *s_items = reinterpret_cast<float *>(smem);                   // [2][64][STRIDE]
     float *s_bias = s_items + 2 * kTileItems * STRIDE;                  // [2][64]
-    float *s_lval = s_bias + 2 * kTileItems;                            // [WAVES][k][64]
-    int *s_lidx = reinterpret_cast<int *>(s_lval + WAVES * k * kWave);  // [WAVES][k][64]
+    unsigned long long *s_heap = reinterpret_cast<unsigned long long *>(s_bias + 2 * kTileItems);   // [WAVES][k][64]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -133,12 +152,12 @@ __global__ __launch_bounds__(WAVES * kWave) void score_topk_kernel(
         if (ex_pos < ex_end) ex_next = excl_col[ex_pos];
     }
 
-    // running top-k: unsorted list in LDS, worst entry tracked in registers
-    float *lval = s_lval + (wid * k) * kWave + lane;
-    int *lidx = s_lidx + (wid * k) * kWave + lane;
-    for (int s = 0; s < k; ++s) { lval[s * kWave] = -INFINITY; lidx[s * kWave] = kIdxNone; }
-    float thr = -INFINITY;
-    int thr_idx = kIdxNone, minpos = 0;
+    // running top-k: per-lane min-heap of sortable keys in LDS; root (= k-th best so far) in registers.
+    // Key 0 = empty slot: ranks below every real entry, masked (-inf) ones included.
+    unsigned long long *heap = s_heap + (wid * k) * kWave + lane;
+    for (int s = 0; s < k; ++s) heap[s * kWave] = 0ull;
+    unsigned long long root = 0ull;
+    float thr = -INFINITY;                                   // score part of the root
 
     const int64_t n_tiles = (item_hi - item_lo + kTileItems - 1) / kTileItems;
     float4 st[NLOAD];
@@ -228,26 +247,42 @@ __global__ __launch_bounds__(WAVES * kWave) void score_topk_kernel(
             }
 
             // --- top-k ---------------------------------------------------------------
-            float m = acc[0];
+            while (true) {
+                float m = acc[0];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-            if (m >= thr) {
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+                if (!__any(m >= thr)) break;                         // nothing in this tile can enter any list
+                // first remaining candidate of this lane; examined scores become NaN (fmaxf skips NaN)
+                unsigned long long cand = 0ull;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float s = acc[r];
-                    const int it = tile_base + row_of(r, h);
-                    if (ranks_before(s, it, thr, thr_idx)) {
-                        lval[minpos * kWave] = s;
-                        lidx[minpos * kWave] = it;
-                        float wv = INFINITY;
-                        int wi = -1, wp = 0;
-                        for (int q = 0; q < k; ++q) {
-                            const float v = lval[q * kWave];
-                            const int i = lidx[q * kWave];
-                            if (ranks_before(wv, wi, v, i)) { wv = v; wi = i; wp = q; }
-                        }
-                        thr = wv; thr_idx = wi; minpos = wp;
+                    if (cand == 0ull && s >= thr) {
+                        const unsigned long long kr = make_key(s, tile_base + row_of(r, h));
+                        if (kr > root) cand = kr;
+                        acc[r] = __uint_as_float(0x7fc00000u);       // examined: NaN is never >= thr again
                     }
+                }
+                if (cand != 0ull) {
+                    // replace the root (worst entry) and sift down
+                    int i = 0;
+                    unsigned long long first_up = 0ull;
+                    while (true) {
+                        int c = 2 * i + 1;
+                        if (c >= k) break;
+                        unsigned long long kc = heap[c * kWave];
+                        if (c + 1 < k) {
+                            const unsigned long long k2 = heap[(c + 1) * kWave];
+                            if (k2 < kc) { kc = k2; ++c; }
+                        }
+                        if (kc >= cand) break;
+                        heap[i * kWave] = kc;
+                        if (i == 0) first_up = kc;
+                        i = c;
+                    }
+                    heap[i * kWave] = cand;
+                    root = i == 0 ? cand : first_up;
+                    thr = root ? key_score(root) : -INFINITY;    // heap not full yet: everything may enter
                 }
             }
         }
@@ -256,22 +291,21 @@ __global__ __launch_bounds__(WAVES * kWave) void score_topk_kernel(
         __syncthreads();
     }
 
-    // merge the two lanes of a user and emit best-first
+    // merge the two lanes of a user and emit best-first (k rounds of arg-max over 2k keys)
     __syncthreads();
     if (h == 0 && user_ok) {
-        float *pval = lval + 32;      // partner lane (l + 32), same wave
-        int *pidx = lidx + 32;
+        unsigned long long *pheap = heap + 32;      // partner lane (l + 32), same wave
         for (int r = 0; r < k; ++r) {
-            float bv = -INFINITY;
-            int bi = kIdxNone, bp = 0, bwho = 0;
+            unsigned long long best = 0ull;
+            int bp = 0, bwho = 0;
             for (int q = 0; q < k; ++q) {
-                const float v0 = lval[q * kWave]; const int i0 = lidx[q * kWave];
-                if (ranks_before(v0, i0, bv, bi)) { bv = v0; bi = i0; bp = q; bwho = 0; }
-                const float v1 = pval[q * kWave]; const int i1 = pidx[q * kWave];
-                if (ranks_before(v1, i1, bv, bi)) { bv = v1; bi = i1; bp = q; bwho = 1; }
+                const unsigned long long k0 = heap[q * kWave], k1 = pheap[q * kWave];
+                if (k0 > best) { best = k0; bp = q; bwho = 0; }
+                if (k1 > best) { best = k1; bp = q; bwho = 1; }
             }
-            if (bwho == 0) { lval[bp * kWave] = -INFINITY; lidx[bp * kWave] = kIdxNone; }
-            else { pval[bp * kWave] = -INFINITY; pidx[bp * kWave] = kIdxNone; }
+            if (bwho == 0) heap[bp * kWave] = 0ull; else pheap[bp * kWave] = 0ull;
+            const float bv = best ? key_score(best) : -INFINITY;
+            const int bi = best ? key_item(best) : kIdxNone;
             if (n_splits == 1) {
                 out_idx[b * k + r] = bi == kIdxNone ? -1 : bi;
                 out_val[b * k + r] = bv;

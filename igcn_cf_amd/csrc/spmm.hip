@@ -63,8 +63,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rows_kernel(
     const int64_t n_virtual = n_rows + n_segments;
 
     for (int64_t vv = wave0; vv < n_virtual; vv += n_waves) {
-        // segments of long rows are scheduled FIRST (seg_first): the heaviest work
-        // items start at once and the launch ends on short rows
+        // optional: segments of long rows scheduled first (measured slower on MI355X; off)
         const int64_t v = seg_first ? (vv < n_segments ? n_rows + vv : vv - n_segments) : vv;
         int64_t start, end, dst;
         bool to_partial;
@@ -148,32 +147,50 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rows_kernel(
     }
 }
 
-// Adds the partial sums of each long row in slot order, applies the epilogue.
+// Adds the partial sums of each long row and applies the epilogue.  One wave per
+// long row; the G lane groups each sum a strided subset of the slots (4 loads in
+// flight), then the groups are folded — a fixed order, so results are reproducible.
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void spmm_long_rows_reduce_kernel(
     const igcn_long_row *__restrict__ long_rows, int64_t n_long, const float *__restrict__ partial,
     float *__restrict__ y, int64_t ldy, int d, SpmmEpilogue ep)
 {
+    constexpr int G = kWave / LPR;
     const int lane = threadIdx.x & (kWave - 1);
+    const int g = lane / LPR, t = lane % LPR;
+    const bool lane_on = (4 * t) < d;
     const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-    if (wave >= n_long || lane >= LPR || 4 * lane >= d) return;
+    if (wave >= n_long) return;
     const igcn_long_row lr = long_rows[wave];
+    const float *base = partial + (int64_t)lr.first_slot * d + 4 * t;
     float4 acc = f4_zero();
-    for (int s = 0; s < lr.n_slots; ++s)
-        f4_add(acc, *reinterpret_cast<const float4 *>(partial + (int64_t)(lr.first_slot + s) * d + 4 * lane));
+    if (lane_on) {
+        int s = g;
+        for (; s + 3 * G < lr.n_slots; s += 4 * G) {
+            const float4 p0 = *reinterpret_cast<const float4 *>(base + (int64_t)s * d);
+            const float4 p1 = *reinterpret_cast<const float4 *>(base + (int64_t)(s + G) * d);
+            const float4 p2 = *reinterpret_cast<const float4 *>(base + (int64_t)(s + 2 * G) * d);
+            const float4 p3 = *reinterpret_cast<const float4 *>(base + (int64_t)(s + 3 * G) * d);
+            f4_add(acc, p0); f4_add(acc, p1); f4_add(acc, p2); f4_add(acc, p3);
+        }
+        for (; s < lr.n_slots; s += G) f4_add(acc, *reinterpret_cast<const float4 *>(base + (int64_t)s * d));
+    }
+#pragma unroll
+    for (int off = LPR; off < kWave; off <<= 1) f4_add(acc, f4_shfl_xor(acc, off));
+    if (g != 0 || !lane_on) return;
     const int64_t dst = lr.row;
     float4 r = make_float4(acc.x * ep.out_scale, acc.y * ep.out_scale, acc.z * ep.out_scale, acc.w * ep.out_scale);
     if (ep.n_adds > 0) {
-        float4 s = f4_zero();
+        float4 sum = f4_zero();
         for (int i = 0; i < ep.n_adds; ++i)
-            f4_add(s, *reinterpret_cast<const float4 *>(ep.add[i] + dst * ldy + 4 * lane));
-        f4_fma(r, ep.add_scale, s);
+            f4_add(sum, *reinterpret_cast<const float4 *>(ep.add[i] + dst * ldy + 4 * t));
+        f4_fma(r, ep.add_scale, sum);
     }
     if (ep.row_scale) {
         const float rs = ep.row_scale[dst];
         r.x *= rs; r.y *= rs; r.z *= rs; r.w *= rs;
     }
-    *reinterpret_cast<float4 *>(y + dst * ldy + 4 * lane) = r;
+    *reinterpret_cast<float4 *>(y + dst * ldy + 4 * t) = r;
 }
 
 // Any d (not a multiple of 4, or misaligned leading dimensions): one wave per
@@ -231,7 +248,7 @@ __global__ void csr_row_pow_kernel(const int64_t *__restrict__ rowptr, const flo
 struct SpmmTuning { int blocks_per_cu; int seg_first; };
 static const SpmmTuning &tuning() {
     static SpmmTuning t = [] {
-        SpmmTuning v{8, 1};
+        SpmmTuning v{8, 0};
         if (const char *e = getenv("IGCN_SPMM_BLOCKS_PER_CU")) { int x = atoi(e); if (x >= 1 && x <= 64) v.blocks_per_cu = x; }
         if (const char *e = getenv("IGCN_SPMM_SEG_FIRST")) v.seg_first = atoi(e) != 0;
         return v;

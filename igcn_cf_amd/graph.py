@@ -16,8 +16,8 @@ import torch
 
 from . import _lib
 
-LONG_THRESHOLD = 1024      # rows with more nonzeros are cut into segments
-SEGMENT_LEN = 512
+LONG_THRESHOLD = 256       # rows with more nonzeros are cut into segments (tuned on MI355X, profiles/)
+SEGMENT_LEN = 256
 
 
 def coo_to_csr_host(row, col, val, shape):

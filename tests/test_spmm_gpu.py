@@ -60,7 +60,7 @@ def test_spmm_long_rows_segments(d):
     rowptr, col, val = _random_csr(rng, n_rows, n_cols, degs)
     x = rng.standard_normal((n_cols, d)).astype(np.float32)
     xt = torch.from_numpy(x).cuda()
-    csr = CsrMatrix(rowptr, col, val, (n_rows, n_cols), 'cuda')
+    csr = CsrMatrix(rowptr, col, val, (n_rows, n_cols), 'cuda', long_threshold=1024, segment_len=512)
     assert csr.n_long == 3 and csr.n_segments == 10 + 3 + 4
     ref = _oracle(rowptr, col, val, x, n_rows)
     y = spmm(csr, xt).cpu().numpy()
