@@ -62,9 +62,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     import torch.distributed as dist
-    if world > 1:
+    sharded = world > 1 or os.environ.get('IGCN_FORCE_DIST') == '1'     # the latter: RCCL smoke of the sharded path at P=1
+    if world > 1 or sharded:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     from igcn_cf_amd.dataset import SyntheticDataset
     from igcn_cf_amd.graph import CsrMatrix, normalized_adjacency_host
@@ -82,11 +84,11 @@ def main():
     emb_host = torch.randn(n, d, generator=gen) * 0.1                    # normal_(std=0.1), model.py:82
 
     def barrier_sync():
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world == 1:
+    if not sharded:
         csr = CsrMatrix(rowptr, col, val, (n, n), device)
         x0 = emb_host.to(device)
         step = lambda: ops.propagate_mean(csr, x0, K)
@@ -116,7 +118,7 @@ def main():
     barrier_sync()
     wall = time.perf_counter() - t0
     dev_ms = e0.elapsed_time(e1)
-    if world > 1:
+    if sharded:
         t = torch.tensor([wall], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
@@ -130,11 +132,11 @@ def main():
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'LightGCN %d-layer d=%d propagation on synthetic %s-like x%d (users=%d items=%d nnz(A_hat)=%d)'
                                % (K, d, args.preset, world, ds.n_users, ds.n_items, nnz),
-                   'parallelism': 'single GPU' if world == 1 else 'row-sharded x%d + RCCL all-gather per half-layer' % world},
+                   'parallelism': 'single GPU' if not sharded else 'row-sharded x%d + RCCL all-gather per half-layer' % world},
     }
 
     # ---- roofline of the dominant kernel (per launch, this rank) ----------------------------------
-    if world == 1:
+    if not sharded:
         b_alg = nnz * (8 + 4 * d) + n * (4 * d + 4)
         b_min = nnz * 8 + n * (8 * d + 4)
         ms_launch = dev_ms / (args.steps * launches_per_step)
@@ -154,16 +156,16 @@ def main():
                                    'bytes/s may exceed the HBM peak; traffic = PMC-measured HBM bytes per launch'}
 
     extras = {}
-    if world == 1 and not args.no_extras:
+    if not sharded and not args.no_extras:
         extras = side_measurements(ds, device, d, K)
     out['extras'] = extras
 
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+    if not sharded and rank == 0 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(rowptr, col, val, emb_host.numpy(), K, nnz, ds.n_users)
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -111,7 +111,7 @@ class RowShardedPropagator:
         return buf[:L.pu] if part == 'u' else buf[L.pu:]
 
     def _allgather(self, buf, part):
-        if self.world == 1:
+        if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
             return None
         return dist.all_gather_into_tensor(self._section(buf, part), self._slot(buf, part), group=self.group,
                                            async_op=True)
@@ -172,7 +172,7 @@ class RowShardedPropagator:
         d = rep_u.shape[1]
         full_u = torch.empty((L.pu, d), dtype=torch.float32, device=self.device)
         full_i = torch.empty((L.pi, d), dtype=torch.float32, device=self.device)
-        if self.world == 1:
+        if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
             full_u.copy_(rep_u); full_i.copy_(rep_i)
         else:
             dist.all_gather_into_tensor(full_u, rep_u.contiguous(), group=self.group)

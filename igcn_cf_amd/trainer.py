@@ -116,7 +116,10 @@ class BasicTrainer:
 
     def initialize_optimizer(self):
         opt = getattr(sys.modules[__name__], self.config['optimizer'])
-        self.opt = opt(self.model.parameters(), lr=self.config['lr'])
+        kw = {}
+        if opt is Adam and self.config.get('fused_optimizer', True):
+            kw['fused'] = True             # same update rule, one kernel over all parameters
+        self.opt = opt(self.model.parameters(), lr=self.config['lr'], **kw)
 
     def train_one_epoch(self):
         raise NotImplementedError
