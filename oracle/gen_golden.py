@@ -75,9 +75,11 @@ class RecordingModel(torch.nn.Module):
         self.trainable = True
         self.n_users, self.n_items = n_users, n_items
         self.rep = torch.nn.Parameter(torch.randn(n_users + n_items, d, generator=g) * 0.3)
-        self.scores = torch.randn(n_users, n_items, generator=g)
-        # a few exact ties to exercise tie handling downstream
-        self.scores[1, 4] = self.scores[1, 2]
+        # scores are a rank-16 product so that a kernel can reproduce them from the factors
+        self.score_u = torch.randn(n_users, 16, generator=g)
+        self.score_i = torch.randn(n_items, 16, generator=g)
+        self.score_i[4] = self.score_i[2]                 # exact ties (two identical items)
+        self.scores = (self.score_u.double() @ self.score_i.double().t()).float()
         self.calls = []
         if template:
             self.embedding = torch.nn.Embedding(n_users + n_items + 2, d)
@@ -159,6 +161,7 @@ def main():
         with quiet:
             tr = ref_trainer.BasicTrainer(cfg)
         g['eval_scores'] = model.scores.numpy()
+        g['eval_score_u'], g['eval_score_i'] = model.score_u.numpy(), model.score_i.numpy()
         g['eval_topks'] = np.array(cfg['topks'])
         rec = {}
         orig = tr.calculate_metrics
@@ -176,6 +179,26 @@ def main():
                 for k in metrics[m]:
                     g['eval_%s_%s_%d' % (tag, m, k)] = np.float64(metrics[m][k])
         g['eval_banned'] = banned
+
+        # BasicTrainer.inductive_eval: the six masked evaluations (trainer.py:179-219)
+        seq = []
+
+        def spy2(eval_data, rec_items, _seq=seq):
+            m = orig(eval_data, rec_items)
+            _seq.append((rec_items.copy(), m))
+            return m
+        tr.calculate_metrics = spy2
+        n_old_users, n_old_items = (2 * ds.n_users) // 3, (2 * ds.n_items) // 3
+        with quiet:
+            tr.inductive_eval(n_old_users, n_old_items)
+        assert len(seq) == 6
+        g['ind_n_old'] = np.array([n_old_users, n_old_items])
+        for j, (rec_j, m_j) in enumerate(seq):
+            g['ind_%d_rec' % j] = rec_j
+            for m in m_j:
+                for k in m_j[m]:
+                    g['ind_%d_%s_%d' % (j, m, k)] = np.float64(m_j[m][k])
+        tr.calculate_metrics = orig
 
         # calculate_metrics on hand-made inputs (k > |eval|, empty eval lists)
         rng = np.random.RandomState(3)

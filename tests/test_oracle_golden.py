@@ -79,6 +79,10 @@ def test_sampler_semantics(golden):
         assert train[u] and p in train[u] and n not in train[u] and 0 <= n < n_items
 
 
+def uniq_all(s, picks):
+    return all(np.sum(s == v) == 1 for v in s[picks])
+
+
 def _excl(train, val, stage):
     if stage == 'train':
         return None
@@ -105,14 +109,14 @@ def test_eval_topk_and_metrics(golden):
                 s[ban] = -np.inf
             np.testing.assert_array_equal(s[rec[u]], s[ref[u]])          # same score sequence
             finite = np.isfinite(s[ref[u]])
-            all_finite &= bool(finite.all())
+            all_finite &= bool(finite.all()) and bool(uniq_all(s, ref[u]))
             uniq = np.array([np.sum(s == v) == 1 for v in s[ref[u]]])
             np.testing.assert_array_equal(rec[u][finite & uniq], ref[u][finite & uniq])
         m = O.calculate_metrics(data[stage], ref, topks)
         for name in m:
             for k in m[name]:
                 assert m[name][k] == golden['eval_%s_%s_%d' % (tag, name, k)]
-        if not all_finite:      # -inf ties inside the top-k: torch.topk's pick among them is arbitrary
+        if not all_finite:      # ties / -inf fill-ins inside the top-k: torch.topk's pick among them is arbitrary
             continue
         m2 = O.calculate_metrics(data[stage], rec, topks)
         for name in m2:

@@ -99,20 +99,40 @@ def test_score_topk_random_floats_match_sets():
     assert bad <= 2
 
 
+def _golden_masked_scores(golden, ex, ban):
+    s = np.array(golden['eval_scores'], dtype=np.float32, copy=True)
+    if ex is not None:
+        for u, items in enumerate(ex):
+            if len(items):
+                s[u, np.asarray(items, dtype=np.int64)] = -np.inf
+    if ban is not None:
+        s[:, ban] = -np.inf
+    return s
+
+
+def _assert_same_ranking(idx, val, ref, s):
+    """Kernel picks vs the reference's picks on masked scores `s`: identical ids wherever the
+    reference's choice is not a tie / -inf fill-in / within fp32 rounding of its neighbours."""
+    for u in range(ref.shape[0]):
+        np.testing.assert_allclose(val[u], s[u][ref[u]], rtol=2e-6, atol=2e-6)
+        fin = np.isfinite(s[u])
+        for j in range(ref.shape[1]):
+            v = s[u, ref[u, j]]
+            if not np.isfinite(v):
+                continue
+            near = np.sum(np.abs(s[u][fin] - v) <= 2e-5 * max(1., abs(v)))
+            if near == 1:
+                assert idx[u, j] == ref[u, j], (u, j)
+
+
 def test_eval_golden_topk(golden):
-    """Reference BasicTrainer.eval outputs (trainer.py:140-164) on the golden score matrix:
-    the fused kernel must reproduce the recommended ids wherever the reference's pick is
-    not an arbitrary tie / -inf fill-in."""
+    """Reference BasicTrainer.eval outputs (trainer.py:140-164): the score matrix the reference
+    ranked is a rank-16 product whose factors are in the fixture; the fused kernel gets the
+    factors and must reproduce the recommended ids."""
     from igcn_cf_amd.ops import score_topk
     lists = _lists(golden)
-    scores = golden['eval_scores']                      # [U, I]
-    n_users, n_items = scores.shape
-    # realise the score matrix as U = scores (d = n_items padded to a multiple of 4), I = identity
-    d = (n_items + 3) // 4 * 4
-    if d > 128:
-        pytest.skip('toy_b scores need d > 128 as an identity product; covered by toy_a and the dense tests')
-    U = np.zeros((n_users, d), dtype=np.float32); U[:, :n_items] = scores
-    I = np.zeros((n_items, d), dtype=np.float32); I[np.arange(n_items), np.arange(n_items)] = 1.
+    U, I = _dev(golden['eval_score_u']), _dev(golden['eval_score_i'])
+    n_items = I.shape[0]
     k = int(max(golden['eval_topks']))
     for tag, stage, ban in (('train', 'train', None), ('val', 'val', None), ('test', 'test', None),
                             ('testban', 'test', golden['eval_banned'])):
@@ -124,18 +144,65 @@ def test_eval_golden_topk(golden):
         if ban is not None:
             bm = np.zeros(n_items, dtype=np.uint8); bm[ban] = 1
             kw['banned'] = _dev(bm)
-        idx, val = score_topk(_dev(U), _dev(I), k, **kw)
-        idx, val = idx.cpu().numpy(), val.cpu().numpy()
-        ref = golden['eval_%s_rec' % tag]
-        for u in range(n_users):
-            s = scores[u].copy()
-            if ex is not None and len(ex[u]):
-                s[np.asarray(ex[u])] = -np.inf
-            if ban is not None:
-                s[ban] = -np.inf
-            np.testing.assert_array_equal(val[u], s[ref[u]])
-            uniq = np.array([np.isfinite(v) and np.sum(s == v) == 1 for v in s[ref[u]]])
-            np.testing.assert_array_equal(idx[u][uniq], ref[u][uniq])
+        idx, val = score_topk(U, I, k, **kw)
+        _assert_same_ranking(idx.cpu().numpy(), val.cpu().numpy(), golden['eval_%s_rec' % tag],
+                             _golden_masked_scores(golden, ex, ban))
+
+
+class _FactorModel:
+    """Scores = U . I^T from fixed factors, through the fused kernel (model.recommend contract)."""
+
+    def __init__(self, U, I):
+        self.U, self.I = U, I
+
+    def eval(self):
+        pass
+
+    def recommend(self, users, k, excl_rowptr=None, excl_col=None, banned=None):
+        from igcn_cf_amd.ops import score_topk
+        return score_topk(self.U, self.I, k, user_ids=users, excl_rowptr=excl_rowptr, excl_col=excl_col, banned=banned)[0]
+
+
+def test_inductive_eval_golden(golden, capsys):
+    """The six masked evaluations of the reference's BasicTrainer.inductive_eval
+    (trainer.py:179-219) on the same split and score factors: same metrics."""
+    from igcn_cf_amd.dataset import get_dataset
+    from igcn_cf_amd.trainer import BasicTrainer
+    ds = get_dataset({'name': 'ProcessedDataset', 'path': golden['path'], 'device': 'cuda'})
+    topks = [int(k) for k in golden['eval_topks']]
+    model = _FactorModel(_dev(golden['eval_score_u']), _dev(golden['eval_score_i']))
+    tr = BasicTrainer({'name': 'BasicTrainer', 'dataset': ds, 'model': model, 'topks': topks, 'device': 'cuda',
+                       'n_epochs': 0, 'test_batch_size': 7})
+    got = []
+    orig = tr.eval
+
+    def spy(stage, banned_items=None):
+        res = orig(stage, banned_items=banned_items)
+        got.append((tr.last_rec_items.cpu().numpy(), res[1], [list(x) for x in ds.test_data]))
+        return res
+    tr.eval = spy
+    test_before = [list(x) for x in ds.test_data]
+    n_old_users, n_old_items = (int(v) for v in golden['ind_n_old'])
+    tr.inductive_eval(n_old_users, n_old_items)
+    assert len(got) == 6 and [list(x) for x in ds.test_data] == test_before      # test lists restored
+    assert 'Old users and old items result.' in capsys.readouterr().out
+    lists = _lists(golden)
+    ex, _, _ = _excl_csr(lists, 'test')
+    n_items = ds.n_items
+    bans = [None, None, None, np.arange(n_old_items, n_items), np.arange(n_old_items), np.arange(n_old_items, n_items)]
+    for j, (rec, metrics, eval_lists) in enumerate(got):
+        ref = golden['ind_%d_rec' % j]
+        s = _golden_masked_scores(golden, ex, bans[j])
+        _assert_same_ranking(rec, np.take_along_axis(s, rec, axis=1), ref, s)
+        # same masked test lists + the reference's own picks -> the reference's metrics, bit for bit
+        # (ties inside a top-k are the only freedom between `rec` and `ref`)
+        m = tr.calculate_metrics(eval_lists, ref)
+        for name in m:
+            for k in m[name]:
+                refv = float(golden['ind_%d_%s_%d' % (j, name, k)])
+                assert m[name][k] == refv or (np.isnan(refv) and np.isnan(m[name][k])), (j, name, k)
+                if np.array_equal(rec, ref):
+                    assert metrics[name][k] == refv or np.isnan(refv)
 
 
 def test_hit_matrix_and_metrics_golden(golden):
