@@ -9,27 +9,36 @@
 //
 // This is the one dense contraction of the path, so it runs on the matrix
 // cores, in exact fp32: v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain, no
-// reduced-precision shortcut).  Layout of one workgroup (WAVES x 64 lanes):
-//   * every wave owns 32 users for the whole item sweep; their embeddings are
-//     the MFMA B operand and stay in D/2 VGPRs per lane;
-//   * items stream through LDS in tiles of 64 rows (register-staged, double
-//     buffered, rows padded by 16 B so the ds_read_b128 fragment reads are
-//     bank-conflict free); each wave multiplies two 32x32xD sub-tiles per tile;
+// reduced-precision shortcut).  The fp32 MFMA is slow enough (64 cycles each,
+// 2048 cycles per 32x32xd=64 tile) that operand traffic is negligible; what
+// decides the speed is keeping every SIMD's matrix pipe busy.  Hence:
+//   * one WAVE = one workgroup = 32 users for a whole item sweep: no LDS staging,
+//     no barriers, nothing shared between waves.  The users' embeddings are the
+//     MFMA B operand and stay in d/2 VGPRs per lane; the item rows (A operand)
+//     are read straight from L2/Infinity Cache, the two lanes of a row taking
+//     adjacent 16-byte pieces so that a load instruction touches 32 lines;
+//   * <=128 VGPRs and k*512 B of LDS per wave, so 4 waves share a SIMD and cover
+//     each other's loads and top-k bookkeeping with their MFMA chains; the waves
+//     of a SIMD take different static priorities (by hardware wave slot) so that
+//     they fall out of lock-step instead of all multiplying, then all selecting;
+//   * the grid is sized so that ALL waves are resident at once and every SIMD
+//     gets the same amount of MFMA work: G = ceil(B/32) user groups over S SIMDs;
+//     floor(G/S)*S groups are swept by one wave each, the remaining groups are
+//     cut into item-range parts (one wave per part) that fill the last wave slot
+//     of every SIMD; parts write partial lists that a small kernel merges;
 //   * the product is computed as S^T = I . U^T, so in the accumulator a lane
 //     holds 16 item scores of ONE user (column = lane&31): the running top-k of
 //     a user is private to a lane pair, no cross-lane traffic in the sweep;
 //   * masking is exact and in-register: each lane walks its user's sorted
-//     exclusion list with a cursor as the item sweep advances; banned items
-//     arrive as a 0/-inf bias staged with the tile;
+//     exclusion list with a cursor as the item sweep advances; banned items are
+//     read as bytes per accumulator row;
 //   * top-k: one compare of the tile maximum against the user's current k-th
 //     best decides whether anything can enter.  Entries are 64-bit sortable keys
 //     (order-preserving image of the fp32 score << 32 | ~item id), kept per lane
 //     as a k-slot binary min-heap in LDS ([slot][lane]: lane l always hits its own
 //     bank pair); a rare insert replaces the root and sifts down, O(log k).  The
 //     wave handles "the first remaining candidate of every lane" per pass, so a
-//     tile costs about one pass however its candidates are spread over lanes;
-//   * when the batch has too few 32-user groups to fill 256 CUs, the item range
-//     is split across workgroups and a small kernel merges the partial lists.
+//     tile costs about one pass however its candidates are spread over lanes.
 // Ties are broken towards the lower item id (torch.topk leaves them unspecified).
 #include <math.h>
 #include <stdlib.h>
@@ -39,45 +48,55 @@ namespace igcn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kTileItems = 64;            // items per staged tile
 constexpr int kIdxNone = 0x7fffffff;
 
 struct TopkPlan {
-    int waves;               // waves per workgroup (32 users each)
     int d_pad;               // 16 / 32 / 64 / 128
-    int n_splits;            // item-range splits
-    int64_t items_per_split; // multiple of kTileItems
-    int64_t user_tiles;
+    int64_t groups;          // 32-user groups
+    int64_t n_full;          // groups swept by a single wave (parts == 1 for them)
+    int parts;               // item-range parts of the remaining groups (1 = none split)
+    int64_t items_per_part;  // multiple of 32
+    int64_t units;           // waves launched
     size_t lds_bytes;
 };
-
-static inline size_t topk_lds_bytes(int waves, int d_pad, int k) {
-    return (size_t)2 * kTileItems * (d_pad + 4) * 4 + (size_t)2 * kTileItems * 4 + (size_t)waves * k * kWave * 8;
-}
 
 static inline int topk_make_plan(int64_t batch, int64_t n_items, int32_t d, int32_t k, TopkPlan *p) {
     if (batch < 1 || n_items < 1) return IGCN_E_SHAPE;
     if (d < 4 || d > 128 || d % 4 != 0) return IGCN_E_SHAPE;
     if (k < 1 || k > IGCN_MAX_TOPK || k > n_items) return IGCN_E_RANGE;
     p->d_pad = d <= 16 ? 16 : d <= 32 ? 32 : d <= 64 ? 64 : 128;
-    p->waves = topk_lds_bytes(4, p->d_pad, k) <= 160 * 1024 ? 4 : 2;  // <= 80 KiB gives two workgroups per CU
-    if (topk_lds_bytes(p->waves, p->d_pad, k) > 160 * 1024) return IGCN_E_RANGE;
-    p->lds_bytes = topk_lds_bytes(p->waves, p->d_pad, k);
-    const int64_t users_per_wg = 32 * p->waves;
-    p->user_tiles = (batch + users_per_wg - 1) / users_per_wg;
-    // Item-range splits only when the user tiles alone cannot fill the chip (2 workgroups per CU):
-    // every split keeps its own k-entry lists, so splitting multiplies the insert work.
-    const int64_t slots = (int64_t)cu_count() * 2;
-    int64_t splits = p->user_tiles >= slots ? 1 : (2 * slots + p->user_tiles - 1) / p->user_tiles;
-    if (const char *e = getenv("IGCN_TOPK_SPLITS")) { int x = atoi(e); if (x >= 1) splits = x; }   // developer knob
-    const int64_t max_by_items = n_items / 4096 > 1 ? n_items / 4096 : 1;
-    if (splits > max_by_items) splits = max_by_items;
-    if (splits > 64) splits = 64;
-    if (splits < 1) splits = 1;
-    int64_t per = (n_items + splits - 1) / splits;
-    per = (per + kTileItems - 1) / kTileItems * kTileItems;
-    p->items_per_split = per;
-    p->n_splits = (int)((n_items + per - 1) / per);
+    p->lds_bytes = (size_t)k * kWave * 8;
+    p->groups = (batch + 31) / 32;
+    const int64_t simds = (int64_t)cu_count() * 4;
+    // waves that can be resident per CU: 4 (3 for d > 64) per SIMD by registers, 160 KiB / lds by LDS
+    int64_t per_cu = (160 * 1024) / (int64_t)p->lds_bytes;
+    const int64_t by_regs = p->d_pad <= 64 ? 16 : 12;        // 104 / 162 VGPRs (hipcc, gfx950)
+    if (per_cu > by_regs) per_cu = by_regs;
+    if (per_cu < 1) return IGCN_E_RANGE;
+    const int64_t slots = per_cu * cu_count();
+    int64_t n_full, parts;
+    if (p->groups >= simds) {
+        // every SIMD gets floor(G/S) whole sweeps; the rest is cut so that each SIMD gets one part more
+        n_full = (p->groups / simds) * simds;
+        const int64_t rest = p->groups - n_full;
+        parts = rest == 0 ? 1 : (simds + rest - 1) / rest;
+        if (rest * 10 > simds * 9) { parts = 1; }              // nearly a whole extra round anyway
+    } else {
+        n_full = 0;                                            // small batch: split every group to fill the chip
+        parts = (slots + p->groups - 1) / p->groups;
+    }
+    const int64_t max_by_items = n_items / 1024 > 1 ? n_items / 1024 : 1;
+    if (parts > max_by_items) parts = max_by_items;
+    if (parts > 64) parts = 64;
+    if (const char *e = getenv("IGCN_TOPK_PARTS")) { int x = atoi(e); if (x >= 1 && x <= 64) parts = x; }   // developer knob
+    if (parts <= 1) { parts = 1; n_full = p->groups; }
+    int64_t per = (n_items + parts - 1) / parts;
+    per = (per + 31) / 32 * 32;
+    p->parts = (int)((n_items + per - 1) / per);
+    if (p->parts <= 1) { p->parts = 1; n_full = p->groups; }
+    p->items_per_part = per;
+    p->n_full = n_full;
+    p->units = n_full + (p->groups - n_full) * p->parts;
     return IGCN_OK;
 }
 
@@ -99,200 +118,183 @@ __device__ __forceinline__ int key_item(unsigned long long key) { return (int)~(
 // (v, i) ranks before (w, j): higher score first, then lower item id
 __device__ __forceinline__ bool ranks_before(float v, int i, float w, int j) { return v > w || (v == w && i < j); }
 
-template <int D, int WAVES>
-__global__ __launch_bounds__(WAVES * kWave) void score_topk_kernel(
+// Static issue priority from the hardware wave slot: the 3-4 waves of a SIMD get different
+// priorities, so one of them always wins the matrix pipe and the others fill in behind it.
+__device__ __forceinline__ void set_priority_by_wave_slot() {
+    // s_getreg_b32 HW_REG_HW_ID (id 4), WAVE_ID = bits [3:0]: simm16 = (size-1) << 11 | offset << 6 | id
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3u;
+    if (slot == 0) __builtin_amdgcn_s_setprio(0);
+    else if (slot == 1) __builtin_amdgcn_s_setprio(1);
+    else if (slot == 2) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(3);
+}
+
+template <int D>
+__global__ __launch_bounds__(kWave, (D <= 64 ? 4 : 2)) void score_topk_kernel(
     const float *__restrict__ user_rows, int64_t ldu, const int64_t *__restrict__ user_ids, int64_t batch,
     const float *__restrict__ item_rows, int64_t ldi, int64_t n_items, int d,
     const int64_t *__restrict__ excl_rowptr, const int32_t *__restrict__ excl_col, const uint8_t *__restrict__ banned,
-    int k, int n_splits, int64_t items_per_split,
+    int k, int64_t n_full, int parts, int64_t items_per_part, int stagger,
     int64_t *__restrict__ out_idx, float *__restrict__ out_val, float *__restrict__ ws_val, int32_t *__restrict__ ws_idx)
 {
-    constexpr int BLOCK = WAVES * kWave;
-    constexpr int STRIDE = D + 4;                            // floats per LDS item row (16 B pad)
-    constexpr int NLOAD = kTileItems * (D / 4) / BLOCK;      // float4 per thread per tile
-    static_assert(NLOAD >= 1 && kTileItems * (D / 4) % BLOCK == 0, "tile must divide over the block");
-
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *s_items = reinterpret_cast<float *>(smem);                   // [2][64][STRIDE]
-    float *s_bias = s_items + 2 * kTileItems * STRIDE;                  // [2][64]
-    unsigned long long *s_heap = reinterpret_cast<unsigned long long *>(s_bias + 2 * kTileItems);   // [WAVES][k][64]
+    unsigned long long *heap = reinterpret_cast<unsigned long long *>(smem) + threadIdx.x;     // [k][64]
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (stagger) set_priority_by_wave_slot();
+    const int lane = threadIdx.x;
     const int j = lane & 31, h = lane >> 5;
-    const int64_t ut = blockIdx.x / n_splits;
-    const int sp = (int)(blockIdx.x % n_splits);
-    const int64_t item_lo = (int64_t)sp * items_per_split;
-    const int64_t item_hi = item_lo + items_per_split < n_items ? item_lo + items_per_split : n_items;
-    const int64_t b = ut * (32 * WAVES) + wid * 32 + j;
+    // unit -> (user group, item part)
+    int64_t group;
+    int part = 0, my_parts = 1;
+    if ((int64_t)blockIdx.x < n_full) {
+        group = blockIdx.x;
+    } else {
+        const int64_t v = (int64_t)blockIdx.x - n_full;
+        group = n_full + v / parts;
+        part = (int)(v % parts);
+        my_parts = parts;
+    }
+    const int item_lo = my_parts == 1 ? 0 : (int)(part * items_per_part);
+    const int item_hi = my_parts == 1 ? (int)n_items : (int)(item_lo + items_per_part < n_items ? item_lo + items_per_part : n_items);
+    const int64_t b = group * 32 + j;
     const bool user_ok = b < batch;
     const int64_t uid = user_ok ? (user_ids ? user_ids[b] : b) : 0;
 
-    // B operand: this lane's user, k-slice [h*D/2, (h+1)*D/2); MFMA step s uses k = h*D/2 + s
+    // B operand: this lane's user.  Lane half h supplies k = 8q + 4h + c (q < D/8, c < 4): the two
+    // lanes of a row read adjacent 16-B pieces, so one load instruction touches 32 lines, not 64.
     float bfrag[D / 2];
 #pragma unroll
     for (int q = 0; q < D / 8; ++q) {
         float4 v = f4_zero();
-        const int e = h * (D / 2) + 4 * q;
+        const int e = 8 * q + 4 * h;
         if (user_ok && e < d) v = *reinterpret_cast<const float4 *>(user_rows + uid * ldu + e);
         bfrag[4 * q + 0] = v.x; bfrag[4 * q + 1] = v.y; bfrag[4 * q + 2] = v.z; bfrag[4 * q + 3] = v.w;
     }
 
-    // exclusion cursor: first excluded item >= item_lo
-    int64_t ex_pos = 0, ex_end = 0;
-    int ex_next = kIdxNone;
+    // exclusion cursor: first excluded item >= item_lo (this user's list as a pointer + 32-bit cursor)
+    const int32_t *ex_ptr = excl_col;
+    int ex_pos = 0, ex_end = 0, ex_next = kIdxNone;
     if (excl_rowptr && user_ok) {
-        int64_t lo = excl_rowptr[uid];
-        ex_end = excl_rowptr[uid + 1];
-        int64_t hi = ex_end;
+        const int64_t r0 = excl_rowptr[uid];
+        ex_ptr = excl_col + r0;
+        ex_end = (int)(excl_rowptr[uid + 1] - r0);
+        int lo = 0, hi = ex_end;
         while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (excl_col[mid] < item_lo) lo = mid + 1; else hi = mid;
+            const int mid = (lo + hi) >> 1;
+            if (ex_ptr[mid] < item_lo) lo = mid + 1; else hi = mid;
         }
         ex_pos = lo;
-        if (ex_pos < ex_end) ex_next = excl_col[ex_pos];
+        if (ex_pos < ex_end) ex_next = ex_ptr[ex_pos];
     }
 
     // running top-k: per-lane min-heap of sortable keys in LDS; root (= k-th best so far) in registers.
     // Key 0 = empty slot: ranks below every real entry, masked (-inf) ones included.
-    unsigned long long *heap = s_heap + (wid * k) * kWave + lane;
     for (int s = 0; s < k; ++s) heap[s * kWave] = 0ull;
     unsigned long long root = 0ull;
     float thr = -INFINITY;                                   // score part of the root
 
-    const int64_t n_tiles = (item_hi - item_lo + kTileItems - 1) / kTileItems;
-    float4 st[NLOAD];
-    float st_bias = 0.f;
-
-    auto stage_load = [&](int64_t t) {
+    for (int tile_base = item_lo; tile_base < item_hi; tile_base += 32) {
+        // A operand: item row (clamped at the ragged end, masked below), k-slice of this lane half
+        int arow_i = tile_base + j;
+        if (arow_i >= item_hi) arow_i = item_hi - 1;
+        const float *arow = item_rows + (int64_t)arow_i * ldi + 4 * h;
+        float4 a[D / 8];
 #pragma unroll
-        for (int i = 0; i < NLOAD; ++i) {
-            const int idx = tid + i * BLOCK;
-            const int row = idx / (D / 4), c4 = idx % (D / 4);
-            const int64_t item = item_lo + t * kTileItems + row;
-            st[i] = (item < item_hi && 4 * c4 < d) ? *reinterpret_cast<const float4 *>(item_rows + item * ldi + 4 * c4)
-                                                    : f4_zero();
+        for (int q = 0; q < D / 8; ++q)
+            a[q] = (8 * q + 4 * h < d) ? *reinterpret_cast<const float4 *>(arow + 8 * q) : f4_zero();
+
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < D / 8; ++q) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bfrag[4 * q + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bfrag[4 * q + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bfrag[4 * q + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bfrag[4 * q + 3], acc, 0, 0, 0);
         }
-        if (banned && tid < kTileItems) {
-            const int64_t item = item_lo + t * kTileItems + tid;
-            st_bias = (item < item_hi && banned[item]) ? -INFINITY : 0.f;
+
+        // --- masking -------------------------------------------------------------
+        if (tile_base + 32 > item_hi) {                        // ragged last tile (wave-uniform)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (tile_base + row_of(r, h) >= item_hi) acc[r] = -INFINITY;
         }
-    };
-    auto stage_store = [&](int buf) {
+        if (banned) {
 #pragma unroll
-        for (int i = 0; i < NLOAD; ++i) {
-            const int idx = tid + i * BLOCK;
-            const int row = idx / (D / 4), c4 = idx % (D / 4);
-            *reinterpret_cast<float4 *>(s_items + (buf * kTileItems + row) * STRIDE + 4 * c4) = st[i];
-        }
-        if (banned && tid < kTileItems) s_bias[buf * kTileItems + tid] = st_bias;
-    };
-
-    stage_load(0);
-    stage_store(0);
-    __syncthreads();
-
-    for (int64_t t = 0; t < n_tiles; ++t) {
-        const int buf = (int)(t & 1);
-        if (t + 1 < n_tiles) stage_load(t + 1);
-
+            for (int g = 0; g < 4; ++g) {
 #pragma unroll
-        for (int sub = 0; sub < kTileItems / 32; ++sub) {
-            const int64_t tile_base64 = item_lo + t * kTileItems + sub * 32;
-            if (tile_base64 >= item_hi) continue;                  // workgroup-uniform
-            const int tile_base = (int)tile_base64;
-
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            const float *arow = s_items + (buf * kTileItems + sub * 32 + j) * STRIDE + h * (D / 2);
-#pragma unroll
-            for (int q = 0; q < D / 8; ++q) {
-                const float4 a = *reinterpret_cast<const float4 *>(arow + 4 * q);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bfrag[4 * q + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bfrag[4 * q + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bfrag[4 * q + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bfrag[4 * q + 3], acc, 0, 0, 0);
-            }
-
-            // --- masking -------------------------------------------------------------
-            if (tile_base64 + 32 > item_hi) {                      // ragged last tile
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (tile_base64 + row_of(r, h) >= item_hi) acc[r] = -INFINITY;
-            }
-            if (banned) {
-                const float *bias = s_bias + buf * kTileItems + sub * 32 + 4 * h;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 bv = *reinterpret_cast<const float4 *>(bias + 8 * g);
-                    acc[4 * g + 0] += bv.x; acc[4 * g + 1] += bv.y; acc[4 * g + 2] += bv.z; acc[4 * g + 3] += bv.w;
+                for (int c = 0; c < 4; ++c) {
+                    const int it = tile_base + 8 * g + 4 * h + c;
+                    if (it < item_hi && banned[it]) acc[4 * g + c] = -INFINITY;
                 }
             }
-            if (excl_rowptr) {
-                const int tile_end = tile_base + 32;
-                while (true) {
-                    const bool need = ex_next < tile_end;
-                    if (!__any(need)) break;
-                    if (need) {
-                        const int rl = ex_next - tile_base;          // 0..31
-                        if (((rl >> 2) & 1) == h) {
-                            const int rr = (rl & 3) + 4 * (rl >> 3);
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[r] = (r == rr) ? -INFINITY : acc[r];
-                        }
-                        ++ex_pos;
-                        ex_next = ex_pos < ex_end ? excl_col[ex_pos] : kIdxNone;
-                    }
-                }
-            }
-
-            // --- top-k ---------------------------------------------------------------
+        }
+        if (excl_rowptr) {
+            const int tile_end = tile_base + 32;
             while (true) {
-                float m = acc[0];
+                const bool need = ex_next < tile_end;
+                if (!__any(need)) break;
+                if (need) {
+                    const int rl = ex_next - tile_base;          // 0..31
+                    if (((rl >> 2) & 1) == h) {
+                        const int rr = (rl & 3) + 4 * (rl >> 3);
 #pragma unroll
-                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-                if (!__any(m >= thr)) break;                         // nothing in this tile can enter any list
-                // first remaining candidate of this lane; examined scores become NaN (fmaxf skips NaN)
-                unsigned long long cand = 0ull;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float s = acc[r];
-                    if (cand == 0ull && s >= thr) {
-                        const unsigned long long kr = make_key(s, tile_base + row_of(r, h));
-                        if (kr > root) cand = kr;
-                        acc[r] = __uint_as_float(0x7fc00000u);       // examined: NaN is never >= thr again
+                        for (int r = 0; r < 16; ++r) acc[r] = (r == rr) ? -INFINITY : acc[r];
                     }
-                }
-                if (cand != 0ull) {
-                    // replace the root (worst entry) and sift down
-                    int i = 0;
-                    unsigned long long first_up = 0ull;
-                    while (true) {
-                        int c = 2 * i + 1;
-                        if (c >= k) break;
-                        unsigned long long kc = heap[c * kWave];
-                        if (c + 1 < k) {
-                            const unsigned long long k2 = heap[(c + 1) * kWave];
-                            if (k2 < kc) { kc = k2; ++c; }
-                        }
-                        if (kc >= cand) break;
-                        heap[i * kWave] = kc;
-                        if (i == 0) first_up = kc;
-                        i = c;
-                    }
-                    heap[i * kWave] = cand;
-                    root = i == 0 ? cand : first_up;
-                    thr = root ? key_score(root) : -INFINITY;    // heap not full yet: everything may enter
+                    ++ex_pos;
+                    ex_next = ex_pos < ex_end ? ex_ptr[ex_pos] : kIdxNone;
                 }
             }
         }
 
-        if (t + 1 < n_tiles) stage_store(buf ^ 1);
-        __syncthreads();
+        // --- top-k ---------------------------------------------------------------
+        while (true) {
+            float m = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+            if (!__any(m >= thr)) break;                         // nothing in this tile can enter any list
+            // first remaining candidate of this lane (float compare only); examined scores become
+            // NaN (fmaxf skips NaN, NaN >= thr is false)
+            float cs = 0.f;
+            int cr = -1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float s = acc[r];
+                const bool take = cr < 0 && s >= thr;
+                cs = take ? s : cs;
+                cr = take ? row_of(r, h) : cr;
+                acc[r] = take ? __uint_as_float(0x7fc00000u) : s;
+            }
+            const unsigned long long cand = cr >= 0 ? make_key(cs, tile_base + cr) : 0ull;
+            if (cand > root) {                                   // (a tie on the score may still lose on the id)
+                // replace the root (worst entry) and sift down
+                int i = 0;
+                unsigned long long first_up = 0ull;
+                while (true) {
+                    int c = 2 * i + 1;
+                    if (c >= k) break;
+                    unsigned long long kc = heap[c * kWave];
+                    if (c + 1 < k) {
+                        const unsigned long long k2 = heap[(c + 1) * kWave];
+                        if (k2 < kc) { kc = k2; ++c; }
+                    }
+                    if (kc >= cand) break;
+                    heap[i * kWave] = kc;
+                    if (i == 0) first_up = kc;
+                    i = c;
+                }
+                heap[i * kWave] = cand;
+                root = i == 0 ? cand : first_up;
+                thr = root ? key_score(root) : -INFINITY;    // heap not full yet: everything may enter
+            }
+        }
     }
 
-    // merge the two lanes of a user and emit best-first (k rounds of arg-max over 2k keys)
-    __syncthreads();
+    // merge the two lanes of a user and emit best-first (k rounds of arg-max over 2k keys).
+    // The heaps are private to this wave; a wave executes its LDS operations in order.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     if (h == 0 && user_ok) {
         unsigned long long *pheap = heap + 32;      // partner lane (l + 32), same wave
         for (int r = 0; r < k; ++r) {
@@ -306,12 +308,17 @@ __global__ __launch_bounds__(WAVES * kWave) void score_topk_kernel(
             if (bwho == 0) heap[bp * kWave] = 0ull; else pheap[bp * kWave] = 0ull;
             const float bv = best ? key_score(best) : -INFINITY;
             const int bi = best ? key_item(best) : kIdxNone;
-            if (n_splits == 1) {
+            if (parts == 1) {
                 out_idx[b * k + r] = bi == kIdxNone ? -1 : bi;
                 out_val[b * k + r] = bv;
             } else {
-                ws_val[(b * n_splits + sp) * k + r] = bv;
-                ws_idx[(b * n_splits + sp) * k + r] = bi;
+                ws_val[(b * parts + part) * k + r] = bv;
+                ws_idx[(b * parts + part) * k + r] = bi;
+                if (my_parts == 1)                               // whole sweep by one wave: other part slots are empty
+                    for (int pp = 1; pp < parts; ++pp) {
+                        ws_val[(b * parts + pp) * k + r] = -INFINITY;
+                        ws_idx[(b * parts + pp) * k + r] = kIdxNone;
+                    }
             }
         }
     }
@@ -365,26 +372,26 @@ __global__ void hit_matrix_kernel(const int64_t *__restrict__ rec, int64_t n_use
     hit[i] = (lo < eval_rowptr[u + 1] && eval_col[lo] == item) ? 1.f : 0.f;
 }
 
-template <int D, int WAVES>
+template <int D>
 static int launch_topk(const TopkPlan &p, hipStream_t st,
                        const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
                        const float *item_rows, int64_t ldi, int64_t n_items, int d,
                        const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned, int k,
                        int64_t *out_idx, float *out_val, float *ws_val, int32_t *ws_idx)
 {
-    auto kern = score_topk_kernel<D, WAVES>;
-    static size_t configured = 0;
-    if (p.lds_bytes > configured) {
+    auto kern = score_topk_kernel<D>;
+    static bool configured = false;
+    if (!configured && p.lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(160 * 1024));
+                                           (int)(64 * 1024));
         if (e != hipSuccess) return (int)e;
-        configured = 160 * 1024;
+        configured = true;
     }
-    const int64_t grid = p.user_tiles * p.n_splits;
-    if (grid >= ((int64_t)1 << 31)) return IGCN_E_SHAPE;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * kWave), p.lds_bytes, st, user_rows, ldu, user_ids, batch,
-                       item_rows, ldi, n_items, d, excl_rowptr, excl_col, banned, k, p.n_splits, p.items_per_split,
-                       out_idx, out_val, ws_val, ws_idx);
+    if (p.units >= ((int64_t)1 << 31)) return IGCN_E_SHAPE;
+    static const int stagger = [] { const char *e = getenv("IGCN_TOPK_STAGGER"); return e ? atoi(e) : 1; }();   // developer knob
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.units), dim3(kWave), p.lds_bytes, st, user_rows, ldu, user_ids, batch,
+                       item_rows, ldi, n_items, d, excl_rowptr, excl_col, banned, k, p.n_full, p.parts, p.items_per_part,
+                       stagger, out_idx, out_val, ws_val, ws_idx);
     return launch_status();
 }
 
@@ -396,7 +403,7 @@ extern "C" int64_t igcn_score_topk_workspace_bytes(int64_t batch, int64_t n_item
 {
     TopkPlan p;
     if (topk_make_plan(batch, n_items, d, k, &p) != IGCN_OK) return -1;
-    return p.n_splits > 1 ? (int64_t)batch * p.n_splits * k * 8 : 0;
+    return p.parts > 1 ? (int64_t)batch * p.parts * k * 8 : 0;
 }
 
 extern "C" int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
@@ -411,35 +418,26 @@ extern "C" int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const in
     if (rc != IGCN_OK) return rc;
     if (ldu < d || ldi < d || ldu % 4 || ldi % 4 || n_items >= ((int64_t)1 << 31) - 64) return IGCN_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(user_rows) | reinterpret_cast<uintptr_t>(item_rows)) % 16) return IGCN_E_ALIGN;
-    if (p.n_splits > 1 && !workspace) return IGCN_E_NULL;
+    if (p.parts > 1 && !workspace) return IGCN_E_NULL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     float *ws_val = static_cast<float *>(workspace);
-    int32_t *ws_idx = reinterpret_cast<int32_t *>(ws_val ? ws_val + (int64_t)batch * p.n_splits * k : nullptr);
+    int32_t *ws_idx = reinterpret_cast<int32_t *>(ws_val ? ws_val + (int64_t)batch * p.parts * k : nullptr);
 
-#define IGCN_TOPK_CASE(DD, WW)                                                                                        \
-    rc = launch_topk<DD, WW>(p, st, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, (int)d, excl_rowptr,    \
-                             excl_col, banned, (int)k, out_idx, out_val, ws_val, ws_idx)
-    if (p.waves == 4) {
-        switch (p.d_pad) {
-        case 16: IGCN_TOPK_CASE(16, 4); break;
-        case 32: IGCN_TOPK_CASE(32, 4); break;
-        case 64: IGCN_TOPK_CASE(64, 4); break;
-        default: IGCN_TOPK_CASE(128, 4); break;
-        }
-    } else {
-        switch (p.d_pad) {
-        case 16: IGCN_TOPK_CASE(16, 2); break;
-        case 32: IGCN_TOPK_CASE(32, 2); break;
-        case 64: IGCN_TOPK_CASE(64, 2); break;
-        default: IGCN_TOPK_CASE(128, 2); break;
-        }
+#define IGCN_TOPK_CASE(DD)                                                                                        \
+    rc = launch_topk<DD>(p, st, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, (int)d, excl_rowptr,    \
+                         excl_col, banned, (int)k, out_idx, out_val, ws_val, ws_idx)
+    switch (p.d_pad) {
+    case 16: IGCN_TOPK_CASE(16); break;
+    case 32: IGCN_TOPK_CASE(32); break;
+    case 64: IGCN_TOPK_CASE(64); break;
+    default: IGCN_TOPK_CASE(128); break;
     }
 #undef IGCN_TOPK_CASE
     if (rc != IGCN_OK) return rc;
-    if (p.n_splits > 1) {
+    if (p.parts > 1) {
         const int64_t blocks = (batch + 3) / 4;
         hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, ws_val, ws_idx, batch,
-                           p.n_splits, (int)k, out_idx, out_val);
+                           p.parts, (int)k, out_idx, out_val);
         rc = launch_status();
     }
     return rc;
