@@ -70,7 +70,7 @@ static inline int topk_make_plan(int64_t batch, int64_t n_items, int32_t d, int3
     const int64_t simds = (int64_t)cu_count() * 4;
     // waves that can be resident per CU: 4 (3 for d > 64) per SIMD by registers, 160 KiB / lds by LDS
     int64_t per_cu = (160 * 1024) / (int64_t)p->lds_bytes;
-    const int64_t by_regs = p->d_pad <= 64 ? 16 : 12;        // 104 / 162 VGPRs (hipcc, gfx950)
+    const int64_t by_regs = p->d_pad <= 64 ? 16 : 8;         // 114 / 179 VGPRs (hipcc, gfx950)
     if (per_cu > by_regs) per_cu = by_regs;
     if (per_cu < 1) return IGCN_E_RANGE;
     const int64_t slots = per_cu * cu_count();
