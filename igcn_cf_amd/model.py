@@ -55,6 +55,13 @@ class BasicModel(nn.Module):
     def predict(self, users):
         raise NotImplementedError
 
+    def train(self, mode=True):
+        # Every train()/eval() switch drops the cached eval-mode representation: fused optimizers
+        # update parameters without bumping tensor version counters, so the version in the cache
+        # key alone cannot be trusted across training steps.
+        self._rep_cache = None
+        return super().train(mode)
+
     def save(self, path):
         torch.save(self.state_dict(), path)
 

@@ -180,6 +180,18 @@ def test_mf_and_trainers_end_to_end(golden):
         assert np.isfinite(l0) and l1 < l0, (mcfg['name'], l0, l1)
         if mcfg['name'] in ('IGCN', 'IMF'):
             assert abs(model.alpha - 0.99 ** 5) < 1e-9
+        if mcfg['name'] == 'LightGCN':
+            # the eval-mode cache must see the trained weights (fused Adam does not bump version counters)
+            model.eval()
+            with torch.no_grad():
+                rep_before = model.get_rep().clone()
+            model.train(); trainer.train_one_epoch(); model.eval()
+            with torch.no_grad():
+                rep_after = model.get_rep()
+            assert not torch.equal(rep_before, rep_after)
+            adj = O.lightgcn_norm_adj(ds.train_array, ds.n_users, ds.n_items)
+            ref = O.lightgcn_get_rep(adj, model.embedding.weight.detach().cpu().numpy(), 3)
+            assert _rel(rep_after.cpu().numpy(), ref) < TOL
         for stage in ('val', 'test'):
             _, metrics = trainer.eval(stage)
             user_rows, item_rows = model.score_tables()
