@@ -178,3 +178,98 @@ class RowShardedPropagator:
             dist.all_gather_into_tensor(full_u, rep_u.contiguous(), group=self.group)
             dist.all_gather_into_tensor(full_i, rep_i.contiguous(), group=self.group)
         return torch.cat([full_u[:L.n_users], full_i[:L.n_items]], dim=0)
+
+
+# ---------------------------------------------------------------------------------------
+# Row-sharded LightGCN training: parameters, gradients and Adam state live on the owner rank.
+# ---------------------------------------------------------------------------------------
+class _ShardedPropagateFn(torch.autograd.Function):
+    """Owned rows of E  ->  owned rows of mean(X_0..X_K).  The operator is
+    P = mean_l A_hat^l with A_hat symmetric, so the backward pass is the same
+    sharded pass applied to the incoming gradient (P^T = P)."""
+
+    @staticmethod
+    def forward(ctx, e_u, e_i, prop):
+        ctx.prop = prop
+        prop.load_local_embedding(e_u.detach(), e_i.detach())
+        ru, ri = prop.propagate()
+        return ru.clone(), ri.clone()
+
+    @staticmethod
+    def backward(ctx, g_u, g_i):
+        prop = ctx.prop
+        prop.load_local_embedding(g_u.contiguous(), g_i.contiguous())
+        gu, gi = prop.propagate()
+        return gu.clone(), gi.clone(), None
+
+
+class _GatherRowsFn(torch.autograd.Function):
+    """Owned blocks -> replicated [n_users + n_items, d].  Every rank evaluates the
+    SAME full batch on the replicated rows, so each rank's gradient w.r.t. the
+    replicated tensor is already the total: the backward pass just keeps the rows
+    this rank owns (no reduce-scatter needed)."""
+
+    @staticmethod
+    def forward(ctx, blk_u, blk_i, prop):
+        ctx.prop = prop
+        ctx.nu, ctx.ni = blk_u.shape[0], blk_i.shape[0]
+        return prop.gather_full_rep(blk_u.detach(), blk_i.detach())
+
+    @staticmethod
+    def backward(ctx, g_full):
+        L, r = ctx.prop.layout, ctx.prop.rank
+        (ulo, uhi), (ilo, ihi) = L.user_rows(r), L.item_rows(r)
+        gu = g_full.new_zeros((ctx.nu, g_full.shape[1]))
+        gi = g_full.new_zeros((ctx.ni, g_full.shape[1]))
+        if uhi > ulo:
+            gu[:uhi - ulo] = g_full[ulo:uhi]
+        if ihi > ilo:
+            gi[:ihi - ilo] = g_full[L.n_users + ilo: L.n_users + ihi]
+        return gu, gi, None
+
+
+class ShardedLightGCN(torch.nn.Module):
+    """LightGCN (model.py:75-123) with the embedding table, its gradient and the
+    optimizer state row-sharded over the ranks.  One step:
+      X_0 exchange + K sharded half-layer passes  ->  owned rows of rep
+      one all-gather of rep (and of E for the L2 term, model.py:110-113)
+      the full batch's fused BPR loss on every rank (identical batch: same sampler seed)
+      backward: owned rows of d loss / d rep  ->  the same sharded pass  ->  d loss / d E (owned rows)
+      Adam on the owned rows.
+    `loss_fn(rep_full, emb_full, users, pos, neg, n_users) -> tensor[2]` defaults to the
+    fused HIP kernel (ops.bpr_loss_terms); the CPU tests inject a torch one."""
+
+    def __init__(self, dataset, embedding_size, n_layers, rank, world, device, group=None, seed=2021,
+                 spmm_fn=None, csr_factory=None, loss_fn=None, full_embedding=None):
+        super().__init__()
+        self.n_users, self.n_items, self.n_layers = dataset.n_users, dataset.n_items, n_layers
+        self.prop = RowShardedPropagator(dataset.train_array, dataset.n_users, dataset.n_items, n_layers, rank, world,
+                                         device, group=group, spmm_fn=spmm_fn, csr_factory=csr_factory)
+        L = self.prop.layout
+        (ulo, uhi), (ilo, ihi) = L.user_rows(rank), L.item_rows(rank)
+        if full_embedding is None:                       # normal_(std=0.1), model.py:82 — same table on every rank
+            g = torch.Generator(device='cpu').manual_seed(seed)
+            full_embedding = torch.randn(self.n_users + self.n_items, embedding_size, generator=g) * 0.1
+        eu = torch.zeros(L.bu, embedding_size)
+        ei = torch.zeros(L.bi, embedding_size)
+        eu[:max(uhi - ulo, 0)] = full_embedding[ulo:uhi]
+        ei[:max(ihi - ilo, 0)] = full_embedding[self.n_users + ilo: self.n_users + ihi]
+        self.emb_users = torch.nn.Parameter(eu.to(device))
+        self.emb_items = torch.nn.Parameter(ei.to(device))
+        if loss_fn is None:
+            from . import ops
+            loss_fn = lambda rep, emb, u, p, n, nu: ops.bpr_loss_terms(rep, rep, emb, emb, None, u, p, n, nu, nu)
+        self.loss_fn = loss_fn
+
+    def get_rep_local(self):
+        return _ShardedPropagateFn.apply(self.emb_users, self.emb_items, self.prop)
+
+    def bpr_loss_terms(self, users, pos_items, neg_items):
+        ru, ri = self.get_rep_local()
+        rep_full = _GatherRowsFn.apply(ru, ri, self.prop)
+        emb_full = _GatherRowsFn.apply(self.emb_users, self.emb_items, self.prop)
+        return self.loss_fn(rep_full, emb_full, users, pos_items, neg_items, self.n_users)
+
+    def full_embedding(self):
+        with torch.no_grad():
+            return self.prop.gather_full_rep(self.emb_users.detach(), self.emb_items.detach())

@@ -88,3 +88,69 @@ def test_shard_layout_padding():
     assert urp.tolist() == [0, 0, 0] and irp.tolist() == [0, 0]          # rank 3 owns padding only
     (urp, ucol, _), (irp, icol, _) = local_blocks_host(rowptr, col, val, L, 2)
     assert urp.tolist() == [0, 1, 1] and ucol.tolist() == [9] and irp.tolist() == [0, 1] and icol.tolist() == [2]
+
+
+# ---- sharded training step (forward + backward + Adam) vs the same step unsharded ----------------
+def torch_bpr_terms(rep, emb, users, pos, neg, n_users):
+    """trainer.py:238-243 + model.py:110-116 in torch (checker implementation for the CPU test)."""
+    ur, pr, nr = rep[users], rep[n_users + pos], rep[n_users + neg]
+    ue, pe, ne = emb[users], emb[n_users + pos], emb[n_users + neg]
+    bpr = torch.nn.functional.softplus((ur * nr).sum(1) - (ur * pr).sum(1)).mean()
+    l2 = ((ue ** 2).sum(1) + (pe ** 2).sum(1) + (ne ** 2).sum(1)).mean()
+    return torch.stack([bpr, l2])
+
+
+def _train_worker(rank, world, port, path, emb, batch, n_layers, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from igcn_cf_amd.dataset import ProcessedDataset
+        from igcn_cf_amd.dist import ShardedLightGCN
+        ds = ProcessedDataset({'name': 'ProcessedDataset', 'path': path, 'device': 'cpu'})
+        model = ShardedLightGCN(ds, emb.shape[1], n_layers, rank, world, 'cpu', spmm_fn=cpu_spmm,
+                                csr_factory=lambda rp, c, v, shape: CpuCsr(rp, c, v, shape), loss_fn=torch_bpr_terms,
+                                full_embedding=torch.from_numpy(emb))
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        b = torch.from_numpy(batch)
+        losses = []
+        for _ in range(2):
+            terms = model.bpr_loss_terms(b[:, 0], b[:, 1], b[:, 2])
+            loss = terms[0] + 1e-2 * terms[1]
+            opt.zero_grad(); loss.backward(); opt.step()
+            losses.append(float(loss))
+        ret[rank] = (losses, model.full_embedding().numpy().copy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_training_step_equals_unsharded(golden):
+    nu, ni = int(golden['n_users']), int(golden['n_items'])
+    ta = golden['train_array']
+    n_layers = 3
+    rng = np.random.default_rng(1)
+    emb = (rng.standard_normal((nu + ni, 8)) * 0.1).astype(np.float32)
+    batch = np.stack([rng.integers(0, nu, 64), rng.integers(0, ni, 64), rng.integers(0, ni, 64)], axis=1).astype(np.int64)
+    # unsharded reference: dense torch chain of the oracle's normalised adjacency
+    row, col, val = O.lightgcn_norm_adj(ta, nu, ni)
+    a = torch.sparse_coo_tensor(np.stack([row, col]), val, (nu + ni, nu + ni)).to_dense()
+    e = torch.nn.Parameter(torch.from_numpy(emb.copy()))
+    opt = torch.optim.Adam([e], lr=1e-2)
+    b = torch.from_numpy(batch)
+    ref_losses = []
+    for _ in range(2):
+        x, layers = e, [e]
+        for _l in range(n_layers):
+            x = a @ x
+            layers.append(x)
+        rep = torch.stack(layers).mean(0)
+        terms = torch_bpr_terms(rep, e, b[:, 0], b[:, 1], b[:, 2], nu)
+        loss = terms[0] + 1e-2 * terms[1]
+        opt.zero_grad(); loss.backward(); opt.step()
+        ref_losses.append(float(loss))
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_train_worker, args=(world, _free_port(), golden['path'], emb, batch, n_layers, ret), nprocs=world, join=True)
+    for r in range(world):
+        losses, full = ret[r]
+        np.testing.assert_allclose(losses, ref_losses, rtol=1e-5)
+        np.testing.assert_allclose(full, e.detach().numpy(), rtol=1e-4, atol=1e-6)

@@ -203,3 +203,41 @@ def test_mf_and_trainers_end_to_end(golden):
             for name in ref:
                 for k in ref[name]:
                     assert abs(metrics[name][k] - ref[name][k]) < 1e-3, (mcfg['name'], stage, name, k)
+
+
+def test_sharded_lightgcn_on_rccl_world1_matches_unsharded(golden):
+    """The row-sharded training step (dist.ShardedLightGCN) through RCCL with one rank and the HIP
+    kernels must reproduce the plain LightGCN step: same loss, same updated embeddings."""
+    import socket
+    import torch.distributed as dist
+    from igcn_cf_amd.dist import ShardedLightGCN
+    from igcn_cf_amd.model import get_model
+    ds = _dataset(golden)
+    if not dist.is_initialized():
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        torch.manual_seed(11)
+        plain = get_model({'name': 'LightGCN', 'embedding_size': 64, 'n_layers': 3, 'device': 'cuda'}, ds)
+        emb0 = plain.embedding.weight.detach().cpu().clone()
+        sharded = ShardedLightGCN(ds, 64, 3, 0, 1, 'cuda', full_embedding=emb0)
+        rng = np.random.default_rng(2)
+        B = 300
+        t = lambda a: torch.from_numpy(a).cuda()
+        users, pos, neg = t(rng.integers(0, ds.n_users, B)), t(rng.integers(0, ds.n_items, B)), t(rng.integers(0, ds.n_items, B))
+        opts = [torch.optim.Adam(m.parameters(), lr=1e-2) for m in (plain, sharded)]
+        for _ in range(2):
+            losses = []
+            for m, opt in zip((plain, sharded), opts):
+                m.train()
+                terms = m.bpr_loss_terms(users, pos, neg)
+                loss = terms[0] + 1e-3 * terms[1]
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(loss.item())
+            assert abs(losses[0] - losses[1]) < 1e-6
+        got, ref = sharded.full_embedding().cpu().numpy(), plain.embedding.weight.detach().cpu().numpy()
+        # Adam turns rounding-level gradient differences into +-lr flips only where |grad| ~ eps
+        assert np.abs(got - ref).max() < 2.5e-2 and np.mean(np.abs(got - ref) > 1e-5) < 1e-3
+    finally:
+        dist.destroy_process_group()
