@@ -144,7 +144,96 @@ class ProcessedDataset(BasicDataset):
         return data
 
 
-class SyntheticDataset(BasicDataset):
+class CsrBackedDataset(BasicDataset):
+    """A dataset whose train/val/test lists are stored as CSR arrays; the Python
+    list-of-lists views of the reference contract (dataset.train_data[user], ...)
+    are materialised lazily and may be re-assigned (inductive_eval does)."""
+
+    def __init__(self, dataset_config, n_users=0, n_items=0, csrs=None):
+        super().__init__(dataset_config)
+        self._lists = {}
+        self._csr = {}
+        if csrs is not None:
+            self._install(n_users, n_items, csrs)
+
+    def _install(self, n_users, n_items, csrs):
+        """csrs: {'train'|'val'|'test': (rowptr int64 [n_users+1], col int64)} in list order."""
+        self.n_users, self.n_items = int(n_users), int(n_items)
+        self._lists = {}
+        self._csr = {(name, False): (np.asarray(rp, dtype=np.int64), np.asarray(col, dtype=np.int64))
+                     for name, (rp, col) in csrs.items()}
+        rp, col = self._csr[('train', False)]
+        self.train_array = np.stack([np.repeat(np.arange(self.n_users, dtype=np.int64), np.diff(rp)), col], axis=1)
+
+    def _get_list(self, name):
+        if name not in self._lists:
+            self._lists[name] = csr_to_lists(*self._csr[(name, False)])
+        return self._lists[name]
+
+    def _set_list(self, name, value):
+        if value is None or not hasattr(self, '_lists'):
+            return
+        self._lists[name] = value
+        for k in [k for k in self._csr if k[0] == name]:
+            del self._csr[k]
+
+    train_data = property(lambda self: self._get_list('train'), lambda self, v: self._set_list('train', v))
+    val_data = property(lambda self: self._get_list('val'), lambda self, v: self._set_list('val', v))
+    test_data = property(lambda self: self._get_list('test'), lambda self, v: self._set_list('test', v))
+
+    def csr(self, which, sort=True):
+        key = (which, sort)
+        if key not in self._csr:
+            if (which, False) in self._csr and which not in self._lists:
+                rp, col = self._csr[(which, False)]
+                row = np.repeat(np.arange(self.n_users, dtype=np.int64), np.diff(rp))
+                self._csr[key] = (rp, col[np.lexsort((col, row))])
+            else:
+                self._csr[key] = lists_to_csr(self._get_list(which), sort=sort)
+        return self._csr[key]
+
+    def invalidate(self):
+        for k in [k for k in self._csr if k[0] in self._lists]:
+            del self._csr[k]
+
+
+def _filter_csr(rowptr, col, keep, n_rows):
+    """Rows [0, n_rows) of a CSR, entries where `keep` is True (order preserved)."""
+    rows = np.repeat(np.arange(len(rowptr) - 1, dtype=np.int64), np.diff(rowptr))
+    m = keep & (rows < n_rows)
+    rp = np.zeros(n_rows + 1, dtype=np.int64)
+    np.cumsum(np.bincount(rows[m], minlength=n_rows)[:n_rows], out=rp[1:])
+    return rp, col[m]
+
+
+def dropit_dataset(dataset, ratio, name=None):
+    """Each user's train list cut to its first int(len * ratio) items; val / test unchanged
+    (the reference's run/dropit/dataset_dropit.py:6-9).  Returns a new dataset."""
+    csrs = {}
+    for which in ('train', 'val', 'test'):
+        rp, col = dataset.csr(which, sort=False)
+        if which == 'train':
+            lens = np.diff(rp)
+            pos = np.arange(col.shape[0], dtype=np.int64) - np.repeat(rp[:-1], lens)
+            keep = pos < np.repeat((lens * ratio).astype(np.int64), lens)
+            rp, col = _filter_csr(rp, col, keep, dataset.n_users)
+        csrs[which] = (rp, col)
+    return CsrBackedDataset({'name': name or dataset.name + '_dropit', 'device': dataset.device},
+                            dataset.n_users, dataset.n_items, csrs)
+
+
+def resize_dataset(dataset, ratio, name=None):
+    """The first int(n_users * ratio) users and int(n_items * ratio) items, all three lists
+    filtered (the reference's run/dropui/dataset_dropui.py:7-29).  Returns a new dataset."""
+    n_users, n_items = int(dataset.n_users * ratio), int(dataset.n_items * ratio)
+    csrs = {}
+    for which in ('train', 'val', 'test'):
+        rp, col = dataset.csr(which, sort=False)
+        csrs[which] = _filter_csr(rp, col, col < n_items, n_users)
+    return CsrBackedDataset({'name': name or dataset.name + '_dropui', 'device': dataset.device}, n_users, n_items, csrs)
+
+
+class SyntheticDataset(CsrBackedDataset):
     """Seeded synthetic implicit-feedback split with the shape of the paper's
     datasets: per-user interaction counts ~ max(min_inter,
     LogNormal), items drawn from a Zipf-Mandelbrot popularity over a random
@@ -205,47 +294,13 @@ class SyntheticDataset(BasicDataset):
         is_test = pos_in_user >= (cnt - n_test)[users]
         is_test &= n_test[users] > 0
         is_val = ~is_train & ~is_test
-        self._csr = {}
+        csrs = {}
         for name, m in (('train', is_train), ('val', is_val), ('test', is_test)):
             c = np.bincount(users[m], minlength=self.n_users)
             rp = np.zeros(self.n_users + 1, dtype=np.int64)
             np.cumsum(c, out=rp[1:])
-            self._csr[(name, False)] = (rp, items[m].astype(np.int64))
-        self._lists = {}
-        rp, col = self._csr[('train', False)]
-        self.train_array = np.stack([np.repeat(np.arange(self.n_users, dtype=np.int64), np.diff(rp)), col], axis=1)
-
-    # lists are materialised lazily: the device path only needs the CSR views
-    def _get_list(self, name):
-        if name not in self._lists:
-            self._lists[name] = csr_to_lists(*self._csr[(name, False)])
-        return self._lists[name]
-
-    train_data = property(lambda self: self._get_list('train'), lambda self, v: self._set_list('train', v))
-    val_data = property(lambda self: self._get_list('val'), lambda self, v: self._set_list('val', v))
-    test_data = property(lambda self: self._get_list('test'), lambda self, v: self._set_list('test', v))
-
-    def _set_list(self, name, value):
-        if value is None:
-            return
-        self._lists[name] = value
-        for k in [k for k in self._csr if k[0] == name]:
-            del self._csr[k]
-
-    def csr(self, which, sort=True):
-        key = (which, sort)
-        if key not in self._csr:
-            if (which, False) in self._csr and which not in self._lists:
-                rp, col = self._csr[(which, False)]
-                row = np.repeat(np.arange(self.n_users, dtype=np.int64), np.diff(rp))
-                self._csr[key] = (rp, col[np.lexsort((col, row))])
-            else:
-                self._csr[key] = lists_to_csr(self._get_list(which), sort=sort)
-        return self._csr[key]
-
-    def invalidate(self):
-        for k in [k for k in self._csr if k[0] in self._lists]:
-            del self._csr[k]
+            csrs[name] = (rp, items[m].astype(np.int64))
+        self._install(self.n_users, self.n_items, csrs)
 
 
 class AuxiliaryDataset(BasicDataset):

@@ -241,3 +241,42 @@ def test_sharded_lightgcn_on_rccl_world1_matches_unsharded(golden):
         assert np.abs(got - ref).max() < 2.5e-2 and np.mean(np.abs(got - ref) > 1e-5) < 1e-3
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('name', ['IGCN', 'IMF'])
+def test_inductive_dropui_new_users_and_items(golden, name):
+    """run/dropui/igcn_dropui.py:26-35: a model trained on the first 80 % of users/items gets the
+    full graph and feature matrix swapped in; new users/items (no templates of their own) receive
+    representations from the trained templates.  Checked against the oracle's INMO restatement."""
+    from igcn_cf_amd.dataset import resize_dataset
+    from igcn_cf_amd.model import get_model
+    from igcn_cf_amd.trainer import get_trainer
+    full = _dataset(golden)
+    small = resize_dataset(full, 0.8)
+    assert small.n_users == int(full.n_users * 0.8) and small.n_items == int(full.n_items * 0.8)
+    torch.manual_seed(4)
+    cfg = {'name': name, 'embedding_size': 32, 'n_layers': 2, 'device': 'cuda', 'dropout': 0.2, 'feature_ratio': 1.}
+    model = get_model(cfg, small)
+    n_templates = model.embedding.weight.shape[0]
+    model.config['dataset'] = full
+    model.n_users, model.n_items = full.n_users, full.n_items
+    model.norm_adj = model.generate_graph(full)
+    model.feat_mat, _, _, model.row_sum = model.generate_feat(full, is_updating=True)
+    model.update_feat_mat()
+    assert model.feat_mat.shape == (full.n_users + full.n_items, n_templates)       # same template table
+    model.eval()
+    with torch.no_grad():
+        rep = model.get_rep().cpu().numpy()
+    nu, ni = full.n_users, full.n_items
+    fr, fc, fv, row_sum, _, _, shape = O.igcn_generate_feat(full.train_array, nu, ni, model.user_map, model.item_map)
+    vals = O.igcn_feat_values(fr, row_sum, model.alpha)
+    ref = O.igcn_get_rep(O.lightgcn_norm_adj(full.train_array, nu, ni), (fr, fc, shape), vals,
+                         model.embedding.weight.detach().cpu().numpy(), 2, imf=(name == 'IMF'))
+    assert _rel(rep, ref) < TOL
+    topks = [5, 10]
+    trainer = get_trainer({'name': 'IGCNTrainer', 'optimizer': 'Adam', 'lr': 1e-3, 'l2_reg': 0., 'aux_reg': 0.01,
+                           'device': 'cuda', 'n_epochs': 1, 'batch_size': 64, 'dataloader_num_workers': 0,
+                           'test_batch_size': 512, 'topks': topks}, full, model)
+    trainer.inductive_eval(small.n_users, small.n_items)                            # six masked evaluations run
+    _, m = trainer.eval('test')
+    assert np.isfinite(m['NDCG'][5])
