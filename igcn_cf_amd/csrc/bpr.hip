@@ -50,6 +50,44 @@ __global__ __launch_bounds__(kBlock) void bpr_fwd_kernel(
     }
 }
 
+// Partial dots of one embedding-column slice (column-sharded multi-GPU path): work = [pos | neg | l2],
+// to be summed over the slices (all-reduce) and finished by bpr_finish_kernel.
+__global__ __launch_bounds__(kBlock) void bpr_dots_kernel(
+    const float *__restrict__ u_tab, const float *__restrict__ p_tab, const float *__restrict__ n_tab, int64_t ld,
+    const float *__restrict__ l2u, const float *__restrict__ l2p, const float *__restrict__ l2n, int64_t ld2,
+    const int64_t *__restrict__ users, const int64_t *__restrict__ pos, const int64_t *__restrict__ neg,
+    int64_t batch, int d, const float *__restrict__ w, float *__restrict__ work)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t b = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (b >= batch) return;
+    const int64_t iu = users[b], ip = pos[b], in = neg[b];
+    float ps = 0.f, ns = 0.f, l2 = 0.f;
+    for (int j = lane; j < d; j += kWave) {
+        const float u = u_tab[iu * ld + j], p = p_tab[ip * ld + j], n = n_tab[in * ld + j];
+        const float uw = w ? u * w[j] : u;
+        ps = fmaf(uw, p, ps);
+        ns = fmaf(uw, n, ns);
+        if (l2u) {
+            const float a = l2u[iu * ld2 + j], c = l2p[ip * ld2 + j], e = l2n[in * ld2 + j];
+            l2 = fmaf(a, a, l2); l2 = fmaf(c, c, l2); l2 = fmaf(e, e, l2);
+        }
+    }
+    ps = wave_sum(ps); ns = wave_sum(ns); l2 = wave_sum(l2);
+    if (lane == 0) { work[b] = ps; work[batch + b] = ns; work[2 * batch + b] = l2; }
+}
+
+// dots [pos | neg | l2] (complete sums) -> work [sigmoid | softplus | l2], the layout of bpr_fwd_kernel
+__global__ void bpr_finish_kernel(const float *__restrict__ dots, int64_t batch, float *__restrict__ work)
+{
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const float x = dots[batch + b] - dots[b];
+    work[b] = 1.f / (1.f + expf(-x));
+    work[batch + b] = x > 20.f ? x : log1pf(expf(x));
+    work[2 * batch + b] = dots[2 * batch + b];
+}
+
 // loss_out[0] = mean(work[B..2B)), loss_out[1] = mean(work[2B..3B)); one block, fixed order.
 __global__ __launch_bounds__(kBlock) void bpr_reduce_kernel(const float *__restrict__ work, int64_t batch,
                                                             float *__restrict__ loss_out)
@@ -126,6 +164,33 @@ extern "C" int igcn_bpr_fwd_f32(const float *u_tab, const float *p_tab, const fl
     hipLaunchKernelGGL(bpr_fwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, u_tab, p_tab, n_tab, ld,
                        l2_u_tab, l2_p_tab, l2_n_tab, ld_l2, users, pos, neg, batch, (int)d, w, work);
     rc = launch_status();
+    if (rc != IGCN_OK) return rc;
+    hipLaunchKernelGGL(bpr_reduce_kernel, dim3(1), dim3(kBlock), 0, st, work, batch, loss_out);
+    return launch_status();
+}
+
+extern "C" int igcn_bpr_dots_f32(const float *u_tab, const float *p_tab, const float *n_tab, int64_t ld,
+                                 const float *l2_u_tab, const float *l2_p_tab, const float *l2_n_tab, int64_t ld_l2,
+                                 const int64_t *users, const int64_t *pos, const int64_t *neg,
+                                 int64_t batch, int32_t d, const float *w, float *dots, void *stream)
+{
+    int rc = bpr_check(u_tab, p_tab, n_tab, ld, l2_u_tab, l2_p_tab, l2_n_tab, ld_l2, users, pos, neg, batch, d);
+    if (rc != IGCN_OK) return rc;
+    if (!dots) return IGCN_E_NULL;
+    if (batch == 0) return IGCN_E_SHAPE;
+    const int64_t blocks = (batch + 3) / 4;
+    hipLaunchKernelGGL(bpr_dots_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), u_tab,
+                       p_tab, n_tab, ld, l2_u_tab, l2_p_tab, l2_n_tab, ld_l2, users, pos, neg, batch, (int)d, w, dots);
+    return launch_status();
+}
+
+extern "C" int igcn_bpr_finish_f32(const float *dots, int64_t batch, float *loss_out, float *work, void *stream)
+{
+    if (!dots || !loss_out || !work) return IGCN_E_NULL;
+    if (batch < 1) return IGCN_E_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(bpr_finish_kernel, dim3((unsigned)((batch + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, dots, batch, work);
+    int rc = launch_status();
     if (rc != IGCN_OK) return rc;
     hipLaunchKernelGGL(bpr_reduce_kernel, dim3(1), dim3(kBlock), 0, st, work, batch, loss_out);
     return launch_status();

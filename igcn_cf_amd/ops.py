@@ -149,7 +149,7 @@ class BprLossFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, u_tab, p_tab, l2u_tab, l2p_tab, w, users, pos, neg, item_offset, l2_item_offset):
+    def forward(ctx, u_tab, p_tab, l2u_tab, l2p_tab, w, users, pos, neg, item_offset, l2_item_offset, reduce_fn=None):
         has_l2 = l2u_tab is not None
         tabs = [u_tab, p_tab] + ([l2u_tab, l2p_tab] if has_l2 else [])
         for t in tabs:
@@ -167,10 +167,22 @@ class BprLossFn(torch.autograd.Function):
         p_ptr = _row_view(p_tab, item_offset)
         l2u_ptr = l2u_tab.data_ptr() if has_l2 else None
         l2p_ptr = _row_view(l2p_tab, l2_item_offset) if has_l2 else None
-        _lib.check(_lib.lib().igcn_bpr_fwd_f32(
-            u_tab.data_ptr(), p_ptr, p_ptr, d, l2u_ptr, l2p_ptr, l2p_ptr, d,
-            users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B, d,
-            _lib.ptr(w), out.data_ptr(), work.data_ptr(), _lib.current_stream()), 'igcn_bpr_fwd_f32')
+        if reduce_fn is None:
+            _lib.check(_lib.lib().igcn_bpr_fwd_f32(
+                u_tab.data_ptr(), p_ptr, p_ptr, d, l2u_ptr, l2p_ptr, l2p_ptr, d,
+                users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B, d,
+                _lib.ptr(w), out.data_ptr(), work.data_ptr(), _lib.current_stream()), 'igcn_bpr_fwd_f32')
+        else:
+            # the tables hold one embedding-column slice: partial dots, summed over the slices by
+            # reduce_fn (an all-reduce), then softplus / sigmoid on the complete dots
+            dots = torch.empty(3 * B, dtype=torch.float32, device=u_tab.device)
+            _lib.check(_lib.lib().igcn_bpr_dots_f32(
+                u_tab.data_ptr(), p_ptr, p_ptr, d, l2u_ptr, l2p_ptr, l2p_ptr, d,
+                users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B, d,
+                _lib.ptr(w), dots.data_ptr(), _lib.current_stream()), 'igcn_bpr_dots_f32')
+            reduce_fn(dots)
+            _lib.check(_lib.lib().igcn_bpr_finish_f32(dots.data_ptr(), B, out.data_ptr(), work.data_ptr(),
+                                                      _lib.current_stream()), 'igcn_bpr_finish_f32')
         ctx.tabs = (u_tab.detach(), p_tab.detach(), l2u_tab.detach() if has_l2 else None,
                     l2p_tab.detach() if has_l2 else None, w.detach() if w is not None else None)
         ctx.idx = (users, pos, neg, work)
@@ -212,11 +224,11 @@ class BprLossFn(torch.autograd.Function):
                 return None
             seen.add(id(bf))
             return bf
-        return once(gu), once(gp), once(g2u), once(g2p), gw, None, None, None, None, None
+        return once(gu), once(gp), once(g2u), once(g2p), gw, None, None, None, None, None, None
 
 
-def bpr_loss_terms(u_tab, p_tab, l2u_tab, l2p_tab, w, users, pos, neg, item_offset=0, l2_item_offset=0):
-    return BprLossFn.apply(u_tab, p_tab, l2u_tab, l2p_tab, w, users, pos, neg, item_offset, l2_item_offset)
+def bpr_loss_terms(u_tab, p_tab, l2u_tab, l2p_tab, w, users, pos, neg, item_offset=0, l2_item_offset=0, reduce_fn=None):
+    return BprLossFn.apply(u_tab, p_tab, l2u_tab, l2p_tab, w, users, pos, neg, item_offset, l2_item_offset, reduce_fn)
 
 
 def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_col=None, banned=None, batch=None):

@@ -127,6 +127,17 @@ int igcn_bpr_fwd_f32(const float *u_tab, const float *p_tab, const float *n_tab,
                      int64_t batch, int32_t d, const float *w,
                      float *loss_out, float *work, void *stream);
 
+/* The forward pass split in two for the embedding-column-sharded multi-GPU path, where a
+ * rank holds only a slice of every row: igcn_bpr_dots_f32 writes the PARTIAL dots of the
+ * slice, dots = [pos_b | neg_b | l2_b] (3*B floats); the caller sums them over the ranks
+ * (all-reduce); igcn_bpr_finish_f32 turns the complete dots into loss_out[0..1] and the
+ * `work` buffer igcn_bpr_bwd_f32 expects.  Arguments as igcn_bpr_fwd_f32. */
+int igcn_bpr_dots_f32(const float *u_tab, const float *p_tab, const float *n_tab, int64_t ld,
+                      const float *l2_u_tab, const float *l2_p_tab, const float *l2_n_tab, int64_t ld_l2,
+                      const int64_t *users, const int64_t *pos, const int64_t *neg,
+                      int64_t batch, int32_t d, const float *w, float *dots, void *stream);
+int igcn_bpr_finish_f32(const float *dots, int64_t batch, float *loss_out, float *work, void *stream);
+
 /* Backward of igcn_bpr_fwd_f32: accumulates (float atomic add, 256-byte row
  * segments) row-sparse gradients into dense gradient tables laid out like the
  * forward tables (same leading dimensions and base offsets).

@@ -154,3 +154,77 @@ def test_sharded_training_step_equals_unsharded(golden):
         losses, full = ret[r]
         np.testing.assert_allclose(losses, ref_losses, rtol=1e-5)
         np.testing.assert_allclose(full, e.detach().numpy(), rtol=1e-4, atol=1e-6)
+
+
+# ---- embedding-column sharding ---------------------------------------------------------------------
+def _col_worker(rank, world, port, path, emb, batch, n_layers, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from igcn_cf_amd.dataset import ProcessedDataset
+        from igcn_cf_amd.dist import ColumnShardedLightGCN
+        ds = ProcessedDataset({'name': 'ProcessedDataset', 'path': path, 'device': 'cpu'})
+        nu, ni = ds.n_users, ds.n_items
+        row, col, val = O.lightgcn_norm_adj(ds.train_array, nu, ni)
+        a = torch.sparse_coo_tensor(np.stack([row, col]), val, (nu + ni, nu + ni)).to_dense()
+
+        def propagate(e):                                   # checker implementation of the local K-layer pass
+            x, layers = e, [e]
+            for _ in range(n_layers):
+                x = a @ x
+                layers.append(x)
+            return torch.stack(layers).mean(0)
+
+        def loss(rep, e, users, pos, neg, n_users, reduce_fn):   # partial dots -> all-reduce -> softplus
+            ur, pr, nr = rep[users], rep[n_users + pos], rep[n_users + neg]
+            ue, pe, ne = e[users], e[n_users + pos], e[n_users + neg]
+            dots = torch.stack([(ur * pr).sum(1), (ur * nr).sum(1), (ue ** 2).sum(1) + (pe ** 2).sum(1) + (ne ** 2).sum(1)])
+            total = dots.detach().clone()
+            reduce_fn(total)
+            full = dots + (total - dots.detach())           # value of the sum, gradient of the local part
+            return torch.stack([torch.nn.functional.softplus(full[1] - full[0]).mean(), full[2].mean()])
+
+        model = ColumnShardedLightGCN(ds, emb.shape[1], n_layers, rank, world, 'cpu', full_embedding=torch.from_numpy(emb),
+                                      propagate_fn=propagate, loss_fn=loss)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        b = torch.from_numpy(batch)
+        losses = []
+        for _ in range(2):
+            terms = model.bpr_loss_terms(b[:, 0], b[:, 1], b[:, 2])
+            l = terms[0] + 1e-2 * terms[1]
+            opt.zero_grad(); l.backward(); opt.step()
+            losses.append(float(l))
+        ret[rank] = (losses, model.full_embedding().numpy().copy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_column_sharded_training_step_equals_unsharded(golden):
+    nu, ni = int(golden['n_users']), int(golden['n_items'])
+    ta = golden['train_array']
+    n_layers = 3
+    rng = np.random.default_rng(1)
+    emb = (rng.standard_normal((nu + ni, 8)) * 0.1).astype(np.float32)
+    batch = np.stack([rng.integers(0, nu, 64), rng.integers(0, ni, 64), rng.integers(0, ni, 64)], axis=1).astype(np.int64)
+    row, col, val = O.lightgcn_norm_adj(ta, nu, ni)
+    a = torch.sparse_coo_tensor(np.stack([row, col]), val, (nu + ni, nu + ni)).to_dense()
+    e = torch.nn.Parameter(torch.from_numpy(emb.copy()))
+    opt = torch.optim.Adam([e], lr=1e-2)
+    b = torch.from_numpy(batch)
+    ref_losses = []
+    for _ in range(2):
+        x, layers = e, [e]
+        for _l in range(n_layers):
+            x = a @ x
+            layers.append(x)
+        terms = torch_bpr_terms(torch.stack(layers).mean(0), e, b[:, 0], b[:, 1], b[:, 2], nu)
+        loss = terms[0] + 1e-2 * terms[1]
+        opt.zero_grad(); loss.backward(); opt.step()
+        ref_losses.append(float(loss.detach()))
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_col_worker, args=(world, _free_port(), golden['path'], emb, batch, n_layers, ret), nprocs=world, join=True)
+    for r in range(world):
+        losses, full = ret[r]
+        np.testing.assert_allclose(losses, ref_losses, rtol=1e-5)
+        np.testing.assert_allclose(full, e.detach().numpy(), rtol=1e-4, atol=1e-6)

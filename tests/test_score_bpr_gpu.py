@@ -315,3 +315,32 @@ def test_device_sampler_semantics(golden):
     exp = len(s) / len(nonempty)
     assert ((cnt - exp) ** 2 / exp).sum() < len(nonempty) + 6 * np.sqrt(2 * len(nonempty))   # chi-square
     assert not np.array_equal(batches[0], batches[1])
+
+
+def test_bpr_column_slices_sum_to_the_full_loss():
+    """Embedding-column sharding: partial dots of the slices (igcn_bpr_dots_f32) summed by reduce_fn and
+    finished (igcn_bpr_finish_f32) give the unsliced loss; each slice's gradient is the slice of the full one."""
+    from igcn_cf_amd.ops import bpr_loss_terms
+    rng = np.random.default_rng(9)
+    n, nu, d, B = 120, 50, 64, 257
+    rep = (rng.standard_normal((n, d)) * 0.3).astype(np.float32)
+    emb = (rng.standard_normal((n, d)) * 0.3).astype(np.float32)
+    users, pos, neg = rng.integers(0, nu, B), rng.integers(0, n - nu, B), rng.integers(0, n - nu, B)
+    u_, p_, n_ = _dev(users), _dev(pos), _dev(neg)
+    R, E = torch.nn.Parameter(_dev(rep)), torch.nn.Parameter(_dev(emb))
+    full = bpr_loss_terms(R, R, E, E, None, u_, p_, n_, nu, nu)
+    (full[0] + 0.1 * full[1]).backward()
+    for P in (2, 4, 8):
+        dl = d // P
+        slices = [(torch.nn.Parameter(_dev(rep[:, r * dl:(r + 1) * dl].copy())), torch.nn.Parameter(_dev(emb[:, r * dl:(r + 1) * dl].copy())))
+                  for r in range(P)]
+        partial = []
+        for Rs, Es in slices:                      # pass 1: every "rank" computes its partial dots
+            bpr_loss_terms(Rs, Rs, Es, Es, None, u_, p_, n_, nu, nu, reduce_fn=lambda t: partial.append(t.clone()))
+        total = torch.stack(partial).sum(0)
+        for r, (Rs, Es) in enumerate(slices):      # pass 2: the all-reduce result is the sum of all partials
+            terms = bpr_loss_terms(Rs, Rs, Es, Es, None, u_, p_, n_, nu, nu, reduce_fn=lambda t: t.copy_(total))
+            assert abs(terms[0].item() - full[0].item()) < 1e-6 and abs(terms[1].item() - full[1].item()) < 1e-5
+            (terms[0] + 0.1 * terms[1]).backward()
+            np.testing.assert_allclose(Rs.grad.cpu().numpy(), R.grad.cpu().numpy()[:, r * dl:(r + 1) * dl], rtol=1e-4, atol=1e-8)
+            np.testing.assert_allclose(Es.grad.cpu().numpy(), E.grad.cpu().numpy()[:, r * dl:(r + 1) * dl], rtol=1e-4, atol=1e-8)
