@@ -325,7 +325,7 @@ class BPRTrainer(BasicTrainer):
 
     def bpr_step(self, inputs):
         """One optimisation step on an int64 [B, 3] batch; returns the loss tensor."""
-        users, pos_items, neg_items = inputs[:, 0].contiguous(), inputs[:, 1].contiguous(), inputs[:, 2].contiguous()
+        users, pos_items, neg_items = inputs.t().contiguous().unbind(0)          # one transpose, three row views
         terms = self.model.bpr_loss_terms(users, pos_items, neg_items)
         loss = terms[0] + self.l2_reg * terms[1]
         self.opt.zero_grad()
@@ -359,9 +359,9 @@ class IGCNTrainer(BasicTrainer):
         self.aux_reg = trainer_config['aux_reg']
 
     def igcn_step(self, inputs, aux_inputs):
-        users, pos_items, neg_items = inputs[:, 0].contiguous(), inputs[:, 1].contiguous(), inputs[:, 2].contiguous()
+        users, pos_items, neg_items = inputs.t().contiguous().unbind(0)
         terms = self.model.bpr_loss_terms(users, pos_items, neg_items)
-        a_users, a_pos, a_neg = aux_inputs[:, 0].contiguous(), aux_inputs[:, 1].contiguous(), aux_inputs[:, 2].contiguous()
+        a_users, a_pos, a_neg = aux_inputs.t().contiguous().unbind(0)
         aux_loss = self.model.aux_loss(a_users, a_pos, a_neg)
         loss = terms[0] + self.l2_reg * terms[1] + self.aux_reg * aux_loss
         self.opt.zero_grad()

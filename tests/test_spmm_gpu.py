@@ -181,3 +181,40 @@ def test_propagate_backward_is_adjoint():
     l1 = torch.sparse.mm(a, x64); l2 = torch.sparse.mm(a, l1); l3 = torch.sparse.mm(a, l2)
     ref = (x64 + l1 + l2 + l3) / 4
     assert ((px.double() - ref).abs().max() / ref.abs().max()).item() < TOL
+
+
+def test_c_abi_error_codes_without_launch():
+    """Bad arguments are rejected by the C ABI with IGCN_E_* codes before anything is launched
+    (include/igcn_hip.h: negative = bad argument, never an exception across the boundary)."""
+    import ctypes as C
+    from igcn_cf_amd import _lib
+    L = _lib.lib()
+    x = torch.zeros(8, 64, device='cuda')
+    y = torch.zeros(8, 64, device='cuda')
+    rowptr = torch.zeros(9, dtype=torch.int64, device='cuda')
+    col = torch.zeros(1, dtype=torch.int32, device='cuda')
+    nul = (C.c_void_p * 1)()
+
+    def call(rowptr_p, x_p, y_p, d=64, ldx=64, n_adds=0, keep=1.0, n_rows=8):
+        return L.igcn_spmm_csr_f32(rowptr_p, col.data_ptr(), None, x_p, ldx, y_p, 64, n_rows, 8, d, 1.0, nul, n_adds, 1.0,
+                                   None, None, None, 0, None, 0, None, 256, None, 0, keep, None)
+    assert call(None, x.data_ptr(), y.data_ptr()) == -1                       # IGCN_E_NULL
+    assert call(rowptr.data_ptr(), x.data_ptr(), y.data_ptr(), d=0) == -2     # IGCN_E_SHAPE
+    assert call(rowptr.data_ptr(), x.data_ptr(), y.data_ptr(), d=300) == -2
+    assert call(rowptr.data_ptr(), x.data_ptr(), y.data_ptr(), ldx=32) == -2
+    assert call(rowptr.data_ptr(), x.data_ptr(), y.data_ptr(), n_adds=9) == -4  # IGCN_E_RANGE
+    assert call(rowptr.data_ptr(), x.data_ptr(), y.data_ptr(), keep=0.0) == -4
+    assert call(rowptr.data_ptr(), x.data_ptr(), x.data_ptr()) == -4          # in-place
+    assert call(rowptr.data_ptr(), x.data_ptr(), y.data_ptr(), n_rows=0) == 0  # empty matrix: nothing to do
+    assert call(rowptr.data_ptr(), x.data_ptr(), y.data_ptr()) == 0
+    torch.cuda.synchronize()
+    # top-k: unsupported shapes are reported by the workspace query and the call
+    assert L.igcn_score_topk_workspace_bytes(10, 100, 64, 0) == -1
+    assert L.igcn_score_topk_workspace_bytes(10, 100, 66, 5) == -1
+    assert L.igcn_score_topk_workspace_bytes(10, 100, 256, 5) == -1
+    assert L.igcn_score_topk_workspace_bytes(10, 100, 64, 101) == -1
+    from igcn_cf_amd.ops import score_topk
+    with pytest.raises(_lib.IgcnError):
+        score_topk(x, y, 9)                                                   # k > n_items
+    with pytest.raises(_lib.IgcnError):
+        score_topk(x.cpu(), y, 2)                                             # CPU tensor
