@@ -17,7 +17,7 @@ MAX_TOPK = 64
 c_i64_p = C.POINTER(C.c_int64)
 vp = C.c_void_p
 
-ROW_SEGMENT_DTYPE = np.dtype([('start', '<i8'), ('len', '<i4'), ('slot', '<i4')])
+ROW_SEGMENT_DTYPE = np.dtype([('start', '<i8'), ('len', '<i4'), ('slot', '<i4'), ('row', '<i4'), ('reserved', '<i4')])
 LONG_ROW_DTYPE = np.dtype([('row', '<i4'), ('first_slot', '<i4'), ('n_slots', '<i4'), ('reserved', '<i4')])
 
 # name -> (restype, argtypes); every symbol of include/igcn_hip.h
@@ -29,7 +29,8 @@ SIGNATURES = {
     'igcn_spmm_csr_f32': (C.c_int, [vp, vp, vp, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                     C.c_float, C.POINTER(vp), C.c_int32, C.c_float, vp, vp,
                                     vp, C.c_int64, vp, C.c_int64, vp, C.c_int32,
-                                    vp, C.c_uint64, C.c_float, vp]),
+                                    vp, C.c_uint64, C.c_float, vp, C.c_int32, vp]),
+    'igcn_mark_rows': (C.c_int, [vp, C.c_int64, vp, vp, vp, vp, C.c_int64, vp]),
     'igcn_csr_row_pow_f32': (C.c_int, [vp, vp, C.c_float, vp, vp, C.c_int64, vp]),
     'igcn_bpr_fwd_f32': (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, vp, C.c_int64, vp, vp, vp,
                                    C.c_int64, C.c_int32, vp, vp, vp, vp]),

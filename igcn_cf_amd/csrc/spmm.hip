@@ -51,7 +51,8 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rows_kernel(
     const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy,
     int64_t n_rows, int d, SpmmEpilogue ep, SpmmDropout dr,
     const igcn_row_segment *__restrict__ segments, int64_t n_segments,
-    float *__restrict__ partial, int long_threshold, int seg_first)
+    float *__restrict__ partial, int long_threshold, int seg_first,
+    const uint8_t *__restrict__ row_mask, int masked_rows_zero)
 {
     constexpr int G = kWave / LPR;           // source rows per gather instruction
     const int lane = threadIdx.x & (kWave - 1);
@@ -73,8 +74,14 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rows_kernel(
             if (n_segments > 0 && end - start > long_threshold) continue;   // handled as segments
             dst = v;
             to_partial = false;
+            if (row_mask && !row_mask[v]) {                                   // output not needed
+                if (masked_rows_zero && g == 0 && lane_on)
+                    *reinterpret_cast<float4 *>(y + dst * ldy + 4 * t) = f4_zero();
+                continue;
+            }
         } else {
             const igcn_row_segment s = segments[v - n_rows];
+            if (row_mask && !row_mask[s.row]) continue;
             start = s.start;
             end = s.start + s.len;
             dst = s.slot;
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rows_kernel(
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void spmm_long_rows_reduce_kernel(
     const igcn_long_row *__restrict__ long_rows, int64_t n_long, const float *__restrict__ partial,
-    float *__restrict__ y, int64_t ldy, int d, SpmmEpilogue ep)
+    float *__restrict__ y, int64_t ldy, int d, SpmmEpilogue ep, const uint8_t *__restrict__ row_mask, int masked_rows_zero)
 {
     constexpr int G = kWave / LPR;
     const int lane = threadIdx.x & (kWave - 1);
@@ -162,6 +169,10 @@ __global__ __launch_bounds__(kBlock) void spmm_long_rows_reduce_kernel(
     const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
     if (wave >= n_long) return;
     const igcn_long_row lr = long_rows[wave];
+    if (row_mask && !row_mask[lr.row]) {
+        if (masked_rows_zero && g == 0 && lane_on) *reinterpret_cast<float4 *>(y + (int64_t)lr.row * ldy + 4 * t) = f4_zero();
+        return;
+    }
     const float *base = partial + (int64_t)lr.first_slot * d + 4 * t;
     float4 acc = f4_zero();
     if (lane_on) {
@@ -256,26 +267,39 @@ static const SpmmTuning &tuning() {
     return t;
 }
 
+// mask1[id] = 1 for the listed rows; mask2[id] = 1 and mask2[c] = 1 for every column c of a listed row.
+__global__ void mark_rows_kernel(const int64_t *__restrict__ ids, int64_t n, const int64_t *__restrict__ rowptr,
+                                 const int32_t *__restrict__ col, uint8_t *__restrict__ mask1, uint8_t *__restrict__ mask2)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int64_t r = ids[i];
+    if (lane == 0) { mask1[r] = 1; if (mask2) mask2[r] = 1; }
+    if (mask2 && rowptr)
+        for (int64_t p = rowptr[r] + lane; p < rowptr[r + 1]; p += kWave) mask2[col[p]] = 1;
+}
+
 template <int LPR>
 static int launch_rows(bool dropout, dim3 grid, hipStream_t st,
                        const int64_t *rowptr, const int32_t *col, const float *val, const float *x, int64_t ldx,
                        float *y, int64_t ldy, int64_t n_rows, int d, const SpmmEpilogue &ep, const SpmmDropout &dr,
                        const igcn_row_segment *segments, int64_t n_segments, float *partial, int long_threshold,
-                       const igcn_long_row *long_rows, int64_t n_long)
+                       const igcn_long_row *long_rows, int64_t n_long, const uint8_t *row_mask, int masked_rows_zero)
 {
     const int seg_first = tuning().seg_first;
     if (dropout)
         hipLaunchKernelGGL((spmm_csr_rows_kernel<LPR, true>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
-                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, seg_first);
+                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, seg_first, row_mask, masked_rows_zero);
     else
         hipLaunchKernelGGL((spmm_csr_rows_kernel<LPR, false>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
-                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, seg_first);
+                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, seg_first, row_mask, masked_rows_zero);
     int rc = launch_status();
     if (rc != IGCN_OK) return rc;
     if (n_long > 0) {
         const int64_t blocks = (n_long + (kBlock / kWave) - 1) / (kBlock / kWave);
         hipLaunchKernelGGL((spmm_long_rows_reduce_kernel<LPR>), dim3((unsigned)blocks), dim3(kBlock), 0, st,
-                           long_rows, n_long, partial, y, ldy, d, ep);
+                           long_rows, n_long, partial, y, ldy, d, ep, row_mask, masked_rows_zero);
         rc = launch_status();
     }
     return rc;
@@ -325,6 +349,8 @@ extern "C" int igcn_spmm_plan_fill_host(const int64_t *rowptr_host, int64_t n_ro
             segments_host[is].start = p;
             segments_host[is].len = (int32_t)((e - p) < segment_len ? (e - p) : segment_len);
             segments_host[is].slot = (int32_t)is;
+            segments_host[is].row = (int32_t)r;
+            segments_host[is].reserved = 0;
         }
     }
     return (il == n_long_rows && is == n_segments) ? IGCN_OK : IGCN_E_SHAPE;
@@ -338,7 +364,8 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
                                  const igcn_long_row *long_rows, int64_t n_long_rows,
                                  const igcn_row_segment *segments, int64_t n_segments,
                                  float *partial, int32_t long_threshold,
-                                 const int32_t *edge_id, uint64_t seed, float keep_prob, void *stream)
+                                 const int32_t *edge_id, uint64_t seed, float keep_prob,
+                                 const uint8_t *row_mask, int32_t masked_rows_zero, void *stream)
 {
     if (!rowptr || !x || !y) return IGCN_E_NULL;
     if (n_rows < 0 || n_cols < 0 || d < 1 || d > 256 || ldx < d || ldy < d) return IGCN_E_SHAPE;
@@ -385,14 +412,14 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
     for (int i = 0; i < n_adds && vec; ++i) vec = reinterpret_cast<uintptr_t>(ep.add[i]) % 16 == 0;
     if (n_segments > 0 && (reinterpret_cast<uintptr_t>(partial) % 16 != 0)) return IGCN_E_ALIGN;
     if (!vec) {
-        if (n_segments > 0) return IGCN_E_ALIGN;   // the plan's partial layout needs the vector path
+        if (n_segments > 0 || row_mask) return IGCN_E_ALIGN;   // plan / row masks need the vector path
         hipLaunchKernelGGL(spmm_csr_scalar_kernel, grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
                            n_rows, (int)d, ep, dr, dropout);
         return launch_status();
     }
 #define IGCN_SPMM_CASE(L)                                                                                         \
     return launch_rows<L>(dropout, grid, st, rowptr, col, val, x, ldx, y, ldy, n_rows, (int)d, ep, dr, segments,  \
-                          n_segments, partial, (int)long_threshold, long_rows, n_long_rows)
+                          n_segments, partial, (int)long_threshold, long_rows, n_long_rows, row_mask, (int)masked_rows_zero)
     const int q = d / 4;
     if (q <= 1) IGCN_SPMM_CASE(1);
     if (q <= 2) IGCN_SPMM_CASE(2);
@@ -402,6 +429,18 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
     if (q <= 32) IGCN_SPMM_CASE(32);
     IGCN_SPMM_CASE(64);
 #undef IGCN_SPMM_CASE
+}
+
+extern "C" int igcn_mark_rows(const int64_t *ids, int64_t n, const int64_t *rowptr, const int32_t *col,
+                              uint8_t *mask1, uint8_t *mask2, int64_t n_rows, void *stream)
+{
+    if (!ids || !mask1) return IGCN_E_NULL;
+    if (mask2 && (!rowptr || !col)) return IGCN_E_NULL;
+    if (n < 0 || n_rows < 0) return IGCN_E_SHAPE;
+    if (n == 0) return IGCN_OK;
+    hipLaunchKernelGGL(mark_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       ids, n, rowptr, col, mask1, mask2);
+    return launch_status();
 }
 
 extern "C" int igcn_csr_row_pow_f32(const int64_t *rowptr, const float *row_sum, float exponent,

@@ -139,11 +139,20 @@ class LightGCN(BasicModel):
         rowptr, col, val = normalized_adjacency_host(dataset.train_array, dataset.n_users, dataset.n_items)
         return CsrMatrix(rowptr, col, val, (n, n), self.device)
 
-    def get_rep(self):
+    def get_rep(self, needed_rows=None):
+        """needed_rows: ids of the only rows the caller will read (training batches); the
+        propagation is then pruned to what those rows depend on (ops.propagate_mean)."""
         w = self.embedding.weight
+        if needed_rows is not None and self.training:
+            return ops.PropagateFn.apply(w, self.norm_adj, self.norm_adj, self.n_layers, needed_rows)
         key = (w._version, id(self.norm_adj), w.data_ptr())
         # A_hat is symmetric, so the same CSR serves the backward pass
         return self._cached_rep(key, lambda: ops.PropagateFn.apply(w, self.norm_adj, self.norm_adj, self.n_layers))
+
+    def _batch_rows(self, users, pos_items, neg_items):
+        if not self.config.get('prune_propagation', True):
+            return None
+        return torch.cat([users, self.n_users + pos_items, self.n_users + neg_items])
 
     def bpr_forward(self, users, pos_items, neg_items):
         rep = self.get_rep()
@@ -156,7 +165,7 @@ class LightGCN(BasicModel):
         return users_r, pos_items_r, neg_items_r, l2_norm_sq
 
     def bpr_loss_terms(self, users, pos_items, neg_items):
-        rep, e = self.get_rep(), self.embedding.weight
+        rep, e = self.get_rep(self._batch_rows(users, pos_items, neg_items)), self.embedding.weight
         return ops.bpr_loss_terms(rep, rep, e, e, None, users, pos_items, neg_items, self.n_users, self.n_users)
 
     def predict(self, users):
@@ -260,15 +269,19 @@ class IGCN(BasicModel):
             return 1., 0
         return 1. - self.dropout, int(torch.randint(0, 2 ** 62, (1,)).item())
 
-    def _compute_rep(self):
+    def _compute_rep(self, needed_rows=None):
         keep_prob, seed = self._dropout_args()
         x0 = self.inductive_rep_layer(self.feat_mat, keep_prob, seed)
-        return ops.PropagateFn.apply(x0, self.norm_adj, self.norm_adj, self.n_layers)
+        return ops.PropagateFn.apply(x0, self.norm_adj, self.norm_adj, self.n_layers, needed_rows)
 
-    def get_rep(self):
+    def get_rep(self, needed_rows=None):
+        if needed_rows is not None and self.training:
+            return self._compute_rep(needed_rows)
         w = self.embedding.weight
         key = (w._version, id(self.norm_adj), id(self.feat_mat), id(self._feat_scale), w.data_ptr())
         return self._cached_rep(key, self._compute_rep)
+
+    _batch_rows = LightGCN._batch_rows
 
     def bpr_forward(self, users, pos_items, neg_items):
         rep = self.get_rep()
@@ -279,7 +292,7 @@ class IGCN(BasicModel):
         return users_r, pos_items_r, neg_items_r, l2_norm_sq
 
     def bpr_loss_terms(self, users, pos_items, neg_items):
-        rep = self.get_rep()
+        rep = self.get_rep(self._batch_rows(users, pos_items, neg_items))
         return ops.bpr_loss_terms(rep, rep, rep, rep, None, users, pos_items, neg_items, self.n_users, self.n_users)
 
     def aux_loss(self, users, pos_items, neg_items):
@@ -310,6 +323,6 @@ class IGCN(BasicModel):
 class IMF(IGCN):
     """INMO-MF, model.py:536-543: the template layer without propagation."""
 
-    def _compute_rep(self):
+    def _compute_rep(self, needed_rows=None):
         keep_prob, seed = self._dropout_args()
         return self.inductive_rep_layer(self.feat_mat, keep_prob, seed)

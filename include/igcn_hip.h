@@ -45,6 +45,8 @@ typedef struct igcn_row_segment {
     int64_t start;
     int32_t len;
     int32_t slot;
+    int32_t row;
+    int32_t reserved;
 } igcn_row_segment;
 
 /* One long row: its partial sums are partial[first_slot .. first_slot+n_slots). */
@@ -77,6 +79,8 @@ int igcn_spmm_plan_fill_host(const int64_t *rowptr_host, int64_t n_rows,
  *           : (hash(seed, edge_id ? edge_id[p] : p) keeps) ? 1/keep_prob : 0
  *   Y[r]    = (out_scale * acc[r] + add_scale * sum_i adds[i][r])
  *             * (row_scale ? row_scale[r] : 1)
+ *   rows with row_mask[r] == 0 (row_mask != NULL) are not computed: Y[r] is left
+ *   untouched (masked_rows_zero == 0) or set to zero (masked_rows_zero != 0).
  *
  * Replaces dgl.ops.gspmm(g,'mul','sum',X,w) at model.py:102, :430, :442, the
  * layer mean of model.py:104-105 / :444-445 (adds + scales on the last layer),
@@ -91,7 +95,11 @@ int igcn_spmm_plan_fill_host(const int64_t *rowptr_host, int64_t n_rows,
  * as produced by igcn_spmm_plan_fill_host, copied to the device, and `partial`
  * a device workspace of n_segments * d floats;
  * edge_id int32 [nnz] or NULL (used when M is a transposed view, so that both
- * views drop the same edges). */
+ * views drop the same edges);
+ * row_mask uint8 [n_rows] or NULL: the rows whose output the caller needs (a
+ * training step needs the propagated rows of its batch only, so the last layer
+ * and the layer before it — and by symmetry the first backward hop — shrink to
+ * the batch rows / their neighbourhood; see igcn_mark_rows). */
 int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val,
                       const float *x, int64_t ldx, float *y, int64_t ldy,
                       int64_t n_rows, int64_t n_cols, int32_t d,
@@ -101,7 +109,15 @@ int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *va
                       const igcn_row_segment *segments, int64_t n_segments,
                       float *partial, int32_t long_threshold,
                       const int32_t *edge_id, uint64_t seed, float keep_prob,
+                      const uint8_t *row_mask, int32_t masked_rows_zero,
                       void *stream);
+
+/* Row masks for igcn_spmm_csr_f32.  mask1[ids[i] + offsets...] = 1 for every listed row;
+ * when rowptr/col are given, mask2[r] = 1 for every listed row r and every column
+ * of row r (its neighbourhood).  ids int64 [n]; masks uint8 [n_rows], zeroed by the
+ * caller; mask2 may be NULL. */
+int igcn_mark_rows(const int64_t *ids, int64_t n, const int64_t *rowptr, const int32_t *col,
+                   uint8_t *mask1, uint8_t *mask2, int64_t n_rows, void *stream);
 
 /* out[e] = row_sum[row(e)] ^ exponent for every stored entry of a CSR matrix:
  * IGCN.update_feat_mat, model.py:374-377, as explicit values (the propagation

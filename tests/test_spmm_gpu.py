@@ -197,7 +197,7 @@ def test_c_abi_error_codes_without_launch():
 
     def call(rowptr_p, x_p, y_p, d=64, ldx=64, n_adds=0, keep=1.0, n_rows=8):
         return L.igcn_spmm_csr_f32(rowptr_p, col.data_ptr(), None, x_p, ldx, y_p, 64, n_rows, 8, d, 1.0, nul, n_adds, 1.0,
-                                   None, None, None, 0, None, 0, None, 256, None, 0, keep, None)
+                                   None, None, None, 0, None, 0, None, 256, None, 0, keep, None, 0, None)
     assert call(None, x.data_ptr(), y.data_ptr()) == -1                       # IGCN_E_NULL
     assert call(rowptr.data_ptr(), x.data_ptr(), y.data_ptr(), d=0) == -2     # IGCN_E_SHAPE
     assert call(rowptr.data_ptr(), x.data_ptr(), y.data_ptr(), d=300) == -2
@@ -218,3 +218,43 @@ def test_c_abi_error_codes_without_launch():
         score_topk(x, y, 9)                                                   # k > n_items
     with pytest.raises(_lib.IgcnError):
         score_topk(x.cpu(), y, 2)                                             # CPU tensor
+
+
+def test_spmm_row_masks_and_pruned_propagation():
+    """Row masks: masked-out rows are left untouched / zeroed, long-row segments included; the pruned
+    K-layer pass equals the full one on the needed rows, and so does its backward pass."""
+    from igcn_cf_amd.dataset import SyntheticDataset
+    from igcn_cf_amd.graph import CsrMatrix, normalized_adjacency_host
+    from igcn_cf_amd.ops import PropagateFn, mark_rows, propagate_mean, spmm
+    ds = SyntheticDataset({'name': 'SyntheticDataset', 'n_users': 3000, 'n_items': 2000, 'n_inter': 120000, 'zipf_q': 0.})
+    n = ds.n_users + ds.n_items
+    rowptr, col, val = normalized_adjacency_host(ds.train_array, ds.n_users, ds.n_items)
+    csr = CsrMatrix(rowptr, col, val, (n, n), 'cuda', long_threshold=64, segment_len=64)
+    assert csr.n_long > 0
+    g = torch.Generator(device='cuda').manual_seed(0)
+    x = torch.randn(n, 64, device='cuda', generator=g) * 0.1
+    ids = torch.randint(0, n, (300,), device='cuda', generator=g)
+    ids[0] = int(np.argmax(np.diff(rowptr)))                       # a long row is among the needed rows
+    m1, m2 = mark_rows(csr, ids)
+    deg = np.diff(rowptr)
+    want2 = np.zeros(n, dtype=bool)
+    for r in ids.cpu().tolist():
+        want2[r] = True; want2[col[rowptr[r]:rowptr[r + 1]]] = True
+    assert np.array_equal(m2.cpu().numpy().astype(bool), want2) and int(m1.sum()) == len(set(ids.cpu().tolist()))
+    full = spmm(csr, x)
+    y = torch.full_like(x, 7.0)
+    spmm(csr, x, out=y, row_mask=m1, masked_rows_zero=False)
+    keep = m1.bool()
+    assert torch.equal(y[keep], full[keep]) and torch.all(y[~keep] == 7.0)
+    spmm(csr, x, out=y, row_mask=m1, masked_rows_zero=True)
+    assert torch.equal(y[keep], full[keep]) and torch.all(y[~keep] == 0.0)
+    for K in (1, 2, 3, 4):
+        e_full = x.clone().requires_grad_(True)
+        e_prun = x.clone().requires_grad_(True)
+        r_full = PropagateFn.apply(e_full, csr, csr, K)
+        r_prun = PropagateFn.apply(e_prun, csr, csr, K, ids)
+        assert torch.equal(r_prun[keep], r_full[keep]) and torch.all(r_prun[~keep] == 0)
+        z = torch.zeros_like(x)
+        z[keep] = torch.randn(int(keep.sum()), 64, device='cuda', generator=g)
+        r_full.backward(z); r_prun.backward(z)
+        assert torch.allclose(e_prun.grad, e_full.grad, rtol=1e-5, atol=1e-8)
