@@ -377,7 +377,7 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
     if (n_segments > 0 && long_threshold < 1) return IGCN_E_RANGE;
     if (x == y) return IGCN_E_RANGE;     // in-place propagation would read rows being written
     if (n_rows == 0) return IGCN_OK;
-    if (!col) return IGCN_E_NULL;
+    // col may be NULL only for a matrix without stored entries (rowptr all zero): it is never read then
 
     SpmmEpilogue ep{};
     ep.n_adds = n_adds;

@@ -272,6 +272,12 @@ def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_co
     n_items, d = item_rows.shape
     if user_rows.shape[1] != d:
         raise _lib.IgcnError('user and item rows differ in width')
+    if d % 4 or user_rows.stride(0) % 4 or item_rows.stride(0) % 4 or user_rows.data_ptr() % 16 or item_rows.data_ptr() % 16:
+        # the kernel reads rows as 16-byte pieces: zero-pad odd widths / realign views (zeros add nothing to a dot)
+        pad = (-d) % 4
+        user_rows = torch.nn.functional.pad(user_rows, (0, pad)).contiguous()
+        item_rows = torch.nn.functional.pad(item_rows, (0, pad)).contiguous()
+        d += pad
     if excl_rowptr is not None and (excl_col is None or excl_col.numel() == 0):
         excl_rowptr = excl_col = None                      # nothing is excluded
     if excl_rowptr is not None:

@@ -89,7 +89,7 @@ int igcn_spmm_plan_fill_host(const int64_t *rowptr_host, int64_t n_rows,
  * (val == NULL, row_scale = row_sum^exponent; the transposed view used by the
  * backward pass takes the same vector as col_scale).
  *
- * rowptr int64 [n_rows+1]; col int32 [nnz]; val fp32 [nnz] or NULL;
+ * rowptr int64 [n_rows+1]; col int32 [nnz] (may be NULL when nnz == 0); val fp32 [nnz] or NULL;
  * adds_host: HOST array of n_adds device pointers, each [n_rows, d] with ldy;
  * long rows (may be NULL / 0 when the matrix has none): long_rows / segments
  * as produced by igcn_spmm_plan_fill_host, copied to the device, and `partial`

@@ -49,7 +49,8 @@ def _check_topk(scores, idx, val, ex_lists, banned, k):
 
 
 @pytest.mark.parametrize('d,n_users,n_items,k', [(64, 300, 1000, 20), (8, 70, 50, 20), (128, 257, 4500, 20),
-                                                  (32, 33, 9000, 5), (64, 1000, 20000, 50), (16, 5, 64, 64)])
+                                                  (32, 33, 9000, 5), (64, 1000, 20000, 50), (16, 5, 64, 64),
+                                                  (50, 100, 3000, 20), (6, 40, 200, 7)])
 def test_score_topk_matches_dense_oracle(d, n_users, n_items, k):
     from igcn_cf_amd.ops import score_topk
     rng = np.random.default_rng(d + n_items)

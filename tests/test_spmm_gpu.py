@@ -258,3 +258,14 @@ def test_spmm_row_masks_and_pruned_propagation():
         z[keep] = torch.randn(int(keep.sum()), 64, device='cuda', generator=g)
         r_full.backward(z); r_prun.backward(z)
         assert torch.allclose(e_prun.grad, e_full.grad, rtol=1e-5, atol=1e-8)
+
+
+def test_spmm_matrix_without_entries():
+    """A graph with no train pairs: every row is empty, col is an empty array (NULL pointer)."""
+    from igcn_cf_amd.graph import CsrMatrix
+    from igcn_cf_amd.ops import propagate_mean, spmm
+    n = 50
+    csr = CsrMatrix(np.zeros(n + 1, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.float32), (n, n), 'cuda')
+    x = torch.randn(n, 64, device='cuda')
+    assert torch.all(spmm(csr, x) == 0)
+    assert torch.allclose(propagate_mean(csr, x, 3), x / 4)
