@@ -62,9 +62,10 @@ class BasicDataset:
             self._csr[key] = lists_to_csr(getattr(self, which + '_data'), sort=sort)
         return self._csr[key]
 
-    def invalidate(self):
-        """Call after mutating train/val/test lists in place (inductive_eval does)."""
-        self._csr = {}
+    def invalidate(self, which=None):
+        """Call after mutating train/val/test lists in place (inductive_eval does); `which`
+        limits the rebuild to one of 'train' / 'val' / 'test'."""
+        self._csr = {k: v for k, v in self._csr.items() if which is not None and k[0] != which}
 
     def _finish(self):
         rowptr, col = lists_to_csr(self.train_data)
@@ -192,8 +193,8 @@ class CsrBackedDataset(BasicDataset):
                 self._csr[key] = lists_to_csr(self._get_list(which), sort=sort)
         return self._csr[key]
 
-    def invalidate(self):
-        for k in [k for k in self._csr if k[0] in self._lists]:
+    def invalidate(self, which=None):
+        for k in [k for k in self._csr if k[0] in self._lists and (which is None or k[0] == which)]:
             del self._csr[k]
 
 

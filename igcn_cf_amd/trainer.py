@@ -203,6 +203,44 @@ class BasicTrainer:
             results['NDCG'][k] = ndcgs[user_masks].mean()
         return results
 
+    def _metrics_from_hits_device(self, hit, eval_len):
+        """The reductions of trainer.py:116-137 on the device (float32, same formulas): only the
+        final scalars cross PCIe.  Used by eval(); calculate_metrics() keeps the numpy path, whose
+        results are bit-identical to the reference's."""
+        results = {'Precision': {}, 'Recall': {}, 'NDCG': {}}
+        lens = eval_len.to(torch.float32)
+        valid = eval_len > 0
+        n_valid = valid.sum().clamp(min=1).to(torch.float32)
+        out = []
+        for k in self.topks:
+            h = hit[:, :k]
+            hit_num = h.sum(dim=1)
+            denom = torch.log2(torch.arange(2, k + 2, dtype=torch.float32, device=hit.device))
+            dcg = (h / denom).sum(dim=1)
+            ideal = (torch.arange(k, device=hit.device)[None, :] < eval_len.clamp(max=k)[:, None]).to(torch.float32)
+            idcg = (ideal / denom).sum(dim=1)
+            zero = torch.zeros((), device=hit.device)
+            out += [torch.where(valid, hit_num / k, zero).sum() / n_valid,
+                    torch.where(valid, hit_num / lens.clamp(min=1), zero).sum() / n_valid,
+                    torch.where(valid, dcg / idcg.clamp(min=1e-30), zero).sum() / n_valid]
+        vals = torch.stack(out).cpu().numpy()
+        for i, k in enumerate(self.topks):
+            results['Precision'][k], results['Recall'][k], results['NDCG'][k] = (np.float32(v) for v in vals[3 * i:3 * i + 3])
+        return results
+
+    def _eval_lists_device(self, val_or_test):
+        """Device CSR of the evaluated lists; rebuilt whenever the dataset hands out new arrays
+        (dataset.invalidate() after the lists were edited in place)."""
+        if hasattr(self.dataset, 'invalidate'):
+            self.dataset.invalidate(val_or_test)
+        rowptr, col = self.dataset.csr(val_or_test, sort=True)
+        key = ('eval', val_or_test, id(rowptr), id(col))
+        if self._excl_cache.get('eval_key') != key:
+            rp, cl = _csr_to_device(rowptr, col, self.device)
+            self._excl_cache['eval_key'] = key
+            self._excl_cache['eval_val'] = (rp, cl, (rp[1:] - rp[:-1]).contiguous())
+        return self._excl_cache['eval_val']
+
     def calculate_metrics(self, eval_data, rec_items):
         """Same signature as trainer.py:109: eval_data list-of-lists, rec_items
         numpy [U, k].  The membership loop runs as one device kernel."""
@@ -248,12 +286,12 @@ class BasicTrainer:
         """trainer.py:140-177; returns (results string, metrics dict)."""
         self.model.eval()
         rec = self.recommend_all(val_or_test, banned_items)
-        if hasattr(self.dataset, 'invalidate'):
-            self.dataset.invalidate()                         # eval lists may have been edited in place
-        rowptr, col = self.dataset.csr(val_or_test, sort=True)
-        rp, cl = _csr_to_device(rowptr, col, self.device)
-        hit = ops.hit_matrix(rec.contiguous(), rp, cl).cpu().numpy()
-        metrics = self._metrics_from_hits(hit, np.diff(rowptr).astype(np.int32))
+        rp, cl, lens = self._eval_lists_device(val_or_test)    # eval lists may have been edited in place
+        hit = ops.hit_matrix(rec.contiguous(), rp, cl)
+        if self.config.get('host_metrics', False):
+            metrics = self._metrics_from_hits(hit.cpu().numpy(), lens.cpu().numpy().astype(np.int32))
+        else:
+            metrics = self._metrics_from_hits_device(hit, lens)
         self.last_rec_items = rec
 
         precison = ''

@@ -202,8 +202,8 @@ def test_inductive_eval_golden(golden, capsys):
             for k in m[name]:
                 refv = float(golden['ind_%d_%s_%d' % (j, name, k)])
                 assert m[name][k] == refv or (np.isnan(refv) and np.isnan(m[name][k])), (j, name, k)
-                if np.array_equal(rec, ref):
-                    assert metrics[name][k] == refv or np.isnan(refv)
+                if np.array_equal(rec, ref):                     # eval() reduces on the device: float32 rounding only
+                    assert abs(metrics[name][k] - refv) < 1e-6 or np.isnan(refv)
 
 
 def test_hit_matrix_and_metrics_golden(golden):
