@@ -31,9 +31,12 @@ def make_shard(n_rows, n_cols, nnz, seed, zipf=False):
 
 def main():
     out = []
-    for d, n_cols, n_rows, nnz in ((128, 12_000_000, 1_500_000, 125_000_000),
-                                   (64, 12_000_000, 1_500_000, 125_000_000),
-                                   (128, 1_500_000, 1_500_000, 125_000_000)):
+    shapes = [(128, 12_000_000, 1_500_000, 125_000_000),
+              (64, 12_000_000, 1_500_000, 125_000_000),
+              (128, 1_500_000, 1_500_000, 125_000_000)]
+    if '--full' in sys.argv:        # the whole config-5 matrix on ONE GPU: 12 M x 12 M, 1 G nonzeros, d = 128
+        shapes = [(128, 12_000_000, 12_000_000, 1_000_000_000)]
+    for d, n_cols, n_rows, nnz in shapes:
         rowptr, col, val, total = make_shard(n_rows, n_cols, nnz, 1)
         csr = CsrMatrix(rowptr.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy(), (n_rows, n_cols), 'cuda')
         x = torch.randn(n_cols, d, device='cuda') * 0.1
