@@ -146,6 +146,34 @@ def main():
         row_sharded = {'ms_per_step': float(tr.item()) * 1e3 / n_row, 'edges_per_s': n_row * K * nnz / float(tr.item()),
                        'steps': n_row}
 
+    sharded_eval = None
+    if sharded and not args.no_extras:
+        # evaluation at N > 1: gather the column slices of the final representation once, then every rank
+        # scores its block of users against all items (fused score / mask / top-20; train lists masked)
+        from igcn_cf_amd.trainer import _csr_to_device
+        rp_h, col_h = ds.csr('train', sort=True)
+        ub = (ds.n_users + world - 1) // world
+        ulo, uhi = rank * ub, min((rank + 1) * ub, ds.n_users)
+        excl_rp, excl_col = _csr_to_device(rp_h, col_h, device)
+        my_users = torch.arange(ulo, uhi, dtype=torch.int64, device=device)
+
+        def eval_once():
+            rep_slice = ops.propagate_mean(csr, x0, K)
+            parts = torch.empty((world * n, dl), dtype=torch.float32, device=device)
+            dist.all_gather_into_tensor(parts, rep_slice.contiguous())
+            full = parts.view(world, n, dl).permute(1, 0, 2).reshape(n, d).contiguous()
+            return ops.score_topk(full, full[ds.n_users:], 20, user_ids=my_users, excl_rowptr=excl_rp, excl_col=excl_col)
+        eval_once()
+        barrier_sync()
+        t2 = time.perf_counter()
+        for _ in range(2):
+            eval_once()
+        barrier_sync()
+        te = torch.tensor([time.perf_counter() - t2], dtype=torch.float64, device=device)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        sharded_eval = {'eval_ms': float(te.item()) * 1e3 / 2, 'eval_users_per_s': 2 * ds.n_users / float(te.item()),
+                        'n_users': ds.n_users, 'n_items': ds.n_items}
+
     edges = args.steps * K * nnz
     value = edges / wall
     out = {
@@ -185,6 +213,8 @@ def main():
         extras = side_measurements(ds, device, d, K)
     if row_sharded is not None:
         extras['row_sharded_allgather'] = row_sharded
+    if sharded_eval is not None:
+        extras['user_sharded_eval'] = sharded_eval
     out['extras'] = extras
 
     if not sharded and rank == 0 and not args.no_cpu_baseline:
