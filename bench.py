@@ -172,7 +172,10 @@ def main():
         te = torch.tensor([time.perf_counter() - t2], dtype=torch.float64, device=device)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         sharded_eval = {'eval_ms': float(te.item()) * 1e3 / 2, 'eval_users_per_s': 2 * ds.n_users / float(te.item()),
-                        'n_users': ds.n_users, 'n_items': ds.n_items}
+                        'n_users': ds.n_users, 'n_items': ds.n_items,
+                        'eval_mfma_tflops_all_gpus': 2.0 * ds.n_users * ds.n_items * d / (float(te.item()) / 2) / 1e12,
+                        'note': 'weak scaling grows users AND items with N: scoring work per evaluation grows as N^2, '
+                                'so users/s stays level while the aggregate TFLOP/s scales with N'}
 
     edges = args.steps * K * nnz
     value = edges / wall
