@@ -8,7 +8,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(PKG, 'libigcn_hip.so')
-SOURCES = [f for f in ('spmm.hip', 'bpr.hip', 'score_topk.hip', 'sampler.hip')
+SOURCES = [f for f in ('spmm.hip', 'bpr.hip', 'score_topk.hip', 'sampler.hip', 'csr_util.hip')
            if os.path.exists(os.path.join(CSRC, f))]
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-Wall', '-Wno-unused-function',
          '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]

@@ -174,12 +174,47 @@ class CsrMatrix:
         self._col_host = col if keep_host else None
         self._transposed = None
 
+    @classmethod
+    def from_device(cls, rowptr, col, val, shape, edge_id=None, long_threshold=LONG_THRESHOLD, segment_len=SEGMENT_LEN):
+        """Wrap CSR arrays that already live in HBM (int64 rowptr, int32 col, float32 val or None);
+        only rowptr is copied to the host, for the long-row schedule."""
+        self = cls.__new__(cls)
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.device = rowptr.device
+        self.rowptr, self.col, self.val, self.edge_id = rowptr, col, val, edge_id
+        self.nnz = int(col.shape[0])
+        self.rowptr_host = rowptr.cpu().numpy()
+        if self.rowptr_host.shape[0] != self.shape[0] + 1 or self.rowptr_host[-1] != self.nnz:
+            raise ValueError('inconsistent CSR arrays')
+        self.long_threshold, self.segment_len = int(long_threshold), int(segment_len)
+        self._build_plan()
+        self._partial = {}
+        self._col_host = None
+        self._transposed = None
+        return self
+
     def transposed_view(self):
-        """CSR of M^T (values all ones) sharing edge ids with M; built on first use."""
+        """CSR of M^T (values all ones) sharing edge ids with M; built on first use, on the
+        device (igcn_csr_transpose) when the matrix lives there."""
         if self._transposed is None:
-            col = self._col_host if self._col_host is not None else self.col.cpu().numpy()
-            self._transposed = CsrMatrix.transposed(self.rowptr_host, col, self.shape, self.device,
-                                                    long_threshold=self.long_threshold, segment_len=self.segment_len)
+            if self.device.type == 'cuda':
+                L = _lib.lib()
+                ws_bytes = L.igcn_csr_transpose_workspace_bytes(self.nnz)
+                if ws_bytes < 0:
+                    raise _lib.IgcnError('matrix too large for igcn_csr_transpose (nnz must be < 2^31)')
+                ws = torch.empty(max(int(ws_bytes), 256), dtype=torch.uint8, device=self.device)
+                t_rowptr = torch.empty(self.shape[1] + 1, dtype=torch.int64, device=self.device)
+                t_col = torch.empty(self.nnz, dtype=torch.int32, device=self.device)
+                edge_id = torch.empty(self.nnz, dtype=torch.int32, device=self.device)
+                _lib.check(L.igcn_csr_transpose(self.rowptr.data_ptr(), _lib.ptr(self.col), self.shape[0], self.shape[1], self.nnz,
+                                                t_rowptr.data_ptr(), _lib.ptr(t_col), _lib.ptr(edge_id), ws.data_ptr(),
+                                                _lib.current_stream()), 'igcn_csr_transpose')
+                self._transposed = CsrMatrix.from_device(t_rowptr, t_col, None, (self.shape[1], self.shape[0]), edge_id=edge_id,
+                                                         long_threshold=self.long_threshold, segment_len=self.segment_len)
+            else:
+                col = self._col_host if self._col_host is not None else self.col.cpu().numpy()
+                self._transposed = CsrMatrix.transposed(self.rowptr_host, col, self.shape, self.device,
+                                                        long_threshold=self.long_threshold, segment_len=self.segment_len)
             self._col_host = None
         return self._transposed
 

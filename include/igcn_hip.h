@@ -119,6 +119,19 @@ int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *va
 int igcn_mark_rows(const int64_t *ids, int64_t n, const int64_t *rowptr, const int32_t *col,
                    uint8_t *mask1, uint8_t *mask2, int64_t n_rows, void *stream);
 
+/* Device-side index utilities for the graph-swap path (model.py:402-421 is_updating,
+ * run/dropui/igcn_dropui.py:26-35): the reference rebuilds its sparse structures on the host
+ * with scipy (utils.py:32-38).
+ *  igcn_csr_from_sorted_coo: rowptr [n_rows+1] of a row-major sorted COO (sorted_row int64 [nnz]).
+ *  igcn_csr_transpose: CSR of M^T (t_rowptr int64 [n_cols+1], t_col int32 [nnz] = source rows in
+ *  ascending order) and edge_id int32 [nnz] = position of each transposed entry in M, so that
+ *  igcn_spmm_csr_f32 drops the same edges in both views.  workspace: 256-byte aligned,
+ *  igcn_csr_transpose_workspace_bytes(nnz) bytes; nnz < 2^31. */
+int igcn_csr_from_sorted_coo(const int64_t *sorted_row, int64_t nnz, int64_t n_rows, int64_t *rowptr, void *stream);
+int64_t igcn_csr_transpose_workspace_bytes(int64_t nnz);
+int igcn_csr_transpose(const int64_t *rowptr, const int32_t *col, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                       int64_t *t_rowptr, int32_t *t_col, int32_t *edge_id, void *workspace, void *stream);
+
 /* out[e] = row_sum[row(e)] ^ exponent for every stored entry of a CSR matrix:
  * IGCN.update_feat_mat, model.py:374-377, as explicit values (the propagation
  * path itself uses row_scale instead and never materialises them). */

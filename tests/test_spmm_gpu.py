@@ -269,3 +269,28 @@ def test_spmm_matrix_without_entries():
     x = torch.randn(n, 64, device='cuda')
     assert torch.all(spmm(csr, x) == 0)
     assert torch.allclose(propagate_mean(csr, x, 3), x / 4)
+
+
+def test_device_csr_utilities_match_host_builders():
+    """igcn_csr_transpose / igcn_csr_from_sorted_coo against graph.transpose_host and the host rowptr."""
+    import ctypes as C
+    from igcn_cf_amd import _lib
+    from igcn_cf_amd.graph import CsrMatrix, feature_matrix_host, transpose_host
+    from igcn_cf_amd.dataset import SyntheticDataset
+    ds = SyntheticDataset({'name': 'SyntheticDataset', 'n_users': 3000, 'n_items': 2000, 'n_inter': 90000})
+    rowptr, col, row_sum, shape = feature_matrix_host(ds.train_array, ds.n_users, ds.n_items)
+    feat = CsrMatrix(rowptr, col, None, shape, 'cuda')
+    t = feat.transposed_view()                                        # device path
+    h_rowptr, h_col, h_eid = transpose_host(rowptr, col, shape[1])
+    np.testing.assert_array_equal(t.rowptr.cpu().numpy(), h_rowptr)
+    np.testing.assert_array_equal(t.col.cpu().numpy(), h_col)
+    np.testing.assert_array_equal(t.edge_id.cpu().numpy(), h_eid)
+    assert t.shape == (shape[1], shape[0]) and t.n_long >= 1          # the two global columns are long rows of F^T
+    # rowptr from a sorted COO row array
+    rows = torch.from_numpy(np.repeat(np.arange(shape[0], dtype=np.int64), np.diff(rowptr))).cuda()
+    out = torch.empty(shape[0] + 1, dtype=torch.int64, device='cuda')
+    _lib.check(_lib.lib().igcn_csr_from_sorted_coo(rows.data_ptr(), rows.numel(), shape[0], out.data_ptr(), None), 'from_sorted_coo')
+    np.testing.assert_array_equal(out.cpu().numpy(), rowptr)
+    # empty matrix
+    e = CsrMatrix(np.zeros(11, dtype=np.int64), np.zeros(0, dtype=np.int32), None, (10, 7), 'cuda')
+    assert e.transposed_view().shape == (7, 10) and int(e.transposed_view().rowptr.sum()) == 0
