@@ -1,0 +1,22 @@
+"""Developer: N training steps of one (preset, index) config, for rocprofv3 --kernel-trace --stats."""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from igcn_cf_amd import config as cfg
+from igcn_cf_amd.dataset import get_dataset
+from igcn_cf_amd.model import get_model
+from igcn_cf_amd.trainer import get_trainer
+
+preset, index = (sys.argv[1], int(sys.argv[2])) if len(sys.argv) > 2 else ('amazon', 2)
+ds_cfg, m_cfg, t_cfg = cfg.get_synthetic_config(torch.device('cuda'), preset)[index]
+ds = get_dataset(ds_cfg)
+torch.manual_seed(2021)
+model = get_model(m_cfg, ds)
+trainer = get_trainer(t_cfg, ds, model)
+model.train()
+its = [b for _, b in zip(range(60), trainer.sampler.epoch_batches(2048))]
+aux = [b for _, b in zip(range(60), trainer.aux_sampler.epoch_batches(2048))] if hasattr(trainer, 'aux_sampler') else None
+for i in range(60):
+    trainer.igcn_step(its[i], aux[i]) if aux else trainer.bpr_step(its[i])
+torch.cuda.synchronize()
