@@ -345,3 +345,36 @@ class ColumnShardedLightGCN(torch.nn.Module):
     def full_embedding(self):
         with torch.no_grad():
             return self.gather_columns(self.emb.detach())
+
+
+def column_shard_model(model_config, dataset, rank, world, group=None, full_state=None, reduce_fn=None):
+    """Any of MF / LightGCN / IGCN / IMF with its embedding COLUMNS cut over the ranks: the model is
+    built with embedding_size / world columns (graph, template features and every kernel unchanged),
+    takes its column slice of `full_state` (a full-width state dict; default: a seeded full-width
+    initialisation, identical on every rank) and sums the partial dots of its losses over the ranks.
+    Propagation needs no exchange (see ColumnShardedLightGCN)."""
+    from .model import get_model
+    d = model_config['embedding_size']
+    if d % world:
+        raise ValueError('embedding_size must be divisible by the number of ranks')
+    dl = d // world
+    if full_state is None:
+        g_state = torch.random.get_rng_state()
+        torch.manual_seed(model_config.get('seed', 2021))
+        full = get_model(model_config, dataset)
+        full_state = {k: v.detach().clone() for k, v in full.state_dict().items()}
+        del full
+        torch.random.set_rng_state(g_state)
+    model = get_model(dict(model_config, embedding_size=dl), dataset)
+    sl = slice(rank * dl, (rank + 1) * dl)
+    with torch.no_grad():
+        for name, p in model.state_dict().items():
+            src = full_state[name]
+            p.copy_(src[..., sl] if src.shape[-1] == d else src)
+    if reduce_fn is None:
+        def reduce_fn(t):
+            if dist.is_available() and dist.is_initialized():
+                dist.all_reduce(t, group=group)
+            return t
+    model.slice_reduce_fn = reduce_fn
+    return model

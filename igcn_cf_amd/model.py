@@ -51,6 +51,9 @@ class BasicModel(nn.Module):
         self.n_items = model_config['dataset'].n_items
         self.trainable = True
         self._rep_cache = None
+        # set by dist.column_shard_model: this model holds d/P embedding columns and the partial dots of a
+        # loss are summed over the ranks with this function (an all-reduce)
+        self.slice_reduce_fn = None
 
     def predict(self, users):
         raise NotImplementedError
@@ -111,7 +114,7 @@ class MF(BasicModel):
 
     def bpr_loss_terms(self, users, pos_items, neg_items):
         u, i = self.user_embedding.weight, self.item_embedding.weight
-        return ops.bpr_loss_terms(u, i, u, i, None, users, pos_items, neg_items)
+        return ops.bpr_loss_terms(u, i, u, i, None, users, pos_items, neg_items, reduce_fn=self.slice_reduce_fn)
 
     def score_tables(self):
         return self.user_embedding.weight.detach(), self.item_embedding.weight.detach()
@@ -166,7 +169,8 @@ class LightGCN(BasicModel):
 
     def bpr_loss_terms(self, users, pos_items, neg_items):
         rep, e = self.get_rep(self._batch_rows(users, pos_items, neg_items)), self.embedding.weight
-        return ops.bpr_loss_terms(rep, rep, e, e, None, users, pos_items, neg_items, self.n_users, self.n_users)
+        return ops.bpr_loss_terms(rep, rep, e, e, None, users, pos_items, neg_items, self.n_users, self.n_users,
+                                  reduce_fn=self.slice_reduce_fn)
 
     def predict(self, users):
         rep = self.get_rep()
@@ -293,14 +297,16 @@ class IGCN(BasicModel):
 
     def bpr_loss_terms(self, users, pos_items, neg_items):
         rep = self.get_rep(self._batch_rows(users, pos_items, neg_items))
-        return ops.bpr_loss_terms(rep, rep, rep, rep, None, users, pos_items, neg_items, self.n_users, self.n_users)
+        return ops.bpr_loss_terms(rep, rep, rep, rep, None, users, pos_items, neg_items, self.n_users, self.n_users,
+                                  reduce_fn=self.slice_reduce_fn)
 
     def aux_loss(self, users, pos_items, neg_items):
         """Self-enhanced auxiliary BPR loss on the raw template rows, weighted by w
         (trainer.py:304-311)."""
         e = self.embedding.weight
         off = len(self.user_map)
-        return ops.bpr_loss_terms(e, e, None, None, self.w, users, pos_items, neg_items, off, 0)[0]
+        return ops.bpr_loss_terms(e, e, None, None, self.w, users, pos_items, neg_items, off, 0,
+                                  reduce_fn=self.slice_reduce_fn)[0]
 
     def predict(self, users):
         return LightGCN.predict(self, users)

@@ -370,3 +370,53 @@ def test_full_scale_amazon_like_epoch_slice():
         if set(order[:20]) != set(rec[u]):
             assert s[order[19]] - s[order[20]] < 1e-6 * max(1., abs(s[order[19]])), u
         assert not (set(rec[u]) & set(c_t[rp_t[u]:rp_t[u + 1]]))          # masked items never recommended
+
+
+@pytest.mark.parametrize('name', ['IGCN', 'MF'])
+def test_column_sharded_models_reproduce_the_full_model(golden, name):
+    """dist.column_shard_model: P = 2 column slices of a model (emulated on one GPU, the all-reduce replaced by
+    the sum of the two slices' partial dots) give the full model's loss and, slice by slice, its gradients."""
+    from igcn_cf_amd.dist import column_shard_model
+    from igcn_cf_amd.model import get_model
+    ds = _dataset(golden)
+    cfg = {'name': name, 'embedding_size': 64, 'n_layers': 3, 'device': 'cuda', 'dropout': 0., 'feature_ratio': 1.}
+    torch.manual_seed(3)
+    full = get_model(cfg, ds)
+    if name == 'IGCN':
+        with torch.no_grad():
+            full.w.copy_(torch.rand(64, device='cuda') + 0.5)
+    state = {k: v.detach().clone() for k, v in full.state_dict().items()}
+    rng = np.random.default_rng(0)
+    B = 200
+    t = lambda a: torch.from_numpy(a).cuda()
+    users, pos, neg = t(rng.integers(0, ds.n_users, B)), t(rng.integers(0, ds.n_items, B)), t(rng.integers(0, ds.n_items, B))
+    full.train()
+
+    def total_loss(m):
+        terms = m.bpr_loss_terms(users, pos, neg)
+        loss = terms[0] + 1e-2 * terms[1]
+        if name == 'IGCN':
+            loss = loss + 0.1 * m.aux_loss(users, pos, neg)
+        return loss
+    ref = total_loss(full)
+    ref.backward()
+    partial = {}
+    slices = []
+    for r in range(2):                                       # pass 1: record every slice's partial dots, call by call
+        calls = []
+        m = column_shard_model(cfg, ds, r, 2, full_state=state, reduce_fn=lambda d_, c=calls: c.append(d_.clone()))
+        m.train()
+        total_loss(m)
+        partial[r] = calls
+        slices.append(m)
+    n_calls = len(partial[0])
+    for r, m in enumerate(slices):                           # pass 2: the all-reduce result = sum over slices
+        it = iter(range(n_calls))
+        m.slice_reduce_fn = lambda d_, it=it: d_.copy_(partial[0][(i := next(it))] + partial[1][i])
+        m.zero_grad()
+        loss = total_loss(m)
+        assert abs(loss.item() - ref.item()) < 1e-5
+        loss.backward()
+        for (pname, p), (_, pf) in zip(m.named_parameters(), full.named_parameters()):
+            want = pf.grad[..., r * 32:(r + 1) * 32] if pf.shape[-1] == 64 else pf.grad
+            assert torch.allclose(p.grad, want, rtol=1e-4, atol=1e-7), (name, pname)
