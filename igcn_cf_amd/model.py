@@ -39,6 +39,11 @@ def get_model(config, dataset):
     return cls(config)
 
 
+def _sq_norms(*row_sets):
+    """Sum over the given [B, d] tensors of their per-row squared L2 norms -> [B]."""
+    return sum(r.square().sum(dim=1) for r in row_sets)
+
+
 class BasicModel(nn.Module):
     def __init__(self, model_config):
         super().__init__()
@@ -106,11 +111,9 @@ class MF(BasicModel):
         self.to(device=self.device)
 
     def bpr_forward(self, users, pos_items, neg_items):
-        users_e = self.user_embedding(users)
-        pos_items_e, neg_items_e = self.item_embedding(pos_items), self.item_embedding(neg_items)
-        l2_norm_sq = torch.norm(users_e, p=2, dim=1) ** 2 + torch.norm(pos_items_e, p=2, dim=1) ** 2 \
-            + torch.norm(neg_items_e, p=2, dim=1) ** 2
-        return users_e, pos_items_e, neg_items_e, l2_norm_sq
+        """Reference signature (model.py:62-67): gathered rows + per-triplet squared L2 norm."""
+        rows = (self.user_embedding(users), self.item_embedding(pos_items), self.item_embedding(neg_items))
+        return (*rows, _sq_norms(*rows))
 
     def bpr_loss_terms(self, users, pos_items, neg_items):
         u, i = self.user_embedding.weight, self.item_embedding.weight
@@ -158,14 +161,11 @@ class LightGCN(BasicModel):
         return torch.cat([users, self.n_users + pos_items, self.n_users + neg_items])
 
     def bpr_forward(self, users, pos_items, neg_items):
-        rep = self.get_rep()
-        users_e = self.embedding(users)
-        pos_items_e, neg_items_e = self.embedding(self.n_users + pos_items), self.embedding(self.n_users + neg_items)
-        l2_norm_sq = torch.norm(users_e, p=2, dim=1) ** 2 + torch.norm(pos_items_e, p=2, dim=1) ** 2 \
-            + torch.norm(neg_items_e, p=2, dim=1) ** 2
-        users_r = rep[users, :]
-        pos_items_r, neg_items_r = rep[self.n_users + pos_items, :], rep[self.n_users + neg_items, :]
-        return users_r, pos_items_r, neg_items_r, l2_norm_sq
+        """Reference signature (model.py:108-116): propagated rows of the triplets; the L2 term is
+        taken on the RAW embedding rows."""
+        rep, raw = self.get_rep(), self.embedding.weight
+        idx = (users, self.n_users + pos_items, self.n_users + neg_items)
+        return (*(rep[i] for i in idx), _sq_norms(*(raw[i] for i in idx)))
 
     def bpr_loss_terms(self, users, pos_items, neg_items):
         rep, e = self.get_rep(self._batch_rows(users, pos_items, neg_items)), self.embedding.weight
@@ -288,12 +288,11 @@ class IGCN(BasicModel):
     _batch_rows = LightGCN._batch_rows
 
     def bpr_forward(self, users, pos_items, neg_items):
+        """Reference signature (model.py:293-299 via :448-449): propagated rows; the L2 term is taken
+        on those same propagated rows."""
         rep = self.get_rep()
-        users_r = rep[users, :]
-        pos_items_r, neg_items_r = rep[self.n_users + pos_items, :], rep[self.n_users + neg_items, :]
-        l2_norm_sq = torch.norm(users_r, p=2, dim=1) ** 2 + torch.norm(pos_items_r, p=2, dim=1) ** 2 \
-            + torch.norm(neg_items_r, p=2, dim=1) ** 2
-        return users_r, pos_items_r, neg_items_r, l2_norm_sq
+        rows = tuple(rep[i] for i in (users, self.n_users + pos_items, self.n_users + neg_items))
+        return (*rows, _sq_norms(*rows))
 
     def bpr_loss_terms(self, users, pos_items, neg_items):
         rep = self.get_rep(self._batch_rows(users, pos_items, neg_items))

@@ -125,83 +125,92 @@ class BasicTrainer:
         raise NotImplementedError
 
     def record(self, writer, stage, metrics):
-        for metric in metrics:
+        """tensorboard-style scalars '<model>_<trainer>/<stage>_<metric>@k' (trainer.py:50-55)."""
+        prefix = f'{self.model.name}_{self.name}/{stage}_'
+        for metric, by_k in metrics.items():
             for k in self.topks:
-                writer.add_scalar('{:s}_{:s}/{:s}_{:s}@{:d}'.format(self.model.name, self.name, stage, metric, k),
-                                  metrics[metric][k], self.epoch)
+                writer.add_scalar(f'{prefix}{metric}@{k:d}', by_k[k], self.epoch)
+
+    def _checkpoint_if_best(self, ndcg):
+        """Keep only the best-validation-NDCG checkpoint on disk (trainer.py:91-100); returns True
+        when `ndcg` is a new best."""
+        if ndcg <= self.best_ndcg:
+            return False
+        if self.save_path:
+            os.remove(self.save_path)
+        fname = f'{self.model.name}_{self.name}_{self.dataset.name}_{ndcg * 100:.3f}.pth'
+        self.save_path = os.path.join('checkpoints', fname)
+        self.best_ndcg = ndcg
+        self.model.save(self.save_path)
+        print(f'Best NDCG, save model to {self.save_path}')
+        return True
 
     def train(self, verbose=True, writer=None):
-        """Epoch loop with validation, best-NDCG checkpoint and patience (trainer.py:57-107)."""
+        """Training driver with the reference's protocol (trainer.py:57-107): per epoch one pass of
+        train_one_epoch and an evaluation on the train lists; every val_interval epochs a validation,
+        whose NDCG@topks[0] decides checkpointing and early stopping (max_patience epochs without
+        improvement); the best checkpoint is reloaded at the end.  A non-trainable model is only
+        validated."""
+        k0 = self.topks[0]
         if not self.model.trainable:
-            results, metrics = self.eval('val')
+            summary, metrics = self.eval('val')
             if verbose:
-                print('Validation result. {:s}'.format(results))
-            return metrics['NDCG'][self.topks[0]]
+                print(f'Validation result. {summary}')
+            return metrics['NDCG'][k0]
 
-        if not os.path.exists('checkpoints'):
-            os.mkdir('checkpoints')
-        patience = self.max_patience
+        os.makedirs('checkpoints', exist_ok=True)
+        tag = f'{self.model.name}_{self.name}'
+        epochs_left = self.max_patience
         for self.epoch in range(self.n_epochs):
-            start_time = time.time()
+            t0 = time.time()
             self.model.train()
             loss = self.train_one_epoch()
-            _, metrics = self.eval('train')
-            consumed_time = time.time() - start_time
+            _, train_metrics = self.eval('train')
             if verbose:
-                print('Epoch {:d}/{:d}, Loss: {:.6f}, Time: {:.3f}s'.format(self.epoch, self.n_epochs, loss, consumed_time))
+                print(f'Epoch {self.epoch:d}/{self.n_epochs:d}, Loss: {loss:.6f}, Time: {time.time() - t0:.3f}s')
             if writer:
-                writer.add_scalar('{:s}_{:s}/train_loss'.format(self.model.name, self.name), loss, self.epoch)
-                self.record(writer, 'train', metrics)
-            if (self.epoch + 1) % self.val_interval != 0:
+                writer.add_scalar(f'{tag}/train_loss', loss, self.epoch)
+                self.record(writer, 'train', train_metrics)
+            if (self.epoch + 1) % self.val_interval:
                 continue
 
-            start_time = time.time()
-            results, metrics = self.eval('val')
-            consumed_time = time.time() - start_time
+            t0 = time.time()
+            summary, val_metrics = self.eval('val')
             if verbose:
-                print('Validation result. {:s}Time: {:.3f}s'.format(results, consumed_time))
+                print(f'Validation result. {summary}Time: {time.time() - t0:.3f}s')
             if writer:
-                self.record(writer, 'validation', metrics)
-
-            ndcg = metrics['NDCG'][self.topks[0]]
-            if ndcg > self.best_ndcg:
-                if self.save_path:
-                    os.remove(self.save_path)
-                self.save_path = os.path.join('checkpoints', '{:s}_{:s}_{:s}_{:.3f}.pth'
-                                              .format(self.model.name, self.name, self.dataset.name, ndcg * 100))
-                self.best_ndcg = ndcg
-                self.model.save(self.save_path)
-                patience = self.max_patience
-                print('Best NDCG, save model to {:s}'.format(self.save_path))
-            else:
-                patience -= self.val_interval
-                if patience <= 0:
-                    print('Early stopping!')
-                    break
+                self.record(writer, 'validation', val_metrics)
+            if self._checkpoint_if_best(val_metrics['NDCG'][k0]):
+                epochs_left = self.max_patience
+                continue
+            epochs_left -= self.val_interval
+            if epochs_left <= 0:
+                print('Early stopping!')
+                break
         self.model.load(self.save_path)
         return self.best_ndcg
 
     # ---- metrics ---------------------------------------------------------------
     def _metrics_from_hits(self, hit_matrix, eval_data_len):
-        """trainer.py:116-137 verbatim in numpy dtypes (float32 hits, int32 lengths)."""
-        results = {'Precision': {}, 'Recall': {}, 'NDCG': {}}
+        """Precision / Recall / NDCG @k from a 0/1 hit matrix, with the array dtypes of trainer.py:116-137
+        (float32 hits and discounts, int32 list lengths, hence a float64 recall) so that the values are
+        bit-identical to the reference's; users without evaluation items are left out of the means."""
+        out = {'Precision': {}, 'Recall': {}, 'NDCG': {}}
+        lens = np.asarray(eval_data_len)
         for k in self.topks:
-            hit_num = np.sum(hit_matrix[:, :k], axis=1)
-            precisions = hit_num / k
+            top = hit_matrix[:, :k]
+            n_hit = top.sum(axis=1)
+            best_possible = np.minimum(lens, k)
+            scored = best_possible > 0
+            discount = np.log2(np.arange(2, k + 2, dtype=np.float32))[None, :]
+            ideal = (np.arange(k)[None, :] < best_possible[:, None]).astype(np.float32)
             with np.errstate(invalid='ignore', divide='ignore'):
-                recalls = hit_num / eval_data_len
-            max_hit_num = np.minimum(eval_data_len, k)
-            max_hit_matrix = (np.arange(k)[None, :] < max_hit_num[:, None]).astype(np.float32)
-            denominator = np.log2(np.arange(2, k + 2, dtype=np.float32))[None, :]
-            dcgs = np.sum(hit_matrix[:, :k] / denominator, axis=1)
-            idcgs = np.sum(max_hit_matrix / denominator, axis=1)
-            with np.errstate(invalid='ignore', divide='ignore'):
-                ndcgs = dcgs / idcgs
-            user_masks = (max_hit_num > 0)
-            results['Precision'][k] = precisions[user_masks].mean()
-            results['Recall'][k] = recalls[user_masks].mean()
-            results['NDCG'][k] = ndcgs[user_masks].mean()
-        return results
+                recall = n_hit / lens
+                ndcg = (top / discount).sum(axis=1) / (ideal / discount).sum(axis=1)
+            out['Precision'][k] = (n_hit / k)[scored].mean()
+            out['Recall'][k] = recall[scored].mean()
+            out['NDCG'][k] = ndcg[scored].mean()
+        return out
 
     def _metrics_from_hits_device(self, hit, eval_len):
         """The reductions of trainer.py:116-137 on the device (float32, same formulas): only the
@@ -294,61 +303,46 @@ class BasicTrainer:
             metrics = self._metrics_from_hits_device(hit, lens)
         self.last_rec_items = rec
 
-        precison = ''
-        recall = ''
-        ndcg = ''
-        for k in self.topks:
-            precison += '{:.3f}%@{:d}, '.format(metrics['Precision'][k] * 100., k)
-            recall += '{:.3f}%@{:d}, '.format(metrics['Recall'][k] * 100., k)
-            ndcg += '{:.3f}%@{:d}, '.format(metrics['NDCG'][k] * 100., k)
-        results = 'Precision: {:s}Recall: {:s}NDCG: {:s}'.format(precison, recall, ndcg)
+        def row(name):
+            return ''.join(f'{metrics[name][k] * 100.:.3f}%@{k:d}, ' for k in self.topks)
+        results = f"Precision: {row('Precision')}Recall: {row('Recall')}NDCG: {row('NDCG')}"
         return results, metrics
 
     def inductive_eval(self, n_old_users, n_old_items):
-        """The six masked evaluations of trainer.py:179-219."""
-        test_data = self.dataset.test_data.copy()
-
-        def restore():
-            self.dataset.test_data = test_data.copy()
-
-        results, _ = self.eval('test')
-        print('All users and all items result. {:s}'.format(results))
-
-        for user in range(n_old_users, self.dataset.n_users):
-            self.dataset.test_data[user] = []
-        results, _ = self.eval('test')
-        print('Old users and all items result. {:s}'.format(results))
-
-        restore()
-        for user in range(n_old_users):
-            self.dataset.test_data[user] = []
-        results, _ = self.eval('test')
-        print('New users and all items result. {:s}'.format(results))
-
-        restore()
-        for user in range(self.dataset.n_users):
-            test_items = np.array(self.dataset.test_data[user])
-            self.dataset.test_data[user] = test_items[test_items < n_old_items].tolist()
-        results, _ = self.eval('test', banned_items=np.arange(n_old_items, self.dataset.n_items))
-        print('All users and old items result. {:s}'.format(results))
-
-        restore()
-        for user in range(self.dataset.n_users):
-            test_items = np.array(self.dataset.test_data[user])
-            self.dataset.test_data[user] = test_items[test_items >= n_old_items].tolist()
-        results, _ = self.eval('test', banned_items=np.arange(n_old_items))
-        print('All users and new items result. {:s}'.format(results))
-
-        restore()
-        for user in range(n_old_users, self.dataset.n_users):
-            self.dataset.test_data[user] = []
-        for user in range(n_old_users):
-            test_items = np.array(self.dataset.test_data[user])
-            self.dataset.test_data[user] = test_items[test_items < n_old_items].tolist()
-        results, _ = self.eval('test', banned_items=np.arange(n_old_items, self.dataset.n_items))
-        print('Old users and old items result. {:s}'.format(results))
-
-        restore()
+        """The six test evaluations of the inductive protocol (trainer.py:179-219) on a model whose
+        graph was extended by users >= n_old_users and items >= n_old_items: every combination the
+        paper reports of {all, old, new} users x {all, old, new} items.  A user outside the evaluated
+        user set gets an empty test list; for an item subset the test lists are filtered to it and
+        the other items are banned from the recommendations.  The dataset's test lists are restored
+        afterwards."""
+        n_users, n_items = self.dataset.n_users, self.dataset.n_items
+        original = self.dataset.test_data
+        old_items = np.arange(n_old_items)
+        new_items = np.arange(n_old_items, n_items)
+        #  label                     evaluated users              kept items  banned items
+        variants = [
+            ('All users and all items', range(n_users),               None,  None),
+            ('Old users and all items', range(n_old_users),           None,  None),
+            ('New users and all items', range(n_old_users, n_users),  None,  None),
+            ('All users and old items', range(n_users),               'old', new_items),
+            ('All users and new items', range(n_users),               'new', old_items),
+            ('Old users and old items', range(n_old_users),           'old', new_items),
+        ]
+        try:
+            for label, users, keep, banned in variants:
+                lists = [[] for _ in range(n_users)]
+                for u in users:
+                    items = original[u]
+                    if keep == 'old':
+                        items = [i for i in items if i < n_old_items]
+                    elif keep == 'new':
+                        items = [i for i in items if i >= n_old_items]
+                    lists[u] = list(items)
+                self.dataset.test_data = lists
+                summary, _ = self.eval('test', banned_items=banned)
+                print(f'{label} result. {summary}')
+        finally:
+            self.dataset.test_data = original
 
 
 class BPRTrainer(BasicTrainer):

@@ -22,21 +22,23 @@ def set_seed(seed=0):
 
 
 class Unbuffered:
-    """utils.py:138-151: a stream that flushes on every write."""
+    """File-like wrapper that flushes after every write, so a redirected log shows progress live
+    (the reference's utils.Unbuffered, utils.py:138-151)."""
 
     def __init__(self, stream):
-        self.stream = stream
+        self._target = stream
 
-    def write(self, data):
-        self.stream.write(data)
-        self.stream.flush()
+    def write(self, text):
+        n = self._target.write(text)
+        self._target.flush()
+        return n
 
-    def writelines(self, datas):
-        self.stream.writelines(datas)
-        self.stream.flush()
+    def writelines(self, lines):
+        self._target.writelines(lines)
+        self._target.flush()
 
-    def __getattr__(self, attr):
-        return getattr(self.stream, attr)
+    def __getattr__(self, name):          # everything else (fileno, close, ...) goes to the wrapped stream
+        return getattr(self._target, name)
 
 
 def init_run(log_path, seed):
