@@ -420,3 +420,24 @@ def test_column_sharded_models_reproduce_the_full_model(golden, name):
         for (pname, p), (_, pf) in zip(m.named_parameters(), full.named_parameters()):
             want = pf.grad[..., r * 32:(r + 1) * 32] if pf.shape[-1] == 64 else pf.grad
             assert torch.allclose(p.grad, want, rtol=1e-4, atol=1e-7), (name, pname)
+
+
+def test_column_sharded_lightgcn_class_world1_matches_plain(golden):
+    """dist.ColumnShardedLightGCN on the HIP kernels with a single slice equals the plain LightGCN step."""
+    from igcn_cf_amd.dist import ColumnShardedLightGCN
+    from igcn_cf_amd.model import get_model
+    ds = _dataset(golden)
+    torch.manual_seed(5)
+    plain = get_model({'name': 'LightGCN', 'embedding_size': 64, 'n_layers': 3, 'device': 'cuda', 'prune_propagation': False}, ds)
+    emb0 = plain.embedding.weight.detach().cpu().clone()
+    col = ColumnShardedLightGCN(ds, 64, 3, 0, 1, 'cuda', full_embedding=emb0)
+    rng = np.random.default_rng(3)
+    t = lambda a: torch.from_numpy(a).cuda()
+    users, pos, neg = t(rng.integers(0, ds.n_users, 128)), t(rng.integers(0, ds.n_items, 128)), t(rng.integers(0, ds.n_items, 128))
+    plain.train()
+    la = plain.bpr_loss_terms(users, pos, neg)
+    lb = col.bpr_loss_terms(users, pos, neg)
+    assert torch.allclose(la, lb, rtol=1e-6, atol=1e-7)
+    (la[0] + 0.01 * la[1]).backward(); (lb[0] + 0.01 * lb[1]).backward()
+    assert torch.allclose(plain.embedding.weight.grad, col.emb.grad, rtol=1e-5, atol=1e-9)
+    assert torch.equal(col.full_embedding().cpu(), emb0)
