@@ -41,8 +41,8 @@ HBM_PEAK_GBPS = 8000.0          # MI355X spec (MI355X_MICROARCH.md: 8 TB/s peak,
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=1000)
+    ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--preset', default='amazon')
     ap.add_argument('--dim', type=int, default=64)
     ap.add_argument('--layers', type=int, default=3)
