@@ -64,10 +64,12 @@ class BasicModel(nn.Module):
         raise NotImplementedError
 
     def train(self, mode=True):
-        # Every train()/eval() switch drops the cached eval-mode representation: fused optimizers
-        # update parameters without bumping tensor version counters, so the version in the cache
-        # key alone cannot be trusted across training steps.
-        self._rep_cache = None
+        # Entering or leaving training mode drops the cached eval-mode representation: fused optimizers
+        # update parameters without bumping tensor version counters, so the version in the cache key
+        # alone cannot be trusted across training steps.  eval() -> eval() keeps the cache (the
+        # reference evaluates 'train' and 'val' back to back every epoch, trainer.py:71, :84).
+        if mode or self.training:
+            self._rep_cache = None
         return super().train(mode)
 
     def save(self, path):
