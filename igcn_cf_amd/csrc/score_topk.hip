@@ -129,6 +129,24 @@ __device__ __forceinline__ void set_priority_by_wave_slot() {
     else __builtin_amdgcn_s_setprio(3);
 }
 
+#ifdef IGCN_TOPK_TRACE
+// Developer build only (scripts/dev_topk_trace.py): shader-clock cycles per phase, summed over waves.
+// [0] load wait  [1] MFMA chain  [2] masking  [3] selection  [4] whole wave  [5] tiles  [6] waves
+__device__ unsigned long long g_topk_trace[8];
+// clock read that cannot issue before `dep` (an SGPR derived from the results being timed) exists
+__device__ __forceinline__ unsigned long long trace_clock(int dep) {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "s"(dep) : "memory");
+    return t;
+}
+__device__ __forceinline__ int trace_dep(const f32x16 &acc) {
+    float m = acc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+    return __builtin_amdgcn_readfirstlane(__float_as_int(m));
+}
+#endif
+
 template <int D>
 __global__ __launch_bounds__(kWave, (D <= 64 ? 4 : 2)) void score_topk_kernel(
     const float *__restrict__ user_rows, int64_t ldu, const int64_t *__restrict__ user_ids, int64_t batch,
@@ -141,6 +159,10 @@ __global__ __launch_bounds__(kWave, (D <= 64 ? 4 : 2)) void score_topk_kernel(
     unsigned long long *heap = reinterpret_cast<unsigned long long *>(smem) + threadIdx.x;     // [k][64]
 
     if (stagger) set_priority_by_wave_slot();
+#ifdef IGCN_TOPK_TRACE
+    unsigned long long tr_load = 0, tr_chain = 0, tr_mask = 0, tr_sel = 0, tr_tiles = 0;
+    const unsigned long long tr_begin = trace_clock(0);
+#endif
     const int lane = threadIdx.x;
     const int j = lane & 31, h = lane >> 5;
     // unit -> (user group, item part)
@@ -195,6 +217,9 @@ __global__ __launch_bounds__(kWave, (D <= 64 ? 4 : 2)) void score_topk_kernel(
 
     for (int tile_base = item_lo; tile_base < item_hi; tile_base += 32) {
         // A operand: item row (clamped at the ragged end, masked below), k-slice of this lane half
+#ifdef IGCN_TOPK_TRACE
+        const unsigned long long tr0 = trace_clock(tile_base);
+#endif
         int arow_i = tile_base + j;
         if (arow_i >= item_hi) arow_i = item_hi - 1;
         const float *arow = item_rows + (int64_t)arow_i * ldi + 4 * h;
@@ -202,6 +227,10 @@ __global__ __launch_bounds__(kWave, (D <= 64 ? 4 : 2)) void score_topk_kernel(
 #pragma unroll
         for (int q = 0; q < D / 8; ++q)
             a[q] = (8 * q + 4 * h < d) ? *reinterpret_cast<const float4 *>(arow + 8 * q) : f4_zero();
+#ifdef IGCN_TOPK_TRACE
+        unsigned long long tr1;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr1), "+v"(a[0].x) : : "memory");
+#endif
 
         f32x16 acc;
 #pragma unroll
@@ -214,6 +243,9 @@ __global__ __launch_bounds__(kWave, (D <= 64 ? 4 : 2)) void score_topk_kernel(
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bfrag[4 * q + 3], acc, 0, 0, 0);
         }
 
+#ifdef IGCN_TOPK_TRACE
+        const unsigned long long tr2 = trace_clock(trace_dep(acc));
+#endif
         // --- masking -------------------------------------------------------------
         if (tile_base + 32 > item_hi) {                        // ragged last tile (wave-uniform)
 #pragma unroll
@@ -248,6 +280,9 @@ __global__ __launch_bounds__(kWave, (D <= 64 ? 4 : 2)) void score_topk_kernel(
             }
         }
 
+#ifdef IGCN_TOPK_TRACE
+        const unsigned long long tr3 = trace_clock(trace_dep(acc));
+#endif
         // --- top-k ---------------------------------------------------------------
         while (true) {
             float m = acc[0];
@@ -289,7 +324,19 @@ __global__ __launch_bounds__(kWave, (D <= 64 ? 4 : 2)) void score_topk_kernel(
                 thr = root ? key_score(root) : -INFINITY;    // heap not full yet: everything may enter
             }
         }
+#ifdef IGCN_TOPK_TRACE
+        const unsigned long long tr4 = trace_clock(__builtin_amdgcn_readfirstlane(__float_as_int(thr)));
+        tr_load += tr1 - tr0; tr_chain += tr2 - tr1; tr_mask += tr3 - tr2; tr_sel += tr4 - tr3; ++tr_tiles;
+#endif
     }
+#ifdef IGCN_TOPK_TRACE
+    if (lane == 0) {
+        atomicAdd(&g_topk_trace[0], tr_load); atomicAdd(&g_topk_trace[1], tr_chain);
+        atomicAdd(&g_topk_trace[2], tr_mask); atomicAdd(&g_topk_trace[3], tr_sel);
+        atomicAdd(&g_topk_trace[4], trace_clock(0) - tr_begin); atomicAdd(&g_topk_trace[5], tr_tiles);
+        atomicAdd(&g_topk_trace[6], 1ull);
+    }
+#endif
 
     // merge the two lanes of a user and emit best-first (k rounds of arg-max over 2k keys).
     // The heaps are private to this wave; a wave executes its LDS operations in order.
@@ -442,6 +489,19 @@ extern "C" int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const in
     }
     return rc;
 }
+
+#ifdef IGCN_TOPK_TRACE
+extern "C" int igcn_debug_topk_trace(unsigned long long *host8, int reset)
+{
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess && host8) e = hipMemcpyFromSymbol(host8, HIP_SYMBOL(igcn::g_topk_trace), 64);
+    if (e == hipSuccess && reset) {
+        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(igcn::g_topk_trace), z, 64);
+    }
+    return (int)e;
+}
+#endif
 
 extern "C" int igcn_hit_matrix(const int64_t *rec, int64_t n_users, int32_t k,
                                const int64_t *eval_rowptr, const int32_t *eval_col, float *hit, void *stream)
