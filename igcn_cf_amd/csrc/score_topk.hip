@@ -53,50 +53,74 @@ constexpr int kIdxNone = 0x7fffffff;
 struct TopkPlan {
     int d_pad;               // 16 / 32 / 64 / 128
     int64_t groups;          // 32-user groups
-    int64_t n_full;          // groups swept by a single wave (parts == 1 for them)
-    int parts;               // item-range parts of the remaining groups (1 = none split)
-    int64_t items_per_part;  // multiple of 32
-    int64_t units;           // waves launched
+    int n_tiles;             // 32-item tiles of one sweep
+    int64_t units;           // waves launched; all resident at once
+    int64_t n_whole;         // whole sweeps per unit: groups [0, n_whole*units), unit u takes u, u+units, ...
+    int64_t rest_tiles;      // tiles of the remaining groups (laid end to end), cut into runs of `run`
+    int64_t run;             // tiles of the rest that one unit takes
+    int p_max;               // bound on the pieces a rest group is cut into (1: runs are whole sweeps)
+    int cap;                 // staging slots per lane
     size_t lds_bytes;
 };
+
+static inline int env_int(const char *name, int lo, int hi, int dflt) {
+    const char *e = getenv(name);
+    if (!e) return dflt;
+    const int x = atoi(e);
+    return x < lo || x > hi ? dflt : x;
+}
 
 static inline int topk_make_plan(int64_t batch, int64_t n_items, int32_t d, int32_t k, TopkPlan *p) {
     if (batch < 1 || n_items < 1) return IGCN_E_SHAPE;
     if (d < 4 || d > 128 || d % 4 != 0) return IGCN_E_SHAPE;
     if (k < 1 || k > IGCN_MAX_TOPK || k > n_items) return IGCN_E_RANGE;
     p->d_pad = d <= 16 ? 16 : d <= 32 ? 32 : d <= 64 ? 64 : 128;
-    p->lds_bytes = (size_t)k * kWave * 8;
     p->groups = (batch + 31) / 32;
-    const int64_t simds = (int64_t)cu_count() * 4;
-    // waves that can be resident per CU: 4 (3 for d > 64) per SIMD by registers, 160 KiB / lds by LDS
-    int64_t per_cu = (160 * 1024) / (int64_t)p->lds_bytes;
-    const int64_t by_regs = p->d_pad <= 64 ? 16 : 8;         // 114 / 179 VGPRs (hipcc, gfx950)
-    if (per_cu > by_regs) per_cu = by_regs;
-    if (per_cu < 1) return IGCN_E_RANGE;
-    const int64_t slots = per_cu * cu_count();
-    int64_t n_full, parts;
-    if (p->groups >= simds) {
-        // every SIMD gets floor(G/S) whole sweeps; the rest is cut so that each SIMD gets one part more
-        n_full = (p->groups / simds) * simds;
-        const int64_t rest = p->groups - n_full;
-        parts = rest == 0 ? 1 : (simds + rest - 1) / rest;
-        if (rest * 10 > simds * 9) { parts = 1; }              // nearly a whole extra round anyway
-    } else {
-        n_full = 0;                                            // small batch: split every group to fill the chip
-        parts = (slots + p->groups - 1) / p->groups;
+    const int64_t L = (n_items + 31) / 32;
+    p->n_tiles = (int)L;
+    // Resident waves per CU.  Registers allow 3 per SIMD (2 for d > 64).  LDS is handed out in
+    // granules of 1280 B (1/128 of the CU's 160 KiB; measured: 12 x 13312 B do not fit, 12 x 12800 B do),
+    // and the count is kept a multiple of 4 so that every SIMD of a CU carries the same number of
+    // waves.  The grid must never exceed what is resident: a wave that starts late runs its whole
+    // share after everybody else has finished.
+    const int by_regs = p->d_pad <= 64 ? 3 : 2;
+    int per_simd = env_int("IGCN_TOPK_WAVES", 1, by_regs, by_regs);                    // developer knob
+    int cap = 0;
+    for (; per_simd >= 1; --per_simd) {
+        const int granules = 128 / (4 * per_simd);
+        cap = granules * 1280 / (kWave * 8) - k;                 // staging slots left beside the k list slots
+        if (cap >= 4) break;
     }
-    const int64_t max_by_items = n_items / 1024 > 1 ? n_items / 1024 : 1;
-    if (parts > max_by_items) parts = max_by_items;
-    if (parts > 64) parts = 64;
-    if (const char *e = getenv("IGCN_TOPK_PARTS")) { int x = atoi(e); if (x >= 1 && x <= 64) parts = x; }   // developer knob
-    if (parts <= 1) { parts = 1; n_full = p->groups; }
-    int64_t per = (n_items + parts - 1) / parts;
-    per = (per + 31) / 32 * 32;
-    p->parts = (int)((n_items + per - 1) / per);
-    if (p->parts <= 1) { p->parts = 1; n_full = p->groups; }
-    p->items_per_part = per;
-    p->n_full = n_full;
-    p->units = n_full + (p->groups - n_full) * p->parts;
+    if (per_simd < 1) return IGCN_E_RANGE;
+    if (cap > 16) cap = 16;
+    p->cap = env_int("IGCN_TOPK_CAP", 1, cap, cap);                                    // developer knob
+    p->lds_bytes = (size_t)(k + p->cap) * kWave * 8;
+    const int64_t per_cu = 4 * per_simd;
+    const int64_t slots = per_cu * cu_count();
+    int64_t rest;
+    if (p->groups >= slots) {
+        p->units = slots;
+        p->n_whole = p->groups / slots;
+        rest = p->groups - p->n_whole * slots;
+    } else {
+        p->units = 0;
+        p->n_whole = 0;
+        rest = p->groups;
+    }
+    p->rest_tiles = rest * L;
+    p->run = 0;
+    p->p_max = 1;
+    if (rest > 0) {
+        // a piece shorter than 32 tiles is mostly list warm-up; a group in more than 31 pieces does
+        // not fit the 64 lanes of the merge
+        int64_t min_run = L < 32 ? L : 32;
+        if ((L + 29) / 30 > min_run) min_run = (L + 29) / 30;
+        int64_t run = (p->rest_tiles + slots - 1) / slots;
+        if (run < min_run) run = min_run;
+        p->run = run;
+        if (p->units == 0) p->units = (p->rest_tiles + run - 1) / run;
+        p->p_max = run % L == 0 ? 1 : (int)((L - 1) / run + 2);
+    }
     return IGCN_OK;
 }
 
@@ -118,7 +142,7 @@ __device__ __forceinline__ int key_item(unsigned long long key) { return (int)~(
 // (v, i) ranks before (w, j): higher score first, then lower item id
 __device__ __forceinline__ bool ranks_before(float v, int i, float w, int j) { return v > w || (v == w && i < j); }
 
-// Static issue priority from the hardware wave slot: the 3-4 waves of a SIMD get different
+// Static issue priority from the hardware wave slot: the waves of a SIMD get different
 // priorities, so one of them always wins the matrix pipe and the others fill in behind it.
 __device__ __forceinline__ void set_priority_by_wave_slot() {
     // s_getreg_b32 HW_REG_HW_ID (id 4), WAVE_ID = bits [3:0]: simm16 = (size-1) << 11 | offset << 6 | id
@@ -129,10 +153,34 @@ __device__ __forceinline__ void set_priority_by_wave_slot() {
     else __builtin_amdgcn_s_setprio(3);
 }
 
+// min-heap of sortable keys in LDS, [slot][lane]: replace the root by `cand` and sift down.
+// Returns the new root.
+__device__ __forceinline__ unsigned long long heap_replace_root(unsigned long long *heap, int n, unsigned long long cand) {
+    int i = 0;
+    unsigned long long first_up = 0ull;
+    while (true) {
+        int c = 2 * i + 1;
+        if (c >= n) break;
+        unsigned long long kc = heap[c * kWave];
+        if (c + 1 < n) {
+            const unsigned long long k2 = heap[(c + 1) * kWave];
+            if (k2 < kc) { kc = k2; ++c; }
+        }
+        if (kc >= cand) break;
+        heap[i * kWave] = kc;
+        if (i == 0) first_up = kc;
+        i = c;
+    }
+    heap[i * kWave] = cand;
+    return i == 0 ? cand : first_up;
+}
+
 #ifdef IGCN_TOPK_TRACE
 // Developer build only (scripts/dev_topk_trace.py): shader-clock cycles per phase, summed over waves.
 // [0] load wait  [1] MFMA chain  [2] masking  [3] selection  [4] whole wave  [5] tiles  [6] waves
+// [7] whole wave in s_memrealtime ticks (100 MHz)
 __device__ unsigned long long g_topk_trace[8];
+__device__ unsigned long long g_topk_wave_times[2 * 8192];     // [begin, end] in s_memrealtime ticks per workgroup
 // clock read that cannot issue before `dep` (an SGPR derived from the results being timed) exists
 __device__ __forceinline__ unsigned long long trace_clock(int dep) {
     unsigned long long t;
@@ -147,187 +195,255 @@ __device__ __forceinline__ int trace_dep(const f32x16 &acc) {
 }
 #endif
 
-template <int D>
-__global__ __launch_bounds__(kWave, (D <= 64 ? 4 : 2)) void score_topk_kernel(
+// FULL: d == D, no k-slice of a row is padding
+template <int D, bool FULL>
+__global__ __launch_bounds__(kWave, (D <= 64 ? 3 : 2)) void score_topk_kernel(
     const float *__restrict__ user_rows, int64_t ldu, const int64_t *__restrict__ user_ids, int64_t batch,
     const float *__restrict__ item_rows, int64_t ldi, int64_t n_items, int d,
     const int64_t *__restrict__ excl_rowptr, const int32_t *__restrict__ excl_col, const uint8_t *__restrict__ banned,
-    int k, int64_t n_full, int parts, int64_t items_per_part, int stagger,
+    int k, int cap, int n_tiles, int64_t n_whole, int64_t rest_tiles, int64_t run, int p_max, int stagger,
     int64_t *__restrict__ out_idx, float *__restrict__ out_val, float *__restrict__ ws_val, int32_t *__restrict__ ws_idx)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *heap = reinterpret_cast<unsigned long long *>(smem) + threadIdx.x;     // [k][64]
+    unsigned long long *stage = heap + k * kWave;                                              // [cap][64]
 
     if (stagger) set_priority_by_wave_slot();
 #ifdef IGCN_TOPK_TRACE
     unsigned long long tr_load = 0, tr_chain = 0, tr_mask = 0, tr_sel = 0, tr_tiles = 0;
     const unsigned long long tr_begin = trace_clock(0);
+    unsigned long long tr_rt_begin;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_rt_begin) : : "memory");
 #endif
     const int lane = threadIdx.x;
     const int j = lane & 31, h = lane >> 5;
-    // unit -> (user group, item part)
-    int64_t group;
-    int part = 0, my_parts = 1;
-    if ((int64_t)blockIdx.x < n_full) {
-        group = blockIdx.x;
-    } else {
-        const int64_t v = (int64_t)blockIdx.x - n_full;
-        group = n_full + v / parts;
-        part = (int)(v % parts);
-        my_parts = parts;
-    }
-    const int item_lo = my_parts == 1 ? 0 : (int)(part * items_per_part);
-    const int item_hi = my_parts == 1 ? (int)n_items : (int)(item_lo + items_per_part < n_items ? item_lo + items_per_part : n_items);
-    const int64_t b = group * 32 + j;
-    const bool user_ok = b < batch;
-    const int64_t uid = user_ok ? (user_ids ? user_ids[b] : b) : 0;
+    const int64_t units = gridDim.x;
+    const int64_t n_full = n_whole * units;
+    int64_t rx = (int64_t)blockIdx.x * run;                     // cursor in the rest groups' tile space
+    const int64_t rx_end = rx + run < rest_tiles ? rx + run : rest_tiles;
 
-    // B operand: this lane's user.  Lane half h supplies k = 8q + 4h + c (q < D/8, c < 4): the two
-    // lanes of a row read adjacent 16-B pieces, so one load instruction touches 32 lines, not 64.
-    float bfrag[D / 2];
-#pragma unroll
-    for (int q = 0; q < D / 8; ++q) {
-        float4 v = f4_zero();
-        const int e = 8 * q + 4 * h;
-        if (user_ok && e < d) v = *reinterpret_cast<const float4 *>(user_rows + uid * ldu + e);
-        bfrag[4 * q + 0] = v.x; bfrag[4 * q + 1] = v.y; bfrag[4 * q + 2] = v.z; bfrag[4 * q + 3] = v.w;
-    }
-
-    // exclusion cursor: first excluded item >= item_lo (this user's list as a pointer + 32-bit cursor)
-    const int32_t *ex_ptr = excl_col;
-    int ex_pos = 0, ex_end = 0, ex_next = kIdxNone;
-    if (excl_rowptr && user_ok) {
-        const int64_t r0 = excl_rowptr[uid];
-        ex_ptr = excl_col + r0;
-        ex_end = (int)(excl_rowptr[uid + 1] - r0);
-        int lo = 0, hi = ex_end;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (ex_ptr[mid] < item_lo) lo = mid + 1; else hi = mid;
+    for (int64_t job = 0;; ++job) {
+        // ---- next piece: users of `group`, item tiles [tin0, tin1) ----------------------------
+        int64_t group;
+        int tin0, tin1, pidx = 0;
+        bool direct = true;
+        if (job < n_whole) {
+            group = (int64_t)blockIdx.x + job * units;
+            tin0 = 0;
+            tin1 = n_tiles;
+        } else {
+            if (rx >= rx_end) break;
+            const int64_t rg = rx / n_tiles;
+            group = n_full + rg;
+            tin0 = (int)(rx - rg * n_tiles);
+            const int64_t left = rx_end - rx;
+            tin1 = left < n_tiles - tin0 ? (int)(tin0 + left) : n_tiles;
+            pidx = (int)((int64_t)blockIdx.x - (rg * n_tiles) / run);
+            direct = p_max == 1;
+            rx += tin1 - tin0;
         }
-        ex_pos = lo;
-        if (ex_pos < ex_end) ex_next = ex_ptr[ex_pos];
-    }
+        const int item_lo = tin0 * 32;
+        const int item_hi = (int64_t)tin1 * 32 < n_items ? tin1 * 32 : (int)n_items;
+        const int64_t b = group * 32 + j;
+        const bool user_ok = b < batch;
+        const int64_t uid = user_ok ? (user_ids ? user_ids[b] : b) : 0;
 
-    // running top-k: per-lane min-heap of sortable keys in LDS; root (= k-th best so far) in registers.
-    // Key 0 = empty slot: ranks below every real entry, masked (-inf) ones included.
-    for (int s = 0; s < k; ++s) heap[s * kWave] = 0ull;
-    unsigned long long root = 0ull;
-    float thr = -INFINITY;                                   // score part of the root
-
-    for (int tile_base = item_lo; tile_base < item_hi; tile_base += 32) {
-        // A operand: item row (clamped at the ragged end, masked below), k-slice of this lane half
-#ifdef IGCN_TOPK_TRACE
-        const unsigned long long tr0 = trace_clock(tile_base);
-#endif
-        int arow_i = tile_base + j;
-        if (arow_i >= item_hi) arow_i = item_hi - 1;
-        const float *arow = item_rows + (int64_t)arow_i * ldi + 4 * h;
-        float4 a[D / 8];
-#pragma unroll
-        for (int q = 0; q < D / 8; ++q)
-            a[q] = (8 * q + 4 * h < d) ? *reinterpret_cast<const float4 *>(arow + 8 * q) : f4_zero();
-#ifdef IGCN_TOPK_TRACE
-        unsigned long long tr1;
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr1), "+v"(a[0].x) : : "memory");
-#endif
-
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // B operand: this lane's user.  Lane half h supplies k = 8q + 4h + c (q < D/8, c < 4): the two
+        // lanes of a row read adjacent 16-B pieces, so one load instruction touches 32 lines, not 64.
+        float bfrag[D / 2];
 #pragma unroll
         for (int q = 0; q < D / 8; ++q) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bfrag[4 * q + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bfrag[4 * q + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bfrag[4 * q + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bfrag[4 * q + 3], acc, 0, 0, 0);
+            float4 v = f4_zero();
+            const int e = 8 * q + 4 * h;
+            if (user_ok && (FULL || e < d)) v = *reinterpret_cast<const float4 *>(user_rows + uid * ldu + e);
+            bfrag[4 * q + 0] = v.x; bfrag[4 * q + 1] = v.y; bfrag[4 * q + 2] = v.z; bfrag[4 * q + 3] = v.w;
         }
 
-#ifdef IGCN_TOPK_TRACE
-        const unsigned long long tr2 = trace_clock(trace_dep(acc));
-#endif
-        // --- masking -------------------------------------------------------------
-        if (tile_base + 32 > item_hi) {                        // ragged last tile (wave-uniform)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (tile_base + row_of(r, h) >= item_hi) acc[r] = -INFINITY;
-        }
-        if (banned) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int it = tile_base + 8 * g + 4 * h + c;
-                    if (it < item_hi && banned[it]) acc[4 * g + c] = -INFINITY;
-                }
+        // exclusion cursor: first excluded item >= item_lo; the entry after it is already on its way
+        const int32_t *ex_ptr = excl_col;
+        int ex_pos = 0, ex_end = 0, ex_next = kIdxNone, ex_after = kIdxNone;
+        if (excl_rowptr && user_ok) {
+            const int64_t r0 = excl_rowptr[uid];
+            ex_ptr = excl_col + r0;
+            ex_end = (int)(excl_rowptr[uid + 1] - r0);
+            int lo = 0, hi = ex_end;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (ex_ptr[mid] < item_lo) lo = mid + 1; else hi = mid;
             }
-        }
-        if (excl_rowptr) {
-            const int tile_end = tile_base + 32;
-            while (true) {
-                const bool need = ex_next < tile_end;
-                if (!__any(need)) break;
-                if (need) {
-                    const int rl = ex_next - tile_base;          // 0..31
-                    if (((rl >> 2) & 1) == h) {
-                        const int rr = (rl & 3) + 4 * (rl >> 3);
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[r] = (r == rr) ? -INFINITY : acc[r];
-                    }
-                    ++ex_pos;
-                    ex_next = ex_pos < ex_end ? ex_ptr[ex_pos] : kIdxNone;
-                }
-            }
+            ex_pos = lo;
+            if (ex_pos < ex_end) ex_next = ex_ptr[ex_pos];
+            if (ex_pos + 1 < ex_end) ex_after = ex_ptr[ex_pos + 1];
         }
 
-#ifdef IGCN_TOPK_TRACE
-        const unsigned long long tr3 = trace_clock(trace_dep(acc));
-#endif
-        // --- top-k ---------------------------------------------------------------
-        while (true) {
-            float m = acc[0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-            if (!__any(m >= thr)) break;                         // nothing in this tile can enter any list
-            // first remaining candidate of this lane (float compare only); examined scores become
-            // NaN (fmaxf skips NaN, NaN >= thr is false)
-            float cs = 0.f;
-            int cr = -1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float s = acc[r];
-                const bool take = cr < 0 && s >= thr;
-                cs = take ? s : cs;
-                cr = take ? row_of(r, h) : cr;
-                acc[r] = take ? __uint_as_float(0x7fc00000u) : s;
+        // running top-k: per-lane min-heap of sortable keys in LDS; root (= k-th best so far) in registers.
+        // Key 0 = empty slot: ranks below every real entry, masked (-inf) ones included.
+        for (int s = 0; s < k; ++s) heap[s * kWave] = 0ull;
+        unsigned long long root = 0ull;
+        float thr = -INFINITY;                                   // score part of the root
+        int cnt = 0;                                             // staged candidates of this lane
+
+        // staged candidates -> heap, all lanes together
+        auto flush = [&]() {
+            const int n = cnt;
+            cnt = 0;
+            for (int i = 0; __any(i < n); ++i) {
+                if (i < n) {
+                    const unsigned long long raw = stage[i * kWave];
+                    const unsigned long long cand = make_key(__uint_as_float((unsigned int)raw), (int)(raw >> 32));
+                    if (cand > root) root = heap_replace_root(heap, k, cand);
+                }
             }
-            const unsigned long long cand = cr >= 0 ? make_key(cs, tile_base + cr) : 0ull;
-            if (cand > root) {                                   // (a tie on the score may still lose on the id)
-                // replace the root (worst entry) and sift down
-                int i = 0;
-                unsigned long long first_up = 0ull;
+            thr = root ? key_score(root) : -INFINITY;            // list not full yet: everything may enter
+        };
+
+        // A operand: item row of this lane, k-slice of its half.  Address = uniform tile base (scalar
+        // registers, advanced by scalar adds) + a lane offset that never changes, so a tile's loads
+        // cost no vector ALU work.  Rows past the end of the table are clamped (and masked below).
+        const int lane_off = j * (int)ldi + 4 * h;
+        int lane_off_last = lane_off;                            // for the ragged last tile of the table
+        {
+            const int64_t last_base = (int64_t)(n_tiles - 1) * 32;
+            if (last_base + j >= n_items) lane_off_last = (int)(n_items - 1 - last_base) * (int)ldi + 4 * h;
+        }
+        float4 a[D / 8];
+        auto load_a = [&](int t) {
+            const float *tile_ptr = item_rows + (int64_t)t * 32 * ldi;
+            const int off = t == n_tiles - 1 ? lane_off_last : lane_off;
+#pragma unroll
+            for (int q = 0; q < D / 8; ++q)
+                a[q] = (FULL || 8 * q + 4 * h < d) ? *reinterpret_cast<const float4 *>(tile_ptr + off + 8 * q) : f4_zero();
+        };
+        load_a(tin0);
+
+        for (int tile = tin0; tile < tin1; ++tile) {
+            const int tile_base = tile * 32;
+#ifdef IGCN_TOPK_TRACE
+            const unsigned long long tr0 = trace_clock(tile_base);
+            unsigned long long tr1;
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr1), "+v"(a[0].x) : : "memory");
+#endif
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int q = 0; q < D / 8; ++q) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bfrag[4 * q + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bfrag[4 * q + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bfrag[4 * q + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bfrag[4 * q + 3], acc, 0, 0, 0);
+            }
+#ifdef IGCN_TOPK_TRACE
+            const unsigned long long tr2 = trace_clock(trace_dep(acc));
+#endif
+            // --- masking ---------------------------------------------------------------------
+            // rows past the end of the piece: NaN = "already examined", never a candidate
+            if (tile_base + 32 > item_hi) {                        // ragged last tile (wave-uniform)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (tile_base + row_of(r, h) >= item_hi) acc[r] = __uint_as_float(0x7fc00000u);
+            }
+            if (excl_rowptr) {
+                const int tile_end = tile_base + 32;
                 while (true) {
-                    int c = 2 * i + 1;
-                    if (c >= k) break;
-                    unsigned long long kc = heap[c * kWave];
-                    if (c + 1 < k) {
-                        const unsigned long long k2 = heap[(c + 1) * kWave];
-                        if (k2 < kc) { kc = k2; ++c; }
+                    const bool need = ex_next < tile_end;
+                    if (!__any(need)) break;
+                    if (need) {
+                        const int rl = ex_next - tile_base;          // 0..31
+                        if (((rl >> 2) & 1) == h) {
+                            const int rr = (rl & 3) + 4 * (rl >> 3);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[r] = (r == rr) ? -INFINITY : acc[r];
+                        }
+                        ++ex_pos;
+                        ex_next = ex_after;
+                        ex_after = ex_pos + 1 < ex_end ? ex_ptr[ex_pos + 1] : kIdxNone;
                     }
-                    if (kc >= cand) break;
-                    heap[i * kWave] = kc;
-                    if (i == 0) first_up = kc;
-                    i = c;
                 }
-                heap[i * kWave] = cand;
-                root = i == 0 ? cand : first_up;
-                thr = root ? key_score(root) : -INFINITY;    // heap not full yet: everything may enter
+            }
+            // next tile's A operand: on its way during the rest of this tile's bookkeeping
+            if (tile + 1 < tin1) load_a(tile + 1);
+            if (banned) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int it = tile_base + 8 * g + 4 * h + c;
+                        if (it < item_hi && banned[it]) acc[4 * g + c] = -INFINITY;
+                    }
+                }
+            }
+#ifdef IGCN_TOPK_TRACE
+            const unsigned long long tr3 = trace_clock(trace_dep(acc));
+#endif
+            // --- top-k -----------------------------------------------------------------------
+            // One compare of the tile maximum against the (slightly stale) k-th best decides whether
+            // anything can enter.  Candidates are only STAGED here; the heap work is batched in flush().
+            {
+                float m = acc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
+                if (__any(m >= thr)) {
+                    bool full;
+                    do {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float sc = acc[r];
+                            const bool take = sc >= thr;
+                            if (__any(take)) {                   // a row without candidates costs a compare and a branch
+                                asm volatile("; row with candidates");       // (keeps this a real, wave-uniform branch)
+                                if (take && cnt < cap) {
+                                    int hh = 4 * h;
+                                    asm volatile("" : "+v"(hh));     // keep the item id arithmetic inside the rare path
+                                    stage[cnt * kWave] = ((unsigned long long)(unsigned int)(tile_base + row_of(r, 0) + hh) << 32) | __float_as_uint(sc);
+                                    ++cnt;
+                                    acc[r] = __uint_as_float(0x7fc00000u);     // examined
+                                }
+                            }
+                        }
+                        full = __any(cnt >= cap);                // a full lane may have left candidates behind
+                        if (full) flush();
+                    } while (full);
+                }
+            }
+#ifdef IGCN_TOPK_TRACE
+            const unsigned long long tr4 = trace_clock(__builtin_amdgcn_readfirstlane(__float_as_int(thr) + cnt));
+            tr_load += tr1 - tr0; tr_chain += tr2 - tr1; tr_mask += tr3 - tr2; tr_sel += tr4 - tr3; ++tr_tiles;
+#endif
+        }
+        flush();
+
+        // ---- emit: heapsort each lane's list in place (best first), then either merge the two lanes
+        // of a user into the output or hand both lists to the merge kernel ------------------------
+        for (int n = k - 1; n > 0; --n) {
+            const unsigned long long last = heap[n * kWave];
+            heap[n * kWave] = heap[0];                           // current minimum goes to the end
+            heap_replace_root(heap, n, last);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (direct) {
+            if (h == 0 && user_ok) {
+                const unsigned long long *pheap = heap + 32;     // partner lane (l + 32), same wave
+                int i0 = 0, i1 = 0;
+                unsigned long long k0 = heap[0], k1 = pheap[0];
+                for (int r = 0; r < k; ++r) {
+                    unsigned long long best;
+                    if (k0 >= k1) { best = k0; ++i0; k0 = i0 < k ? heap[i0 * kWave] : 0ull; }
+                    else          { best = k1; ++i1; k1 = i1 < k ? pheap[i1 * kWave] : 0ull; }
+                    out_idx[b * k + r] = best ? key_item(best) : -1;
+                    out_val[b * k + r] = best ? key_score(best) : -INFINITY;
+                }
+            }
+        } else if (user_ok) {
+            const int64_t slot = ((b - n_full * 32) * (2 * p_max) + 2 * pidx + h) * k;
+            for (int r = 0; r < k; ++r) {
+                const unsigned long long key = heap[r * kWave];
+                ws_val[slot + r] = key ? key_score(key) : -INFINITY;
+                ws_idx[slot + r] = key ? key_item(key) : kIdxNone;
             }
         }
-#ifdef IGCN_TOPK_TRACE
-        const unsigned long long tr4 = trace_clock(__builtin_amdgcn_readfirstlane(__float_as_int(thr)));
-        tr_load += tr1 - tr0; tr_chain += tr2 - tr1; tr_mask += tr3 - tr2; tr_sel += tr4 - tr3; ++tr_tiles;
-#endif
+        __builtin_amdgcn_wave_barrier();
     }
 #ifdef IGCN_TOPK_TRACE
     if (lane == 0) {
@@ -335,53 +451,29 @@ __global__ __launch_bounds__(kWave, (D <= 64 ? 4 : 2)) void score_topk_kernel(
         atomicAdd(&g_topk_trace[2], tr_mask); atomicAdd(&g_topk_trace[3], tr_sel);
         atomicAdd(&g_topk_trace[4], trace_clock(0) - tr_begin); atomicAdd(&g_topk_trace[5], tr_tiles);
         atomicAdd(&g_topk_trace[6], 1ull);
+        unsigned long long tr_rt_end;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_rt_end) : : "memory");
+        atomicAdd(&g_topk_trace[7], tr_rt_end - tr_rt_begin);      // wave lifetime in 100 MHz ticks
+        if (blockIdx.x < 8192) { g_topk_wave_times[2 * blockIdx.x] = tr_rt_begin; g_topk_wave_times[2 * blockIdx.x + 1] = tr_rt_end; }
     }
 #endif
-
-    // merge the two lanes of a user and emit best-first (k rounds of arg-max over 2k keys).
-    // The heaps are private to this wave; a wave executes its LDS operations in order.
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (h == 0 && user_ok) {
-        unsigned long long *pheap = heap + 32;      // partner lane (l + 32), same wave
-        for (int r = 0; r < k; ++r) {
-            unsigned long long best = 0ull;
-            int bp = 0, bwho = 0;
-            for (int q = 0; q < k; ++q) {
-                const unsigned long long k0 = heap[q * kWave], k1 = pheap[q * kWave];
-                if (k0 > best) { best = k0; bp = q; bwho = 0; }
-                if (k1 > best) { best = k1; bp = q; bwho = 1; }
-            }
-            if (bwho == 0) heap[bp * kWave] = 0ull; else pheap[bp * kWave] = 0ull;
-            const float bv = best ? key_score(best) : -INFINITY;
-            const int bi = best ? key_item(best) : kIdxNone;
-            if (parts == 1) {
-                out_idx[b * k + r] = bi == kIdxNone ? -1 : bi;
-                out_val[b * k + r] = bv;
-            } else {
-                ws_val[(b * parts + part) * k + r] = bv;
-                ws_idx[(b * parts + part) * k + r] = bi;
-                if (my_parts == 1)                               // whole sweep by one wave: other part slots are empty
-                    for (int pp = 1; pp < parts; ++pp) {
-                        ws_val[(b * parts + pp) * k + r] = -INFINITY;
-                        ws_idx[(b * parts + pp) * k + r] = kIdxNone;
-                    }
-            }
-        }
-    }
 }
 
-// One wave per user, lane = item-range split: k rounds of a wave-wide arg-best
-// over the heads of the (already best-first) partial lists.
+// One wave per user of the groups that were cut: lane = one (piece, lane half) list, already
+// best-first; k rounds of a wave-wide arg-best over the heads.
 __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restrict__ ws_val, const int32_t *__restrict__ ws_idx,
-                                                            int64_t batch, int n_splits, int k,
+                                                            int64_t first_user, int64_t batch, int n_tiles, int64_t run,
+                                                            int p_max, int k,
                                                             int64_t *__restrict__ out_idx, float *__restrict__ out_val)
 {
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t b = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    const int64_t rb = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    const int64_t b = first_user + rb;
     if (b >= batch) return;
-    const float *v = ws_val + (b * n_splits + lane) * k;
-    const int32_t *ix = ws_idx + (b * n_splits + lane) * k;
+    const int64_t rg = rb / 32;
+    const int n_splits = 2 * (int)((((rg + 1) * n_tiles - 1) / run) - (rg * n_tiles) / run + 1);
+    const float *v = ws_val + (rb * (2 * p_max) + lane) * k;
+    const int32_t *ix = ws_idx + (rb * (2 * p_max) + lane) * k;
     int cur = 0;
     float hv = -INFINITY;
     int hi = kIdxNone;
@@ -419,14 +511,14 @@ __global__ void hit_matrix_kernel(const int64_t *__restrict__ rec, int64_t n_use
     hit[i] = (lo < eval_rowptr[u + 1] && eval_col[lo] == item) ? 1.f : 0.f;
 }
 
-template <int D>
+template <int D, bool FULL>
 static int launch_topk(const TopkPlan &p, hipStream_t st,
                        const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
                        const float *item_rows, int64_t ldi, int64_t n_items, int d,
                        const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned, int k,
                        int64_t *out_idx, float *out_val, float *ws_val, int32_t *ws_idx)
 {
-    auto kern = score_topk_kernel<D>;
+    auto kern = score_topk_kernel<D, FULL>;
     static bool configured = false;
     if (!configured && p.lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -435,11 +527,18 @@ static int launch_topk(const TopkPlan &p, hipStream_t st,
         configured = true;
     }
     if (p.units >= ((int64_t)1 << 31)) return IGCN_E_SHAPE;
-    static const int stagger = [] { const char *e = getenv("IGCN_TOPK_STAGGER"); return e ? atoi(e) : 1; }();   // developer knob
+    const int stagger = env_int("IGCN_TOPK_STAGGER", 0, 1, 1);                          // developer knob
     hipLaunchKernelGGL(kern, dim3((unsigned)p.units), dim3(kWave), p.lds_bytes, st, user_rows, ldu, user_ids, batch,
-                       item_rows, ldi, n_items, d, excl_rowptr, excl_col, banned, k, p.n_full, p.parts, p.items_per_part,
-                       stagger, out_idx, out_val, ws_val, ws_idx);
+                       item_rows, ldi, n_items, d, excl_rowptr, excl_col, banned, k, p.cap, p.n_tiles, p.n_whole,
+                       p.rest_tiles, p.run, p.p_max, stagger, out_idx, out_val, ws_val, ws_idx);
     return launch_status();
+}
+
+// users whose lists come back in pieces (rows of the workspace)
+static inline int64_t topk_rest_users(const TopkPlan &p, int64_t batch) {
+    if (p.p_max <= 1) return 0;
+    const int64_t first = p.n_whole * p.units * 32;
+    return batch > first ? batch - first : 0;
 }
 
 }  // namespace igcn
@@ -450,7 +549,7 @@ extern "C" int64_t igcn_score_topk_workspace_bytes(int64_t batch, int64_t n_item
 {
     TopkPlan p;
     if (topk_make_plan(batch, n_items, d, k, &p) != IGCN_OK) return -1;
-    return p.parts > 1 ? (int64_t)batch * p.parts * k * 8 : 0;
+    return topk_rest_users(p, batch) * 2 * p.p_max * k * 8;
 }
 
 extern "C" int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
@@ -463,16 +562,18 @@ extern "C" int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const in
     TopkPlan p;
     int rc = topk_make_plan(batch, n_items, d, k, &p);
     if (rc != IGCN_OK) return rc;
-    if (ldu < d || ldi < d || ldu % 4 || ldi % 4 || n_items >= ((int64_t)1 << 31) - 64) return IGCN_E_SHAPE;
+    if (ldu < d || ldi < d || ldu % 4 || ldi % 4 || n_items >= ((int64_t)1 << 31) - 64 || ldi > (1 << 20)) return IGCN_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(user_rows) | reinterpret_cast<uintptr_t>(item_rows)) % 16) return IGCN_E_ALIGN;
-    if (p.parts > 1 && !workspace) return IGCN_E_NULL;
+    const int64_t rest_users = topk_rest_users(p, batch);
+    if (rest_users > 0 && !workspace) return IGCN_E_NULL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     float *ws_val = static_cast<float *>(workspace);
-    int32_t *ws_idx = reinterpret_cast<int32_t *>(ws_val ? ws_val + (int64_t)batch * p.parts * k : nullptr);
+    int32_t *ws_idx = reinterpret_cast<int32_t *>(ws_val ? ws_val + rest_users * 2 * p.p_max * k : nullptr);
 
 #define IGCN_TOPK_CASE(DD)                                                                                        \
-    rc = launch_topk<DD>(p, st, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, (int)d, excl_rowptr,    \
-                         excl_col, banned, (int)k, out_idx, out_val, ws_val, ws_idx)
+    rc = (d == DD ? launch_topk<DD, true> : launch_topk<DD, false>)(                                             \
+        p, st, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, (int)d, excl_rowptr, excl_col, banned,   \
+        (int)k, out_idx, out_val, ws_val, ws_idx)
     switch (p.d_pad) {
     case 16: IGCN_TOPK_CASE(16); break;
     case 32: IGCN_TOPK_CASE(32); break;
@@ -481,16 +582,28 @@ extern "C" int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const in
     }
 #undef IGCN_TOPK_CASE
     if (rc != IGCN_OK) return rc;
-    if (p.parts > 1) {
-        const int64_t blocks = (batch + 3) / 4;
-        hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, ws_val, ws_idx, batch,
-                           p.parts, (int)k, out_idx, out_val);
+    if (rest_users > 0) {
+        const int64_t blocks = (rest_users + 3) / 4;
+        hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, ws_val, ws_idx,
+                           p.n_whole * p.units * 32, batch, p.n_tiles, p.run, p.p_max, (int)k, out_idx, out_val);
         rc = launch_status();
     }
     return rc;
 }
 
 #ifdef IGCN_TOPK_TRACE
+extern "C" int igcn_debug_topk_wave_times(unsigned long long *host, int n_waves)
+{
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(host, HIP_SYMBOL(igcn::g_topk_wave_times), (size_t)n_waves * 16);
+    return (int)e;
+}
+extern "C" int igcn_debug_topk_occupancy(int lds_bytes)
+{
+    int n = -1;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igcn::score_topk_kernel<64, true>, 64, (size_t)lds_bytes);
+    return e == hipSuccess ? n : -(int)e;
+}
 extern "C" int igcn_debug_topk_trace(unsigned long long *host8, int reset)
 {
     hipError_t e = hipDeviceSynchronize();

@@ -40,7 +40,15 @@ def main():
     rp, cl = _csr_to_device(excl[0], excl[1], 'cuda')
     users = torch.arange(ds.n_users, device='cuda')
     buf = (C.c_uint64 * 8)()
-    for masks in (True, False):
+    occ = _lib.handle().igcn_debug_topk_occupancy
+    occ.restype, occ.argtypes = C.c_int, [C.c_int]
+    print(json.dumps({'occupancy_api_blocks_per_cu': {str(b): occ(b) for b in (0, 8192, 10240, 13312, 14336, 16384, 20480)}}))
+    wt = _lib.handle().igcn_debug_topk_wave_times
+    wt.restype, wt.argtypes = C.c_int, [C.POINTER(C.c_uint64), C.c_int]
+    for cap, waves_per_simd in ((5, 3), (16, 2)):
+      os.environ['IGCN_TOPK_CAP'], os.environ['IGCN_TOPK_WAVES'] = str(cap), str(waves_per_simd)
+      masks = True
+      if True:
         kw = dict(excl_rowptr=rp, excl_col=cl) if masks else {}
         score_topk(U, I, 20, user_ids=users, **kw)
         dbg(buf, 1)
@@ -51,10 +59,21 @@ def main():
         torch.cuda.synchronize()
         dbg(buf, 1)
         t = list(buf)
+        nw = min(int(t[6]), 8192)
+        wbuf = (C.c_uint64 * (2 * nw))()
+        wt(wbuf, nw)
+        import numpy as np
+        w = np.frombuffer(wbuf, dtype=np.uint64).reshape(nw, 2).astype(np.int64)
+        t0 = w[:, 0].min()
+        begin_ms, end_ms = (w[:, 0] - t0) / 1e5, (w[:, 1] - t0) / 1e5
+        print(json.dumps(dict(cap=cap, waves_per_simd=waves_per_simd, waves=nw, started_within_0p2ms=int((begin_ms < 0.2).sum()),
+                              begin_ms_quantiles=[round(float(x), 2) for x in np.quantile(begin_ms, [0.5, 0.6, 0.7, 0.8, 0.9, 1.0])],
+                              end_ms_quantiles=[round(float(x), 2) for x in np.quantile(end_ms, [0.0, 0.1, 0.5, 0.9, 1.0])])))
         tiles = max(t[5], 1)
         print(json.dumps(dict(masks=masks, ms=round(e0.elapsed_time(e1), 2), waves=t[6], tiles_per_wave=t[5] / max(t[6], 1),
                               per_tile=dict(load_wait=t[0] / tiles, chain=t[1] / tiles, mask=t[2] / tiles, select=t[3] / tiles),
-                              wave_total_per_tile=t[4] / tiles)), flush=True)
+                              wave_total_per_tile=t[4] / tiles,
+                              wave_life_ms=t[7] / max(t[6], 1) / 1e5, shader_clock_GHz=t[4] / max(t[7], 1) * 0.1)), flush=True)
 
 
 if __name__ == '__main__':
