@@ -15,7 +15,7 @@ excl = _merge_sorted_csr(ds.csr('train'), ds.csr('val'))
 rp, cl = _csr_to_device(excl[0], excl[1], 'cuda')
 users = torch.arange(ds.n_users, device='cuda')
 res = {}
-for rnd in range(4):
+for rnd in range(3):
     for mode in ('0', '1', '2', '3'):
         os.environ['IGCN_TOPK_STAGGER'] = mode
         res.setdefault(mode, []).append(time_ms(lambda: score_topk(U, I, 20, user_ids=users, excl_rowptr=rp, excl_col=cl), reps=3, warm=1))

@@ -1,3 +1,8 @@
+// EXPERIMENT, NOT BUILT INTO THE LIBRARY (kept for the record).
+// Variant of score_topk.hip with the MFMA operands swapped (users = rows, one item per lane), ONE
+// best-first list per user in LDS and wave-cooperative insertion.  Correct (passes the same GPU tests)
+// and faster for k >= 50 or k = 1, but its per-candidate insertion is serial, so every piece pays a long
+// list warm-up: 2.7x slower than the shipped kernel at batch 512, equal at the full evaluation.
 // Fused  score = U . I^T  ->  mask  ->  top-k  for MI355X (gfx950).
 //
 // Replaces, without ever materialising the [B, n_items] score matrix
@@ -11,34 +16,38 @@
 // cores, in exact fp32: v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain, no
 // reduced-precision shortcut).  The fp32 MFMA is slow enough (64 cycles each,
 // 2048 cycles per 32x32xd=64 tile) that operand traffic is negligible; what
-// decides the speed is keeping every SIMD's matrix pipe busy.  Hence:
-//   * one WAVE = one workgroup = 32 users for a whole item sweep: no LDS staging,
-//     no barriers, nothing shared between waves.  The users' embeddings are the
-//     MFMA B operand and stay in d/2 VGPRs per lane; the item rows (A operand)
-//     are read straight from L2/Infinity Cache, the two lanes of a row taking
-//     adjacent 16-byte pieces so that a load instruction touches 32 lines;
-//   * <=128 VGPRs and k*512 B of LDS per wave, so 4 waves share a SIMD and cover
-//     each other's loads and top-k bookkeeping with their MFMA chains; the waves
-//     of a SIMD take different static priorities (by hardware wave slot) so that
-//     they fall out of lock-step instead of all multiplying, then all selecting;
-//   * the grid is sized so that ALL waves are resident at once and every SIMD
-//     gets the same amount of MFMA work: G = ceil(B/32) user groups over S SIMDs;
-//     floor(G/S)*S groups are swept by one wave each, the remaining groups are
-//     cut into item-range parts (one wave per part) that fill the last wave slot
-//     of every SIMD; parts write partial lists that a small kernel merges;
-//   * the product is computed as S^T = I . U^T, so in the accumulator a lane
-//     holds 16 item scores of ONE user (column = lane&31): the running top-k of
-//     a user is private to a lane pair, no cross-lane traffic in the sweep;
-//   * masking is exact and in-register: each lane walks its user's sorted
-//     exclusion list with a cursor as the item sweep advances; banned items are
-//     read as bytes per accumulator row;
-//   * top-k: one compare of the tile maximum against the user's current k-th
-//     best decides whether anything can enter.  Entries are 64-bit sortable keys
-//     (order-preserving image of the fp32 score << 32 | ~item id), kept per lane
-//     as a k-slot binary min-heap in LDS ([slot][lane]: lane l always hits its own
-//     bank pair); a rare insert replaces the root and sifts down, O(log k).  The
-//     wave handles "the first remaining candidate of every lane" per pass, so a
-//     tile costs about one pass however its candidates are spread over lanes.
+// decides the speed is keeping every SIMD's matrix pipe busy, and what keeps it
+// idle is everything a wave does between two MFMA chains.  Measured on the chip
+// (scripts/probes/mfma_valu_overlap_probe.hip, scripts/dev_topk_trace.py): while
+// the matrix pipe of a SIMD is busy, the other waves' ordinary instructions issue
+// at well under half their normal rate, so the bookkeeping per tile has to be a
+// few dozen instructions, and enough waves must be resident to cover it.  Hence:
+//   * one WAVE = one workgroup = 32 users for a run of item tiles: no barriers,
+//     nothing shared between waves.  The users' embeddings are the MFMA A operand
+//     and stay in d/2 VGPRs per lane; the item rows (B operand) are read straight
+//     from L2/Infinity Cache one tile ahead, addressed as a scalar tile base plus a
+//     constant lane offset; the two lanes of a row take adjacent 16-byte pieces so
+//     that a load instruction touches 32 lines;
+//   * S = U . I^T puts 16 users x 1 item into a lane (column = item = lane&31).  A
+//     user's candidates therefore appear across lanes, and ONE list per user is
+//     enough: 32 lists of k sortable 64-bit keys (order-preserving image of the fp32
+//     score << 32 | ~item id), sorted best-first in k*256 B of LDS.  16 compares per
+//     tile against the users' k-th best (kept in 16 VGPRs) decide whether anything
+//     can enter; the rare candidate is inserted by the whole wave at once: k lanes
+//     read the list, a ballot gives the rank, one shifted write stores it back;
+//   * <=128 VGPRs and 5 KiB of LDS per wave (k = 20): 4 waves per SIMD, given
+//     different static priorities (by hardware wave slot) so that they fall out of
+//     lock-step instead of all multiplying, then all selecting;
+//   * the grid never exceeds what is resident at once (a wave that starts late runs
+//     its whole share after everybody else has finished; LDS is handed out in
+//     1280-B granules, registers in blocks of 8), and every wave gets the same
+//     number of tiles: with G 32-user groups and W resident waves, each wave sweeps
+//     floor(G/W) whole groups; the tiles of the remaining groups, laid end to end,
+//     are cut into W equal runs.  A group that is cut returns one best-first list
+//     per piece, merged by a small second kernel;
+//   * masking is exact and in-register: lane u < 32 walks user u's sorted exclusion
+//     list with a cursor as the sweep advances (the entry after the current one is
+//     always already loaded); banned items are one byte per lane, read a tile ahead.
 // Ties are broken towards the lower item id (torch.topk leaves them unspecified).
 #include <math.h>
 #include <stdlib.h>
@@ -49,6 +58,10 @@ namespace igcn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kIdxNone = 0x7fffffff;
+constexpr int kExPending = -2;              // "entry after the cursor not loaded yet"
+#ifndef IGCN_TOPK_WPS
+#define IGCN_TOPK_WPS 3                    // waves per SIMD the d <= 64 kernels are register-limited to
+#endif
 
 struct TopkPlan {
     int d_pad;               // 16 / 32 / 64 / 128
@@ -59,7 +72,6 @@ struct TopkPlan {
     int64_t rest_tiles;      // tiles of the remaining groups (laid end to end), cut into runs of `run`
     int64_t run;             // tiles of the rest that one unit takes
     int p_max;               // bound on the pieces a rest group is cut into (1: runs are whole sweeps)
-    int cap;                 // staging slots per lane
     size_t lds_bytes;
 };
 
@@ -78,25 +90,15 @@ static inline int topk_make_plan(int64_t batch, int64_t n_items, int32_t d, int3
     p->groups = (batch + 31) / 32;
     const int64_t L = (n_items + 31) / 32;
     p->n_tiles = (int)L;
-    // Resident waves per CU.  Registers allow 3 per SIMD (2 for d > 64).  LDS is handed out in
-    // granules of 1280 B (1/128 of the CU's 160 KiB; measured: 12 x 13312 B do not fit, 12 x 12800 B do),
-    // and the count is kept a multiple of 4 so that every SIMD of a CU carries the same number of
-    // waves.  The grid must never exceed what is resident: a wave that starts late runs its whole
-    // share after everybody else has finished.
-    const int by_regs = p->d_pad <= 64 ? 3 : 2;
+    // Resident waves per CU.  Registers allow 4 per SIMD (2 for d > 64).  LDS is handed out in
+    // granules of 1280 B (1/128 of the CU's 160 KiB; measured: 12 x 13312 B do not fit, 12 x 12800 B
+    // do); the count is kept a multiple of 4 so that every SIMD of a CU carries the same number.
+    p->lds_bytes = (size_t)32 * k * 8;
+    const int by_regs = p->d_pad <= 64 ? IGCN_TOPK_WPS : 2;
     int per_simd = env_int("IGCN_TOPK_WAVES", 1, by_regs, by_regs);                    // developer knob
-    int cap = 0;
-    for (; per_simd >= 1; --per_simd) {
-        const int granules = 128 / (4 * per_simd);
-        cap = granules * 1280 / (kWave * 8) - k;                 // staging slots left beside the k list slots
-        if (cap >= 4) break;
-    }
-    if (per_simd < 1) return IGCN_E_RANGE;
-    if (cap > 16) cap = 16;
-    p->cap = env_int("IGCN_TOPK_CAP", 1, cap, cap);                                    // developer knob
-    p->lds_bytes = (size_t)(k + p->cap) * kWave * 8;
-    const int64_t per_cu = 4 * per_simd;
-    const int64_t slots = per_cu * cu_count();
+    const int granules = (int)((p->lds_bytes + 1279) / 1280);
+    while (per_simd > 1 && 4 * per_simd * granules > 128) --per_simd;
+    const int64_t slots = (int64_t)4 * per_simd * cu_count();
     int64_t rest;
     if (p->groups >= slots) {
         p->units = slots;
@@ -111,12 +113,16 @@ static inline int topk_make_plan(int64_t batch, int64_t n_items, int32_t d, int3
     p->run = 0;
     p->p_max = 1;
     if (rest > 0) {
-        // a piece shorter than 32 tiles is mostly list warm-up; a group in more than 31 pieces does
+        // a piece shorter than 32 tiles is mostly list warm-up; a group in more than 63 pieces does
         // not fit the 64 lanes of the merge
         int64_t min_run = L < 32 ? L : 32;
-        if ((L + 29) / 30 > min_run) min_run = (L + 29) / 30;
+        if ((L + 61) / 62 > min_run) min_run = (L + 61) / 62;
         int64_t run = (p->rest_tiles + slots - 1) / slots;
         if (run < min_run) run = min_run;
+        // nearly as many leftover groups as waves: one whole sweep each beats cutting every group
+        // in two (each piece pays the list warm-up again, and the merge)
+        const int whole_pct = env_int("IGCN_TOPK_WHOLE_PCT", 0, 101, 75);              // developer knob
+        if (p->units == 0 ? rest * 100 >= slots * whole_pct : false) run = L;
         p->run = run;
         if (p->units == 0) p->units = (p->rest_tiles + run - 1) / run;
         p->p_max = run % L == 0 ? 1 : (int)((L - 1) / run + 2);
@@ -153,26 +159,24 @@ __device__ __forceinline__ void set_priority_by_wave_slot() {
     else __builtin_amdgcn_s_setprio(3);
 }
 
-// min-heap of sortable keys in LDS, [slot][lane]: replace the root by `cand` and sift down.
-// Returns the new root.
-__device__ __forceinline__ unsigned long long heap_replace_root(unsigned long long *heap, int n, unsigned long long cand) {
-    int i = 0;
-    unsigned long long first_up = 0ull;
-    while (true) {
-        int c = 2 * i + 1;
-        if (c >= n) break;
-        unsigned long long kc = heap[c * kWave];
-        if (c + 1 < n) {
-            const unsigned long long k2 = heap[(c + 1) * kWave];
-            if (k2 < kc) { kc = k2; ++c; }
-        }
-        if (kc >= cand) break;
-        heap[i * kWave] = kc;
-        if (i == 0) first_up = kc;
-        i = c;
-    }
-    heap[i * kWave] = cand;
-    return i == 0 ? cand : first_up;
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// The whole wave inserts `cand` (wave-uniform) into one user's best-first list of k keys in LDS
+// (key 0 = empty slot, at the end).  Returns the list's new k-th best score: -inf while a slot is
+// still empty, and `thr` unchanged if the candidate loses (only possible on a score tie).
+__device__ __forceinline__ float list_insert(unsigned long long *row, int k, unsigned long long cand, int lane, float thr) {
+    const bool in = lane < k;
+    const unsigned long long e = in ? row[lane] : 0ull;
+    const unsigned long long e_prev = (in && lane > 0) ? row[lane - 1] : 0ull;
+    const int pos = __builtin_popcountll(__ballot(in && e > cand));        // entries ahead of cand: a prefix
+    if (pos >= k) return thr;
+    if (in && lane >= pos) row[lane] = lane == pos ? cand : e_prev;
+    const unsigned long long last = pos == k - 1 ? cand : readlane_u64(e, k - 2);
+    return last ? key_score(last) : -INFINITY;
 }
 
 #ifdef IGCN_TOPK_TRACE
@@ -180,7 +184,7 @@ __device__ __forceinline__ unsigned long long heap_replace_root(unsigned long lo
 // [0] load wait  [1] MFMA chain  [2] masking  [3] selection  [4] whole wave  [5] tiles  [6] waves
 // [7] whole wave in s_memrealtime ticks (100 MHz)
 __device__ unsigned long long g_topk_trace[8];
-__device__ unsigned long long g_topk_wave_times[4 * 8192];     // [begin, end] in s_memrealtime ticks, HW_ID, reserved per workgroup
+__device__ unsigned long long g_topk_wave_times[4 * 8192];     // [begin, end] in s_memrealtime ticks, HW_ID, insertions per workgroup
 // clock read that cannot issue before `dep` (an SGPR derived from the results being timed) exists
 __device__ __forceinline__ unsigned long long trace_clock(int dep) {
     unsigned long long t;
@@ -197,20 +201,19 @@ __device__ __forceinline__ int trace_dep(const f32x16 &acc) {
 
 // FULL: d == D, no k-slice of a row is padding
 template <int D, bool FULL>
-__global__ __launch_bounds__(kWave, (D <= 64 ? 3 : 2)) void score_topk_kernel(
+__global__ __launch_bounds__(kWave, (D <= 64 ? IGCN_TOPK_WPS : 2)) void score_topk_kernel(
     const float *__restrict__ user_rows, int64_t ldu, const int64_t *__restrict__ user_ids, int64_t batch,
     const float *__restrict__ item_rows, int64_t ldi, int64_t n_items, int d,
     const int64_t *__restrict__ excl_rowptr, const int32_t *__restrict__ excl_col, const uint8_t *__restrict__ banned,
-    int k, int cap, int n_tiles, int64_t n_whole, int64_t rest_tiles, int64_t run, int p_max, int stagger,
+    int k, int n_tiles, int64_t n_whole, int64_t rest_tiles, int64_t run, int p_max, int stagger,
     int64_t *__restrict__ out_idx, float *__restrict__ out_val, float *__restrict__ ws_val, int32_t *__restrict__ ws_idx)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long *heap = reinterpret_cast<unsigned long long *>(smem) + threadIdx.x;     // [k][64]
-    unsigned long long *stage = heap + k * kWave;                                              // [cap][64]
+    unsigned long long *lists = reinterpret_cast<unsigned long long *>(smem);                  // [32 users][k]
 
-    if (stagger) set_priority_by_wave_slot();
+    if (stagger == 1) set_priority_by_wave_slot();
 #ifdef IGCN_TOPK_TRACE
-    unsigned long long tr_load = 0, tr_chain = 0, tr_mask = 0, tr_sel = 0, tr_tiles = 0;
+    unsigned long long tr_load = 0, tr_chain = 0, tr_mask = 0, tr_sel = 0, tr_tiles = 0, tr_cands = 0, tr_excl = 0;
     const unsigned long long tr_begin = trace_clock(0);
     unsigned long long tr_rt_begin;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_rt_begin) : : "memory");
@@ -221,6 +224,7 @@ __global__ __launch_bounds__(kWave, (D <= 64 ? 3 : 2)) void score_topk_kernel(
     const int64_t n_full = n_whole * units;
     int64_t rx = (int64_t)blockIdx.x * run;                     // cursor in the rest groups' tile space
     const int64_t rx_end = rx + run < rest_tiles ? rx + run : rest_tiles;
+    const float kNaN = __uint_as_float(0x7fc00000u);
 
     for (int64_t job = 0;; ++job) {
         // ---- next piece: users of `group`, item tiles [tin0, tin1) ----------------------------
@@ -244,25 +248,26 @@ __global__ __launch_bounds__(kWave, (D <= 64 ? 3 : 2)) void score_topk_kernel(
         }
         const int item_lo = tin0 * 32;
         const int item_hi = (int64_t)tin1 * 32 < n_items ? tin1 * 32 : (int)n_items;
-        const int64_t b = group * 32 + j;
+        const int64_t b = group * 32 + j;                        // user of this lane (as A row / as cursor owner)
         const bool user_ok = b < batch;
         const int64_t uid = user_ok ? (user_ids ? user_ids[b] : b) : 0;
 
-        // B operand: this lane's user.  Lane half h supplies k = 8q + 4h + c (q < D/8, c < 4): the two
+        // A operand: this lane's user.  Lane half h supplies k = 8q + 4h + c (q < D/8, c < 4): the two
         // lanes of a row read adjacent 16-B pieces, so one load instruction touches 32 lines, not 64.
-        float bfrag[D / 2];
+        float afrag[D / 2];
 #pragma unroll
         for (int q = 0; q < D / 8; ++q) {
             float4 v = f4_zero();
             const int e = 8 * q + 4 * h;
             if (user_ok && (FULL || e < d)) v = *reinterpret_cast<const float4 *>(user_rows + uid * ldu + e);
-            bfrag[4 * q + 0] = v.x; bfrag[4 * q + 1] = v.y; bfrag[4 * q + 2] = v.z; bfrag[4 * q + 3] = v.w;
+            afrag[4 * q + 0] = v.x; afrag[4 * q + 1] = v.y; afrag[4 * q + 2] = v.z; afrag[4 * q + 3] = v.w;
         }
 
-        // exclusion cursor: first excluded item >= item_lo; the entry after it is already on its way
+        // exclusion cursor of user j, kept by lane j (h == 0): first excluded item >= item_lo, and
+        // the entry after it
         const int32_t *ex_ptr = excl_col;
         int ex_pos = 0, ex_end = 0, ex_next = kIdxNone, ex_after = kIdxNone;
-        if (excl_rowptr && user_ok) {
+        if (excl_rowptr && user_ok && h == 0) {
             const int64_t r0 = excl_rowptr[uid];
             ex_ptr = excl_col + r0;
             ex_end = (int)(excl_rowptr[uid + 1] - r0);
@@ -276,172 +281,174 @@ __global__ __launch_bounds__(kWave, (D <= 64 ? 3 : 2)) void score_topk_kernel(
             if (ex_pos + 1 < ex_end) ex_after = ex_ptr[ex_pos + 1];
         }
 
-        // running top-k: per-lane min-heap of sortable keys in LDS; root (= k-th best so far) in registers.
-        // Key 0 = empty slot: ranks below every real entry, masked (-inf) ones included.
-        for (int s = 0; s < k; ++s) heap[s * kWave] = 0ull;
-        unsigned long long root = 0ull;
-        float thr = -INFINITY;                                   // score part of the root
-        int cnt = 0;                                             // staged candidates of this lane
+        // running top-k: one best-first list of sortable keys per user in LDS (key 0 = empty slot:
+        // ranks below every real entry, masked (-inf) ones included); the users' k-th best scores
+        // (16 users per lane half) in registers.  NaN = nothing may enter (user past the batch).
+        for (int e = lane; e < 32 * k; e += kWave) lists[e] = 0ull;
+        float thr_v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) thr_v[r] = group * 32 + row_of(r, h) < batch ? -INFINITY : kNaN;
 
-        // staged candidates -> heap, all lanes together
-        auto flush = [&]() {
-            const int n = cnt;
-            cnt = 0;
-            for (int i = 0; __any(i < n); ++i) {
-                if (i < n) {
-                    const unsigned long long raw = stage[i * kWave];
-                    const unsigned long long cand = make_key(__uint_as_float((unsigned int)raw), (int)(raw >> 32));
-                    if (cand > root) root = heap_replace_root(heap, k, cand);
-                }
-            }
-            thr = root ? key_score(root) : -INFINITY;            // list not full yet: everything may enter
-        };
-
-        // A operand: item row of this lane, k-slice of its half.  Address = uniform tile base (scalar
-        // registers, advanced by scalar adds) + a lane offset that never changes, so a tile's loads
-        // cost no vector ALU work.  Rows past the end of the table are clamped (and masked below).
+        // B operand: item row of this lane, k-slice of its half.  Address = uniform tile base (scalar
+        // registers) + a lane offset that never changes, so a tile's loads cost no vector ALU work.
+        // Rows past the end of the table are clamped (and masked below).
         const int lane_off = j * (int)ldi + 4 * h;
         int lane_off_last = lane_off;                            // for the ragged last tile of the table
         {
             const int64_t last_base = (int64_t)(n_tiles - 1) * 32;
             if (last_base + j >= n_items) lane_off_last = (int)(n_items - 1 - last_base) * (int)ldi + 4 * h;
         }
-        float4 a[D / 8];
-        auto load_a = [&](int t) {
+        float4 bf[D / 8];
+        int ban_next = 0;                                        // banned flag of this lane's item, next tile
+        auto load_b = [&](int t) {
             const float *tile_ptr = item_rows + (int64_t)t * 32 * ldi;
             const int off = t == n_tiles - 1 ? lane_off_last : lane_off;
 #pragma unroll
             for (int q = 0; q < D / 8; ++q)
-                a[q] = (FULL || 8 * q + 4 * h < d) ? *reinterpret_cast<const float4 *>(tile_ptr + off + 8 * q) : f4_zero();
+                bf[q] = (FULL || 8 * q + 4 * h < d) ? *reinterpret_cast<const float4 *>(tile_ptr + off + 8 * q) : f4_zero();
+            if (banned) {
+                const int64_t it = (int64_t)t * 32 + j;
+                ban_next = it < n_items ? banned[it] : 0;
+            }
         };
-        load_a(tin0);
+        load_b(tin0);
 
         for (int tile = tin0; tile < tin1; ++tile) {
             const int tile_base = tile * 32;
 #ifdef IGCN_TOPK_TRACE
             const unsigned long long tr0 = trace_clock(tile_base);
             unsigned long long tr1;
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr1), "+v"(a[0].x) : : "memory");
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr1), "+v"(bf[0].x) : : "memory");
 #endif
+            const int ban = ban_next;
+            if (stagger == 2) __builtin_amdgcn_s_setprio(0);          // the chain needs one issue slot per 64 cycles
+            else if (stagger == 3) __builtin_amdgcn_s_setprio(3);
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
             for (int q = 0; q < D / 8; ++q) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bfrag[4 * q + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bfrag[4 * q + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bfrag[4 * q + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bfrag[4 * q + 3], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[4 * q + 0], bf[q].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[4 * q + 1], bf[q].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[4 * q + 2], bf[q].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[4 * q + 3], bf[q].w, acc, 0, 0, 0);
             }
 #ifdef IGCN_TOPK_TRACE
             const unsigned long long tr2 = trace_clock(trace_dep(acc));
 #endif
+            if (stagger == 2) __builtin_amdgcn_s_setprio(3);          // bookkeeping: get it over with
+            else if (stagger == 3) __builtin_amdgcn_s_setprio(0);
+
             // --- masking ---------------------------------------------------------------------
-            // rows past the end of the piece: NaN = "already examined", never a candidate
+#ifndef IGCN_X_NOMASK
+            // items past the end of the piece: NaN = never a candidate
             if (tile_base + 32 > item_hi) {                        // ragged last tile (wave-uniform)
                 asm volatile("; ragged tile");                     // (a real branch: the common path skips all of this)
+                if (tile_base + j >= item_hi) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (tile_base + row_of(r, h) >= item_hi) acc[r] = __uint_as_float(0x7fc00000u);
+                    for (int r = 0; r < 16; ++r) acc[r] = kNaN;
+                }
+            }
+            if (banned) {
+                if (__any(ban != 0)) {
+                    asm volatile("; tile with banned items");
+                    if (ban) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[r] = isnan(acc[r]) ? acc[r] : -INFINITY;
+                    }
+                }
             }
             if (excl_rowptr) {
                 const int tile_end = tile_base + 32;
+                bool refill = false;
                 while (true) {
-                    const bool need = ex_next < tile_end;
-                    if (!__any(need)) break;
-                    if (need) {
-                        const int rl = ex_next - tile_base;          // 0..31
-                        if (((rl >> 2) & 1) == h) {
-                            const int rr = (rl & 3) + 4 * (rl >> 3);
+                    const unsigned long long need = __ballot(ex_next < tile_end);
+                    if (!need) break;
+                    asm volatile("; excluded item in this tile");
+#ifdef IGCN_TOPK_TRACE
+                    ++tr_excl;
+#endif
+                    const int l = __builtin_ctzll(need);         // user l (of the group): one exclusion at a time
+                    const int it = __builtin_amdgcn_readlane(ex_next, l);
+                    const int target = (it - tile_base) + 32 * ((l >> 2) & 1);
+                    const int rr = (l & 3) + 4 * (l >> 3);
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[r] = (r == rr) ? -INFINITY : acc[r];
-                        }
+                    for (int r = 0; r < 16; ++r)
+                        if (r == rr) acc[r] = lane == target ? -INFINITY : acc[r];
+                    if (lane == l) {
                         ++ex_pos;
+                        if (ex_after == kExPending) ex_after = ex_pos < ex_end ? ex_ptr[ex_pos] : kIdxNone;   // twice in one tile: rare
                         ex_next = ex_after;
-                        ex_after = ex_pos + 1 < ex_end ? ex_ptr[ex_pos + 1] : kIdxNone;
+                        ex_after = kExPending;
+                        refill = true;
                     }
                 }
+                if (refill) ex_after = ex_pos + 1 < ex_end ? ex_ptr[ex_pos + 1] : kIdxNone;
             }
-            // next tile's A operand: on its way during the rest of this tile's bookkeeping
-            if (tile + 1 < tin1) load_a(tile + 1);
-            if (banned) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int it = tile_base + 8 * g + 4 * h + c;
-                        if (it < item_hi && banned[it]) acc[4 * g + c] = -INFINITY;
-                    }
-                }
-            }
+#endif
+            // next tile's B operand: on its way during the rest of this tile's bookkeeping.  Issued after
+            // the exclusion cursor moved: its loads are then older than these, and no wait in the cursor
+            // code can stall on a tile that has only just been requested.
+#ifndef IGCN_X_NOLOAD
+            if (tile + 1 < tin1) load_b(tile + 1);
+#endif
 #ifdef IGCN_TOPK_TRACE
             const unsigned long long tr3 = trace_clock(trace_dep(acc));
 #endif
             // --- top-k -----------------------------------------------------------------------
-            // One compare of the tile maximum against the (slightly stale) k-th best decides whether
-            // anything can enter.  Candidates are only STAGED here; the heap work is batched in flush().
+            // 16 compares against the users' k-th best decide whether anything of this tile can enter
+#ifdef IGCN_X_NOSELECT
+            if (acc[3] == 12345.f) thr_v[0] = 0.f;
+#else
             {
-                float m = acc[0];
+                bool hit = false;
 #pragma unroll
-                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-                if (__any(m >= thr)) {
-                    bool full;
-                    do {
+                for (int r = 0; r < 16; ++r) hit |= acc[r] >= thr_v[r];
+                if (__any(hit)) {
+                    asm volatile("; tile with candidates");
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float sc = acc[r];
-                            const bool take = sc >= thr;
-                            if (__any(take)) {                   // a row without candidates costs a compare and a branch
-                                asm volatile("; row with candidates");       // (keeps this a real, wave-uniform branch)
-                                if (take && cnt < cap) {
-                                    int hh = 4 * h;
-                                    asm volatile("" : "+v"(hh));     // keep the item id arithmetic inside the rare path
-                                    stage[cnt * kWave] = ((unsigned long long)(unsigned int)(tile_base + row_of(r, 0) + hh) << 32) | __float_as_uint(sc);
-                                    ++cnt;
-                                    acc[r] = __uint_as_float(0x7fc00000u);     // examined
-                                }
-                            }
+                    for (int r = 0; r < 16; ++r) {
+                        unsigned long long m = __ballot(acc[r] >= thr_v[r]);
+                        while (m) {
+                            asm volatile("; candidate");
+#ifdef IGCN_TOPK_TRACE
+                            ++tr_cands;
+#endif
+                            const int l = __builtin_ctzll(m);
+                            m &= m - 1;
+                            const float sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc[r]), l));
+                            const int hl = l >> 5;
+                            const int u = row_of(r, hl);
+                            const float t_old = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(thr_v[r]), l));
+                            const float t_new = list_insert(lists + u * k, k, make_key(sc, tile_base + (l & 31)), lane, t_old);
+                            thr_v[r] = h == hl ? t_new : thr_v[r];
                         }
-                        full = __any(cnt >= cap);                // a full lane may have left candidates behind
-                        if (full) flush();
-                    } while (full);
+                    }
                 }
             }
+#endif
 #ifdef IGCN_TOPK_TRACE
-            const unsigned long long tr4 = trace_clock(__builtin_amdgcn_readfirstlane(__float_as_int(thr) + cnt));
+            const unsigned long long tr4 = trace_clock(__builtin_amdgcn_readfirstlane(__float_as_int(thr_v[0])));
             tr_load += tr1 - tr0; tr_chain += tr2 - tr1; tr_mask += tr3 - tr2; tr_sel += tr4 - tr3; ++tr_tiles;
 #endif
         }
-        flush();
 
-        // ---- emit: heapsort each lane's list in place (best first), then either merge the two lanes
-        // of a user into the output or hand both lists to the merge kernel ------------------------
-        for (int n = k - 1; n > 0; --n) {
-            const unsigned long long last = heap[n * kWave];
-            heap[n * kWave] = heap[0];                           // current minimum goes to the end
-            heap_replace_root(heap, n, last);
-        }
+        // ---- emit: the lists are best-first already ------------------------------------------------
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (direct) {
-            if (h == 0 && user_ok) {
-                const unsigned long long *pheap = heap + 32;     // partner lane (l + 32), same wave
-                int i0 = 0, i1 = 0;
-                unsigned long long k0 = heap[0], k1 = pheap[0];
-                for (int r = 0; r < k; ++r) {
-                    unsigned long long best;
-                    if (k0 >= k1) { best = k0; ++i0; k0 = i0 < k ? heap[i0 * kWave] : 0ull; }
-                    else          { best = k1; ++i1; k1 = i1 < k ? pheap[i1 * kWave] : 0ull; }
-                    out_idx[b * k + r] = best ? key_item(best) : -1;
-                    out_val[b * k + r] = best ? key_score(best) : -INFINITY;
+        const int n_users = batch - group * 32 < 32 ? (int)(batch - group * 32) : 32;
+        for (int u = 0; u < n_users; ++u) {
+            if (lane < k) {
+                const unsigned long long key = lists[u * k + lane];
+                const int64_t bu = group * 32 + u;
+                if (direct) {
+                    out_idx[bu * k + lane] = key ? key_item(key) : -1;
+                    out_val[bu * k + lane] = key ? key_score(key) : -INFINITY;
+                } else {
+                    const int64_t slot = ((bu - n_full * 32) * p_max + pidx) * k + lane;
+                    ws_val[slot] = key ? key_score(key) : -INFINITY;
+                    ws_idx[slot] = key ? key_item(key) : kIdxNone;
                 }
-            }
-        } else if (user_ok) {
-            const int64_t slot = ((b - n_full * 32) * (2 * p_max) + 2 * pidx + h) * k;
-            for (int r = 0; r < k; ++r) {
-                const unsigned long long key = heap[r * kWave];
-                ws_val[slot + r] = key ? key_score(key) : -INFINITY;
-                ws_idx[slot + r] = key ? key_item(key) : kIdxNone;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -458,14 +465,14 @@ __global__ __launch_bounds__(kWave, (D <= 64 ? 3 : 2)) void score_topk_kernel(
         if (blockIdx.x < 8192) {
             g_topk_wave_times[4 * blockIdx.x] = tr_rt_begin; g_topk_wave_times[4 * blockIdx.x + 1] = tr_rt_end;
             g_topk_wave_times[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
-            g_topk_wave_times[4 * blockIdx.x + 3] = 0;
+            g_topk_wave_times[4 * blockIdx.x + 3] = tr_cands | (tr_excl << 32);
         }
     }
 #endif
 }
 
-// One wave per user of the groups that were cut: lane = one (piece, lane half) list, already
-// best-first; k rounds of a wave-wide arg-best over the heads.
+// One wave per user of the groups that were cut: lane = one piece's list, already best-first;
+// k rounds of a wave-wide arg-best over the heads.
 __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restrict__ ws_val, const int32_t *__restrict__ ws_idx,
                                                             int64_t first_user, int64_t batch, int n_tiles, int64_t run,
                                                             int p_max, int k,
@@ -476,9 +483,9 @@ __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restr
     const int64_t b = first_user + rb;
     if (b >= batch) return;
     const int64_t rg = rb / 32;
-    const int n_splits = 2 * (int)((((rg + 1) * n_tiles - 1) / run) - (rg * n_tiles) / run + 1);
-    const float *v = ws_val + (rb * (2 * p_max) + lane) * k;
-    const int32_t *ix = ws_idx + (rb * (2 * p_max) + lane) * k;
+    const int n_splits = (int)((((rg + 1) * n_tiles - 1) / run) - (rg * n_tiles) / run + 1);
+    const float *v = ws_val + (rb * p_max + lane) * k;
+    const int32_t *ix = ws_idx + (rb * p_max + lane) * k;
     int cur = 0;
     float hv = -INFINITY;
     int hi = kIdxNone;
@@ -524,17 +531,10 @@ static int launch_topk(const TopkPlan &p, hipStream_t st,
                        int64_t *out_idx, float *out_val, float *ws_val, int32_t *ws_idx)
 {
     auto kern = score_topk_kernel<D, FULL>;
-    static bool configured = false;
-    if (!configured && p.lds_bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(64 * 1024));
-        if (e != hipSuccess) return (int)e;
-        configured = true;
-    }
-    if (p.units >= ((int64_t)1 << 31)) return IGCN_E_SHAPE;
-    const int stagger = env_int("IGCN_TOPK_STAGGER", 0, 1, 1);                          // developer knob
+    if (p.units >= ((int64_t)1 << 31) || p.lds_bytes > 48 * 1024) return IGCN_E_SHAPE;
+    const int stagger = env_int("IGCN_TOPK_STAGGER", 0, 3, 1);                          // developer knob
     hipLaunchKernelGGL(kern, dim3((unsigned)p.units), dim3(kWave), p.lds_bytes, st, user_rows, ldu, user_ids, batch,
-                       item_rows, ldi, n_items, d, excl_rowptr, excl_col, banned, k, p.cap, p.n_tiles, p.n_whole,
+                       item_rows, ldi, n_items, d, excl_rowptr, excl_col, banned, k, p.n_tiles, p.n_whole,
                        p.rest_tiles, p.run, p.p_max, stagger, out_idx, out_val, ws_val, ws_idx);
     return launch_status();
 }
@@ -554,7 +554,7 @@ extern "C" int64_t igcn_score_topk_workspace_bytes(int64_t batch, int64_t n_item
 {
     TopkPlan p;
     if (topk_make_plan(batch, n_items, d, k, &p) != IGCN_OK) return -1;
-    return topk_rest_users(p, batch) * 2 * p.p_max * k * 8;
+    return topk_rest_users(p, batch) * p.p_max * k * 8;
 }
 
 extern "C" int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
@@ -573,7 +573,7 @@ extern "C" int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const in
     if (rest_users > 0 && !workspace) return IGCN_E_NULL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     float *ws_val = static_cast<float *>(workspace);
-    int32_t *ws_idx = reinterpret_cast<int32_t *>(ws_val ? ws_val + rest_users * 2 * p.p_max * k : nullptr);
+    int32_t *ws_idx = reinterpret_cast<int32_t *>(ws_val ? ws_val + rest_users * p.p_max * k : nullptr);
 
 #define IGCN_TOPK_CASE(DD)                                                                                        \
     rc = (d == DD ? launch_topk<DD, true> : launch_topk<DD, false>)(                                             \
