@@ -11,34 +11,38 @@
 // cores, in exact fp32: v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain, no
 // reduced-precision shortcut).  The fp32 MFMA is slow enough (64 cycles each,
 // 2048 cycles per 32x32xd=64 tile) that operand traffic is negligible; what
-// decides the speed is keeping every SIMD's matrix pipe busy.  Hence:
-//   * one WAVE = one workgroup = 32 users for a whole item sweep: no LDS staging,
+// decides the speed is keeping every SIMD's matrix pipe busy, and what keeps it
+// idle is everything a wave does between two MFMA chains (measured: while the
+// pipe of a SIMD is saturated the other waves' ordinary instructions issue at
+// 45 % of their normal rate; scripts/probes/mfma_valu_overlap_probe.hip).  Hence:
+//   * one WAVE = one workgroup = 32 users for a run of item tiles: no LDS staging,
 //     no barriers, nothing shared between waves.  The users' embeddings are the
 //     MFMA B operand and stay in d/2 VGPRs per lane; the item rows (A operand)
-//     are read straight from L2/Infinity Cache, the two lanes of a row taking
+//     are read straight from L2/Infinity Cache ONE TILE AHEAD, addressed as a
+//     scalar tile base + a constant lane offset; the two lanes of a row take
 //     adjacent 16-byte pieces so that a load instruction touches 32 lines;
-//   * <=128 VGPRs and k*512 B of LDS per wave, so 4 waves share a SIMD and cover
-//     each other's loads and top-k bookkeeping with their MFMA chains; the waves
-//     of a SIMD take different static priorities (by hardware wave slot) so that
-//     they fall out of lock-step instead of all multiplying, then all selecting;
-//   * the grid is sized so that ALL waves are resident at once and every SIMD
-//     gets the same amount of MFMA work: G = ceil(B/32) user groups over S SIMDs;
-//     floor(G/S)*S groups are swept by one wave each, the remaining groups are
-//     cut into item-range parts (one wave per part) that fill the last wave slot
-//     of every SIMD; parts write partial lists that a small kernel merges;
 //   * the product is computed as S^T = I . U^T, so in the accumulator a lane
 //     holds 16 item scores of ONE user (column = lane&31): the running top-k of
 //     a user is private to a lane pair, no cross-lane traffic in the sweep;
 //   * masking is exact and in-register: each lane walks its user's sorted
-//     exclusion list with a cursor as the item sweep advances; banned items are
-//     read as bytes per accumulator row;
-//   * top-k: one compare of the tile maximum against the user's current k-th
-//     best decides whether anything can enter.  Entries are 64-bit sortable keys
+//     exclusion list with a cursor as the item sweep advances (the entry after
+//     the cursor is always already loaded); banned items are read as bytes;
+//   * top-k: one compare of the tile maximum against the lane's (slightly stale)
+//     k-th best decides whether anything can enter; a row with candidates costs a
+//     compare and a wave-uniform branch.  Entries are 64-bit sortable keys
 //     (order-preserving image of the fp32 score << 32 | ~item id), kept per lane
 //     as a k-slot binary min-heap in LDS ([slot][lane]: lane l always hits its own
-//     bank pair); a rare insert replaces the root and sifts down, O(log k).  The
-//     wave handles "the first remaining candidate of every lane" per pass, so a
-//     tile costs about one pass however its candidates are spread over lanes.
+//     bank pair).  Candidates are only STAGED in a few more LDS slots per lane;
+//     the replace-root/sift-down work is done for all lanes together when some
+//     lane's staging area is full, i.e. with most lanes active instead of one;
+//   * the grid never exceeds what is resident at once: a wave that starts late
+//     runs its whole share after everybody else has finished.  Registers allow 3
+//     waves per SIMD (2 for d > 64); LDS is handed out in 1280-B granules, and
+//     the staging depth is whatever they leave beside the heap.  Every wave gets
+//     the same number of tiles: with G 32-user groups and W resident waves each
+//     wave sweeps floor(G/W) whole groups, and the tiles of the remaining groups,
+//     laid end to end, are cut into W equal runs.  A group that is cut returns
+//     one best-first list per (piece, lane half), merged by a small second kernel.
 // Ties are broken towards the lower item id (torch.topk leaves them unspecified).
 #include <math.h>
 #include <stdlib.h>
