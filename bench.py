@@ -192,24 +192,27 @@ def main():
     }
 
     # ---- roofline of the dominant kernel (per launch, this rank) ----------------------------------
-    if not sharded:
-        b_alg = nnz * (8 + 4 * d) + n * (4 * d + 4)
-        b_min = nnz * 8 + n * (8 * d + 4)
-        ms_launch = dev_ms / (args.steps * launches_per_step)
-        traffic = None
-        tp = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get('spmm_hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
-        ach = b_alg / ms_launch / 1e6
-        out['roofline'] = {'bound': 'hbm', 'kernel': 'spmm_csr_rows_kernel<16,false>', 'achieved': ach, 'peak': HBM_PEAK_GBPS,
-                           'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS, 'traffic': traffic,
-                           'algorithmic_bytes_per_launch': b_alg, 'compulsory_bytes_per_launch': b_min,
-                           'avg_launch_ms': ms_launch,
-                           'note': 'X (52.8 MB) fits the 256 MiB Infinity Cache: gathers are served on-die, so algorithmic '
-                                   'bytes/s may exceed the HBM peak; traffic = PMC-measured HBM bytes per launch'}
+    dcols = d if not sharded else d // world                              # embedding columns this rank carries
+    b_alg = nnz * (8 + 4 * dcols) + n * (4 * dcols + 4)
+    b_min = nnz * 8 + n * (8 * dcols + 4)
+    ms_launch = dev_ms / (args.steps * launches_per_step)
+    traffic = None
+    tp = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if not sharded and os.path.exists(tp):
+        try:
+            traffic = json.load(open(tp)).get('spmm_hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
+    ach = b_alg / ms_launch / 1e6
+    x_mb = n * dcols * 4 / 1e6
+    out['roofline'] = {'bound': 'hbm', 'kernel': 'spmm_csr_rows_kernel<%d,false>' % max(1, dcols // 4), 'achieved': ach,
+                       'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS, 'traffic': traffic,
+                       'algorithmic_bytes_per_launch': b_alg, 'compulsory_bytes_per_launch': b_min,
+                       'avg_launch_ms': ms_launch,
+                       'note': ('rank 0 of %d; ' % world if sharded else '') +
+                               ('X (%.1f MB) fits the 256 MiB Infinity Cache: gathers are served on-die, so algorithmic '
+                                'bytes/s may exceed the HBM peak; ' % x_mb if x_mb < 256 else 'X = %.1f MB; ' % x_mb) +
+                               'traffic = PMC-measured HBM bytes per launch (profiles/pmc_traffic.json, N=1 only)'}
 
     extras = {}
     if not sharded and not args.no_extras:
