@@ -100,7 +100,8 @@ static inline int topk_make_plan(int64_t batch, int64_t n_items, int32_t d, int3
     p->cap = env_int("IGCN_TOPK_CAP", 1, cap, cap);                                    // developer knob
     p->lds_bytes = (size_t)(k + p->cap) * kWave * 8;
     const int64_t per_cu = 4 * per_simd;
-    const int64_t slots = per_cu * cu_count();
+    int64_t slots = per_cu * cu_count();
+    slots = env_int("IGCN_TOPK_SLOTS", 1, (int)slots, (int)slots);                    // developer knob (tests: whole sweeps + cut rest at small sizes)
     int64_t rest;
     if (p->groups >= slots) {
         p->units = slots;

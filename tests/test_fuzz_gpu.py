@@ -58,10 +58,11 @@ def test_score_topk_fuzz(monkeypatch):
         n_items = int(rng.integers(1, 3000))
         d = int(rng.choice([4, 8, 16, 20, 32, 64, 100, 128]))
         k = int(rng.integers(1, min(n_items, 64) + 1))
-        if case % 5 == 0:
-            monkeypatch.setenv('IGCN_TOPK_PARTS', str(int(rng.integers(2, 6))))     # force item-range parts + merge
+        if case % 3 == 1:
+            # few wave slots: every wave sweeps whole groups AND a run of the leftover groups' tiles (+ merge)
+            monkeypatch.setenv('IGCN_TOPK_SLOTS', str(int(rng.integers(1, 8))))
         else:
-            monkeypatch.delenv('IGCN_TOPK_PARTS', raising=False)
+            monkeypatch.delenv('IGCN_TOPK_SLOTS', raising=False)
         U = rng.integers(-4, 5, size=(n_users, d)).astype(np.float32)             # exact dot products
         I = rng.integers(-4, 5, size=(n_items, d)).astype(np.float32)
         scores = U @ I.T
