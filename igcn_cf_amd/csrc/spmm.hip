@@ -25,6 +25,7 @@
 //   * persistent grid: 8 workgroups of 4 waves per CU, wave-strided over the
 //     virtual rows, so neighbouring waves stream neighbouring col/val lines.
 #include <stdlib.h>
+#include <stdio.h>
 #include "common.h"
 
 namespace igcn {
@@ -45,6 +46,16 @@ struct SpmmDropout {
     float keep_prob;
 };
 
+#ifdef IGCN_SPMM_TRACE
+// Developer build only (scripts/dev_spmm_trace.py): [begin, end] of every wave in s_memrealtime ticks (100 MHz)
+__device__ unsigned long long g_spmm_wave_times[3 * 16384];   // begin, end, HW_ID
+__device__ __forceinline__ unsigned long long spmm_realtime() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
+    return t;
+}
+#endif
+
 template <int LPR, bool DROPOUT>
 __global__ __launch_bounds__(kBlock) void spmm_csr_rows_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
@@ -62,6 +73,9 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rows_kernel(
     const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)));
     const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
     const int64_t n_virtual = n_rows + n_segments;
+#ifdef IGCN_SPMM_TRACE
+    const unsigned long long tr_begin = spmm_realtime();
+#endif
 
     for (int64_t vv = wave0; vv < n_virtual; vv += n_waves) {
         // optional: segments of long rows scheduled first (measured slower on MI355X; off)
@@ -152,6 +166,13 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rows_kernel(
             }
         }
     }
+#ifdef IGCN_SPMM_TRACE
+    if (lane == 0 && wave0 < 16384) {
+        g_spmm_wave_times[3 * wave0] = tr_begin;
+        g_spmm_wave_times[3 * wave0 + 1] = spmm_realtime();
+        g_spmm_wave_times[3 * wave0 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+    }
+#endif
 }
 
 // Adds the partial sums of each long row and applies the epilogue.  One wave per
@@ -255,16 +276,13 @@ __global__ void csr_row_pow_kernel(const int64_t *__restrict__ rowptr, const flo
     }
 }
 
-// Developer tuning knobs (environment, read once): IGCN_SPMM_BLOCKS_PER_CU, IGCN_SPMM_SEG_FIRST.
+// Developer tuning knobs (environment, read per call): IGCN_SPMM_BLOCKS_PER_CU, IGCN_SPMM_SEG_FIRST.
 struct SpmmTuning { int blocks_per_cu; int seg_first; };
-static const SpmmTuning &tuning() {
-    static SpmmTuning t = [] {
-        SpmmTuning v{8, 0};
-        if (const char *e = getenv("IGCN_SPMM_BLOCKS_PER_CU")) { int x = atoi(e); if (x >= 1 && x <= 64) v.blocks_per_cu = x; }
-        if (const char *e = getenv("IGCN_SPMM_SEG_FIRST")) v.seg_first = atoi(e) != 0;
-        return v;
-    }();
-    return t;
+static SpmmTuning tuning() {
+    SpmmTuning v{0, 0};                                       // 0 = resident_blocks_per_cu() of the kernel variant
+    if (const char *e = getenv("IGCN_SPMM_BLOCKS_PER_CU")) { int x = atoi(e); if (x >= 1 && x <= 64) v.blocks_per_cu = x; }
+    if (const char *e = getenv("IGCN_SPMM_SEG_FIRST")) v.seg_first = atoi(e) != 0;
+    return v;
 }
 
 // mask1[id] = 1 for the listed rows; mask2[id] = 1 and mask2[c] = 1 for every column c of a listed row.
@@ -280,14 +298,38 @@ __global__ void mark_rows_kernel(const int64_t *__restrict__ ids, int64_t n, con
         for (int64_t p = rowptr[r] + lane; p < rowptr[r + 1]; p += kWave) mask2[col[p]] = 1;
 }
 
+// Workgroups of this kernel variant that a CU really holds at once.  The persistent grid deals rows to
+// its waves statically, so a workgroup that is not resident from the start runs its whole share after
+// the others have finished: measured on MI355X (scripts/dev_spmm_trace.py), 8 workgroups per CU of the
+// d = 64 variant (58 VGPRs, 90 SGPRs) leave 1 in 8 starting 77 us late in a 156 us kernel, although
+// hipOccupancyMaxActiveBlocksPerMultiprocessor answers 8; 7 per CU is 17 % faster.  The query was one
+// too high for every variant measured (scripts/dev_spmm_blocks_ab.py, scripts/probes/residency_probe.hip:
+// kernels near an SGPR allocation boundary), so the grid uses one less than it says.
+template <int LPR, bool DROPOUT>
+static int resident_blocks_per_cu() {
+    static const int n = [] {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, spmm_csr_rows_kernel<LPR, DROPOUT>, kBlock, 0) != hipSuccess) nb = 0;
+        (void)hipGetLastError();
+        return nb > 1 ? nb - 1 : (nb == 1 ? 1 : 6);
+    }();
+    return n;
+}
+
 template <int LPR>
-static int launch_rows(bool dropout, dim3 grid, hipStream_t st,
+static int launch_rows(bool dropout, int64_t blocks, hipStream_t st,
                        const int64_t *rowptr, const int32_t *col, const float *val, const float *x, int64_t ldx,
                        float *y, int64_t ldy, int64_t n_rows, int d, const SpmmEpilogue &ep, const SpmmDropout &dr,
                        const igcn_row_segment *segments, int64_t n_segments, float *partial, int long_threshold,
                        const igcn_long_row *long_rows, int64_t n_long, const uint8_t *row_mask, int masked_rows_zero)
 {
-    const int seg_first = tuning().seg_first;
+    const SpmmTuning tune = tuning();
+    const int seg_first = tune.seg_first;
+    const int per_cu = tune.blocks_per_cu > 0 ? tune.blocks_per_cu
+                       : (dropout ? resident_blocks_per_cu<LPR, true>() : resident_blocks_per_cu<LPR, false>());
+    const int64_t max_blocks = (int64_t)cu_count() * per_cu;
+    if (blocks > max_blocks) blocks = max_blocks;
+    const dim3 grid((unsigned)blocks);
     if (dropout)
         hipLaunchKernelGGL((spmm_csr_rows_kernel<LPR, true>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
                            n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, seg_first, row_mask, masked_rows_zero);
@@ -403,9 +445,8 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
     const int waves_per_block = kBlock / kWave;
     const int64_t n_virtual = n_rows + n_segments;
     int64_t blocks = (n_virtual + waves_per_block - 1) / waves_per_block;
-    const int64_t max_blocks = (int64_t)cu_count() * tuning().blocks_per_cu;
-    if (blocks > max_blocks) blocks = max_blocks;
-    dim3 grid((unsigned)blocks);
+    const int64_t scalar_cap = (int64_t)cu_count() * 8;
+    const dim3 scalar_grid((unsigned)(blocks < scalar_cap ? blocks : scalar_cap));
 
     bool vec = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) &&
                ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) % 16 == 0);
@@ -413,12 +454,12 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
     if (n_segments > 0 && (reinterpret_cast<uintptr_t>(partial) % 16 != 0)) return IGCN_E_ALIGN;
     if (!vec) {
         if (n_segments > 0 || row_mask) return IGCN_E_ALIGN;   // plan / row masks need the vector path
-        hipLaunchKernelGGL(spmm_csr_scalar_kernel, grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
+        hipLaunchKernelGGL(spmm_csr_scalar_kernel, scalar_grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
                            n_rows, (int)d, ep, dr, dropout);
         return launch_status();
     }
 #define IGCN_SPMM_CASE(L)                                                                                         \
-    return launch_rows<L>(dropout, grid, st, rowptr, col, val, x, ldx, y, ldy, n_rows, (int)d, ep, dr, segments,  \
+    return launch_rows<L>(dropout, blocks, st, rowptr, col, val, x, ldx, y, ldy, n_rows, (int)d, ep, dr, segments,  \
                           n_segments, partial, (int)long_threshold, long_rows, n_long_rows, row_mask, (int)masked_rows_zero)
     const int q = d / 4;
     if (q <= 1) IGCN_SPMM_CASE(1);
@@ -456,6 +497,15 @@ extern "C" int igcn_csr_row_pow_f32(const int64_t *rowptr, const float *row_sum,
                        rowptr, row_sum, exponent, val_out, row_scale_out, n_rows);
     return launch_status();
 }
+
+#ifdef IGCN_SPMM_TRACE
+extern "C" int igcn_debug_spmm_wave_times(unsigned long long *host, int n_waves)
+{
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(host, HIP_SYMBOL(igcn::g_spmm_wave_times), (size_t)n_waves * 24);
+    return (int)e;
+}
+#endif
 
 extern "C" int igcn_abi_version(void) { return IGCN_ABI_VERSION; }
 
