@@ -22,10 +22,13 @@
 //     scheduled like ordinary rows ("virtual rows" after the real ones), write
 //     partial sums, and a second tiny kernel adds the partials in a fixed order
 //     — results are bitwise reproducible, no float atomics;
-//   * persistent grid: 8 workgroups of 4 waves per CU, wave-strided over the
-//     virtual rows, so neighbouring waves stream neighbouring col/val lines.
+//   * rows are dealt round-robin to the waves of the grid, so neighbouring waves
+//     stream neighbouring col/val lines.  The grid is sized for about 21 KB of
+//     gathered cache lines per wave (4 rows per wave on the Amazon-like graph at
+//     d = 64, one at d = 128): enough workgroups that the dispatcher evens out a
+//     power-law load, few enough to amortise the per-wave set-up — and never just
+//     above what is resident at once (see resident_blocks_per_cu below).
 #include <stdlib.h>
-#include <stdio.h>
 #include "common.h"
 
 namespace igcn {
@@ -48,7 +51,7 @@ struct SpmmDropout {
 
 #ifdef IGCN_SPMM_TRACE
 // Developer build only (scripts/dev_spmm_trace.py): [begin, end] of every wave in s_memrealtime ticks (100 MHz)
-__device__ unsigned long long g_spmm_wave_times[3 * 16384];   // begin, end, HW_ID
+__device__ unsigned long long g_spmm_wave_times[6 * 16384];   // begin, end, HW_ID, rows, nonzeros, 64-entry chunks
 __device__ __forceinline__ unsigned long long spmm_realtime() {
     unsigned long long t;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rows_kernel(
     const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy,
     int64_t n_rows, int d, SpmmEpilogue ep, SpmmDropout dr,
     const igcn_row_segment *__restrict__ segments, int64_t n_segments,
-    float *__restrict__ partial, int long_threshold, int seg_first,
+    float *__restrict__ partial, int long_threshold,
     const uint8_t *__restrict__ row_mask, int masked_rows_zero)
 {
     constexpr int G = kWave / LPR;           // source rows per gather instruction
@@ -75,11 +78,10 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rows_kernel(
     const int64_t n_virtual = n_rows + n_segments;
 #ifdef IGCN_SPMM_TRACE
     const unsigned long long tr_begin = spmm_realtime();
+    unsigned long long tr_rows = 0, tr_nnz = 0, tr_chunks = 0;
 #endif
 
-    for (int64_t vv = wave0; vv < n_virtual; vv += n_waves) {
-        // optional: segments of long rows scheduled first (measured slower on MI355X; off)
-        const int64_t v = seg_first ? (vv < n_segments ? n_rows + vv : vv - n_segments) : vv;
+    for (int64_t v = wave0; v < n_virtual; v += n_waves) {
         int64_t start, end, dst;
         bool to_partial;
         if (v < n_rows) {
@@ -103,6 +105,9 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rows_kernel(
         }
 
         float4 acc = f4_zero();
+#ifdef IGCN_SPMM_TRACE
+        ++tr_rows; tr_nnz += end - start; tr_chunks += (end - start + kWave - 1) / kWave;
+#endif
         for (int64_t base = start; base < end; base += kWave) {
             const int64_t rem = end - base;
             const int cnt = rem < kWave ? (int)rem : kWave;     // wave-uniform
@@ -168,9 +173,10 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_rows_kernel(
     }
 #ifdef IGCN_SPMM_TRACE
     if (lane == 0 && wave0 < 16384) {
-        g_spmm_wave_times[3 * wave0] = tr_begin;
-        g_spmm_wave_times[3 * wave0 + 1] = spmm_realtime();
-        g_spmm_wave_times[3 * wave0 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+        g_spmm_wave_times[6 * wave0] = tr_begin;
+        g_spmm_wave_times[6 * wave0 + 1] = spmm_realtime();
+        g_spmm_wave_times[6 * wave0 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+        g_spmm_wave_times[6 * wave0 + 3] = tr_rows; g_spmm_wave_times[6 * wave0 + 4] = tr_nnz; g_spmm_wave_times[6 * wave0 + 5] = tr_chunks;
     }
 #endif
 }
@@ -276,12 +282,11 @@ __global__ void csr_row_pow_kernel(const int64_t *__restrict__ rowptr, const flo
     }
 }
 
-// Developer tuning knobs (environment, read per call): IGCN_SPMM_BLOCKS_PER_CU, IGCN_SPMM_SEG_FIRST.
-struct SpmmTuning { int blocks_per_cu; int seg_first; };
+// Developer tuning knob (environment, read per call): IGCN_SPMM_BLOCKS_PER_CU.
+struct SpmmTuning { int blocks_per_cu; };
 static SpmmTuning tuning() {
-    SpmmTuning v{0, 0};                                       // 0 = resident_blocks_per_cu() of the kernel variant
-    if (const char *e = getenv("IGCN_SPMM_BLOCKS_PER_CU")) { int x = atoi(e); if (x >= 1 && x <= 64) v.blocks_per_cu = x; }
-    if (const char *e = getenv("IGCN_SPMM_SEG_FIRST")) v.seg_first = atoi(e) != 0;
+    SpmmTuning v{0};                                          // 0 = resident_blocks_per_cu() of the kernel variant
+    if (const char *e = getenv("IGCN_SPMM_BLOCKS_PER_CU")) { int x = atoi(e); if (x >= 1 && x <= 4096) v.blocks_per_cu = x; }
     return v;
 }
 
@@ -298,13 +303,12 @@ __global__ void mark_rows_kernel(const int64_t *__restrict__ ids, int64_t n, con
         for (int64_t p = rowptr[r] + lane; p < rowptr[r + 1]; p += kWave) mask2[col[p]] = 1;
 }
 
-// Workgroups of this kernel variant that a CU really holds at once.  The persistent grid deals rows to
-// its waves statically, so a workgroup that is not resident from the start runs its whole share after
-// the others have finished: measured on MI355X (scripts/dev_spmm_trace.py), 8 workgroups per CU of the
-// d = 64 variant (58 VGPRs, 90 SGPRs) leave 1 in 8 starting 77 us late in a 156 us kernel, although
-// hipOccupancyMaxActiveBlocksPerMultiprocessor answers 8; 7 per CU is 17 % faster.  The query was one
-// too high for every variant measured (scripts/dev_spmm_blocks_ab.py, scripts/probes/residency_probe.hip:
-// kernels near an SGPR allocation boundary), so the grid uses one less than it says.
+// Workgroups of this kernel variant that a CU really holds at once (a floor for the grid).  Rows are
+// dealt to the waves round-robin, so a grid only slightly larger than what is resident is the worst
+// case: measured on MI355X (scripts/dev_spmm_trace.py), 8 workgroups per CU of the d = 64 variant left 1
+// in 8 starting 77 us late in a 156 us kernel, although hipOccupancyMaxActiveBlocksPerMultiprocessor
+// answers 8 (7 per CU: 17 % faster; the query was one too high for every variant measured,
+// scripts/dev_spmm_blocks_ab.py, scripts/probes/residency_probe.hip).  One less than it says is safe.
 template <int LPR, bool DROPOUT>
 static int resident_blocks_per_cu() {
     static const int n = [] {
@@ -321,21 +325,40 @@ static int launch_rows(bool dropout, int64_t blocks, hipStream_t st,
                        const int64_t *rowptr, const int32_t *col, const float *val, const float *x, int64_t ldx,
                        float *y, int64_t ldy, int64_t n_rows, int d, const SpmmEpilogue &ep, const SpmmDropout &dr,
                        const igcn_row_segment *segments, int64_t n_segments, float *partial, int long_threshold,
-                       const igcn_long_row *long_rows, int64_t n_long, const uint8_t *row_mask, int masked_rows_zero)
+                       const igcn_long_row *long_rows, int64_t n_long, const uint8_t *row_mask, int masked_rows_zero,
+                       int64_t nnz)
 {
+    // Grid: `blocks` on entry = one wave per row.  Fewer, longer-lived waves amortise the per-wave set-up;
+    // many short ones let the hardware dispatcher even out the load (a power-law graph deals very
+    // different amounts of work to equal row counts: per-wave time follows the nonzeros, 43 ns each,
+    // scripts/dev_spmm_trace.py).  Measured on MI355X, two boxes (profiles/r01f_*): for the Amazon-like
+    // graph (21 nonzeros per row) the best grids have 1 row per wave at d = 128, 1-4 at d = 64, 4-8 at
+    // d <= 32, all within 5 % of each other and 10-20 % ahead of a grid of just the resident waves;
+    // heavier rows get proportionally fewer per wave.  Never fewer workgroups than are resident at once.
     const SpmmTuning tune = tuning();
-    const int seg_first = tune.seg_first;
-    const int per_cu = tune.blocks_per_cu > 0 ? tune.blocks_per_cu
-                       : (dropout ? resident_blocks_per_cu<LPR, true>() : resident_blocks_per_cu<LPR, false>());
-    const int64_t max_blocks = (int64_t)cu_count() * per_cu;
-    if (blocks > max_blocks) blocks = max_blocks;
+    const int resident = dropout ? resident_blocks_per_cu<LPR, true>() : resident_blocks_per_cu<LPR, false>();
+    const int64_t n_virtual = n_rows + n_segments;
+    int64_t want;
+    if (tune.blocks_per_cu > 0) {
+        want = (int64_t)cu_count() * tune.blocks_per_cu;
+    } else {
+        const int64_t base_rows = d >= 128 ? 1 : d >= 64 ? 2 : 6;           // at 21 nonzeros per row
+        const int64_t mean_deg = nnz > 0 ? (nnz + n_virtual - 1) / n_virtual : 21;
+        int64_t rows_per_wave = (base_rows * 21 + mean_deg / 2) / (mean_deg > 0 ? mean_deg : 1);
+        if (rows_per_wave < 1) rows_per_wave = 1;
+        if (rows_per_wave > 8) rows_per_wave = 8;
+        want = (n_virtual + rows_per_wave * (kBlock / kWave) - 1) / (rows_per_wave * (kBlock / kWave));
+        const int64_t fill = (int64_t)cu_count() * resident;
+        if (want < fill) want = fill;
+    }
+    if (blocks > want) blocks = want;
     const dim3 grid((unsigned)blocks);
     if (dropout)
         hipLaunchKernelGGL((spmm_csr_rows_kernel<LPR, true>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
-                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, seg_first, row_mask, masked_rows_zero);
+                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero);
     else
         hipLaunchKernelGGL((spmm_csr_rows_kernel<LPR, false>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
-                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, seg_first, row_mask, masked_rows_zero);
+                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero);
     int rc = launch_status();
     if (rc != IGCN_OK) return rc;
     if (n_long > 0) {
@@ -407,7 +430,8 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
                                  const igcn_row_segment *segments, int64_t n_segments,
                                  float *partial, int32_t long_threshold,
                                  const int32_t *edge_id, uint64_t seed, float keep_prob,
-                                 const uint8_t *row_mask, int32_t masked_rows_zero, void *stream)
+                                 const uint8_t *row_mask, int32_t masked_rows_zero,
+                                 int64_t nnz, void *stream)
 {
     if (!rowptr || !x || !y) return IGCN_E_NULL;
     if (n_rows < 0 || n_cols < 0 || d < 1 || d > 256 || ldx < d || ldy < d) return IGCN_E_SHAPE;
@@ -460,7 +484,8 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
     }
 #define IGCN_SPMM_CASE(L)                                                                                         \
     return launch_rows<L>(dropout, blocks, st, rowptr, col, val, x, ldx, y, ldy, n_rows, (int)d, ep, dr, segments,  \
-                          n_segments, partial, (int)long_threshold, long_rows, n_long_rows, row_mask, (int)masked_rows_zero)
+                          n_segments, partial, (int)long_threshold, long_rows, n_long_rows, row_mask, (int)masked_rows_zero, \
+                          nnz)
     const int q = d / 4;
     if (q <= 1) IGCN_SPMM_CASE(1);
     if (q <= 2) IGCN_SPMM_CASE(2);
@@ -502,7 +527,7 @@ extern "C" int igcn_csr_row_pow_f32(const int64_t *rowptr, const float *row_sum,
 extern "C" int igcn_debug_spmm_wave_times(unsigned long long *host, int n_waves)
 {
     hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipMemcpyFromSymbol(host, HIP_SYMBOL(igcn::g_spmm_wave_times), (size_t)n_waves * 24);
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(host, HIP_SYMBOL(igcn::g_spmm_wave_times), (size_t)n_waves * 48);
     return (int)e;
 }
 #endif

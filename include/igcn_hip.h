@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IGCN_ABI_VERSION 1
+#define IGCN_ABI_VERSION 2
 
 #define IGCN_OK            0
 #define IGCN_E_NULL       -1   /* a required pointer is NULL               */
@@ -99,7 +99,9 @@ int igcn_spmm_plan_fill_host(const int64_t *rowptr_host, int64_t n_rows,
  * row_mask uint8 [n_rows] or NULL: the rows whose output the caller needs (a
  * training step needs the propagated rows of its batch only, so the last layer
  * and the layer before it — and by symmetry the first backward hop — shrink to
- * the batch rows / their neighbourhood; see igcn_mark_rows). */
+ * the batch rows / their neighbourhood; see igcn_mark_rows);
+ * nnz = rowptr[n_rows] as the caller knows it (it sizes the launch: the heavier the rows, the fewer
+ * of them a wave is given; <= 0 = unknown, a mean degree of 21 is assumed). */
 int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val,
                       const float *x, int64_t ldx, float *y, int64_t ldy,
                       int64_t n_rows, int64_t n_cols, int32_t d,
@@ -110,7 +112,7 @@ int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *va
                       float *partial, int32_t long_threshold,
                       const int32_t *edge_id, uint64_t seed, float keep_prob,
                       const uint8_t *row_mask, int32_t masked_rows_zero,
-                      void *stream);
+                      int64_t nnz, void *stream);
 
 /* Row masks for igcn_spmm_csr_f32.  mask1[ids[i] + offsets...] = 1 for every listed row;
  * when rowptr/col are given, mask2[r] = 1 for every listed row r and every column

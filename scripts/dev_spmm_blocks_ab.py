@@ -20,7 +20,7 @@ for d in (64, 128, 32, 8):
     y = torch.empty_like(x)
     res = {}
     for rnd in range(2):
-        for bpc in ('auto', 5, 6, 7, 8, 12, 14):
+        for bpc in ('auto', 7, 21, 28, 56, 112, 4096):
             if bpc == 'auto':
                 os.environ.pop('IGCN_SPMM_BLOCKS_PER_CU', None)       # library default: measured-residency rule
             else:
@@ -28,4 +28,4 @@ for d in (64, 128, 32, 8):
             ms1 = min(time_ms(lambda: spmm(csr, x, out=y), reps=50) for _ in range(2))
             ms3 = min(time_ms(lambda: propagate_mean(csr, x, 3), reps=30) for _ in range(2))
             res.setdefault(bpc, []).append((round(ms1 * 1e3, 1), round(ms3 * 1e3, 1)))
-    print(json.dumps(dict(d=d, us_layer_and_3layer_by_blocks_per_cu=res)), flush=True)
+    print(json.dumps(dict(d=d, us_layer__3layer__by_blocks_per_cu=res)), flush=True)

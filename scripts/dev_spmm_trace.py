@@ -42,15 +42,15 @@ def main():
     for _ in range(3):
         y = ops.spmm(csr, x)
     torch.cuda.synchronize()
-    nw = 256 * 8 * 4
-    buf = (C.c_uint64 * (3 * nw))()
+    nw = 16384
+    buf = (C.c_uint64 * (6 * nw))()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     y = ops.spmm(csr, x)
     e1.record()
     torch.cuda.synchronize()
     wt(buf, nw)
-    w = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 3).astype(np.int64)
+    w = np.frombuffer(buf, dtype=np.uint64).reshape(nw, 6).astype(np.int64)
     w = w[w[:, 1] > 0]
     t0 = w[:, 0].min()
     b, e = (w[:, 0] - t0) / 100.0, (w[:, 1] - t0) / 100.0           # microseconds
@@ -70,6 +70,16 @@ def main():
                           late_per_cu_quantiles=[int(v) for v in np.quantile(counts[:, 1], [0, 0.1, 0.5, 0.9, 1.0])],
                           simd_of_late=np.bincount((hw[~early] >> 4) & 3, minlength=4).tolist(),
                           wave_slot_of_late=np.bincount(hw[~early] & 15, minlength=16).tolist())))
+    busy = e - b
+    A = np.stack([w[:, 3], w[:, 5], w[:, 4], np.ones(len(w))], axis=1).astype(np.float64)
+    coef, *_ = np.linalg.lstsq(A, busy, rcond=None)
+    pred = A @ coef
+    print(json.dumps(dict(fit_busy_us='a*rows + b*chunks + c*nnz + e', a=round(float(coef[0]), 3), b=round(float(coef[1]), 3),
+                          c=round(float(coef[2]), 4), e=round(float(coef[3]), 2),
+                          r2=round(float(1 - ((busy - pred) ** 2).sum() / ((busy - busy.mean()) ** 2).sum()), 3),
+                          rows_per_wave=[int(v) for v in np.quantile(w[:, 3], [0, 0.5, 1])],
+                          nnz_per_wave=[int(v) for v in np.quantile(w[:, 4], [0, 0.1, 0.5, 0.9, 1])],
+                          corr_busy_nnz=round(float(np.corrcoef(busy, w[:, 4])[0, 1]), 3))))
     print(json.dumps(dict(kernel_us=round(e0.elapsed_time(e1) * 1e3, 1), waves=int(len(w)),
                           begin_us=[round(float(v), 1) for v in np.quantile(b, q)],
                           end_us=[round(float(v), 1) for v in np.quantile(e, q)],

@@ -197,7 +197,7 @@ def test_c_abi_error_codes_without_launch():
 
     def call(rowptr_p, x_p, y_p, d=64, ldx=64, n_adds=0, keep=1.0, n_rows=8):
         return L.igcn_spmm_csr_f32(rowptr_p, col.data_ptr(), None, x_p, ldx, y_p, 64, n_rows, 8, d, 1.0, nul, n_adds, 1.0,
-                                   None, None, None, 0, None, 0, None, 256, None, 0, keep, None, 0, None)
+                                   None, None, None, 0, None, 0, None, 256, None, 0, keep, None, 0, 0, None)
     assert call(None, x.data_ptr(), y.data_ptr()) == -1                       # IGCN_E_NULL
     assert call(rowptr.data_ptr(), x.data_ptr(), y.data_ptr(), d=0) == -2     # IGCN_E_SHAPE
     assert call(rowptr.data_ptr(), x.data_ptr(), y.data_ptr(), d=300) == -2
