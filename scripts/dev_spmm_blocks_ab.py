@@ -15,12 +15,12 @@ ds = SyntheticDataset({'name': 'SyntheticDataset', 'preset': 'amazon'})
 n = ds.n_users + ds.n_items
 rowptr, col, val = normalized_adjacency_host(ds.train_array, ds.n_users, ds.n_items)
 csr = CsrMatrix(rowptr, col, val, (n, n), 'cuda')
-for d in (64, 128, 32, 8):
+for d in (64,):
     x = torch.randn(n, d, device='cuda') * 0.1
     y = torch.empty_like(x)
     res = {}
-    for rnd in range(2):
-        for bpc in ('auto', 7, 21, 28, 56, 112, 4096):
+    for rnd in range(3):
+        for bpc in ('auto', 8, 7, 112):
             if bpc == 'auto':
                 os.environ.pop('IGCN_SPMM_BLOCKS_PER_CU', None)       # library default: measured-residency rule
             else:
