@@ -125,6 +125,17 @@ class ProcessedDataset(BasicDataset):
 
     def __init__(self, dataset_config):
         super().__init__(dataset_config)
+        path = dataset_config['path']
+        cache = os.path.join(path, BINARY_SPLITS)
+        texts = [os.path.join(path, f) for f in ('train.txt', 'val.txt', 'test.txt')]
+        if dataset_config.get('binary_cache') and os.path.exists(cache) and \
+                all(os.path.getmtime(cache) >= os.path.getmtime(t) for t in texts if os.path.exists(t)):
+            self.n_users, self.n_items, csrs = _load_binary(path)       # parsed once before: skip the text
+            for name, (rp, col) in csrs.items():
+                setattr(self, name + '_data', csr_to_lists(rp, col))
+                self._csr[(name, False)] = (rp, col)
+            self._finish()
+            return
         self.train_data = self.read_data(os.path.join(dataset_config['path'], 'train.txt'))
         self.val_data = self.read_data(os.path.join(dataset_config['path'], 'val.txt'))
         self.test_data = self.read_data(os.path.join(dataset_config['path'], 'test.txt'))
@@ -132,6 +143,11 @@ class ProcessedDataset(BasicDataset):
         assert len(self.train_data) == len(self.test_data)
         self.n_users = len(self.train_data)
         self._finish()
+        if dataset_config.get('binary_cache'):
+            try:
+                save_binary(self, path)
+            except OSError:
+                pass                                                     # read-only data directory: no cache
 
     def read_data(self, file_path):
         data = []
@@ -143,6 +159,30 @@ class ProcessedDataset(BasicDataset):
                 self.n_items = max(self.n_items, max(items) + 1)
             data.append(items)
         return data
+
+
+BINARY_SPLITS = 'splits_csr_v1.npz'
+
+
+def save_binary(dataset, path):
+    """Writes the train/val/test lists as CSR arrays (one .npz): the on-disk form for splits too large
+    for the text format (BASELINE config 5: 500 M pairs), read back by BinaryDataset and used as a
+    cache by ProcessedDataset(binary_cache=True).  List order is kept (training samples positives by
+    position, dataset.py:124)."""
+    os.makedirs(path, exist_ok=True)
+    arrays = {'n_users': np.int64(dataset.n_users), 'n_items': np.int64(dataset.n_items)}
+    for name in ('train', 'val', 'test'):
+        rp, col = dataset.csr(name, sort=False)
+        arrays[name + '_rowptr'], arrays[name + '_col'] = rp, col
+    tmp = os.path.join(path, BINARY_SPLITS + '.tmp.npz')
+    np.savez(tmp, **arrays)
+    os.replace(tmp, os.path.join(path, BINARY_SPLITS))
+
+
+def _load_binary(path):
+    with np.load(os.path.join(path, BINARY_SPLITS)) as z:
+        csrs = {name: (z[name + '_rowptr'], z[name + '_col']) for name in ('train', 'val', 'test')}
+        return int(z['n_users']), int(z['n_items']), csrs
 
 
 class CsrBackedDataset(BasicDataset):
@@ -196,6 +236,16 @@ class CsrBackedDataset(BasicDataset):
     def invalidate(self, which=None):
         for k in [k for k in self._csr if k[0] in self._lists and (which is None or k[0] == which)]:
             del self._csr[k]
+
+
+class BinaryDataset(CsrBackedDataset):
+    """Splits stored by save_binary() (config: {'name': 'BinaryDataset', 'path': dir}); the list views of
+    the reference contract are materialised only if something asks for them."""
+
+    def __init__(self, dataset_config):
+        super().__init__(dataset_config)
+        n_users, n_items, csrs = _load_binary(dataset_config['path'])
+        self._install(n_users, n_items, csrs)
 
 
 def _filter_csr(rowptr, col, keep, n_rows):

@@ -211,3 +211,28 @@ def test_c_oracle_matches_numpy_oracle(golden):
                                rtol=1e-5, atol=1e-7)
     idx, _ = CO.score_topk(x[:nu], x[nu:], 5)
     np.testing.assert_array_equal(idx, O.eval_topk(x[:nu] @ x[nu:].T, None, None, k=5))
+
+
+def test_binary_splits_roundtrip_and_cache(tmp_path):
+    """save_binary / BinaryDataset / ProcessedDataset(binary_cache=True): same lists (in list order), same
+    train_array, same n_items as the text reader (dataset.py:140-164)."""
+    import shutil
+    from igcn_cf_amd.dataset import BINARY_SPLITS, get_dataset, save_binary
+    src = os.path.join(ROOT, 'tests', 'golden', 'toy_a')
+    text = get_dataset({'name': 'ProcessedDataset', 'path': src, 'device': 'cpu'})
+    save_binary(text, str(tmp_path / 'bin'))
+    binary = get_dataset({'name': 'BinaryDataset', 'path': str(tmp_path / 'bin'), 'device': 'cpu'})
+    assert (binary.n_users, binary.n_items) == (text.n_users, text.n_items)
+    assert np.array_equal(binary.train_array, text.train_array)
+    for name in ('train_data', 'val_data', 'test_data'):
+        assert getattr(binary, name) == getattr(text, name)
+    # the cache: written on the first read, used on the second (the text files can even disappear)
+    work = tmp_path / 'work'
+    shutil.copytree(src, work)
+    first = get_dataset({'name': 'ProcessedDataset', 'path': str(work), 'device': 'cpu', 'binary_cache': True})
+    assert os.path.exists(work / BINARY_SPLITS)
+    os.remove(work / 'val.txt')
+    second = get_dataset({'name': 'ProcessedDataset', 'path': str(work), 'device': 'cpu', 'binary_cache': True})
+    assert second.val_data == text.val_data and second.train_data == first.train_data
+    assert np.array_equal(second.train_array, text.train_array) and second.n_items == text.n_items
+    assert [second[i].tolist() for i in range(1)][0][0][0] in range(text.n_users)      # sampling still works
