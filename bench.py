@@ -205,10 +205,23 @@ def main():
             traffic = None
     ach = b_alg / ms_launch / 1e6
     x_mb = n * dcols * 4 / 1e6
+    copy_gbps = None
+    if not sharded:                                                  # what a plain copy reaches on THIS box (read + write)
+        src = torch.empty(1 << 28, dtype=torch.float32, device=device)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 5 * 2 * src.numel() * 4 / c0.elapsed_time(c1) / 1e6
+        del src, dst
     out['roofline'] = {'bound': 'hbm', 'kernel': 'spmm_csr_rows_kernel<%d,false>' % max(1, dcols // 4), 'achieved': ach,
                        'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS, 'traffic': traffic,
                        'algorithmic_bytes_per_launch': b_alg, 'compulsory_bytes_per_launch': b_min,
-                       'avg_launch_ms': ms_launch,
+                       'avg_launch_ms': ms_launch, 'hbm_copy_measured_GBps': copy_gbps,
                        'note': ('rank 0 of %d; ' % world if sharded else '') +
                                ('X (%.1f MB) fits the 256 MiB Infinity Cache: gathers are served on-die, so algorithmic '
                                 'bytes/s may exceed the HBM peak; ' % x_mb if x_mb < 256 else 'X = %.1f MB; ' % x_mb) +
@@ -299,10 +312,38 @@ def cpu_baseline(rowptr, col, val, x, K, nnz, n_users):
     t0 = time.perf_counter()
     CO.score_topk(U, items, 20)
     ev = n_sample / (time.perf_counter() - t0)
-    return {'value': v, 'unit': 'edges/s', 'cores': threads, 'kind': 'port',
-            'sample': '%d full %d-layer passes of the same graph (%.1f s) with the OpenMP C restatement on %d threads; '
-                      'eval side: %d users x all items -> %.0f users/s' % (reps, K, dt, threads, n_sample, ev),
-            'eval_users_per_s': ev}
+    out = {'value': v, 'unit': 'edges/s', 'cores': threads, 'kind': 'port',
+           'sample': '%d full %d-layer passes of the same graph (%.1f s) with the OpenMP C restatement on %d threads; '
+                     'eval side: %d users x all items -> %.0f users/s' % (reps, K, dt, threads, n_sample, ev),
+           'eval_users_per_s': ev}
+    # what a user of the reference would run on this host without DGL: torch CSR / COO sparse
+    # matmul on all threads, scipy CSR on one; a few seconds each
+    try:
+        import warnings
+        import numpy as np
+        import scipy.sparse as sp
+        warnings.filterwarnings('ignore', message='Sparse CSR tensor support is in beta state')
+        xt = torch.from_numpy(x)
+        crow, ccol, cval = torch.from_numpy(rowptr), torch.from_numpy(col.astype(np.int64)), torch.from_numpy(val)
+        n = rowptr.shape[0] - 1
+        a_csr = torch.sparse_csr_tensor(crow, ccol, cval, size=(n, n))
+        a_coo = a_csr.to_sparse_coo().coalesce()
+        a_sp = sp.csr_matrix((val, col, rowptr), shape=(n, n))
+
+        def rate(fn, budget):
+            fn()
+            t0, reps = time.perf_counter(), 0
+            while time.perf_counter() - t0 < budget:
+                fn()
+                reps += 1
+            return reps * nnz / (time.perf_counter() - t0)
+        out['other_host_paths_edges_per_s'] = {
+            'torch_sparse_csr_matmul_%d_threads' % torch.get_num_threads(): rate(lambda: a_csr @ xt, 3.0),
+            'torch_sparse_coo_mm_%d_threads' % torch.get_num_threads(): rate(lambda: torch.sparse.mm(a_coo, xt), 3.0),
+            'scipy_csr_1_thread': rate(lambda: a_sp @ x, 3.0)}
+    except Exception as e:                                           # reported, never fatal for the bench line
+        out['other_host_paths_edges_per_s'] = {'error': repr(e)}
+    return out
 
 
 if __name__ == '__main__':
