@@ -87,18 +87,18 @@ static inline int topk_make_plan(int64_t batch, int64_t n_items, int32_t d, int3
     // and the count is kept a multiple of 4 so that every SIMD of a CU carries the same number of
     // waves.  The grid must never exceed what is resident: a wave that starts late runs its whole
     // share after everybody else has finished.
-    const int by_regs = p->d_pad <= 64 ? 3 : 2;
+    const int by_regs = 2;
     int per_simd = env_int("IGCN_TOPK_WAVES", 1, by_regs, by_regs);                    // developer knob
     int cap = 0;
     for (; per_simd >= 1; --per_simd) {
         const int granules = 128 / (4 * per_simd);
-        cap = granules * 1280 / (kWave * 8) - k;                 // staging slots left beside the k list slots
+        cap = granules * 1280 / (kWave * 8) - k - 1;             // staging slots left beside the k list slots and a spare one
         if (cap >= 4) break;
     }
     if (per_simd < 1) return IGCN_E_RANGE;
     if (cap > 16) cap = 16;
     p->cap = env_int("IGCN_TOPK_CAP", 1, cap, cap);                                    // developer knob
-    p->lds_bytes = (size_t)(k + p->cap) * kWave * 8;
+    p->lds_bytes = (size_t)(k + p->cap + 1) * kWave * 8;
     const int64_t per_cu = 4 * per_simd;
     int64_t slots = per_cu * cu_count();
     slots = env_int("IGCN_TOPK_SLOTS", 1, (int)slots, (int)slots);                    // developer knob (tests: whole sweeps + cut rest at small sizes)
@@ -202,7 +202,7 @@ __device__ __forceinline__ int trace_dep(const f32x16 &acc) {
 
 // FULL: d == D, no k-slice of a row is padding
 template <int D, bool FULL>
-__global__ __launch_bounds__(kWave, (D <= 64 ? 3 : 2)) void score_topk_kernel(
+__global__ __launch_bounds__(kWave, 2) void score_topk_kernel(
     const float *__restrict__ user_rows, int64_t ldu, const int64_t *__restrict__ user_ids, int64_t batch,
     const float *__restrict__ item_rows, int64_t ldi, int64_t n_items, int d,
     const int64_t *__restrict__ excl_rowptr, const int32_t *__restrict__ excl_col, const uint8_t *__restrict__ banned,
@@ -222,6 +222,7 @@ __global__ __launch_bounds__(kWave, (D <= 64 ? 3 : 2)) void score_topk_kernel(
 #endif
     const int lane = threadIdx.x;
     const int j = lane & 31, h = lane >> 5;
+    const float kNaN = __uint_as_float(0x7fc00000u);
     const int64_t units = gridDim.x;
     const int64_t n_full = n_whole * units;
     int64_t rx = (int64_t)blockIdx.x * run;                     // cursor in the rest groups' tile space
@@ -312,42 +313,27 @@ __global__ __launch_bounds__(kWave, (D <= 64 ? 3 : 2)) void score_topk_kernel(
             if (last_base + j >= n_items) lane_off_last = (int)(n_items - 1 - last_base) * (int)ldi + 4 * h;
         }
         float4 a[D / 8];
+        auto tile_addr = [&](int t, const float *&tile_ptr, int &off) {
+            tile_ptr = item_rows + (int64_t)t * 32 * ldi;
+            off = t == n_tiles - 1 ? lane_off_last : lane_off;
+        };
         auto load_a = [&](int t) {
-            const float *tile_ptr = item_rows + (int64_t)t * 32 * ldi;
-            const int off = t == n_tiles - 1 ? lane_off_last : lane_off;
+            const float *tile_ptr; int off;
+            tile_addr(t, tile_ptr, off);
 #pragma unroll
             for (int q = 0; q < D / 8; ++q)
                 a[q] = (FULL || 8 * q + 4 * h < d) ? *reinterpret_cast<const float4 *>(tile_ptr + off + 8 * q) : f4_zero();
         };
-        load_a(tin0);
 
-        for (int tile = tin0; tile < tin1; ++tile) {
-            const int tile_base = tile * 32;
-#ifdef IGCN_TOPK_TRACE
-            const unsigned long long tr0 = trace_clock(tile_base);
-            unsigned long long tr1;
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr1), "+v"(a[0].x) : : "memory");
-#endif
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-            for (int q = 0; q < D / 8; ++q) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bfrag[4 * q + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bfrag[4 * q + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bfrag[4 * q + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bfrag[4 * q + 3], acc, 0, 0, 0);
-            }
-#ifdef IGCN_TOPK_TRACE
-            const unsigned long long tr2 = trace_clock(trace_dep(acc));
-#endif
-            // --- masking ---------------------------------------------------------------------
+        // ---- the parts of a tile's bookkeeping ------------------------------------------------------
+        // masks of tile t on its scores (rare events, branches): ragged end, exclusion cursor, banned items
+        auto mask_tile = [&](f32x16 &acc, int tile_base) {
             // rows past the end of the piece: NaN = "already examined", never a candidate
             if (tile_base + 32 > item_hi) {                        // ragged last tile (wave-uniform)
                 asm volatile("; ragged tile");                     // (a real branch: the common path skips all of this)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (tile_base + row_of(r, h) >= item_hi) acc[r] = __uint_as_float(0x7fc00000u);
+                    if (tile_base + row_of(r, h) >= item_hi) acc[r] = kNaN;
             }
             if (excl_rowptr) {
                 const int tile_end = tile_base + 32;
@@ -367,8 +353,6 @@ __global__ __launch_bounds__(kWave, (D <= 64 ? 3 : 2)) void score_topk_kernel(
                     }
                 }
             }
-            // next tile's A operand: on its way during the rest of this tile's bookkeeping
-            if (tile + 1 < tin1) load_a(tile + 1);
             if (banned) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -379,43 +363,120 @@ __global__ __launch_bounds__(kWave, (D <= 64 ? 3 : 2)) void score_topk_kernel(
                     }
                 }
             }
-#ifdef IGCN_TOPK_TRACE
-            const unsigned long long tr3 = trace_clock(trace_dep(acc));
-#endif
-            // --- top-k -----------------------------------------------------------------------
-            // One compare of the tile maximum against the (slightly stale) k-th best decides whether
-            // anything can enter.  Candidates are only STAGED here; the heap work is batched in flush().
-            {
-                float m = acc[0];
+        };
+        // candidates of a tile -> staging slots, straight-line (predicated LDS writes, no branches), so
+        // that it can be scheduled between the MFMAs of the NEXT tile's chain: while the matrix pipe of
+        // a SIMD works on a wave's MFMA, the only instructions that issue are that same wave's own
+        // independent ones (scripts/probes/mfma_valu_overlap_probe.hip).  Returns whether a lane had a
+        // candidate but no free slot (those scores stay unmarked for stage_rows_slow).
+        // One row of the fast staging: write (score, item id) to the lane's next free staging slot; a
+        // candidate then advances the slot counter.  No branch, no select on the address: slots past
+        // `cap` all map to one spare slot.  A lane that ran past it lost candidates; the caller then
+        // discards this tile's staged entries and redoes the tile the slow way.
+        unsigned int *const stage32 = reinterpret_cast<unsigned int *>(stage);
+        auto stage_row_fast = [&](float sc, int item, int &slot) {
+            const int w = (slot < cap ? slot : cap) * (2 * kWave);
+            stage32[w] = __float_as_uint(sc);
+            stage32[w + 1] = (unsigned int)item;
+            slot += sc >= thr ? 1 : 0;
+        };
+        // the same with flushes in between, for a tile that overflowed some lane's staging slots
+        auto stage_rows_slow = [&](f32x16 &acc, int tile_base) {
+            bool full;
+            do {
 #pragma unroll
-                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-                if (__any(m >= thr)) {
-                    bool full;
-                    do {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float sc = acc[r];
-                            const bool take = sc >= thr;
-                            if (__any(take)) {                   // a row without candidates costs a compare and a branch
-                                asm volatile("; row with candidates");       // (keeps this a real, wave-uniform branch)
-                                if (take && cnt < cap) {
-                                    int hh = 4 * h;
-                                    asm volatile("" : "+v"(hh));     // keep the item id arithmetic inside the rare path
-                                    stage[cnt * kWave] = ((unsigned long long)(unsigned int)(tile_base + row_of(r, 0) + hh) << 32) | __float_as_uint(sc);
-                                    ++cnt;
-                                    acc[r] = __uint_as_float(0x7fc00000u);     // examined
-                                }
-                            }
+                for (int r = 0; r < 16; ++r) {
+                    const float sc = acc[r];
+                    const bool take = sc >= thr;
+                    if (__any(take)) {                           // a row without candidates costs a compare and a branch
+                        asm volatile("; row with candidates");
+                        if (take && cnt < cap) {
+                            stage[cnt * kWave] = ((unsigned long long)(unsigned int)(tile_base + row_of(r, h)) << 32) | __float_as_uint(sc);
+                            ++cnt;
+                            acc[r] = kNaN;
                         }
-                        full = __any(cnt >= cap);                // a full lane may have left candidates behind
-                        if (full) flush();
-                    } while (full);
+                    }
                 }
+                full = __any(cnt >= cap);                        // a full lane may have left candidates behind
+                if (full) flush();
+            } while (full);
+        };
+        // One step of the software pipeline: `cur` holds the raw scores of tile t, a[] the A operand of
+        // tile t+1.  The chain of tile t+1 (into `nxt`), the loads of tile t+2 (each a[q] as soon as the
+        // chain has consumed it) and the staging of tile t's candidates are ONE basic block.
+        auto tile_step = [&](f32x16 &cur, f32x16 &nxt, int tile) {
+            const int tile_base = tile * 32;
+            mask_tile(cur, tile_base);
+            const int item_h = tile_base + 4 * h;
+            int slot = cnt;
+            if (tile + 1 < tin1) {
+                const float *tile_ptr; int off;
+                tile_addr(tile + 2 < tin1 ? tile + 2 : tin1 - 1, tile_ptr, off);   // (re-reads the last tile at the end)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) nxt[r] = 0.f;
+                // The schedule is written out by hand and pinned (sched_barrier after every MFMA): each MFMA of
+                // the next tile's chain is followed by its share of this tile's 16 staging rows, and every
+                // a[q] is re-loaded for the tile after next as soon as its four MFMAs have issued.
+                constexpr int RPG = 128 / D;                     // staging rows per group of four MFMAs (D = 64: 2)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < D / 8; ++q) {
+                    const float4 aq = a[q];
+                    nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(aq.x, bfrag[4 * q + 0], nxt, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < (RPG + 3) / 4; ++i)
+                        if (RPG * q + i < 16 && i < RPG) stage_row_fast(cur[RPG * q + i], item_h + row_of(RPG * q + i, 0), slot);
+                    __builtin_amdgcn_sched_barrier(0);
+                    nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(aq.y, bfrag[4 * q + 1], nxt, 0, 0, 0);
+#pragma unroll
+                    for (int i = (RPG + 3) / 4; i < (RPG + 1) / 2; ++i)
+                        if (i < RPG) stage_row_fast(cur[RPG * q + i], item_h + row_of(RPG * q + i, 0), slot);
+                    __builtin_amdgcn_sched_barrier(0);
+                    nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(aq.z, bfrag[4 * q + 2], nxt, 0, 0, 0);
+#pragma unroll
+                    for (int i = (RPG + 1) / 2; i < (3 * RPG + 3) / 4; ++i)
+                        if (i < RPG) stage_row_fast(cur[RPG * q + i], item_h + row_of(RPG * q + i, 0), slot);
+                    __builtin_amdgcn_sched_barrier(0);
+                    nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(aq.w, bfrag[4 * q + 3], nxt, 0, 0, 0);
+#pragma unroll
+                    for (int i = (3 * RPG + 3) / 4; i < RPG; ++i)
+                        stage_row_fast(cur[RPG * q + i], item_h + row_of(RPG * q + i, 0), slot);
+                    a[q] = (FULL || 8 * q + 4 * h < d) ? *reinterpret_cast<const float4 *>(tile_ptr + off + 8 * q) : f4_zero();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stage_row_fast(cur[r], item_h + row_of(r, 0), slot);
+            }
+            if (__any(slot > cap)) {
+                asm volatile("; staging overflow");
+                flush();                                         // cnt still excludes this tile's entries
+                stage_rows_slow(cur, tile_base);
+            } else {
+                cnt = slot;
+                if (__any(cnt >= cap)) flush();
             }
 #ifdef IGCN_TOPK_TRACE
-            const unsigned long long tr4 = trace_clock(__builtin_amdgcn_readfirstlane(__float_as_int(thr) + cnt));
-            tr_load += tr1 - tr0; tr_chain += tr2 - tr1; tr_mask += tr3 - tr2; tr_sel += tr4 - tr3; ++tr_tiles;
+            ++tr_tiles;
 #endif
+        };
+
+        // prologue: scores of the first tile, A operand of the second
+        f32x16 acc_a, acc_b;
+        load_a(tin0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_a[r] = 0.f;
+#pragma unroll
+        for (int q = 0; q < D / 8; ++q) {
+            acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bfrag[4 * q + 0], acc_a, 0, 0, 0);
+            acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bfrag[4 * q + 1], acc_a, 0, 0, 0);
+            acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bfrag[4 * q + 2], acc_a, 0, 0, 0);
+            acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bfrag[4 * q + 3], acc_a, 0, 0, 0);
+        }
+        if (tin0 + 1 < tin1) load_a(tin0 + 1);
+        for (int tile = tin0; tile < tin1; tile += 2) {
+            tile_step(acc_a, acc_b, tile);
+            if (tile + 1 < tin1) tile_step(acc_b, acc_a, tile + 1);
         }
         flush();
 
