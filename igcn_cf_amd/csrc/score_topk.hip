@@ -9,39 +9,49 @@
 //
 // This is the one dense contraction of the path, so it runs on the matrix
 // cores, in exact fp32: v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain, no
-// reduced-precision shortcut).  The fp32 MFMA is slow enough (64 cycles each,
-// 2048 cycles per 32x32xd=64 tile) that operand traffic is negligible; what
-// decides the speed is keeping every SIMD's matrix pipe busy, and what keeps it
-// idle is everything a wave does between two MFMA chains (measured: while the
-// pipe of a SIMD is saturated the other waves' ordinary instructions issue at
-// 45 % of their normal rate; scripts/probes/mfma_valu_overlap_probe.hip).  Hence:
-//   * one WAVE = one workgroup = 32 users for a run of item tiles: no LDS staging,
-//     no barriers, nothing shared between waves.  The users' embeddings are the
-//     MFMA B operand and stay in d/2 VGPRs per lane; the item rows (A operand)
-//     are read straight from L2/Infinity Cache ONE TILE AHEAD, addressed as a
-//     scalar tile base + a constant lane offset; the two lanes of a row take
-//     adjacent 16-byte pieces so that a load instruction touches 32 lines;
+// reduced-precision shortcut): 64 cycles each, 2048 cycles per 32x32xd=64 tile.
+// Operand traffic is negligible; what decides the speed is what a SIMD issues
+// BESIDES the MFMAs.  Measured on this chip (scripts/probes/mfma_shadow_probe.hip,
+// mfma_valu_overlap_probe.hip): the fp32 MFMA leaves no shadow — every vector
+// instruction a wave puts between two dependent MFMAs costs its full ~5 cycles,
+// and while one wave runs a dependent MFMA chain a co-resident wave's vector
+// instructions do not issue at all.  So the bookkeeping per tile is written to be
+// as few instructions as possible, and waves only help to hide memory latency:
+//   * one WAVE = one workgroup = 32 users for a run of item tiles: no barriers,
+//     nothing shared between waves.  The users' embeddings are the MFMA B operand
+//     and stay in d/2 VGPRs per lane; the item rows (A operand) are read straight
+//     from L2/Infinity Cache, addressed as a scalar tile base + a constant lane
+//     offset; the two lanes of a row take adjacent 16-byte pieces so that a load
+//     instruction touches 32 lines;
+//   * the tile loop is software-pipelined by hand: while tile t's scores sit in one
+//     accumulator, ONE pinned basic block runs the MFMA chain of tile t+1 into the
+//     other, re-loads each a[q] for tile t+2 as soon as its four MFMAs have issued
+//     (two chains ahead of its use) and stages tile t's candidates, a row or two
+//     after every MFMA.  Left alone the compiler clusters the MFMAs and sinks the
+//     loads to the end of the chain, one tile too late (+25 % time);
 //   * the product is computed as S^T = I . U^T, so in the accumulator a lane
 //     holds 16 item scores of ONE user (column = lane&31): the running top-k of
 //     a user is private to a lane pair, no cross-lane traffic in the sweep;
-//   * masking is exact and in-register: each lane walks its user's sorted
-//     exclusion list with a cursor as the item sweep advances (the entry after
-//     the cursor is always already loaded); banned items are read as bytes;
-//   * top-k: one compare of the tile maximum against the lane's (slightly stale)
-//     k-th best decides whether anything can enter; a row with candidates costs a
-//     compare and a wave-uniform branch.  Entries are 64-bit sortable keys
-//     (order-preserving image of the fp32 score << 32 | ~item id), kept per lane
-//     as a k-slot binary min-heap in LDS ([slot][lane]: lane l always hits its own
-//     bank pair).  Candidates are only STAGED in a few more LDS slots per lane;
-//     the replace-root/sift-down work is done for all lanes together when some
-//     lane's staging area is full, i.e. with most lanes active instead of one;
+//   * top-k entries are 64-bit sortable keys (order-preserving image of the fp32
+//     score << 32 | ~item id), kept per lane as a k-slot binary min-heap in LDS
+//     ([slot][lane]: lane l always hits its own bank pair).  In the tile loop a row
+//     costs 4 vector instructions and one LDS write, no branch: compare with the
+//     lane's (slightly stale) k-th best, add-with-carry into the slot counter,
+//     clamp, address; (score, item) goes to the lane's next free STAGING slot
+//     whether it is a candidate or not.  The replace-root/sift-down work is done
+//     for all lanes together when some lane's staging area is full.  A lane that
+//     had more candidates than free slots in one tile is rare: the tile's staged
+//     entries are then discarded and the tile is redone with per-row branches;
+//   * masking: each lane walks its user's sorted exclusion list with a cursor as
+//     the item sweep advances; banned items are read as bytes; both only set
+//     scores to -inf before the tile is staged;
 //   * the grid never exceeds what is resident at once: a wave that starts late
-//     runs its whole share after everybody else has finished.  Registers allow 3
-//     waves per SIMD (2 for d > 64); LDS is handed out in 1280-B granules, and
-//     the staging depth is whatever they leave beside the heap.  Every wave gets
-//     the same number of tiles: with G 32-user groups and W resident waves each
-//     wave sweeps floor(G/W) whole groups, and the tiles of the remaining groups,
-//     laid end to end, are cut into W equal runs.  A group that is cut returns
+//     runs its whole share after everybody else has finished.  Registers allow 2
+//     waves per SIMD (two accumulators + operands: 207 VGPRs); LDS is handed out in
+//     1280-B granules, and the staging depth is whatever they leave beside the heap.
+//     Every wave gets the same number of tiles: with G 32-user groups and W resident
+//     waves each wave sweeps floor(G/W) whole groups, and the tiles of the remaining
+//     groups, laid end to end, are cut into W equal runs.  A group that is cut returns
 //     one best-first list per (piece, lane half), merged by a small second kernel.
 // Ties are broken towards the lower item id (torch.topk leaves them unspecified).
 #include <math.h>
