@@ -92,7 +92,7 @@ static inline int topk_make_plan(int64_t batch, int64_t n_items, int32_t d, int3
     p->groups = (batch + 31) / 32;
     const int64_t L = (n_items + 31) / 32;
     p->n_tiles = (int)L;
-    // Resident waves per CU.  Registers allow 3 per SIMD (2 for d > 64).  LDS is handed out in
+    // Resident waves per CU.  Registers allow 2 per SIMD (two accumulators + both operands).  LDS is handed out in
     // granules of 1280 B (1/128 of the CU's 160 KiB; measured: 12 x 13312 B do not fit, 12 x 12800 B do),
     // and the count is kept a multiple of 4 so that every SIMD of a CU carries the same number of
     // waves.  The grid must never exceed what is resident: a wave that starts late runs its whole
