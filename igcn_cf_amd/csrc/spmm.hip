@@ -59,8 +59,10 @@ __device__ __forceinline__ unsigned long long spmm_realtime() {
 }
 #endif
 
+// 80 scalar registers at most: a wave is charged its SGPRs + 16 (rounded up to 16) out of 800 per SIMD, so 80 is
+// the most that still lets 8 waves share a SIMD; without the cap the d = 32 variant took 100 and ran 6 (-15 %).
 template <int LPR, bool DROPOUT>
-__global__ __launch_bounds__(kBlock) void spmm_csr_rows_kernel(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void spmm_csr_rows_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy,
     int64_t n_rows, int d, SpmmEpilogue ep, SpmmDropout dr,
