@@ -2,7 +2,9 @@
 
 Builds a second copy of the library with -DIGCN_TOPK_TRACE (never shipped; the product
 library has no trace code) and prints the average cycles a wave spends per 32-item tile in
-load wait / MFMA chain / masking / selection."""
+load wait / MFMA chain / masking / selection — for kernel versions whose tile loop still has the four
+stamps (v3-v5; the shipped pipelined loop is one pinned block and only reports the per-wave timeline:
+begin / end / HW_ID of every wave, i.e. residency and balance)."""
 import ctypes as C
 import json
 import os

@@ -294,3 +294,32 @@ def test_device_csr_utilities_match_host_builders():
     # empty matrix
     e = CsrMatrix(np.zeros(11, dtype=np.int64), np.zeros(0, dtype=np.int32), None, (10, 7), 'cuda')
     assert e.transposed_view().shape == (7, 10) and int(e.transposed_view().rowptr.sum()) == 0
+
+
+def test_launch_shape_does_not_change_results(monkeypatch):
+    """The nnz hint and the developer grid knob only change how rows are dealt to waves: outputs are
+    bit-identical (each row is summed by one wave in storage order whatever the grid is)."""
+    import ctypes as C
+    from igcn_cf_amd import _lib
+    from igcn_cf_amd.graph import CsrMatrix
+    from igcn_cf_amd.ops import spmm
+    rng = np.random.default_rng(3)
+    n_rows, n_cols, d = 20000, 3000, 64
+    degs = np.minimum((rng.pareto(1.2, n_rows) * 5).astype(np.int64), n_cols)
+    rowptr, col, val = _random_csr(rng, n_rows, n_cols, degs)
+    csr = CsrMatrix(rowptr, col, val, (n_rows, n_cols), 'cuda')
+    x = torch.randn(n_cols, d, device='cuda')
+    ref = spmm(csr, x)
+    for bpc in ('1', '7', '64', '4096'):
+        monkeypatch.setenv('IGCN_SPMM_BLOCKS_PER_CU', bpc)
+        assert torch.equal(spmm(csr, x), ref)
+    monkeypatch.delenv('IGCN_SPMM_BLOCKS_PER_CU')
+    for nnz_hint in (0, 1, 10 ** 12):                                   # unknown / absurdly light / absurdly heavy rows
+        y = torch.empty_like(ref)
+        nul = (C.c_void_p * 1)()
+        rc = _lib.lib().igcn_spmm_csr_f32(csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.val.data_ptr(), x.data_ptr(), d,
+                                          y.data_ptr(), d, n_rows, n_cols, d, 1.0, nul, 0, 0.0, None, None,
+                                          _lib.ptr(csr.long_rows), csr.n_long, _lib.ptr(csr.segments), csr.n_segments,
+                                          _lib.ptr(csr.partial(d)), csr.long_threshold, None, 0, 1.0, None, 0, nnz_hint,
+                                          torch.cuda.current_stream().cuda_stream)
+        assert rc == 0 and torch.equal(y, ref)
