@@ -281,6 +281,22 @@ def side_measurements(ds, device, d, K):
     res['eval_users_per_s'] = ds.n_users / dt
     res['eval_ms'] = dt * 1e3
     res['eval_mfma_tflops'] = 2.0 * ds.n_users * ds.n_items * d / dt / 1e12
+    # roofline of the evaluation's dominant kernel (score_topk_kernel, timed alone on the same representation)
+    from igcn_cf_amd import ops
+    with torch.no_grad():
+        rep = model.get_rep()
+    users = torch.arange(ds.n_users, dtype=torch.int64, device=device)
+    ops.score_topk(rep, rep[ds.n_users:], 20, user_ids=users)
+    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    k0.record()
+    for _ in range(3):
+        ops.score_topk(rep, rep[ds.n_users:], 20, user_ids=users)
+    k1.record()
+    torch.cuda.synchronize()
+    tf = 3 * 2.0 * ds.n_users * ds.n_items * d / (k0.elapsed_time(k1) / 1e3) / 1e12
+    res['eval_roofline'] = {'bound': 'mfma', 'kernel': 'score_topk_kernel<64,true> (+ merge)', 'achieved': tf, 'peak': 157.3,
+                            'unit': 'TFLOP/s', 'frac': tf / 157.3,
+                            'note': 'fp32 v_mfma_f32_32x32x2_f32; 2*U*I*d flops per evaluation, no masks in this timing'}
     trainer.eval('test')                                   # first call builds the device CSR of the test lists
     model._rep_cache = None
     torch.cuda.synchronize()

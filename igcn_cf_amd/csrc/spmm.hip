@@ -183,6 +183,114 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
 #endif
 }
 
+// Narrow embeddings (d <= 32): R rows at a time per wave, one per sub-wave of S = 64/R lanes.
+// With one row per wave a 32-byte-wide row keeps only a few of the 64 lanes busy per dependent step
+// (row pointers -> col/val chunk -> gathers), and at these widths the kernel is bound by that latency
+// chain, not by bandwidth; R independent chains per wave give R times the requests in flight.  Same
+// arithmetic per row (each lane group sums its neighbours in storage order, groups folded in a fixed
+// order); every control decision is per sub-wave, so the loops run while ANY sub-wave has work.
+template <int LPR, int R, bool DROPOUT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void spmm_csr_multirow_kernel(
+    const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
+    const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy,
+    int64_t n_rows, int d, SpmmEpilogue ep, SpmmDropout dr,
+    const igcn_row_segment *__restrict__ segments, int64_t n_segments,
+    float *__restrict__ partial, int long_threshold,
+    const uint8_t *__restrict__ row_mask, int masked_rows_zero)
+{
+    constexpr int S = kWave / R;             // lanes of a sub-wave
+    constexpr int G = S / LPR;               // source rows per gather instruction and sub-wave
+    static_assert(G >= 1 && S * R == kWave && G * LPR == S, "bad sub-wave shape");
+    const int lane = threadIdx.x & (kWave - 1);
+    const int sub_base = lane / S * S;
+    const int sl = lane % S;
+    const int g = sl / LPR;
+    const int t = sl % LPR;
+    const bool lane_on = (4 * t) < d;
+    const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)));
+    const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
+    const int64_t n_virtual = n_rows + n_segments;
+
+    for (int64_t vb = wave0 * R; vb < n_virtual; vb += n_waves * R) {
+        const int64_t v = vb + lane / S;                          // this sub-wave's virtual row
+        // kind: 0 nothing, 1 ordinary row -> y, 2 row segment -> partial, 3 masked row that must read as zero
+        int64_t start = 0, dst = 0;
+        int len = 0, kind = 0;
+        if (v < n_rows) {
+            const int64_t s0 = rowptr[v], e0 = rowptr[v + 1];
+            const bool is_long = n_segments > 0 && e0 - s0 > long_threshold;
+            const bool masked = row_mask && !row_mask[v];
+            start = s0; len = (int)(e0 - s0); dst = v;
+            kind = is_long ? 0 : masked ? (masked_rows_zero ? 3 : 0) : 1;
+        } else if (v < n_virtual) {
+            const igcn_row_segment sg = segments[v - n_rows];
+            const bool masked = row_mask && !row_mask[sg.row];
+            start = sg.start; len = sg.len; dst = sg.slot;
+            kind = masked ? 0 : 2;
+        }
+        if (kind != 1 && kind != 2) len = 0;
+
+        float4 acc = f4_zero();
+        for (int off = 0; __any(off < len); off += S) {
+            const int rem = len - off;
+            const int cnt = rem < 0 ? 0 : rem < S ? rem : S;       // per sub-wave
+            int c = 0;
+            float w = 0.f;
+            if (sl < cnt) {
+                const int64_t p = start + off + sl;
+                c = col[p];
+                w = val ? val[p] : 1.f;
+                if (ep.col_scale) w *= ep.col_scale[c];
+                if (DROPOUT) {
+                    const uint64_t e = dr.edge_id ? (uint64_t)(uint32_t)dr.edge_id[p] : (uint64_t)p;
+                    w = hash_counter(e, dr.s0, dr.s1) < dr.keep_below ? w / dr.keep_prob : 0.f;
+                }
+            }
+            // 4 gather instructions in flight; a group past the end of its row takes no part
+            for (int k = 0; __any(k < cnt); k += 4 * G) {
+                const int s0 = k + g, s1 = k + G + g, s2 = k + 2 * G + g, s3 = k + 3 * G + g;
+                const int c0 = __shfl(c, sub_base + (s0 & (S - 1))), c1 = __shfl(c, sub_base + (s1 & (S - 1)));
+                const int c2 = __shfl(c, sub_base + (s2 & (S - 1))), c3 = __shfl(c, sub_base + (s3 & (S - 1)));
+                const float w0 = __shfl(w, sub_base + (s0 & (S - 1))), w1 = __shfl(w, sub_base + (s1 & (S - 1)));
+                const float w2 = __shfl(w, sub_base + (s2 & (S - 1))), w3 = __shfl(w, sub_base + (s3 & (S - 1)));
+                float4 x0 = f4_zero(), x1 = f4_zero(), x2 = f4_zero(), x3 = f4_zero();
+                if (lane_on && s0 < cnt) x0 = *reinterpret_cast<const float4 *>(x + (int64_t)c0 * ldx + 4 * t);
+                if (lane_on && s1 < cnt) x1 = *reinterpret_cast<const float4 *>(x + (int64_t)c1 * ldx + 4 * t);
+                if (lane_on && s2 < cnt) x2 = *reinterpret_cast<const float4 *>(x + (int64_t)c2 * ldx + 4 * t);
+                if (lane_on && s3 < cnt) x3 = *reinterpret_cast<const float4 *>(x + (int64_t)c3 * ldx + 4 * t);
+                if (s0 < cnt) f4_fma(acc, w0, x0);
+                if (s1 < cnt) f4_fma(acc, w1, x1);
+                if (s2 < cnt) f4_fma(acc, w2, x2);
+                if (s3 < cnt) f4_fma(acc, w3, x3);
+            }
+        }
+        // fold the G groups of the sub-wave (fixed order -> deterministic)
+#pragma unroll
+        for (int o = LPR; o < S; o <<= 1) f4_add(acc, f4_shfl_xor(acc, o));
+
+        if (g == 0 && lane_on) {
+            if (kind == 3) {
+                *reinterpret_cast<float4 *>(y + dst * ldy + 4 * t) = f4_zero();
+            } else if (kind == 2) {
+                *reinterpret_cast<float4 *>(partial + dst * (int64_t)d + 4 * t) = acc;
+            } else if (kind == 1) {
+                float4 r = make_float4(acc.x * ep.out_scale, acc.y * ep.out_scale, acc.z * ep.out_scale, acc.w * ep.out_scale);
+                if (ep.n_adds > 0) {
+                    float4 sum = f4_zero();
+                    for (int i = 0; i < ep.n_adds; ++i)
+                        f4_add(sum, *reinterpret_cast<const float4 *>(ep.add[i] + dst * ldy + 4 * t));
+                    f4_fma(r, ep.add_scale, sum);
+                }
+                if (ep.row_scale) {
+                    const float rs = ep.row_scale[dst];
+                    r.x *= rs; r.y *= rs; r.z *= rs; r.w *= rs;
+                }
+                *reinterpret_cast<float4 *>(y + dst * ldy + 4 * t) = r;
+            }
+        }
+    }
+}
+
 // Adds the partial sums of each long row and applies the epilogue.  One wave per
 // long row; the G lane groups each sum a strided subset of the slots (4 loads in
 // flight), then the groups are folded — a fixed order, so results are reproducible.
@@ -284,11 +392,12 @@ __global__ void csr_row_pow_kernel(const int64_t *__restrict__ rowptr, const flo
     }
 }
 
-// Developer tuning knob (environment, read per call): IGCN_SPMM_BLOCKS_PER_CU.
-struct SpmmTuning { int blocks_per_cu; };
+// Developer tuning knobs (environment, read per call): IGCN_SPMM_BLOCKS_PER_CU, IGCN_SPMM_MULTIROW.
+struct SpmmTuning { int blocks_per_cu; int multirow; };
 static SpmmTuning tuning() {
-    SpmmTuning v{0};                                          // 0 = resident_blocks_per_cu() of the kernel variant
+    SpmmTuning v{0, 1};                                       // 0 = resident_blocks_per_cu() of the kernel variant
     if (const char *e = getenv("IGCN_SPMM_BLOCKS_PER_CU")) { int x = atoi(e); if (x >= 1 && x <= 4096) v.blocks_per_cu = x; }
+    if (const char *e = getenv("IGCN_SPMM_MULTIROW")) v.multirow = atoi(e) != 0;
     return v;
 }
 
@@ -355,7 +464,20 @@ static int launch_rows(bool dropout, int64_t blocks, hipStream_t st,
     }
     if (blocks > want) blocks = want;
     const dim3 grid((unsigned)blocks);
-    if (dropout)
+    // rows a wave works on at once: 2 at d = 32, 4 below (8 was measured too: no different — at d <= 16 the
+    // kernel then moves ~8 TB/s of 128-byte lines, the gather granularity, and is bound by that)
+    constexpr int R = LPR == 8 ? 2 : LPR <= 4 ? 4 : 1;
+    const bool multirow = R > 1 && tune.multirow;
+    if (multirow) {
+        if constexpr (R > 1) {
+            if (dropout)
+                hipLaunchKernelGGL((spmm_csr_multirow_kernel<LPR, R, true>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y,
+                                   ldy, n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero);
+            else
+                hipLaunchKernelGGL((spmm_csr_multirow_kernel<LPR, R, false>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y,
+                                   ldy, n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero);
+        }
+    } else if (dropout)
         hipLaunchKernelGGL((spmm_csr_rows_kernel<LPR, true>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
                            n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero);
     else
