@@ -18,7 +18,7 @@ Also reported (outside `value`): full-evaluation users/s (propagate once + fused
 score/mask/top-20 over every user) and the full training step (sample + forward
 + BPR + backward + Adam).
 
-roofline: the dominant kernel is spmm_csr_rows_kernel<16,false>; `achieved` =
+roofline: the dominant kernel is spmm_csr_multirow_kernel<16,2,false>; `achieved` =
 algorithmic bytes per launch (nnz*(8+4d) + N*(4d+4)) / average
 launch duration measured with HIP events over the timed region.
 cpu_baseline (rank 0, N = 1): the C restatement of the path (oracle/oracle_c.c,
@@ -218,7 +218,8 @@ def main():
         torch.cuda.synchronize()
         copy_gbps = 5 * 2 * src.numel() * 4 / c0.elapsed_time(c1) / 1e6
         del src, dst
-    out['roofline'] = {'bound': 'hbm', 'kernel': 'spmm_csr_rows_kernel<%d,false>' % max(1, dcols // 4), 'achieved': ach,
+    out['roofline'] = {'bound': 'hbm', 'kernel': ('spmm_csr_multirow_kernel<%d,%d,false>' % (max(1, dcols // 4), 2 if dcols >= 32 else 4)) if dcols <= 64
+                       else 'spmm_csr_rows_kernel<%d,false>' % (dcols // 4), 'achieved': ach,
                        'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS, 'traffic': traffic,
                        'algorithmic_bytes_per_launch': b_alg, 'compulsory_bytes_per_launch': b_min,
                        'avg_launch_ms': ms_launch, 'hbm_copy_measured_GBps': copy_gbps,

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
 #endif
 }
 
-// Narrow embeddings (d <= 32): R rows at a time per wave, one per sub-wave of S = 64/R lanes.
+// Embeddings of up to 64 columns: R rows at a time per wave, one per sub-wave of S = 64/R lanes.
 // With one row per wave a 32-byte-wide row keeps only a few of the 64 lanes busy per dependent step
 // (row pointers -> col/val chunk -> gathers), and at these widths the kernel is bound by that latency
 // chain, not by bandwidth; R independent chains per wave give R times the requests in flight.  Same
@@ -464,9 +464,10 @@ static int launch_rows(bool dropout, int64_t blocks, hipStream_t st,
     }
     if (blocks > want) blocks = want;
     const dim3 grid((unsigned)blocks);
-    // rows a wave works on at once: 2 at d = 32, 4 below (8 was measured too: no different — at d <= 16 the
-    // kernel then moves ~8 TB/s of 128-byte lines, the gather granularity, and is bound by that)
-    constexpr int R = LPR == 8 ? 2 : LPR <= 4 ? 4 : 1;
+    // rows a wave works on at once: 2 at d = 64 and 32 (-7 % / -23 %), 4 below (-17...-22 %; 8 was measured too: no
+    // different — at d <= 16 the kernel then moves ~8 TB/s of 128-byte lines, the gather granularity, and is bound
+    // by that); at d >= 128 one row already fills the wave's loads (2: +1...6 %)
+    constexpr int R = LPR >= 32 ? 1 : LPR >= 8 ? 2 : 4;
     const bool multirow = R > 1 && tune.multirow;
     if (multirow) {
         if constexpr (R > 1) {

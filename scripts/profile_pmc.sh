@@ -18,7 +18,7 @@ for P in "$P1" "$P2" "$P3"; do
 done
 python3 - <<PY
 import csv, glob, collections
-for sub, kern in (('topk', 'score_topk_kernel'), ('spmm', 'spmm_csr_rows_kernel')):
+for sub, kern in (('topk', 'score_topk_kernel'), ('spmm', 'spmm_csr_')):
     agg = collections.defaultdict(lambda: [0.0, 0])
     for f in glob.glob('$OUT/%s_p*/**/*counter_collection.csv' % sub, recursive=True):
         for r in csv.DictReader(open(f)):
