@@ -61,6 +61,60 @@
 namespace igcn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ---- fp32 as the exact sum of three bf16 (MODE 1 of the kernel) -----------------------------------------
+// v = h0 + h1 + h2 + r with |r| <= 2^-24 |v|: round to nearest bf16, subtract (exact in fp32), repeat.
+__device__ __forceinline__ unsigned int bf16_rne_bits(float v) {
+    const unsigned int u = __float_as_uint(v);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split3(float v, unsigned int &h0, unsigned int &h1, unsigned int &h2) {
+    h0 = bf16_rne_bits(v);
+    const float r1 = v - __uint_as_float(h0 << 16);
+    h1 = bf16_rne_bits(r1);
+    const float r2 = r1 - __uint_as_float(h1 << 16);
+    h2 = bf16_rne_bits(r2);
+}
+// eight consecutive fp32 -> three bf16x8 planes (as float4 bit patterns: two bf16 per dword, low half first)
+__device__ __forceinline__ void split3_x8(const float4 &lo, const float4 &hi, float4 out[3]) {
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    unsigned int w[3][4];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        unsigned int a0, a1, a2, b0, b1, b2;
+        split3(v[e], a0, a1, a2);
+        split3(v[e + 1], b0, b1, b2);
+        w[0][e / 2] = a0 | (b0 << 16); w[1][e / 2] = a1 | (b1 << 16); w[2][e / 2] = a2 | (b2 << 16);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+        out[p] = make_float4(__uint_as_float(w[p][0]), __uint_as_float(w[p][1]), __uint_as_float(w[p][2]), __uint_as_float(w[p][3]));
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(const float4 &v) { return __builtin_bit_cast(bf16x8, v); }
+
+// Item table -> MFMA-ready bf16 planes: [tile][plane 0..2][k-step 0..3][lane 0..63] x 16 B, lane (j, kg)
+// holding k = 16 s + 8 kg .. + 7 of item 32 tile + j.  One thread per (tile, k-step, lane).
+__global__ __launch_bounds__(kBlock) void topk_pack_items_kernel(const float *__restrict__ item_rows, int64_t ldi, int64_t n_items,
+                                                                 int n_tiles, float4 *__restrict__ packed)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_tiles * 4 * kWave) return;
+    const int lane = (int)(i % kWave);
+    const int s = (int)(i / kWave % 4);
+    const int64_t tile = i / (4 * kWave);
+    const int64_t item = tile * 32 + (lane & 31);
+    float4 lo = f4_zero(), hi = f4_zero();
+    if (item < n_items) {
+        const float *src = item_rows + item * ldi + 16 * s + 8 * (lane >> 5);
+        lo = *reinterpret_cast<const float4 *>(src);
+        hi = *reinterpret_cast<const float4 *>(src + 4);
+    }
+    float4 planes[3];
+    split3_x8(lo, hi, planes);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) packed[((tile * 3 + p) * 4 + s) * kWave + lane] = planes[p];
+}
 
 constexpr int kIdxNone = 0x7fffffff;
 
@@ -210,15 +264,20 @@ __device__ __forceinline__ int trace_dep(const f32x16 &acc) {
 }
 #endif
 
-// FULL: d == D, no k-slice of a row is padding
-template <int D, bool FULL>
+// FULL: d == D, no k-slice of a row is padding.  MODE 0: fp32 MFMA, the exact fmaf chain.  MODE 1 (D = 64, FULL):
+// both operands as three bf16 planes (exact split), 6 of the 9 plane products on the bf16 matrix cores with fp32
+// accumulation — products good to 2^-23, i.e. fp32-grade scores, but not the bit pattern of the fmaf chain; the
+// item planes come pre-packed (topk_pack_items_kernel).
+template <int D, bool FULL, int MODE>
 __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(
     const float *__restrict__ user_rows, int64_t ldu, const int64_t *__restrict__ user_ids, int64_t batch,
     const float *__restrict__ item_rows, int64_t ldi, int64_t n_items, int d,
     const int64_t *__restrict__ excl_rowptr, const int32_t *__restrict__ excl_col, const uint8_t *__restrict__ banned,
     int k, int cap, int n_tiles, int64_t n_whole, int64_t rest_tiles, int64_t run, int p_max, int stagger,
-    int64_t *__restrict__ out_idx, float *__restrict__ out_val, float *__restrict__ ws_val, int32_t *__restrict__ ws_idx)
+    int64_t *__restrict__ out_idx, float *__restrict__ out_val, float *__restrict__ ws_val, int32_t *__restrict__ ws_idx,
+    const float4 *__restrict__ packed)
 {
+    static_assert(MODE == 0 || (D == 64 && FULL), "the split mode is built for d = 64");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *heap = reinterpret_cast<unsigned long long *>(smem) + threadIdx.x;     // [k][64]
     unsigned long long *stage = heap + k * kWave;                                              // [cap][64]
@@ -266,13 +325,29 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(
 
         // B operand: this lane's user.  Lane half h supplies k = 8q + 4h + c (q < D/8, c < 4): the two
         // lanes of a row read adjacent 16-B pieces, so one load instruction touches 32 lines, not 64.
-        float bfrag[D / 2];
+        float bfrag[MODE == 0 ? D / 2 : 1];
+        float4 ub[MODE == 1 ? 3 : 1][MODE == 1 ? 4 : 1];        // MODE 1: [plane][k-step], 8 bf16 each: k = 16 s + 8 h .. + 7
+        if constexpr (MODE == 0) {
 #pragma unroll
-        for (int q = 0; q < D / 8; ++q) {
-            float4 v = f4_zero();
-            const int e = 8 * q + 4 * h;
-            if (user_ok && (FULL || e < d)) v = *reinterpret_cast<const float4 *>(user_rows + uid * ldu + e);
-            bfrag[4 * q + 0] = v.x; bfrag[4 * q + 1] = v.y; bfrag[4 * q + 2] = v.z; bfrag[4 * q + 3] = v.w;
+            for (int q = 0; q < D / 8; ++q) {
+                float4 v = f4_zero();
+                const int e = 8 * q + 4 * h;
+                if (user_ok && (FULL || e < d)) v = *reinterpret_cast<const float4 *>(user_rows + uid * ldu + e);
+                bfrag[4 * q + 0] = v.x; bfrag[4 * q + 1] = v.y; bfrag[4 * q + 2] = v.z; bfrag[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                float4 lo = f4_zero(), hi = f4_zero();
+                if (user_ok) {
+                    const float *src = user_rows + uid * ldu + 16 * st + 8 * h;
+                    lo = *reinterpret_cast<const float4 *>(src);
+                    hi = *reinterpret_cast<const float4 *>(src + 4);
+                }
+                float4 planes[3];
+                split3_x8(lo, hi, planes);
+                ub[0][st] = planes[0]; ub[1][st] = planes[1]; ub[2][st] = planes[2];
+            }
         }
 
         // exclusion cursor: first excluded item >= item_lo; the entry after it is already on its way
@@ -323,17 +398,46 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(
             const int64_t last_base = (int64_t)(n_tiles - 1) * 32;
             if (last_base + j >= n_items) lane_off_last = (int)(n_items - 1 - last_base) * (int)ldi + 4 * h;
         }
-        float4 a[D / 8];
+        float4 a[MODE == 0 ? D / 8 : 12];                        // MODE 1: [plane * 4 + k-step], 8 bf16 each
         auto tile_addr = [&](int t, const float *&tile_ptr, int &off) {
             tile_ptr = item_rows + (int64_t)t * 32 * ldi;
             off = t == n_tiles - 1 ? lane_off_last : lane_off;
         };
         auto load_a = [&](int t) {
-            const float *tile_ptr; int off;
-            tile_addr(t, tile_ptr, off);
+            if constexpr (MODE == 0) {
+                const float *tile_ptr; int off;
+                tile_addr(t, tile_ptr, off);
 #pragma unroll
-            for (int q = 0; q < D / 8; ++q)
-                a[q] = (FULL || 8 * q + 4 * h < d) ? *reinterpret_cast<const float4 *>(tile_ptr + off + 8 * q) : f4_zero();
+                for (int q = 0; q < D / 8; ++q)
+                    a[q] = (FULL || 8 * q + 4 * h < d) ? *reinterpret_cast<const float4 *>(tile_ptr + off + 8 * q) : f4_zero();
+            } else {
+                const float4 *pk = packed + (int64_t)t * 12 * kWave + lane;
+#pragma unroll
+                for (int i = 0; i < 12; ++i) a[i] = pk[i * kWave];
+            }
+        };
+        // MODE 1: the six plane products, smallest first: (item plane, user plane)
+        constexpr int kTermA[6] = {2, 1, 0, 1, 0, 0};
+        constexpr int kTermB[6] = {0, 1, 2, 0, 1, 0};
+        // the whole chain of one tile, nothing interleaved (prologue of a piece)
+        auto chain_plain = [&](f32x16 &acc) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            if constexpr (MODE == 0) {
+#pragma unroll
+                for (int q = 0; q < D / 8; ++q) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bfrag[4 * q + 0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bfrag[4 * q + 1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bfrag[4 * q + 2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bfrag[4 * q + 3], acc, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int tm = 0; tm < 6; ++tm)
+#pragma unroll
+                    for (int st = 0; st < 4; ++st)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[kTermA[tm] * 4 + st]), as_bf16x8(ub[kTermB[tm]][st]), acc, 0, 0, 0);
+            }
         };
 
         // ---- the parts of a tile's bookkeeping ------------------------------------------------------
@@ -391,10 +495,14 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(
             // matrix-pipe time on this chip, scripts/probes/mfma_shadow_probe.hip): clamp, address, item id,
             // compare, add-with-carry.  The store is written as ds_write2_b32 by hand: the compiler would
             // build a register pair with a move for ds_write_b64.  flush() waits for these stores itself.
+#ifdef IGCN_X_NOSTAGE
+            if (sc == 12345.f) slot += item;
+#else
             const unsigned w = stage_base + (unsigned)(slot < cap ? slot : cap) * (unsigned)(kWave * 8);
             asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" : : "v"(w), "v"(sc), "v"(item) : "memory");
             slot += sc >= thr ? 1 : 0;
             asm volatile("" : "+v"(slot));                       // one add-with-carry per row, no re-association
+#endif
         };
         // the same with flushes in between, for a tile that overflowed some lane's staging slots
         auto stage_rows_slow = [&](f32x16 &acc, int tile_base) {
@@ -426,13 +534,34 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(
             const int item_h = tile_base + 4 * h;
             int slot = cnt;
             if (tile + 1 < tin1) {
-                const float *tile_ptr; int off;
-                tile_addr(tile + 2 < tin1 ? tile + 2 : tin1 - 1, tile_ptr, off);   // (re-reads the last tile at the end)
+                const float *tile_ptr = nullptr; int off = 0;
+                if constexpr (MODE == 0) tile_addr(tile + 2 < tin1 ? tile + 2 : tin1 - 1, tile_ptr, off);   // (re-reads the last tile at the end)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) nxt[r] = 0.f;
                 // The schedule is written out by hand and pinned (sched_barrier after every MFMA): each MFMA of
                 // the next tile's chain is followed by its share of this tile's 16 staging rows, and every
                 // a[q] is re-loaded for the tile after next as soon as its four MFMAs have issued.
+                if constexpr (MODE == 1) {
+                    // 24 bf16 MFMAs; a staging row after each of the first 16 (the bf16 MFMA, unlike the fp32 one,
+                    // has a shadow of ~5 vector instructions: scripts/probes/mfma_bf16_shadow_probe.hip); every
+                    // item plane register is re-loaded for the tile after next right after its last use
+                    const float4 *pk = packed + (int64_t)(tile + 2 < tin1 ? tile + 2 : tin1 - 1) * 12 * kWave + lane;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int tm = 0; tm < 6; ++tm) {
+#pragma unroll
+                        for (int st = 0; st < 4; ++st) {
+                            const int m = tm * 4 + st;
+                            const int ai = kTermA[tm] * 4 + st;
+                            nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[ai]), as_bf16x8(ub[kTermB[tm]][st]), nxt, 0, 0, 0);
+                            if (m < 16) stage_row_fast(cur[m], item_h + row_of(m, 0), slot);
+#ifndef IGCN_X_NOLOADA
+                            if (tm == 0 || tm == 3 || tm == 5) a[ai] = pk[ai * kWave];   // last use of planes 2, 1, 0
+#endif
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                } else {
                 constexpr int RPG = 128 / D;                     // staging rows per group of four MFMAs (D = 64: 2)
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -460,6 +589,7 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(
                     a[q] = (FULL || 8 * q + 4 * h < d) ? *reinterpret_cast<const float4 *>(tile_ptr + off + 8 * q) : f4_zero();
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) stage_row_fast(cur[r], item_h + row_of(r, 0), slot);
@@ -480,15 +610,7 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(
         // prologue: scores of the first tile, A operand of the second
         f32x16 acc_a, acc_b;
         load_a(tin0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc_a[r] = 0.f;
-#pragma unroll
-        for (int q = 0; q < D / 8; ++q) {
-            acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bfrag[4 * q + 0], acc_a, 0, 0, 0);
-            acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bfrag[4 * q + 1], acc_a, 0, 0, 0);
-            acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bfrag[4 * q + 2], acc_a, 0, 0, 0);
-            acc_a = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bfrag[4 * q + 3], acc_a, 0, 0, 0);
-        }
+        chain_plain(acc_a);
         if (tin0 + 1 < tin1) load_a(tin0 + 1);
         for (int tile = tin0; tile < tin1; tile += 2) {
             tile_step(acc_a, acc_b, tile);
@@ -598,14 +720,14 @@ __global__ void hit_matrix_kernel(const int64_t *__restrict__ rec, int64_t n_use
     hit[i] = (lo < eval_rowptr[u + 1] && eval_col[lo] == item) ? 1.f : 0.f;
 }
 
-template <int D, bool FULL>
+template <int D, bool FULL, int MODE = 0>
 static int launch_topk(const TopkPlan &p, hipStream_t st,
                        const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
                        const float *item_rows, int64_t ldi, int64_t n_items, int d,
                        const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned, int k,
-                       int64_t *out_idx, float *out_val, float *ws_val, int32_t *ws_idx)
+                       int64_t *out_idx, float *out_val, float *ws_val, int32_t *ws_idx, const float4 *packed = nullptr)
 {
-    auto kern = score_topk_kernel<D, FULL>;
+    auto kern = score_topk_kernel<D, FULL, MODE>;
     static bool configured = false;
     if (!configured && p.lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -617,7 +739,7 @@ static int launch_topk(const TopkPlan &p, hipStream_t st,
     const int stagger = env_int("IGCN_TOPK_STAGGER", 0, 1, 1);                          // developer knob
     hipLaunchKernelGGL(kern, dim3((unsigned)p.units), dim3(kWave), p.lds_bytes, st, user_rows, ldu, user_ids, batch,
                        item_rows, ldi, n_items, d, excl_rowptr, excl_col, banned, k, p.cap, p.n_tiles, p.n_whole,
-                       p.rest_tiles, p.run, p.p_max, stagger, out_idx, out_val, ws_val, ws_idx);
+                       p.rest_tiles, p.run, p.p_max, stagger, out_idx, out_val, ws_val, ws_idx, packed);
     return launch_status();
 }
 
@@ -660,7 +782,7 @@ extern "C" int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const in
 #define IGCN_TOPK_CASE(DD)                                                                                        \
     rc = (d == DD ? launch_topk<DD, true> : launch_topk<DD, false>)(                                             \
         p, st, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, (int)d, excl_rowptr, excl_col, banned,   \
-        (int)k, out_idx, out_val, ws_val, ws_idx)
+        (int)k, out_idx, out_val, ws_val, ws_idx, nullptr)
     switch (p.d_pad) {
     case 16: IGCN_TOPK_CASE(16); break;
     case 32: IGCN_TOPK_CASE(32); break;
@@ -668,6 +790,58 @@ extern "C" int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const in
     default: IGCN_TOPK_CASE(128); break;
     }
 #undef IGCN_TOPK_CASE
+    if (rc != IGCN_OK) return rc;
+    if (rest_users > 0) {
+        const int64_t blocks = (rest_users + 3) / 4;
+        hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, ws_val, ws_idx,
+                           p.n_whole * p.units * 32, batch, p.n_tiles, p.run, p.p_max, (int)k, out_idx, out_val);
+        rc = launch_status();
+    }
+    return rc;
+}
+
+// ---- the same evaluation with the products on the bf16 matrix cores (exact 3-way bf16 split of both operands,
+// 6 of the 9 plane products, fp32 accumulation): fp32-grade scores (products to 2^-23), ~2.5x the throughput, but
+// not the bit pattern of the fp32 fmaf chain.  d = 64 only.  Workspace = merge lists + the packed item planes.
+static inline int64_t topk_split_packed_bytes(int64_t n_items) { return (n_items + 31) / 32 * 12 * kWave * 16; }
+
+extern "C" int64_t igcn_score_topk_bf16x3_workspace_bytes(int64_t batch, int64_t n_items, int32_t d, int32_t k)
+{
+    if (d != 64) return -1;
+    TopkPlan p;
+    if (topk_make_plan(batch, n_items, d, k, &p) != IGCN_OK) return -1;
+    const int64_t merge = (topk_rest_users(p, batch) * 2 * p.p_max * k * 8 + 255) / 256 * 256;
+    return merge + topk_split_packed_bytes(n_items);
+}
+
+extern "C" int igcn_score_topk_bf16x3_f32(const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
+                                          const float *item_rows, int64_t ldi, int64_t n_items, int32_t d,
+                                          const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned,
+                                          int32_t k, int64_t *out_idx, float *out_val, void *workspace, void *stream)
+{
+    if (!user_rows || !item_rows || !out_idx || !out_val || !workspace) return IGCN_E_NULL;
+    if ((excl_rowptr == nullptr) != (excl_col == nullptr)) return IGCN_E_NULL;
+    if (d != 64) return IGCN_E_SHAPE;
+    TopkPlan p;
+    int rc = topk_make_plan(batch, n_items, d, k, &p);
+    if (rc != IGCN_OK) return rc;
+    if (ldu < d || ldi < d || ldu % 4 || ldi % 4 || n_items >= ((int64_t)1 << 31) - 64 || ldi > (1 << 20)) return IGCN_E_SHAPE;
+    if ((reinterpret_cast<uintptr_t>(user_rows) | reinterpret_cast<uintptr_t>(item_rows) | reinterpret_cast<uintptr_t>(workspace)) % 16)
+        return IGCN_E_ALIGN;
+    const int64_t rest_users = topk_rest_users(p, batch);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *ws_val = static_cast<float *>(workspace);
+    int32_t *ws_idx = reinterpret_cast<int32_t *>(ws_val + rest_users * 2 * p.p_max * k);
+    const int64_t merge_bytes = (rest_users * 2 * p.p_max * k * 8 + 255) / 256 * 256;
+    float4 *packed = reinterpret_cast<float4 *>(static_cast<char *>(workspace) + merge_bytes);
+
+    const int64_t threads = (int64_t)p.n_tiles * 4 * kWave;
+    hipLaunchKernelGGL(topk_pack_items_kernel, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                       item_rows, ldi, n_items, p.n_tiles, packed);
+    rc = launch_status();
+    if (rc != IGCN_OK) return rc;
+    rc = launch_topk<64, true, 1>(p, st, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, (int)d, excl_rowptr, excl_col,
+                                  banned, (int)k, out_idx, out_val, ws_val, ws_idx, packed);
     if (rc != IGCN_OK) return rc;
     if (rest_users > 0) {
         const int64_t blocks = (rest_users + 3) / 4;
@@ -688,7 +862,7 @@ extern "C" int igcn_debug_topk_wave_times(unsigned long long *host, int n_waves)
 extern "C" int igcn_debug_topk_occupancy(int lds_bytes)
 {
     int n = -1;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igcn::score_topk_kernel<64, true>, 64, (size_t)lds_bytes);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igcn::score_topk_kernel<64, true, 0>, 64, (size_t)lds_bytes);
     return e == hipSuccess ? n : -(int)e;
 }
 extern "C" int igcn_debug_topk_trace(unsigned long long *host8, int reset)

@@ -205,6 +205,19 @@ int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const int64_t *user
                         int32_t k, int64_t *out_idx, float *out_val,
                         void *workspace, void *stream);
 
+/* igcn_score_topk_f32 with the products on the bf16 matrix cores: both operands are split EXACTLY into three
+ * bf16 planes (v = h0 + h1 + h2 up to 2^-24 |v|), 6 of the 9 plane products are accumulated in fp32.  Scores are
+ * fp32-grade (each product good to 2^-23 — the order of the rounding of an fp32 dot product) but are not the
+ * bit pattern of the fp32 fmaf chain, so the ranking can differ from igcn_score_topk_f32 where two scores are
+ * within fp32 rounding of each other.  About 2.5x the throughput.  d must be 64 (IGCN_E_SHAPE otherwise);
+ * workspace (16-byte aligned, never NULL): igcn_score_topk_bf16x3_workspace_bytes — merge lists + the item table
+ * re-packed per call as bf16 planes.  Same masks, same tie rule, same outputs. */
+int64_t igcn_score_topk_bf16x3_workspace_bytes(int64_t batch, int64_t n_items, int32_t d, int32_t k);
+int igcn_score_topk_bf16x3_f32(const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
+                               const float *item_rows, int64_t ldi, int64_t n_items, int32_t d,
+                               const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned,
+                               int32_t k, int64_t *out_idx, float *out_val, void *workspace, void *stream);
+
 /* hit[u, j] = 1 if rec[u, j] is in eval_col[eval_rowptr[u]..eval_rowptr[u+1])
  * (sorted ascending), else 0: the membership loop of trainer.py:111-115. */
 int igcn_hit_matrix(const int64_t *rec, int64_t n_users, int32_t k,

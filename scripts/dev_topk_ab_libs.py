@@ -28,9 +28,9 @@ for rnd in range(3):
         _lib._handle, _lib._bound = handle, {}
         for masks in (False, True):
             kw = dict(excl_rowptr=rp, excl_col=cl) if masks else {}
-            ms = time_ms(lambda: score_topk(U, I, 20, user_ids=users, **kw), reps=3, warm=1)
+            ms = time_ms(lambda: score_topk(U, I, 20, user_ids=users, precision=os.environ.get('IGCN_AB_PRECISION', 'fp32'), **kw), reps=3, warm=1)
             res.setdefault('%s masks=%d' % (name, masks), []).append(round(ms, 2))
-            outs[(name, masks)] = score_topk(U, I, 20, user_ids=users, **kw)[0]
+            outs[(name, masks)] = score_topk(U, I, 20, user_ids=users, precision=os.environ.get('IGCN_AB_PRECISION', 'fp32'), **kw)[0]
 names = list(libs)
 same = all(torch.equal(outs[(names[0], m)], outs[(n, m)]) for n in names[1:] for m in (False, True))
 print(json.dumps(dict(ms=res, identical_ids=same)))
