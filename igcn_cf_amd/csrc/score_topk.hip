@@ -411,9 +411,14 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(
                 for (int q = 0; q < D / 8; ++q)
                     a[q] = (FULL || 8 * q + 4 * h < d) ? *reinterpret_cast<const float4 *>(tile_ptr + off + 8 * q) : f4_zero();
             } else {
+                // planes 2, 1, 0 — the order in which the pipelined block re-loads them: the compiler sizes the
+                // s_waitcnt before each MFMA for the worse of the two ways into the block, and with the planes in
+                // storage order here it waited for all but the last 3 loads at the top of every block (+25 % time)
                 const float4 *pk = packed + (int64_t)t * 12 * kWave + lane;
 #pragma unroll
-                for (int i = 0; i < 12; ++i) a[i] = pk[i * kWave];
+                for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) a[pl * 4 + st] = pk[(pl * 4 + st) * kWave];
             }
         };
         // MODE 1: the six plane products, smallest first: (item plane, user plane)
