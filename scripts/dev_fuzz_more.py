@@ -1,0 +1,75 @@
+"""Developer: the randomised top-k / SpMM parity sweeps of tests/test_fuzz_gpu.py with other seeds and more cases."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from oracle import oracle as O
+from igcn_cf_amd.graph import CsrMatrix
+from igcn_cf_amd.ops import score_topk, spmm
+
+n_bad = 0
+for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
+    rng = np.random.default_rng(1000 + seed)
+    for case in range(80):
+        n_users = int(rng.integers(1, 600))
+        n_items = int(rng.integers(1, 6000))
+        d = int(rng.choice([4, 8, 16, 20, 32, 64, 64, 64, 100, 128]))
+        k = int(rng.integers(1, min(n_items, 64) + 1))
+        if case % 3 == 1:
+            os.environ['IGCN_TOPK_SLOTS'] = str(int(rng.integers(1, 8)))
+        else:
+            os.environ.pop('IGCN_TOPK_SLOTS', None)
+        U = rng.integers(-4, 5, size=(n_users, d)).astype(np.float32)
+        I = rng.integers(-4, 5, size=(n_items, d)).astype(np.float32)
+        scores = U @ I.T
+        kw, ex, ban = {}, None, None
+        if case % 2 and n_items > k + 2:
+            ex = [sorted(rng.choice(n_items, size=int(rng.integers(0, min(40, n_items - k))), replace=False).tolist()) for _ in range(n_users)]
+            rowptr = np.zeros(n_users + 1, dtype=np.int64)
+            np.cumsum([len(e) for e in ex], out=rowptr[1:])
+            colx = np.array([i for e in ex for i in e], dtype=np.int32)
+            kw.update(excl_rowptr=torch.from_numpy(rowptr).cuda(), excl_col=torch.from_numpy(colx).cuda())
+        if case % 3 == 0 and n_items > k + 5:
+            ban = np.sort(rng.choice(n_items, size=max(1, (n_items - k) // 3), replace=False))
+            bm = np.zeros(n_items, dtype=np.uint8); bm[ban] = 1
+            kw['banned'] = torch.from_numpy(bm).cuda()
+        ids = rng.permutation(n_users).astype(np.int64)
+        s = scores[ids].copy()
+        if ex is not None:
+            for b, u in enumerate(ids):
+                if len(ex[u]):
+                    s[b, np.asarray(ex[u])] = -np.inf
+        if ban is not None:
+            s[:, ban] = -np.inf
+        ref = O.eval_topk(s, None, None, k=k)
+        for prec in (('fp32', 'bf16x3') if d == 64 else ('fp32',)):
+            idx, val = score_topk(torch.from_numpy(U).cuda(), torch.from_numpy(I).cuda(), k, user_ids=torch.from_numpy(ids).cuda(), precision=prec, **kw)
+            ok = np.array_equal(idx.cpu().numpy(), ref) and np.array_equal(val.cpu().numpy(), np.take_along_axis(s, ref, axis=1))
+            if not ok:
+                n_bad += 1
+                print('TOPK MISMATCH', seed, case, n_users, n_items, d, k, prec, flush=True)
+    os.environ.pop('IGCN_TOPK_SLOTS', None)
+    for case in range(60):
+        n_rows, n_cols = int(rng.integers(1, 3000)), int(rng.integers(1, 3000))
+        d = int(rng.choice([4, 8, 16, 32, 64, 128, 12, 48]))
+        deg = np.minimum((rng.pareto(1.0 + rng.random(), n_rows) * rng.integers(1, 12)).astype(np.int64), n_cols)
+        rowptr = np.zeros(n_rows + 1, dtype=np.int64)
+        np.cumsum(deg, out=rowptr[1:])
+        col = np.concatenate([np.sort(rng.choice(n_cols, size=int(x), replace=False)) for x in deg] + [np.zeros(0, dtype=np.int64)]).astype(np.int32)
+        val = rng.standard_normal(col.shape[0]).astype(np.float32)
+        x = rng.standard_normal((n_cols, d)).astype(np.float32)
+        lt = int(rng.choice([64, 128, 256, 1024]))
+        csr = CsrMatrix(rowptr, col, val, (n_rows, n_cols), 'cuda', long_threshold=lt, segment_len=int(rng.choice([s2 for s2 in (32, 64, 128, 256) if s2 <= lt])))
+        y = spmm(csr, torch.from_numpy(x).cuda()).cpu().numpy()
+        row = np.repeat(np.arange(n_rows, dtype=np.int64), deg)
+        want = O.spmm_coo_f64(row, col.astype(np.int64), val, x, n_rows)
+        err = np.abs(y - want).max() / (np.abs(want).max() + 1e-30)
+        if err > 1e-4:
+            n_bad += 1
+            print('SPMM MISMATCH', seed, case, n_rows, n_cols, d, err, flush=True)
+print('done, mismatches:', n_bad)
