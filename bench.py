@@ -20,7 +20,15 @@ score/mask/top-20 over every user) and the full training step (sample + forward
 
 roofline: the dominant kernel is spmm_csr_multirow_kernel<16,2,false>; `achieved` =
 algorithmic bytes per launch (nnz*(8+4d) + N*(4d+4)) / average
-launch duration measured with HIP events over the timed region.
+launch duration measured with HIP events over the timed region.  The 52.8 MB operand of this
+workload lives in the 256 MiB Infinity Cache, so the 8 TB/s HBM roof does not bind it; `peak` is
+therefore the roof that does, MEASURED IN THIS RUN: a row-structure-free gather + FMA + store
+kernel over the same index stream (igcn_cf_amd/csrc/roof_probe.hip), expressed in the same
+algorithmic bytes/s, and `frac` = achieved / peak <= 1.  The figure against the HBM spec is kept
+as `frac_of_hbm_spec` (not a bound).  The HBM-bound leg — one GPU's 1/8 row share of BASELINE
+config 5 (125 M nonzeros against a 12 M x 128 operand = 6.1 GB, kernel
+spmm_csr_rows_kernel<32,false>) — is timed in the same run: extras.roofline_hbm_bound, against
+the 8 TB/s HBM peak.
 cpu_baseline (rank 0, N = 1): the C restatement of the path (oracle/oracle_c.c,
 kind "port") on all host cores, on the same graph, bounded to ~10-30 s.
 """
@@ -48,6 +56,7 @@ def parse():
     ap.add_argument('--layers', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the eval / train-step side measurements')
+    ap.add_argument('--no-hbm-leg', action='store_true', help='skip the HBM-bound config-5 shard leg (extras.roofline_hbm_bound)')
     return ap.parse_args()
 
 
@@ -56,8 +65,9 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with python -m torch.distributed.run --nproc-per-node %d'
+                         % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs the MI355X (no CPU fallback for the product path)')
     torch.cuda.set_device(local_rank)
@@ -186,6 +196,7 @@ def main():
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'LightGCN %d-layer d=%d propagation on synthetic %s-like x%d (users=%d items=%d nnz(A_hat)=%d)'
                                % (K, d, args.preset, world, ds.n_users, ds.n_items, nnz),
+                   'preset': args.preset, 'nnz': nnz, 'd': d, 'n_layers': K,
                    'parallelism': 'single GPU' if not sharded else
                    'embedding-column sharding x%d: replicated CSR, d/%d = %d columns per rank, no exchange inside the pass '
                    '(row-sharded + RCCL all-gather variant in extras)' % (world, world, d // world)},
@@ -196,41 +207,42 @@ def main():
     b_alg = nnz * (8 + 4 * dcols) + n * (4 * dcols + 4)
     b_min = nnz * 8 + n * (8 * dcols + 4)
     ms_launch = dev_ms / (args.steps * launches_per_step)
-    traffic = None
-    tp = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    if not sharded and os.path.exists(tp):
-        try:
-            traffic = json.load(open(tp)).get('spmm_hbm_bytes_per_launch')
-        except Exception:
-            traffic = None
     ach = b_alg / ms_launch / 1e6
     x_mb = n * dcols * 4 / 1e6
-    copy_gbps = None
-    if not sharded:                                                  # what a plain copy reaches on THIS box (read + write)
-        src = torch.empty(1 << 28, dtype=torch.float32, device=device)
-        dst = torch.empty_like(src)
-        dst.copy_(src)
-        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        c0.record()
-        for _ in range(5):
-            dst.copy_(src)
-        c1.record()
-        torch.cuda.synchronize()
-        copy_gbps = 5 * 2 * src.numel() * 4 / c0.elapsed_time(c1) / 1e6
-        del src, dst
-    out['roofline'] = {'bound': 'hbm', 'kernel': ('spmm_csr_multirow_kernel<%d,%d,false>' % (max(1, dcols // 4), 2 if dcols >= 32 else 4)) if dcols <= 64
-                       else 'spmm_csr_rows_kernel<%d,false>' % (dcols // 4), 'achieved': ach,
-                       'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS, 'traffic': traffic,
-                       'algorithmic_bytes_per_launch': b_alg, 'compulsory_bytes_per_launch': b_min,
-                       'avg_launch_ms': ms_launch, 'hbm_copy_measured_GBps': copy_gbps,
-                       'note': ('rank 0 of %d; ' % world if sharded else '') +
-                               ('X (%.1f MB) fits the 256 MiB Infinity Cache: gathers are served on-die, so algorithmic '
-                                'bytes/s may exceed the HBM peak; ' % x_mb if x_mb < 256 else 'X = %.1f MB; ' % x_mb) +
-                               'traffic = PMC-measured HBM bytes per launch (profiles/pmc_traffic.json, N=1 only)'}
+    kernel_name = ('spmm_csr_multirow_kernel<%d,%d,false>' % (max(1, dcols // 4), 2 if dcols >= 32 else 4)) if dcols <= 64 \
+        else 'spmm_csr_rows_kernel<%d,false>' % (dcols // 4)
+    roof = {'bound': 'hbm', 'kernel': kernel_name, 'achieved': ach, 'unit': 'GB/s',
+            'algorithmic_bytes_per_launch': b_alg, 'compulsory_bytes_per_launch': b_min, 'avg_launch_ms': ms_launch,
+            'frac_of_hbm_spec': ach / HBM_PEAK_GBPS, 'hbm_spec_GBps': HBM_PEAK_GBPS,
+            'frac_of_compulsory': b_min / b_alg,
+            'avg_launch_note': 'HIP events over the timed region / launches: one igcn_spmm_csr_f32 call = the main kernel + the '
+                               'long-row reduce kernel (~5 us) + the launch gap'}
+    if not sharded:
+        copy_gbps = measured_copy_GBps(device)
+        g = gather_roof(device, csr.col, csr.val, x0, n, dcols)
+        # same units as `achieved`: the algorithmic rate this SpMM would have at the bare-gather speed
+        peak = b_alg / g['best_ms'] / 1e6
+        roof.update({'peak': peak, 'frac': ach / peak, 'hbm_copy_measured_GBps': copy_gbps,
+                     'peak_source': 'measured in this run: row-structure-free gather+FMA+store kernel over the SAME col/val '
+                                    'stream and operand (roof_probe.hip), best of %d grids' % len(g['same_stream_ms']),
+                     'gather_roof': g,
+                     'note': 'X (%.1f MB) fits the 256 MiB Infinity Cache: the HBM roof (8 TB/s) does not bind this workload '
+                             '(frac_of_hbm_spec may exceed 1); peak/frac use the measured cache-resident gather roof; the '
+                             'HBM-bound leg is extras.roofline_hbm_bound' % x_mb})
+        t = stored_traffic(kernel_name, args.preset, nnz, dcols)
+        roof['traffic'] = t['bytes'] if t else None
+        roof['traffic_source'] = t['source'] if t else 'no PMC pass on file for this kernel/workload'
+    else:
+        roof.update({'peak': HBM_PEAK_GBPS, 'frac': ach / HBM_PEAK_GBPS, 'traffic': None, 'note': 'rank 0 of %d' % world})
+    out['roofline'] = roof
 
     extras = {}
     if not sharded and not args.no_extras:
         extras = side_measurements(ds, device, d, K)
+    if not sharded and not args.no_hbm_leg:
+        del csr, x0
+        torch.cuda.empty_cache()
+        extras['roofline_hbm_bound'] = hbm_bound_leg(device)
     if row_sharded is not None:
         extras['row_sharded_allgather'] = row_sharded
     if sharded_eval is not None:
@@ -244,6 +256,126 @@ def main():
         print(json.dumps(out))
     if sharded:
         dist.destroy_process_group()
+
+
+def time_ms(fn, reps, warm):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def measured_copy_GBps(device):
+    """What a plain device copy reaches on THIS box (read + write bytes)."""
+    src = torch.empty(1 << 28, dtype=torch.float32, device=device)
+    dst = torch.empty_like(src)
+    ms = time_ms(lambda: dst.copy_(src), 5, 1)
+    return 2 * src.numel() * 4 / ms / 1e6
+
+
+_roof_lib = None
+
+
+def roof_lib():
+    global _roof_lib
+    if _roof_lib is None:
+        import ctypes as C
+        path = os.path.join(ROOT, 'igcn_cf_amd', 'libigcn_roof.so')
+        lib = C.CDLL(path)
+        lib.igcn_roof_gather_f32.restype = C.c_int
+        lib.igcn_roof_gather_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                             C.c_int64, C.c_int32, C.c_int64, C.c_void_p]
+        _roof_lib = lib
+    return _roof_lib
+
+
+def gather_roof(device, col, val, x, n_out, d, reps=20):
+    """In-run roof of a cache- or HBM-resident CSR SpMM (roof_probe.hip): milliseconds of the bare gather over the
+    same index stream, and over uniformly random indices of the same count, each the best of a few grid sizes."""
+    lib = roof_lib()
+    nnz = col.numel()
+    y = torch.empty((n_out, d), dtype=torch.float32, device=device)
+    stream = torch.cuda.current_stream().cuda_stream
+    n_chunks = (nnz + 63) // 64
+    res = {}
+    gen = torch.Generator(device=device).manual_seed(7)
+    rnd = torch.randint(0, x.shape[0], (nnz,), device=device, generator=gen, dtype=torch.int32)
+    for name, idx in (('same_stream_ms', col), ('uniform_random_ms', rnd)):
+        times = {}
+        for chunks_per_wave in (1, 2, 4, 8, 16):
+            blocks = max(1, (n_chunks + 4 * chunks_per_wave - 1) // (4 * chunks_per_wave))
+
+            def run():
+                rc = lib.igcn_roof_gather_f32(idx.data_ptr(), val.data_ptr(), nnz, x.data_ptr(), x.stride(0), y.data_ptr(),
+                                              y.stride(0), n_out, d, blocks, stream)
+                if rc != 0:
+                    raise RuntimeError('igcn_roof_gather_f32 failed: %d' % rc)
+            times[str(chunks_per_wave)] = time_ms(run, reps, 3)
+        res[name] = times
+    res['best_same_stream_ms'] = min(res['same_stream_ms'].values())
+    res['best_uniform_random_ms'] = min(res['uniform_random_ms'].values())
+    res['best_ms'] = min(res['best_same_stream_ms'], res['best_uniform_random_ms'])
+    res['gathered_row_GBps_same_stream'] = nnz * 4 * d / res['best_same_stream_ms'] / 1e6
+    res['gathered_row_GBps_uniform_random'] = nnz * 4 * d / res['best_uniform_random_ms'] / 1e6
+    return res
+
+
+def stored_traffic(kernel_name, preset, nnz, d):
+    """PMC-measured bytes beyond L2 per launch, from a committed rocprofv3 --pmc pass of this same command —
+    only if that pass was taken on this kernel and workload; never measured in this run."""
+    tp = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        t = json.load(open(tp))
+    except Exception:
+        return None
+    stored_kernel = t.get('kernel', '').replace('void ', '').replace(' ', '')
+    if stored_kernel != kernel_name.replace(' ', '') or t.get('preset') != preset or t.get('nnz') != nnz or t.get('d') != d:
+        return None
+    return {'bytes': t.get('spmm_hbm_bytes_per_launch'),
+            'source': 'profiles/pmc_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2 x FETCH + WRITE '
+                      '(gfx950 correction); L2-miss traffic incl. Infinity-Cache hits; NOT measured in this run' % t.get('tag', '?')}
+
+
+def hbm_bound_leg(device, reps=5):
+    """The HBM-bound leg: ONE GPU's share of BASELINE config 5 under row sharding — 1/8 of the rows of A_hat
+    (1.5 M rows, 125 M nonzeros) against the full replicated operand X (12 M x 128 fp32 = 6.1 GB, far beyond the
+    Infinity Cache), generated on the device.  One launch of igcn_spmm_csr_f32 (spmm_csr_rows_kernel<32,false>)."""
+    from igcn_cf_amd.graph import CsrMatrix
+    from igcn_cf_amd import ops
+    d, n_cols, n_rows, nnz_target = 128, 12_000_000, 1_500_000, 125_000_000
+    g = torch.Generator(device=device).manual_seed(1)
+    w = torch.exp(torch.randn(n_rows, device=device, generator=g))              # log-normal row lengths
+    deg = torch.clamp((w / w.sum() * nnz_target).round().long(), min=1)
+    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=device)
+    torch.cumsum(deg, 0, out=rowptr[1:])
+    nnz = int(rowptr[-1].item())
+    col = torch.randint(0, n_cols, (nnz,), device=device, generator=g, dtype=torch.int32)
+    val = torch.rand(nnz, device=device, generator=g) * 0.1
+    csr = CsrMatrix.from_device(rowptr, col, val, (n_rows, n_cols))
+    x = torch.randn(n_cols, d, device=device, generator=g) * 0.1
+    y = torch.empty(n_rows, d, device=device)
+    ms = min(time_ms(lambda: ops.spmm(csr, x, out=y), reps, 2) for _ in range(2))
+    b_alg = nnz * (8 + 4 * d) + n_rows * (4 * d + 4)
+    # f64 check of a row sample (the leg is timed on the product kernel: it must also be right)
+    rows = torch.randint(0, n_rows, (64,), device=device, generator=g)
+    err = 0.0
+    for r in rows.tolist():
+        s, e = int(rowptr[r]), int(rowptr[r + 1])
+        ref = (x[col[s:e].long()].double() * val[s:e].double()[:, None]).sum(0)
+        err = max(err, float((y[r].double() - ref).abs().max() / (ref.abs().max() + 1e-30)))
+    gr = gather_roof(device, col, val, x, n_rows, d, reps=3)
+    ach = b_alg / ms / 1e6
+    return {'bound': 'hbm', 'kernel': 'spmm_csr_rows_kernel<32,false>', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+            'frac': ach / HBM_PEAK_GBPS, 'avg_launch_ms': ms, 'algorithmic_bytes_per_launch': b_alg,
+            'workload': 'BASELINE config 5 (10M x 2M x 500M edges, d=128), one rank of 8 under row sharding: '
+                        '%d rows, %d nonzeros, operand %d x %d fp32 = %.1f GB' % (n_rows, nnz, n_cols, d, n_cols * d * 4 / 1e9),
+            'gedges_per_s': nnz / ms / 1e6, 'sample_rel_err_vs_f64': err,
+            'frac_of_measured_gather_roof': gr['best_ms'] / ms, 'gather_roof_ms': gr['best_ms']}
 
 
 def side_measurements(ds, device, d, K):

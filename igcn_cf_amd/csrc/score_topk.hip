@@ -717,12 +717,14 @@ __global__ void hit_matrix_kernel(const int64_t *__restrict__ rec, int64_t n_use
     if (i >= n_users * k) return;
     const int64_t u = i / k;
     const int64_t item = rec[i];
-    int64_t lo = eval_rowptr[u], hi = eval_rowptr[u + 1];
+    const int64_t end = eval_rowptr[u + 1];
+    int64_t lo = eval_rowptr[u], hi = end;
+    if (!eval_col) lo = hi = end;                                // no column array: every list is empty
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
         if (eval_col[mid] < item) lo = mid + 1; else hi = mid;
     }
-    hit[i] = (lo < eval_rowptr[u + 1] && eval_col[lo] == item) ? 1.f : 0.f;
+    hit[i] = (lo < end && eval_col[lo] == item) ? 1.f : 0.f;
 }
 
 template <int D, bool FULL, int MODE = 0>
@@ -889,7 +891,6 @@ extern "C" int igcn_hit_matrix(const int64_t *rec, int64_t n_users, int32_t k,
     if (n_users < 0 || k < 1) return IGCN_E_SHAPE;
     const int64_t n = n_users * k;
     if (n == 0) return IGCN_OK;
-    if (!eval_col) return IGCN_E_NULL;
     hipLaunchKernelGGL(hit_matrix_kernel, dim3((unsigned)((n + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                        static_cast<hipStream_t>(stream), rec, n_users, (int)k, eval_rowptr, eval_col, hit);
     return launch_status();

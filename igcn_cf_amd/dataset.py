@@ -38,7 +38,14 @@ def csr_to_lists(rowptr, col):
 
 
 class BasicDataset:
-    """Attribute contract of the reference's BasicDataset (dataset.py:47-64)."""
+    """Attribute contract of the reference's BasicDataset (dataset.py:47-64).
+
+    train_data / val_data / test_data are properties: assigning a new list-of-lists bumps the split's
+    version (what the trainers key their device copies on) and drops its cached CSR views.  Code that
+    edits a list IN PLACE (dataset.test_data[user] = [], as trainer.py:183-184 does) must call
+    invalidate(which) afterwards."""
+
+    SPLITS = ('train', 'val', 'test')
 
     def __init__(self, dataset_config):
         self.config = dataset_config
@@ -47,13 +54,32 @@ class BasicDataset:
         self.negative_sample_ratio = dataset_config.get('neg_ratio', 1)
         self.n_users = 0
         self.n_items = 0
-        self.train_data = None
-        self.val_data = None
-        self.test_data = None
         self.train_array = None
+        self._lists = {}
         self._csr = {}
+        self._version = dict.fromkeys(self.SPLITS, 0)
 
     # ---- list views <-> CSR views ------------------------------------------------
+    def _get_list(self, name):
+        return self._lists.get(name)
+
+    def _set_list(self, name, value):
+        self._lists[name] = value
+        self._drop_csr(name)
+        self._version[name] += 1
+
+    def _drop_csr(self, which):
+        for k in [k for k in self._csr if which is None or k[0] == which]:
+            del self._csr[k]
+
+    train_data = property(lambda self: self._get_list('train'), lambda self, v: self._set_list('train', v))
+    val_data = property(lambda self: self._get_list('val'), lambda self, v: self._set_list('val', v))
+    test_data = property(lambda self: self._get_list('test'), lambda self, v: self._set_list('test', v))
+
+    def version(self, which):
+        """Counter of the changes made to a split's lists (assignment or invalidate())."""
+        return self._version[which]
+
     def csr(self, which, sort=True):
         """(rowptr int64, col int64) of train/val/test lists; `sort` orders each
         user's items ascending (what the device membership tests expect)."""
@@ -63,9 +89,11 @@ class BasicDataset:
         return self._csr[key]
 
     def invalidate(self, which=None):
-        """Call after mutating train/val/test lists in place (inductive_eval does); `which`
-        limits the rebuild to one of 'train' / 'val' / 'test'."""
-        self._csr = {k: v for k, v in self._csr.items() if which is not None and k[0] != which}
+        """Call after mutating train/val/test lists in place; `which` limits it to one split."""
+        self._drop_csr(which)
+        for name in self.SPLITS:
+            if which is None or name == which:
+                self._version[name] += 1
 
     def _finish(self):
         rowptr, col = lists_to_csr(self.train_data)
@@ -76,18 +104,25 @@ class BasicDataset:
         return len(self.train_array)
 
     def __getitem__(self, index):
-        """One BPR draw, same procedure as dataset.py:119-131 (index ignored)."""
-        user = random.randint(0, self.n_users - 1)
-        while not self.train_data[user]:
+        """negative_sample_ratio BPR draws for one random user, int64 [ratio, 3]; `index` is ignored — the
+        sampling protocol of dataset.py:119-131 (uniform user among those with train items, one uniform
+        positive shared by the draws, negatives rejected while they are train items of the user).  Kept for
+        DataLoader-style callers; the trainers draw on the device (igcn_bpr_sample)."""
+        lists = self.train_data
+        while True:
             user = random.randint(0, self.n_users - 1)
-        pos_item = np.random.choice(self.train_data[user])
-        out = [[user, pos_item] for _ in range(self.negative_sample_ratio)]
-        for idx in range(self.negative_sample_ratio):
-            neg_item = random.randint(0, self.n_items - 1)
-            while neg_item in self.train_data[user]:
-                neg_item = random.randint(0, self.n_items - 1)
-            out[idx].append(neg_item)
-        return np.array(out, dtype=np.int64)
+            if lists[user]:
+                break
+        seen = lists[user]
+        draws = np.empty((self.negative_sample_ratio, 3), dtype=np.int64)
+        draws[:, 0] = user
+        draws[:, 1] = np.random.choice(seen)
+        for row in draws:
+            candidate = random.randint(0, self.n_items - 1)
+            while candidate in seen:
+                candidate = random.randint(0, self.n_items - 1)
+            row[2] = candidate
+        return draws
 
     def sample_batch_host(self, batch_size, rng):
         """Vectorised host sampler with the distribution of __getitem__:
@@ -150,14 +185,13 @@ class ProcessedDataset(BasicDataset):
                 pass                                                     # read-only data directory: no cache
 
     def read_data(self, file_path):
-        data = []
+        """One list of item ids per line ('user item item ...', dataset.py:154-164); the user id in the
+        first column is positional and not read; n_items grows to the largest id seen + 1."""
         with open(file_path, 'r') as f:
-            lines = f.read().strip().split('\n')
-        for line in lines:
-            items = [int(item) for item in line.split(' ')[1:]]
-            if items:
-                self.n_items = max(self.n_items, max(items) + 1)
-            data.append(items)
+            rows = [line.split(' ')[1:] for line in f.read().strip().split('\n')]
+        data = [list(map(int, fields)) for fields in rows]
+        largest = max((max(items) for items in data if items), default=-1)
+        self.n_items = max(self.n_items, largest + 1)
         return data
 
 
@@ -192,8 +226,6 @@ class CsrBackedDataset(BasicDataset):
 
     def __init__(self, dataset_config, n_users=0, n_items=0, csrs=None):
         super().__init__(dataset_config)
-        self._lists = {}
-        self._csr = {}
         if csrs is not None:
             self._install(n_users, n_items, csrs)
 
@@ -203,6 +235,8 @@ class CsrBackedDataset(BasicDataset):
         self._lists = {}
         self._csr = {(name, False): (np.asarray(rp, dtype=np.int64), np.asarray(col, dtype=np.int64))
                      for name, (rp, col) in csrs.items()}
+        for name in self.SPLITS:
+            self._version[name] += 1
         rp, col = self._csr[('train', False)]
         self.train_array = np.stack([np.repeat(np.arange(self.n_users, dtype=np.int64), np.diff(rp)), col], axis=1)
 
@@ -210,17 +244,6 @@ class CsrBackedDataset(BasicDataset):
         if name not in self._lists:
             self._lists[name] = csr_to_lists(*self._csr[(name, False)])
         return self._lists[name]
-
-    def _set_list(self, name, value):
-        if value is None or not hasattr(self, '_lists'):
-            return
-        self._lists[name] = value
-        for k in [k for k in self._csr if k[0] == name]:
-            del self._csr[k]
-
-    train_data = property(lambda self: self._get_list('train'), lambda self, v: self._set_list('train', v))
-    val_data = property(lambda self: self._get_list('val'), lambda self, v: self._set_list('val', v))
-    test_data = property(lambda self: self._get_list('test'), lambda self, v: self._set_list('test', v))
 
     def csr(self, which, sort=True):
         key = (which, sort)
@@ -234,8 +257,12 @@ class CsrBackedDataset(BasicDataset):
         return self._csr[key]
 
     def invalidate(self, which=None):
-        for k in [k for k in self._csr if k[0] in self._lists and (which is None or k[0] == which)]:
-            del self._csr[k]
+        """The CSR arrays are the primary storage: only the splits whose LISTS were materialised (and may
+        have been edited) are rebuilt from them."""
+        for name in self.SPLITS:
+            if (which is None or name == which) and name in self._lists:
+                self._drop_csr(name)
+                self._version[name] += 1
 
 
 class BinaryDataset(CsrBackedDataset):

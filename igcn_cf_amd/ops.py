@@ -319,8 +319,10 @@ def hit_matrix(rec, eval_rowptr, eval_col):
     _require_i64(rec, 'rec')
     _require_i64(eval_rowptr, 'eval_rowptr')
     hit = torch.empty(rec.shape, dtype=torch.float32, device=rec.device)
+    # a split whose lists are all empty has no column array to point at: the kernel then reports no hit anywhere
+    col_ptr = eval_col.data_ptr() if eval_col is not None and eval_col.numel() else None
     _lib.check(_lib.lib().igcn_hit_matrix(rec.data_ptr(), rec.shape[0], rec.shape[1], eval_rowptr.data_ptr(),
-                                          eval_col.data_ptr(), hit.data_ptr(), _lib.current_stream()), 'igcn_hit_matrix')
+                                          col_ptr, hit.data_ptr(), _lib.current_stream()), 'igcn_hit_matrix')
     return hit
 
 

@@ -49,6 +49,23 @@ class AverageMeter:
         self.avg = self.sum / self.count
 
 
+_M64 = 0xFFFFFFFFFFFFFFFF
+
+
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+def batch_seed(seed, call):
+    """64-bit seed of the call-th batch: both words change unpredictably from one batch to the next, so the
+    counter hash of the device sampler (csrc/common.h hash_counter XORs the low seed word into the draw
+    counter) cannot line up draw i of one batch with draw i^1 of the next."""
+    return _splitmix64((seed & _M64) ^ _splitmix64(call & _M64))
+
+
 def _csr_to_device(rowptr, col, device):
     return (torch.from_numpy(np.ascontiguousarray(rowptr, dtype=np.int64)).to(device),
             torch.from_numpy(np.ascontiguousarray(col, dtype=np.int32)).to(device))
@@ -89,8 +106,7 @@ class DeviceSampler:
             b = min(batch_size, left)
             left -= b
             self.calls += 1
-            yield ops.bpr_sample(self.rowptr, self.col, self.nonempty, self.n_items, b,
-                                 (self.seed * 0x9E3779B97F4A7C15 + self.calls) & 0xFFFFFFFFFFFFFFFF)
+            yield ops.bpr_sample(self.rowptr, self.col, self.nonempty, self.n_items, b, batch_seed(self.seed, self.calls))
 
 
 class BasicTrainer:
@@ -219,7 +235,7 @@ class BasicTrainer:
         results = {'Precision': {}, 'Recall': {}, 'NDCG': {}}
         lens = eval_len.to(torch.float32)
         valid = eval_len > 0
-        n_valid = valid.sum().clamp(min=1).to(torch.float32)
+        n_valid = valid.sum().to(torch.float32)                  # no evaluated user: 0/0 = nan, as the reference's empty mean
         out = []
         for k in self.topks:
             h = hit[:, :k]
@@ -237,14 +253,18 @@ class BasicTrainer:
             results['Precision'][k], results['Recall'][k], results['NDCG'][k] = (np.float32(v) for v in vals[3 * i:3 * i + 3])
         return results
 
+    def _split_version(self, *splits):
+        """What the device copies of a dataset's lists are keyed on: the dataset object and the version
+        counters of the splits involved (bumped by list assignment and by dataset.invalidate())."""
+        ver = getattr(self.dataset, 'version', None)
+        return (id(self.dataset),) + tuple(ver(s) if ver else None for s in splits)
+
     def _eval_lists_device(self, val_or_test):
-        """Device CSR of the evaluated lists; rebuilt whenever the dataset hands out new arrays
-        (dataset.invalidate() after the lists were edited in place)."""
-        if hasattr(self.dataset, 'invalidate'):
-            self.dataset.invalidate(val_or_test)
-        rowptr, col = self.dataset.csr(val_or_test, sort=True)
-        key = ('eval', val_or_test, id(rowptr), id(col))
-        if self._excl_cache.get('eval_key') != key:
+        """Device CSR of the evaluated lists (rowptr, sorted items, lengths); rebuilt only when the
+        split's version changed.  In-place edits of the lists need dataset.invalidate(split)."""
+        key = ('eval', val_or_test) + self._split_version(val_or_test)
+        if self._excl_cache.get('eval_key') != key or None in key:
+            rowptr, col = self.dataset.csr(val_or_test, sort=True)
             rp, cl = _csr_to_device(rowptr, col, self.device)
             self._excl_cache['eval_key'] = key
             self._excl_cache['eval_val'] = (rp, cl, (rp[1:] - rp[:-1]).contiguous())
@@ -267,13 +287,14 @@ class BasicTrainer:
         the evaluation protocols."""
         if val_or_test == 'train':
             return None, None
-        key = (val_or_test, id(self.dataset))
-        if key not in self._excl_cache:
+        key = ('excl', val_or_test) + self._split_version('train', 'val')
+        if self._excl_cache.get('excl_key_' + val_or_test) != key or None in key:
             excl = self.dataset.csr('train', sort=True)
             if val_or_test == 'test':
                 excl = _merge_sorted_csr(excl, self.dataset.csr('val', sort=True))
-            self._excl_cache[key] = _csr_to_device(excl[0], excl[1], self.device)
-        return self._excl_cache[key]
+            self._excl_cache['excl_key_' + val_or_test] = key
+            self._excl_cache['excl_val_' + val_or_test] = _csr_to_device(excl[0], excl[1], self.device)
+        return self._excl_cache['excl_val_' + val_or_test]
 
     def recommend_all(self, val_or_test, banned_items=None):
         """[n_users, max(topks)] recommended item ids on the device."""

@@ -219,7 +219,8 @@ int igcn_score_topk_bf16x3_f32(const float *user_rows, int64_t ldu, const int64_
                                int32_t k, int64_t *out_idx, float *out_val, void *workspace, void *stream);
 
 /* hit[u, j] = 1 if rec[u, j] is in eval_col[eval_rowptr[u]..eval_rowptr[u+1])
- * (sorted ascending), else 0: the membership loop of trainer.py:111-115. */
+ * (sorted ascending), else 0: the membership loop of trainer.py:111-115.
+ * eval_col may be NULL when every list is empty (eval_rowptr all equal): no hit anywhere. */
 int igcn_hit_matrix(const int64_t *rec, int64_t n_users, int32_t k,
                     const int64_t *eval_rowptr, const int32_t *eval_col,
                     float *hit, void *stream);

@@ -60,7 +60,18 @@ def main():
         k = spmm[0]
         fetch_kib = pmc['FETCH_SIZE'][k][0]
         write_kib = pmc.get('WRITE_SIZE', {}).get(k, (0, 0))[0]
-        out = {'kernel': k, 'FETCH_SIZE_KiB_raw': fetch_kib, 'WRITE_SIZE_KiB_raw': write_kib,
+        cfg = {}
+        try:                                   # the bench line of the FETCH_SIZE pass names the workload the counters belong to
+            for line in open(os.path.join(src, 'pmc_fetch.log')):
+                if line.startswith('{'):
+                    cfg = json.loads(line).get('config', {})
+        except Exception:
+            pass
+        hit = pmc.get('TCC_HIT_sum', {}).get(k, (0, 0))[0]
+        miss = pmc.get('TCC_MISS_sum', {}).get(k, (0, 0))[0]
+        out = {'tag': tag, 'kernel': k, 'preset': cfg.get('preset'), 'nnz': cfg.get('nnz'), 'd': cfg.get('d'),
+               'l2_hit_rate': hit / (hit + miss) if hit + miss else None,
+               'FETCH_SIZE_KiB_raw': fetch_kib, 'WRITE_SIZE_KiB_raw': write_kib,
                'spmm_hbm_bytes_per_launch': int(2 * fetch_kib * 1024 + write_kib * 1024),
                'correction': 'read bytes = 2 x FETCH_SIZE x 1024 (gfx950 tallies 128-B requests at 64 B), '
                              'write bytes = WRITE_SIZE x 1024; Infinity-Cache hits are included in FETCH_SIZE'}

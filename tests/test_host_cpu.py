@@ -236,3 +236,38 @@ def test_binary_splits_roundtrip_and_cache(tmp_path):
     assert second.val_data == text.val_data and second.train_data == first.train_data
     assert np.array_equal(second.train_array, text.train_array) and second.n_items == text.n_items
     assert [second[i].tolist() for i in range(1)][0][0][0] in range(text.n_users)      # sampling still works
+
+
+def test_split_versions_track_list_changes(golden):
+    """The trainers key their device copies of the lists on (split, version): assignment and invalidate()
+    bump the version of exactly the split concerned and drop its cached CSR views."""
+    from igcn_cf_amd.dataset import ProcessedDataset, SyntheticDataset
+    for ds in (ProcessedDataset({'name': 'ProcessedDataset', 'path': golden['path'], 'device': 'cpu'}),
+               SyntheticDataset({'name': 'SyntheticDataset', 'n_users': 50, 'n_items': 40, 'n_inter': 600})):
+        v = {s: ds.version(s) for s in ds.SPLITS}
+        rp0, col0 = ds.csr('test', sort=True)
+        assert ds.csr('test', sort=True)[0] is rp0                       # cached, version unchanged
+        assert ds.version('test') == v['test']
+        lists = [list(x) for x in ds.test_data]
+        lists[0] = []
+        ds.test_data = lists
+        assert ds.version('test') == v['test'] + 1 and ds.version('train') == v['train']
+        rp1, _ = ds.csr('test', sort=True)
+        assert rp1[1] == 0 and rp1[-1] == rp0[-1] - (rp0[1] - rp0[0])
+        ds.test_data[1] = []                                             # in place: needs invalidate()
+        ds.invalidate('test')
+        assert ds.version('test') == v['test'] + 2 and ds.version('val') == v['val']
+        assert ds.csr('test', sort=True)[0][2] == 0
+
+
+def test_batch_seeds_are_mixed():
+    """Consecutive batches must not get seeds that differ in the low word by 1 (the device hash
+    XORs the low seed word into the draw counter)."""
+    from igcn_cf_amd.trainer import batch_seed
+    seeds = [batch_seed(2021, c) for c in range(1, 2001)]
+    assert len(set(seeds)) == len(seeds)
+    lows = np.array([s & 0xFFFFFFFF for s in seeds], dtype=np.int64)
+    diffs = np.abs(np.diff(lows))
+    assert (diffs > 8).all()
+    flips = [bin(a ^ b).count('1') for a, b in zip(seeds[:-1], seeds[1:])]
+    assert 24 < np.mean(flips) < 40                                      # ~32 of 64 bits change per step

@@ -318,6 +318,58 @@ def test_device_sampler_semantics(golden):
     assert not np.array_equal(batches[0], batches[1])
 
 
+def test_device_sampler_batches_are_independent_across_roles():
+    """with seeds s and s+1 the user draw of batch t lined up with the positive / negative draw of
+    batch t+1.  With mixed per-batch seeds no pair of roles of consecutive batches is correlated."""
+    from igcn_cf_amd.dataset import SyntheticDataset
+    from igcn_cf_amd.trainer import DeviceSampler
+    ds = SyntheticDataset({'name': 'SyntheticDataset', 'n_users': 5000, 'n_items': 4000, 'n_inter': 200000, 'device': 'cuda'})
+    sm = DeviceSampler(ds, 'cuda', seed=2021)
+    it = sm.epoch_batches(4096)
+    a, b = next(it).cpu().numpy().astype(np.float64), next(it).cpu().numpy().astype(np.float64)
+    rp, _ = ds.csr('train', sort=True)
+    lens = np.diff(rp)
+
+    def fractions(x):                                    # each role as a fraction in [0, 1): what the hash feeds
+        u = x[:, 0].astype(np.int64)
+        return np.stack([x[:, 0] / ds.n_users, (x[:, 1] % 97) / 97.0, x[:, 2] / ds.n_items], axis=1), lens[u]
+    fa, _ = fractions(a)
+    fb, _ = fractions(b)
+    for shift in (0, 1, 3):                              # draw i against draw i, i^1, i^3 of the next batch
+        idx = np.arange(len(fa)) ^ shift
+        for ra in range(3):
+            for rb in range(3):
+                if ra == 1 or rb == 1:
+                    continue                             # positives depend on the user's list, not a plain fraction
+                c = np.corrcoef(fa[:, ra], fb[idx, rb])[0, 1]
+                assert abs(c) < 0.08, (shift, ra, rb, c)
+
+
+def test_eval_with_all_lists_empty_gives_nan_like_the_reference():
+    """An evaluated split whose lists are all empty (trainer.py:109-138 then takes the mean of an empty
+    selection: nan): igcn_hit_matrix gets no column array and reports no hits."""
+    import torch
+    from igcn_cf_amd import ops
+    rec = torch.randint(0, 50, (8, 5), dtype=torch.int64, device='cuda')
+    rp = torch.zeros(9, dtype=torch.int64, device='cuda')
+    hit = ops.hit_matrix(rec, rp, torch.empty(0, dtype=torch.int32, device='cuda'))
+    assert float(hit.abs().sum()) == 0.0
+    from igcn_cf_amd.trainer import BasicTrainer
+
+    class DS:
+        n_users, n_items = 8, 50
+    tr = BasicTrainer({'name': 'BasicTrainer', 'dataset': DS(), 'model': None, 'topks': [5], 'device': 'cuda',
+                       'n_epochs': 0, 'test_batch_size': 7})
+    m = tr._metrics_from_hits_device(hit, torch.zeros(8, dtype=torch.int64, device='cuda'))
+    assert all(np.isnan(m[name][5]) for name in m)
+    with np.errstate(all='ignore'):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            m2 = tr.calculate_metrics([[] for _ in range(8)], rec.cpu().numpy())
+    assert all(np.isnan(m2[name][5]) for name in m2)
+
+
 def test_bpr_column_slices_sum_to_the_full_loss():
     """Embedding-column sharding: partial dots of the slices (igcn_bpr_dots_f32) summed by reduce_fn and
     finished (igcn_bpr_finish_f32) give the unsliced loss; each slice's gradient is the slice of the full one."""
