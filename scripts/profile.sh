@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="$REPO/bench.py --steps 100 --warmup 10 --no-cpu-baseline"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $ARGS > $OUT/kt.log 2>&1 || exit 1
-ARGS2="$REPO/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extras"
+ARGS2="$REPO/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-extras --no-hbm-leg"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS2 > $OUT/pmc_fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS2 > $OUT/pmc_write.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_l2 -- python3 $ARGS2 > $OUT/pmc_l2.log 2>&1 || exit 1
