@@ -427,18 +427,7 @@ def side_measurements(ds, device, d, K):
     k1.record()
     torch.cuda.synchronize()
     tf = 3 * 2.0 * ds.n_users * ds.n_items * d / (k0.elapsed_time(k1) / 1e3) / 1e12
-    k2, k3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ops.score_topk(rep, rep[ds.n_users:], 20, user_ids=users, precision='bf16x3')
-    k2.record()
-    for _ in range(3):
-        ops.score_topk(rep, rep[ds.n_users:], 20, user_ids=users, precision='bf16x3')
-    k3.record()
-    torch.cuda.synchronize()
-    res['eval_scoring_opt_in_bf16x3'] = {
-        'ms': k2.elapsed_time(k3) / 3, 'users_per_s': 3 * ds.n_users / (k2.elapsed_time(k3) / 1e3),
-        'note': "NOT part of any number above: the opt-in scoring kernel (config eval_precision='bf16x3'), exact 3-way bf16 split "
-                'of both operands on the bf16 matrix cores, fp32 accumulation; fp32-grade scores, not the fp32 fmaf chain'}
-    res['eval_roofline'] = {'bound': 'mfma', 'kernel': 'score_topk_kernel<64,true> (+ merge)', 'achieved': tf, 'peak': 157.3,
+    res['eval_roofline'] = {'bound': 'mfma', 'kernel': 'score_topk_kernel<64,2,true> (+ merge)', 'achieved': tf, 'peak': 157.3,
                             'unit': 'TFLOP/s', 'frac': tf / 157.3,
                             'note': 'fp32 v_mfma_f32_32x32x2_f32; 2*U*I*d flops per evaluation, no masks in this timing'}
     trainer.eval('test')                                   # first call builds the device CSR of the test lists

@@ -12,7 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libigcn_hip.so')
 
 MAX_ADDS = 8
-MAX_TOPK = 64
+MAX_TOPK = 256
 
 c_i64_p = C.POINTER(C.c_int64)
 vp = C.c_void_p
@@ -24,6 +24,7 @@ LONG_ROW_DTYPE = np.dtype([('row', '<i4'), ('first_slot', '<i4'), ('n_slots', '<
 SIGNATURES = {
     'igcn_abi_version': (C.c_int, []),
     'igcn_error_string': (C.c_char_p, [C.c_int]),
+    'igcn_set_tuning': (C.c_int, [C.c_char_p, C.c_int32]),
     'igcn_spmm_plan_count_host': (C.c_int, [vp, C.c_int64, C.c_int32, C.c_int32, c_i64_p, c_i64_p]),
     'igcn_spmm_plan_fill_host': (C.c_int, [vp, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int64, vp, C.c_int64]),
     'igcn_spmm_csr_f32': (C.c_int, [vp, vp, vp, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
@@ -46,9 +47,6 @@ SIGNATURES = {
     'igcn_score_topk_workspace_bytes': (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     'igcn_score_topk_f32': (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32,
                                       vp, vp, vp, C.c_int32, vp, vp, vp, vp]),
-    'igcn_score_topk_bf16x3_workspace_bytes': (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
-    'igcn_score_topk_bf16x3_f32': (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32,
-                                             vp, vp, vp, C.c_int32, vp, vp, vp, vp]),
     'igcn_hit_matrix': (C.c_int, [vp, C.c_int64, C.c_int32, vp, vp, vp, vp]),
     'igcn_bpr_sample': (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, vp, vp]),
 }
@@ -101,6 +99,11 @@ def check(code, what):
     if code != 0:
         msg = lib().igcn_error_string(int(code))
         raise IgcnError('%s failed: %s (code %d)' % (what, msg.decode() if msg else '?', code))
+
+
+def set_tuning(name, value=None):
+    """Developer / test knob of the launch heuristics (igcn_set_tuning); value None restores the default."""
+    check(lib().igcn_set_tuning(name.encode(), -1 if value is None else int(value)), 'igcn_set_tuning(%s)' % name)
 
 
 def ptr(t):

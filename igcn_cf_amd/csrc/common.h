@@ -27,6 +27,20 @@ inline int cu_count() {
     return n;
 }
 
+// Developer / test knobs, set through igcn_set_tuning() (never read from the environment: a getenv() per launch is
+// host time on a launch-bound path).  -1 = library default.
+enum {
+    IGCN_TUNE_SPMM_BLOCKS_PER_CU = 0,   // grid = CUs x this many workgroups (default: sized by rows per wave)
+    IGCN_TUNE_SPMM_MULTIROW,            // 0: one row per wave at every width
+    IGCN_TUNE_TOPK_SLOTS,               // resident-wave count the top-k plan assumes (tests: cut sweeps at small sizes)
+    IGCN_TUNE_TOPK_WAVES_PER_CU,        // 8, 4, 2 or 1
+    IGCN_TUNE_TOPK_CAP,                 // staging slots per lane and group
+    IGCN_TUNE_TOPK_STAGGER,             // 0: no static wave priorities
+    IGCN_TUNE_COUNT
+};
+extern int g_tuning[IGCN_TUNE_COUNT];   // defined in spmm.hip
+inline int tuning_get(int key) { return g_tuning[key]; }
+
 // 32-bit finaliser (lowbias32-style); used as a counter-based RNG: the value
 // depends only on (seed, counter), so a matrix and its transposed view agree.
 __host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {

@@ -12,7 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace {
+namespace roof {
 
 constexpr int kWave = 64;
 constexpr int kBlock = 256;
@@ -20,7 +20,7 @@ constexpr int kBlock = 256;
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void gather_roof_kernel(
     const int32_t *__restrict__ idx, const float *__restrict__ val, int64_t n_idx,
-    const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy, int64_t n_out)
+    const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy, int64_t n_out, double rows_per_idx)
 {
     constexpr int G = kWave / LPR;
     const int lane = threadIdx.x & (kWave - 1);
@@ -58,16 +58,18 @@ __global__ __launch_bounds__(kBlock) void gather_roof_kernel(
                 acc.x = fmaf(ww, xv.x, acc.x); acc.y = fmaf(ww, xv.y, acc.y); acc.z = fmaf(ww, xv.z, acc.z); acc.w = fmaf(ww, xv.w, acc.w);
             }
         }
-        // the output rows this chunk's share of the index stream stands for: row r covers indices
-        // [r * n_idx / n_out, (r + 1) * n_idx / n_out); groups take them in turn (no fold: any sum will do)
-        const int64_t r0 = (int64_t)((__int128)base * n_out / n_idx);
-        const int64_t r1 = (int64_t)((__int128)(base + cnt) * n_out / n_idx);
+        // the output rows this chunk's share of the index stream stands for (n_out / n_idx rows per index);
+        // groups take them in turn (no fold: any sum will do)
+        const int64_t r0 = (int64_t)((double)base * rows_per_idx);
+        int64_t r1 = (int64_t)((double)(base + cnt) * rows_per_idx);
+        if (r1 > n_out) r1 = n_out;
         for (int64_t r = r0 + g; r < r1; r += G)
             *reinterpret_cast<float4 *>(y + r * ldy + 4 * t) = acc;
     }
 }
 
-}  // namespace
+}  // namespace roof
+using namespace roof;
 
 // idx [n_idx] int32 in [0, n_x_rows), val [n_idx], x [n_x_rows, d] (ldx), y [n_out, d] (ldy); d in {16, 32, 64, 128, 256}.
 // blocks: workgroups of 256 threads to launch.  Returns 0 or a hipError_t / -1 on a bad argument.
@@ -78,12 +80,13 @@ extern "C" int igcn_roof_gather_f32(const int32_t *idx, const float *val, int64_
     if (ldx < d || ldy < d || ldx % 4 || ldy % 4) return -1;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)blocks), block(kBlock);
+    const double rpi = (double)n_out / (double)n_idx;
     switch (d) {
-    case 16: hipLaunchKernelGGL(gather_roof_kernel<4>, grid, block, 0, st, idx, val, n_idx, x, ldx, y, ldy, n_out); break;
-    case 32: hipLaunchKernelGGL(gather_roof_kernel<8>, grid, block, 0, st, idx, val, n_idx, x, ldx, y, ldy, n_out); break;
-    case 64: hipLaunchKernelGGL(gather_roof_kernel<16>, grid, block, 0, st, idx, val, n_idx, x, ldx, y, ldy, n_out); break;
-    case 128: hipLaunchKernelGGL(gather_roof_kernel<32>, grid, block, 0, st, idx, val, n_idx, x, ldx, y, ldy, n_out); break;
-    case 256: hipLaunchKernelGGL(gather_roof_kernel<64>, grid, block, 0, st, idx, val, n_idx, x, ldx, y, ldy, n_out); break;
+    case 16: hipLaunchKernelGGL(gather_roof_kernel<4>, grid, block, 0, st, idx, val, n_idx, x, ldx, y, ldy, n_out, rpi); break;
+    case 32: hipLaunchKernelGGL(gather_roof_kernel<8>, grid, block, 0, st, idx, val, n_idx, x, ldx, y, ldy, n_out, rpi); break;
+    case 64: hipLaunchKernelGGL(gather_roof_kernel<16>, grid, block, 0, st, idx, val, n_idx, x, ldx, y, ldy, n_out, rpi); break;
+    case 128: hipLaunchKernelGGL(gather_roof_kernel<32>, grid, block, 0, st, idx, val, n_idx, x, ldx, y, ldy, n_out, rpi); break;
+    case 256: hipLaunchKernelGGL(gather_roof_kernel<64>, grid, block, 0, st, idx, val, n_idx, x, ldx, y, ldy, n_out, rpi); break;
     default: return -1;
     }
     return (int)hipGetLastError();

@@ -7,165 +7,105 @@
 //   torch.topk(scores, k)                       trainer.py:163
 // and the membership loop of calculate_metrics  trainer.py:111-115 (igcn_hit_matrix).
 //
-// This is the one dense contraction of the path, so it runs on the matrix
-// cores, in exact fp32: v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain, no
-// reduced-precision shortcut): 64 cycles each, 2048 cycles per 32x32xd=64 tile.
-// Operand traffic is negligible; what decides the speed is what a SIMD issues
-// BESIDES the MFMAs.  Measured on this chip (scripts/probes/mfma_shadow_probe.hip,
-// mfma_valu_overlap_probe.hip): the fp32 MFMA leaves no shadow — every vector
-// instruction a wave puts between two dependent MFMAs costs its full ~5 cycles,
-// and while one wave runs a dependent MFMA chain a co-resident wave's vector
-// instructions do not issue at all.  So the bookkeeping per tile is written to be
-// as few instructions as possible, and waves only help to hide memory latency:
-//   * one WAVE = one workgroup = 32 users for a run of item tiles: no barriers,
-//     nothing shared between waves.  The users' embeddings are the MFMA B operand
-//     and stay in d/2 VGPRs per lane; the item rows (A operand) are read straight
-//     from L2/Infinity Cache, addressed as a scalar tile base + a constant lane
-//     offset; the two lanes of a row take adjacent 16-byte pieces so that a load
-//     instruction touches 32 lines;
-//   * the tile loop is software-pipelined by hand: while tile t's scores sit in one
-//     accumulator, ONE pinned basic block runs the MFMA chain of tile t+1 into the
-//     other, re-loads each a[q] for tile t+2 as soon as its four MFMAs have issued
-//     (two chains ahead of its use) and stages tile t's candidates, a row or two
-//     after every MFMA.  Left alone the compiler clusters the MFMAs and sinks the
-//     loads to the end of the chain, one tile too late (+25 % time);
-//   * the product is computed as S^T = I . U^T, so in the accumulator a lane
-//     holds 16 item scores of ONE user (column = lane&31): the running top-k of
-//     a user is private to a lane pair, no cross-lane traffic in the sweep;
-//   * top-k entries are 64-bit sortable keys (order-preserving image of the fp32
-//     score << 32 | ~item id), kept per lane as a k-slot binary min-heap in LDS
-//     ([slot][lane]: lane l always hits its own bank pair).  In the tile loop a row
-//     costs 4 vector instructions and one LDS write, no branch: compare with the
-//     lane's (slightly stale) k-th best, add-with-carry into the slot counter,
-//     clamp, address; (score, item) goes to the lane's next free STAGING slot
-//     whether it is a candidate or not.  The replace-root/sift-down work is done
-//     for all lanes together when some lane's staging area is full.  A lane that
-//     had more candidates than free slots in one tile is rare: the tile's staged
-//     entries are then discarded and the tile is redone with per-row branches;
-//   * masking: each lane walks its user's sorted exclusion list with a cursor as
-//     the item sweep advances; banned items are read as bytes; both only set
-//     scores to -inf before the tile is staged;
-//   * the grid never exceeds what is resident at once: a wave that starts late
-//     runs its whole share after everybody else has finished.  Registers allow 2
-//     waves per SIMD (two accumulators + operands: 207 VGPRs); LDS is handed out in
-//     1280-B granules, and the staging depth is whatever they leave beside the heap.
-//     Every wave gets the same number of tiles: with G 32-user groups and W resident
-//     waves each wave sweeps floor(G/W) whole groups, and the tiles of the remaining
-//     groups, laid end to end, are cut into W equal runs.  A group that is cut returns
-//     one best-first list per (piece, lane half), merged by a small second kernel.
+// This is the one dense contraction of the path, so it runs on the matrix cores, in exact fp32:
+// v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain, no reduced-precision shortcut), 64 cycles each,
+// 2048 cycles per 32 x 32 x (d = 64) tile.  The fp32 MFMA runs on the same lanes as the vector ALU: it
+// leaves no shadow (scripts/probes/mfma_shadow_probe.hip: every vector instruction a wave puts between
+// two MFMAs costs its full ~5 cycles, and a co-resident wave's vector instructions do not issue while a
+// chain runs).  A SIMD's time is therefore 2048 cycles per tile PLUS everything else its waves issue,
+// and the kernel is built to issue as little else as possible:
+//   * one WAVE = one workgroup = 64 users (two 32-user groups; one group at d = 128) for a run of
+//     32-item tiles: no barriers, nothing shared between waves.  The users' embeddings are the MFMA B
+//     operands and stay in registers; an item tile (A operand) is read ONCE per 64 users, straight from
+//     L2 / Infinity Cache, addressed as a scalar tile base + a constant lane offset.  The two groups'
+//     chains are independent and interleaved MFMA by MFMA, so neither waits for its own accumulator;
+//   * S^T = I . U^T: in the accumulator a lane holds 16 item scores of ONE user (column = lane & 31),
+//     the two lanes l, l + 32 of a user hold its 32 scores of the tile;
+//   * selection costs 12 vector instructions per 32 x 32 tile when nothing qualifies: the 16 scores of a
+//     lane are folded to four quad maxima (v_max3 + v_max) and each is compared with the user's k-th
+//     best so far (one threshold per USER, shared by its two lanes); the four wave-wide compare masks
+//     go to scalar registers.  These 12 instructions are placed by hand between the MFMAs of the NEXT
+//     tile's chain (one pinned basic block per tile: the loads of the tile after next into the second A
+//     buffer, then MFMAs and selection).  Only quads whose mask is non-zero are looked at again, after the block, by scalar
+//     branches: their four rows are appended — branch-free, 4 instructions and one LDS write a row —
+//     to per-lane STAGING lists in LDS;
+//   * the running top-k of a user is a k-slot 4-ary min-heap of 64-bit sortable keys
+//     (order-preserving fp32 image << 32 | ~item id) in LDS, one per user, owned by ONE lane (lane
+//     g * 32 + u owns user u of group g).  When some lane's staging list is nearly full every owner
+//     lane drains the two lists of its user into its heap, all 64 lanes together, and the thresholds
+//     are re-read;
+//   * masking never touches the accumulators: each lane walks its users' sorted exclusion lists with a
+//     cursor as the sweep advances, banned items arrive as one 32-bit word per tile through the scalar
+//     cache (packed by a tiny pre-kernel); both become one bit per item of the current tile, looked at
+//     only when a row is staged (a masked row is staged as -inf);
+//   * the grid never exceeds what is resident: a wave that starts late runs its whole share after
+//     everybody else has finished.  Registers allow 2 waves per SIMD; LDS is handed out in 1280-B
+//     granules and the staging depth is what they leave beside the heaps (k <= 24: 8 waves per CU;
+//     larger k: 4, 2 or 1).  Every wave gets the same number of tiles: with G 64-user groups and W
+//     resident waves each wave sweeps floor(G / W) whole groups, and the tiles of the remaining groups,
+//     laid end to end, are cut into W equal runs.  A group that is cut returns one best-first list per
+//     piece, merged by a small second kernel.
 // Ties are broken towards the lower item id (torch.topk leaves them unspecified).
 #include <math.h>
-#include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 
 namespace igcn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// ---- fp32 as the exact sum of three bf16 (MODE 1 of the kernel) -----------------------------------------
-// v = h0 + h1 + h2 + r with |r| <= 2^-24 |v|: round to nearest bf16, subtract (exact in fp32), repeat.
-__device__ __forceinline__ unsigned int bf16_rne_bits(float v) {
-    const unsigned int u = __float_as_uint(v);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ void split3(float v, unsigned int &h0, unsigned int &h1, unsigned int &h2) {
-    h0 = bf16_rne_bits(v);
-    const float r1 = v - __uint_as_float(h0 << 16);
-    h1 = bf16_rne_bits(r1);
-    const float r2 = r1 - __uint_as_float(h1 << 16);
-    h2 = bf16_rne_bits(r2);
-}
-// eight consecutive fp32 -> three bf16x8 planes (as float4 bit patterns: two bf16 per dword, low half first)
-__device__ __forceinline__ void split3_x8(const float4 &lo, const float4 &hi, float4 out[3]) {
-    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    unsigned int w[3][4];
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-        unsigned int a0, a1, a2, b0, b1, b2;
-        split3(v[e], a0, a1, a2);
-        split3(v[e + 1], b0, b1, b2);
-        w[0][e / 2] = a0 | (b0 << 16); w[1][e / 2] = a1 | (b1 << 16); w[2][e / 2] = a2 | (b2 << 16);
-    }
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-        out[p] = make_float4(__uint_as_float(w[p][0]), __uint_as_float(w[p][1]), __uint_as_float(w[p][2]), __uint_as_float(w[p][3]));
-}
-__device__ __forceinline__ bf16x8 as_bf16x8(const float4 &v) { return __builtin_bit_cast(bf16x8, v); }
-
-// Item table -> MFMA-ready bf16 planes: [tile][plane 0..2][k-step 0..3][lane 0..63] x 16 B, lane (j, kg)
-// holding k = 16 s + 8 kg .. + 7 of item 32 tile + j.  One thread per (tile, k-step, lane).
-__global__ __launch_bounds__(kBlock) void topk_pack_items_kernel(const float *__restrict__ item_rows, int64_t ldi, int64_t n_items,
-                                                                 int n_tiles, float4 *__restrict__ packed)
-{
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)n_tiles * 4 * kWave) return;
-    const int lane = (int)(i % kWave);
-    const int s = (int)(i / kWave % 4);
-    const int64_t tile = i / (4 * kWave);
-    const int64_t item = tile * 32 + (lane & 31);
-    float4 lo = f4_zero(), hi = f4_zero();
-    if (item < n_items) {
-        const float *src = item_rows + item * ldi + 16 * s + 8 * (lane >> 5);
-        lo = *reinterpret_cast<const float4 *>(src);
-        hi = *reinterpret_cast<const float4 *>(src + 4);
-    }
-    float4 planes[3];
-    split3_x8(lo, hi, planes);
-#pragma unroll
-    for (int p = 0; p < 3; ++p) packed[((tile * 3 + p) * 4 + s) * kWave + lane] = planes[p];
-}
 
 constexpr int kIdxNone = 0x7fffffff;
 
 struct TopkPlan {
     int d_pad;               // 16 / 32 / 64 / 128
-    int64_t groups;          // 32-user groups
+    int ng;                  // 32-user groups per wave
+    int64_t groups;          // wave-groups (32 * ng users each)
     int n_tiles;             // 32-item tiles of one sweep
     int64_t units;           // waves launched; all resident at once
     int64_t n_whole;         // whole sweeps per unit: groups [0, n_whole*units), unit u takes u, u+units, ...
     int64_t rest_tiles;      // tiles of the remaining groups (laid end to end), cut into runs of `run`
     int64_t run;             // tiles of the rest that one unit takes
     int p_max;               // bound on the pieces a rest group is cut into (1: runs are whole sweeps)
-    int cap;                 // staging slots per lane
+    int cap;                 // staging slots per lane and group
     size_t lds_bytes;
 };
 
-static inline int env_int(const char *name, int lo, int hi, int dflt) {
-    const char *e = getenv(name);
-    if (!e) return dflt;
-    const int x = atoi(e);
-    return x < lo || x > hi ? dflt : x;
-}
+constexpr int kMinCap = 8, kMaxCap = 16, kQuad = 4;
+
+static inline int topk_groups_per_wave(int d_pad) { return d_pad <= 64 ? 2 : 1; }
 
 static inline int topk_make_plan(int64_t batch, int64_t n_items, int32_t d, int32_t k, TopkPlan *p) {
     if (batch < 1 || n_items < 1) return IGCN_E_SHAPE;
     if (d < 4 || d > 128 || d % 4 != 0) return IGCN_E_SHAPE;
     if (k < 1 || k > IGCN_MAX_TOPK || k > n_items) return IGCN_E_RANGE;
     p->d_pad = d <= 16 ? 16 : d <= 32 ? 32 : d <= 64 ? 64 : 128;
-    p->groups = (batch + 31) / 32;
+    p->ng = topk_groups_per_wave(p->d_pad);
+    const int upw = 32 * p->ng;
+    p->groups = (batch + upw - 1) / upw;
     const int64_t L = (n_items + 31) / 32;
     p->n_tiles = (int)L;
-    // Resident waves per CU.  Registers allow 2 per SIMD (two accumulators + both operands).  LDS is handed out in
-    // granules of 1280 B (1/128 of the CU's 160 KiB; measured: 12 x 13312 B do not fit, 12 x 12800 B do),
-    // and the count is kept a multiple of 4 so that every SIMD of a CU carries the same number of
-    // waves.  The grid must never exceed what is resident: a wave that starts late runs its whole
-    // share after everybody else has finished.
-    const int by_regs = 2;
-    int per_simd = env_int("IGCN_TOPK_WAVES", 1, by_regs, by_regs);                    // developer knob
+    // Resident waves per CU.  Registers allow 2 per SIMD.  LDS is handed out in granules of 1280 B (1/128 of the
+    // CU's 160 KiB; measured: 12 x 13312 B do not fit, 12 x 12800 B do): a wave gets 128 / per_cu of them, holds
+    // the heaps (k slots x 64 owner lanes x 8 B) and gives the rest to the staging lists.  The grid must never
+    // exceed what is resident: a wave that starts late runs its whole share after everybody else has finished.
+    int per_cu = 8;
+    const int want = tuning_get(IGCN_TUNE_TOPK_WAVES_PER_CU);
+    if (want == 8 || want == 4 || want == 2 || want == 1) per_cu = want;
     int cap = 0;
-    for (; per_simd >= 1; --per_simd) {
-        const int granules = 128 / (4 * per_simd);
-        cap = granules * 1280 / (kWave * 8) - k - 1;             // staging slots left beside the k list slots and a spare one
-        if (cap >= 4) break;
+    for (; per_cu >= 1; per_cu >>= 1) {
+        const int64_t budget = (int64_t)(128 / per_cu) * 1280;
+        cap = (int)((budget - (int64_t)k * kWave * 8) / (p->ng * kWave * 8));
+        if (cap >= kMinCap) break;
     }
-    if (per_simd < 1) return IGCN_E_RANGE;
-    if (cap > 16) cap = 16;
-    p->cap = env_int("IGCN_TOPK_CAP", 1, cap, cap);                                    // developer knob
-    p->lds_bytes = (size_t)(k + p->cap + 1) * kWave * 8;
-    const int64_t per_cu = 4 * per_simd;
-    int64_t slots = per_cu * cu_count();
-    slots = env_int("IGCN_TOPK_SLOTS", 1, (int)slots, (int)slots);                    // developer knob (tests: whole sweeps + cut rest at small sizes)
+    if (per_cu < 1) return IGCN_E_RANGE;
+    if (cap > kMaxCap) cap = kMaxCap;
+    const int cap_t = tuning_get(IGCN_TUNE_TOPK_CAP);
+    if (cap_t >= kMinCap && cap_t <= cap) cap = cap_t;
+    p->cap = cap;
+    p->lds_bytes = (size_t)(k + p->ng * cap) * kWave * 8;
+    int64_t slots = (int64_t)per_cu * cu_count();
+    const int slots_t = tuning_get(IGCN_TUNE_TOPK_SLOTS);       // tests: whole sweeps + cut rest at small sizes
+    if (slots_t >= 1 && slots_t <= slots) slots = slots_t;
     int64_t rest;
     if (p->groups >= slots) {
         p->units = slots;
@@ -180,10 +120,10 @@ static inline int topk_make_plan(int64_t batch, int64_t n_items, int32_t d, int3
     p->run = 0;
     p->p_max = 1;
     if (rest > 0) {
-        // a piece shorter than 32 tiles is mostly list warm-up; a group in more than 31 pieces does
+        // a piece shorter than 32 tiles is mostly list warm-up; a group in more than 60 pieces does
         // not fit the 64 lanes of the merge
         int64_t min_run = L < 32 ? L : 32;
-        if ((L + 29) / 30 > min_run) min_run = (L + 29) / 30;
+        if ((L + 57) / 58 > min_run) min_run = (L + 57) / 58;
         int64_t run = (p->rest_tiles + slots - 1) / slots;
         if (run < min_run) run = min_run;
         p->run = run;
@@ -202,107 +142,127 @@ __device__ __forceinline__ unsigned long long make_key(float s, int item) {
     return ((unsigned long long)u << 32) | (unsigned int)(~item);
 }
 __device__ __forceinline__ float key_score(unsigned long long key) {
-    unsigned int u = (unsigned int)(key >> 32);
-    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-    return __uint_as_float(u);
+    const unsigned int u = (unsigned int)(key >> 32);
+    // inverse of the map in make_key, written as one xor: clearing the top bit with an AND reads as fabs() to the
+    // instruction selector, which then crashes folding it into the threshold compare (ROCm 7.2 clang, gfx950)
+    const unsigned int m = (unsigned int)((int)u >> 31);          // all ones: the score was >= +0
+    return __uint_as_float(u ^ (~m | 0x80000000u));
 }
 __device__ __forceinline__ int key_item(unsigned long long key) { return (int)~(unsigned int)key; }
 
 // (v, i) ranks before (w, j): higher score first, then lower item id
 __device__ __forceinline__ bool ranks_before(float v, int i, float w, int j) { return v > w || (v == w && i < j); }
 
-// Static issue priority from the hardware wave slot: the waves of a SIMD get different
-// priorities, so one of them always wins the matrix pipe and the others fill in behind it.
-__device__ __forceinline__ void set_priority_by_wave_slot() {
+// Issue priority.  Base priority 0 or 1 from the hardware wave slot: the two waves of a SIMD get different ones, so
+// one of them always wins the matrix pipe and the other fills in behind it.  A wave in its slow path (staging
+// candidates, draining them into the heaps) raises itself to 3: its few vector instructions then go ahead of the
+// partner's next MFMA instead of queueing behind every one of them, the slow path is over sooner, and both waves
+// are back to feeding the matrix pipe.
+__device__ __forceinline__ unsigned wave_slot() {
     // s_getreg_b32 HW_REG_HW_ID (id 4), WAVE_ID = bits [3:0]: simm16 = (size-1) << 11 | offset << 6 | id
-    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 3u;
-    if (slot == 0) __builtin_amdgcn_s_setprio(0);
-    else if (slot == 1) __builtin_amdgcn_s_setprio(1);
-    else if (slot == 2) __builtin_amdgcn_s_setprio(2);
-    else __builtin_amdgcn_s_setprio(3);
+    return __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;
+}
+__device__ __forceinline__ void set_base_priority(unsigned slot) {
+    if (slot) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
 }
 
-// min-heap of sortable keys in LDS, [slot][lane]: replace the root by `cand` and sift down.
+// 4-ary min-heap of sortable keys in LDS, [slot][owner lane] (children of slot i: 4i+1 .. 4i+4): replace the root
+// by `cand` and sift down.  The four children of a level are read together, so a level costs one LDS round trip
+// and a 20-slot heap has two levels below the root (a binary heap: four, with two dependent reads each).
 // Returns the new root.
 __device__ __forceinline__ unsigned long long heap_replace_root(unsigned long long *heap, int n, unsigned long long cand) {
     int i = 0;
     unsigned long long first_up = 0ull;
     while (true) {
-        int c = 2 * i + 1;
+        const int c = 4 * i + 1;
         if (c >= n) break;
-        unsigned long long kc = heap[c * kWave];
-        if (c + 1 < n) {
-            const unsigned long long k2 = heap[(c + 1) * kWave];
-            if (k2 < kc) { kc = k2; ++c; }
-        }
-        if (kc >= cand) break;
-        heap[i * kWave] = kc;
-        if (i == 0) first_up = kc;
-        i = c;
+        const unsigned long long none = ~0ull;
+        unsigned long long k0 = heap[c * kWave];
+        unsigned long long k1 = c + 1 < n ? heap[(c + 1) * kWave] : none;
+        unsigned long long k2 = c + 2 < n ? heap[(c + 2) * kWave] : none;
+        unsigned long long k3 = c + 3 < n ? heap[(c + 3) * kWave] : none;
+        int m01 = c, m23 = c + 2;
+        if (k1 < k0) { k0 = k1; m01 = c + 1; }
+        if (k3 < k2) { k2 = k3; m23 = c + 3; }
+        if (k2 < k0) { k0 = k2; m01 = m23; }
+        if (k0 >= cand) break;
+        heap[i * kWave] = k0;
+        if (i == 0) first_up = k0;
+        i = m01;
     }
     heap[i * kWave] = cand;
     return i == 0 ? cand : first_up;
 }
 
-#ifdef IGCN_TOPK_TRACE
-// Developer build only (scripts/dev_topk_trace.py): shader-clock cycles per phase, summed over waves.
-// [0] load wait  [1] MFMA chain  [2] masking  [3] selection  [4] whole wave  [5] tiles  [6] waves
-// [7] whole wave in s_memrealtime ticks (100 MHz)
-__device__ unsigned long long g_topk_trace[8];
-__device__ unsigned long long g_topk_wave_times[4 * 8192];     // [begin, end] in s_memrealtime ticks, HW_ID, reserved per workgroup
-// clock read that cannot issue before `dep` (an SGPR derived from the results being timed) exists
-__device__ __forceinline__ unsigned long long trace_clock(int dep) {
-    unsigned long long t;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "s"(dep) : "memory");
-    return t;
+// hand-written vector instructions of the pinned block (the compiler would canonicalise the operands of an fmaxf
+// with v_max_f32 x, x first).
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float m;
+    asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+    return m;
 }
-__device__ __forceinline__ int trace_dep(const f32x16 &acc) {
-    float m = acc[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[r]);
-    return __builtin_amdgcn_readfirstlane(__float_as_int(m));
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float m;
+    asm volatile("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+    return m;
 }
+
+#ifdef IGCN_TOPK_STATS
+// Developer build only (scripts/dev_topk_variants.py): event counts summed over waves.
+// [0] tiles  [1] tiles with a hit quad  [2] hit quads  [3] flushes  [4] flush iterations  [5] staged candidates  [6] waves
+// [7] shader cycles inside flush()  [8] inside stage_hits()  [9] whole wave  [10] inside build_masks()
+__device__ unsigned long long g_topk_stats[12];
+__device__ unsigned long long g_topk_wave_times[3 * 4096];   // begin, end (100 MHz ticks), HW_ID per workgroup
+#define IGCN_CLOCK() __builtin_amdgcn_s_memtime()
+#define IGCN_STAT(i, v) (st_##i += (v))
+#else
+#define IGCN_STAT(i, v) ((void)0)
 #endif
 
-// FULL: d == D, no k-slice of a row is padding.  MODE 0: fp32 MFMA, the exact fmaf chain.  MODE 1 (D = 64, FULL):
-// both operands as three bf16 planes (exact split), 6 of the 9 plane products on the bf16 matrix cores with fp32
-// accumulation — products good to 2^-23, i.e. fp32-grade scores, but not the bit pattern of the fmaf chain; the
-// item planes come pre-packed (topk_pack_items_kernel).
-template <int D, bool FULL, int MODE>
-__global__ __launch_bounds__(kWave, 2) void score_topk_kernel(
-    const float *__restrict__ user_rows, int64_t ldu, const int64_t *__restrict__ user_ids, int64_t batch,
-    const float *__restrict__ item_rows, int64_t ldi, int64_t n_items, int d,
-    const int64_t *__restrict__ excl_rowptr, const int32_t *__restrict__ excl_col, const uint8_t *__restrict__ banned,
-    int k, int cap, int n_tiles, int64_t n_whole, int64_t rest_tiles, int64_t run, int p_max, int stagger,
-    int64_t *__restrict__ out_idx, float *__restrict__ out_val, float *__restrict__ ws_val, int32_t *__restrict__ ws_idx,
-    const float4 *__restrict__ packed)
-{
-    static_assert(MODE == 0 || (D == 64 && FULL), "the split mode is built for d = 64");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long *heap = reinterpret_cast<unsigned long long *>(smem) + threadIdx.x;     // [k][64]
-    unsigned long long *stage = heap + k * kWave;                                              // [cap][64]
+struct TopkArgs {
+    const float *user_rows; int64_t ldu; const int64_t *user_ids; int64_t batch;
+    const float *item_rows; int64_t ldi; int64_t n_items; int d;
+    const int64_t *excl_rowptr; const int32_t *excl_col; const uint32_t *banned_bits;
+    int k, cap, n_tiles, p_max, stagger;
+    int64_t n_whole, rest_tiles, run;
+    int64_t *out_idx; float *out_val; float *ws_val; int32_t *ws_idx;
+};
 
-    if (stagger) set_priority_by_wave_slot();
-#ifdef IGCN_TOPK_TRACE
-    unsigned long long tr_load = 0, tr_chain = 0, tr_mask = 0, tr_sel = 0, tr_tiles = 0;
-    const unsigned long long tr_begin = trace_clock(0);
-    unsigned long long tr_rt_begin;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_rt_begin) : : "memory");
+// FULL: d == D, no k-slice of a row is padding.  NG: 32-user groups of a wave.
+template <int D, int NG, bool FULL>
+__global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long *const heap_base = reinterpret_cast<unsigned long long *>(smem);       // [k][64 owner lanes]
+    unsigned long long *const heap = heap_base + threadIdx.x;                                  // this lane's own heap
+    unsigned long long *const stage_all = heap_base + A.k * kWave;                             // [NG][cap][64 lanes]
+
+    const unsigned prio_slot = (A.stagger & 1) ? wave_slot() : 0u;
+    const bool prio_boost = (A.stagger & 2) != 0;
+    set_base_priority(prio_slot);
+#ifdef IGCN_TOPK_STATS
+    unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0, st_5 = 0, st_7 = 0, st_8 = 0, st_10 = 0;
+    const unsigned long long st_begin = IGCN_CLOCK();
+    const unsigned long long st_rt_begin = __builtin_amdgcn_s_memrealtime();
 #endif
     const int lane = threadIdx.x;
     const int j = lane & 31, h = lane >> 5;
-    const float kNaN = __uint_as_float(0x7fc00000u);
+    const int k = A.k, cap = A.cap, n_tiles = A.n_tiles;
+    const int64_t ldi = A.ldi, n_items = A.n_items;
+    constexpr int UPW = 32 * NG;                                 // users of a wave
+    const int own_g = NG == 2 ? h : 0;                           // the group whose user (own_g, j) this lane's heap belongs to
+    const bool owner = NG == 2 || h == 0;
     const int64_t units = gridDim.x;
-    const int64_t n_full = n_whole * units;
-    int64_t rx = (int64_t)blockIdx.x * run;                     // cursor in the rest groups' tile space
-    const int64_t rx_end = rx + run < rest_tiles ? rx + run : rest_tiles;
+    const int64_t n_full = A.n_whole * units;
+    int64_t rx = (int64_t)blockIdx.x * A.run;                    // cursor in the rest groups' tile space
+    const int64_t rx_end = rx + A.run < A.rest_tiles ? rx + A.run : A.rest_tiles;
 
     for (int64_t job = 0;; ++job) {
-        // ---- next piece: users of `group`, item tiles [tin0, tin1) ----------------------------
+        // ---- next piece: users of wave-group `group`, item tiles [tin0, tin1) -------------------
         int64_t group;
         int tin0, tin1, pidx = 0;
         bool direct = true;
-        if (job < n_whole) {
+        if (job < A.n_whole) {
             group = (int64_t)blockIdx.x + job * units;
             tin0 = 0;
             tin1 = n_tiles;
@@ -313,385 +273,440 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(
             tin0 = (int)(rx - rg * n_tiles);
             const int64_t left = rx_end - rx;
             tin1 = left < n_tiles - tin0 ? (int)(tin0 + left) : n_tiles;
-            pidx = (int)((int64_t)blockIdx.x - (rg * n_tiles) / run);
-            direct = p_max == 1;
+            pidx = (int)((int64_t)blockIdx.x - (rg * n_tiles) / A.run);
+            direct = A.p_max == 1;
             rx += tin1 - tin0;
         }
         const int item_lo = tin0 * 32;
         const int item_hi = (int64_t)tin1 * 32 < n_items ? tin1 * 32 : (int)n_items;
-        const int64_t b = group * 32 + j;
-        const bool user_ok = b < batch;
-        const int64_t uid = user_ok ? (user_ids ? user_ids[b] : b) : 0;
 
-        // B operand: this lane's user.  Lane half h supplies k = 8q + 4h + c (q < D/8, c < 4): the two
+        // B operands: user (g, j) of this lane.  Lane half h supplies k = 8q + 4h + c (q < D/8, c < 4): the two
         // lanes of a row read adjacent 16-B pieces, so one load instruction touches 32 lines, not 64.
-        float bfrag[MODE == 0 ? D / 2 : 1];
-        float4 ub[MODE == 1 ? 3 : 1][MODE == 1 ? 4 : 1];        // MODE 1: [plane][k-step], 8 bf16 each: k = 16 s + 8 h .. + 7
-        if constexpr (MODE == 0) {
+        float bfrag[NG][D / 2];
+        int64_t uid[NG];
+        bool user_ok[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int64_t b = group * UPW + g * 32 + j;
+            user_ok[g] = b < A.batch;
+            uid[g] = user_ok[g] ? (A.user_ids ? A.user_ids[b] : b) : 0;
 #pragma unroll
             for (int q = 0; q < D / 8; ++q) {
                 float4 v = f4_zero();
                 const int e = 8 * q + 4 * h;
-                if (user_ok && (FULL || e < d)) v = *reinterpret_cast<const float4 *>(user_rows + uid * ldu + e);
-                bfrag[4 * q + 0] = v.x; bfrag[4 * q + 1] = v.y; bfrag[4 * q + 2] = v.z; bfrag[4 * q + 3] = v.w;
+                if (user_ok[g] && (FULL || e < A.d)) v = *reinterpret_cast<const float4 *>(A.user_rows + uid[g] * A.ldu + e);
+                bfrag[g][4 * q + 0] = v.x; bfrag[g][4 * q + 1] = v.y; bfrag[g][4 * q + 2] = v.z; bfrag[g][4 * q + 3] = v.w;
             }
-        } else {
+        }
+
+        // exclusion cursors: first excluded item >= item_lo of each of this lane's users; the entry after it is
+        // already on its way
+        const int32_t *ex_ptr[NG];
+        int ex_pos[NG], ex_end[NG], ex_next[NG], ex_after[NG];
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                float4 lo = f4_zero(), hi = f4_zero();
-                if (user_ok) {
-                    const float *src = user_rows + uid * ldu + 16 * st + 8 * h;
-                    lo = *reinterpret_cast<const float4 *>(src);
-                    hi = *reinterpret_cast<const float4 *>(src + 4);
+        for (int g = 0; g < NG; ++g) {
+            ex_ptr[g] = A.excl_col;
+            ex_pos[g] = 0; ex_end[g] = 0; ex_next[g] = kIdxNone; ex_after[g] = kIdxNone;
+            if (A.excl_rowptr && user_ok[g]) {
+                const int64_t r0 = A.excl_rowptr[uid[g]];
+                ex_ptr[g] = A.excl_col + r0;
+                ex_end[g] = (int)(A.excl_rowptr[uid[g] + 1] - r0);
+                int lo = 0, hi = ex_end[g];
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (ex_ptr[g][mid] < item_lo) lo = mid + 1; else hi = mid;
                 }
-                float4 planes[3];
-                split3_x8(lo, hi, planes);
-                ub[0][st] = planes[0]; ub[1][st] = planes[1]; ub[2][st] = planes[2];
+                ex_pos[g] = lo;
+                if (lo < ex_end[g]) ex_next[g] = ex_ptr[g][lo];
+                if (lo + 1 < ex_end[g]) ex_after[g] = ex_ptr[g][lo + 1];
             }
         }
 
-        // exclusion cursor: first excluded item >= item_lo; the entry after it is already on its way
-        const int32_t *ex_ptr = excl_col;
-        int ex_pos = 0, ex_end = 0, ex_next = kIdxNone, ex_after = kIdxNone;
-        if (excl_rowptr && user_ok) {
-            const int64_t r0 = excl_rowptr[uid];
-            ex_ptr = excl_col + r0;
-            ex_end = (int)(excl_rowptr[uid + 1] - r0);
-            int lo = 0, hi = ex_end;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (ex_ptr[mid] < item_lo) lo = mid + 1; else hi = mid;
-            }
-            ex_pos = lo;
-            if (ex_pos < ex_end) ex_next = ex_ptr[ex_pos];
-            if (ex_pos + 1 < ex_end) ex_after = ex_ptr[ex_pos + 1];
-        }
-
-        // running top-k: per-lane min-heap of sortable keys in LDS; root (= k-th best so far) in registers.
-        // Key 0 = empty slot: ranks below every real entry, masked (-inf) ones included.
+        // running top-k: one min-heap of sortable keys per user in LDS, owned by one lane; its root (= the user's
+        // k-th best so far) in the owner's registers.  Key 0 = empty slot: ranks below every real entry, masked
+        // (-inf) ones included.
         for (int s = 0; s < k; ++s) heap[s * kWave] = 0ull;
         unsigned long long root = 0ull;
-        float thr = -INFINITY;                                   // score part of the root
-        int cnt = 0;                                             // staged candidates of this lane
+        float thr[NG];                                           // k-th best score of user (g, j): the same in both lanes of a user
+        int cnt[NG];                                             // staged candidates of this lane, per group
+        unsigned stage_addr[NG];                                 // LDS byte address of this lane's first staging slot
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            // a lane without a user (past the end of the batch) never has a candidate: its zero embedding would
+            // otherwise tie every score with its threshold and flood the staging lists
+            thr[g] = user_ok[g] ? -INFINITY : INFINITY;
+            cnt[g] = 0;
+            stage_addr[g] = (unsigned)(uintptr_t)(stage_all + (g * cap) * kWave + lane);
+        }
 
-        // staged candidates -> heap, all lanes together
+        unsigned exm[NG];                                        // mask bits of the current tile (see build_masks)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) exm[g] = 0u;
+        bool mflag = false;
+
+        // staged candidates -> heaps: every owner lane drains the two lists of its user (lane halves 0 and 1)
         auto flush = [&]() {
+#ifdef IGCN_TOPK_STATS
+            const unsigned long long t_in = IGCN_CLOCK();
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");  // the hand-written staging stores
-            const int n = cnt;
-            cnt = 0;
+            int n0, n1;
+            if constexpr (NG == 2) {
+                const int a0 = __shfl(cnt[0], j), a1 = __shfl(cnt[0], j + 32);
+                const int b0 = __shfl(cnt[1], j), b1 = __shfl(cnt[1], j + 32);
+                n0 = h ? b0 : a0;
+                n1 = h ? b1 : a1;
+            } else {
+                n0 = __shfl(cnt[0], j);
+                n1 = __shfl(cnt[0], j + 32);
+                if (!owner) n0 = n1 = 0;
+            }
+            const unsigned long long *l0 = stage_all + (own_g * cap) * kWave + j;
+            const int n = n0 + n1;
+            IGCN_STAT(3, 1);
             for (int i = 0; __any(i < n); ++i) {
+                IGCN_STAT(4, 1);
                 if (i < n) {
-                    const unsigned long long raw = stage[i * kWave];
+                    IGCN_STAT(5, 1);
+                    const unsigned long long raw = i < n0 ? l0[i * kWave] : l0[(i - n0) * kWave + 32];
                     const unsigned long long cand = make_key(__uint_as_float((unsigned int)raw), (int)(raw >> 32));
                     if (cand > root) root = heap_replace_root(heap, k, cand);
                 }
             }
-            thr = root ? key_score(root) : -INFINITY;            // list not full yet: everything may enter
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                cnt[g] = 0;
+                const unsigned long long r = heap_base[g * 32 + j];     // root of user (g, j), kept by lane g * 32 + j
+                thr[g] = !user_ok[g] ? INFINITY : r ? key_score(r) : -INFINITY;   // list not full yet: everything may enter
+            }
+#ifdef IGCN_TOPK_STATS
+            asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(thr[0]) : "memory");
+            st_7 += IGCN_CLOCK() - t_in;
+#endif
         };
 
         // A operand: item row of this lane, k-slice of its half.  Address = uniform tile base (scalar
         // registers, advanced by scalar adds) + a lane offset that never changes, so a tile's loads
         // cost no vector ALU work.  Rows past the end of the table are clamped (and masked below).
-        const int lane_off = j * (int)ldi + 4 * h;
-        int lane_off_last = lane_off;                            // for the ragged last tile of the table
+        const unsigned lane_off = (unsigned)(j * (int)ldi + 4 * h) * 4u;       // bytes
+        unsigned lane_off_last = lane_off;                       // for the ragged last tile of the table
         {
             const int64_t last_base = (int64_t)(n_tiles - 1) * 32;
-            if (last_base + j >= n_items) lane_off_last = (int)(n_items - 1 - last_base) * (int)ldi + 4 * h;
+            if (last_base + j >= n_items) lane_off_last = (unsigned)((int)(n_items - 1 - last_base) * (int)ldi + 4 * h) * 4u;
         }
-        float4 a[MODE == 0 ? D / 8 : 12];                        // MODE 1: [plane * 4 + k-step], 8 bf16 each
-        auto tile_addr = [&](int t, const float *&tile_ptr, int &off) {
-            tile_ptr = item_rows + (int64_t)t * 32 * ldi;
+        // Two A buffers at d <= 64 (registers allow it): the loads of the tile after next are issued at the START of
+        // a block into the buffer the block does not use, so they have a whole block to land and nothing the
+        // bookkeeping between two blocks waits for (vmcnt counts in order) is ever behind a load just issued.
+        // At d = 128 one buffer: each piece is re-loaded as soon as the block has consumed it.
+        constexpr bool kTwoBuffers = D <= 64;
+        float4 a[D / 8], a2[kTwoBuffers ? D / 8 : 1];
+        auto tile_addr = [&](int t, const char *&tile_ptr, unsigned &off) {
+            tile_ptr = reinterpret_cast<const char *>(A.item_rows + (int64_t)t * 32 * ldi);
             off = t == n_tiles - 1 ? lane_off_last : lane_off;
         };
-        auto load_a = [&](int t) {
-            if constexpr (MODE == 0) {
-                const float *tile_ptr; int off;
-                tile_addr(t, tile_ptr, off);
+        auto load_into = [&](float4 (&buf)[D / 8], int t) {
+            const char *tile_ptr; unsigned off;
+            tile_addr(t, tile_ptr, off);
 #pragma unroll
-                for (int q = 0; q < D / 8; ++q)
-                    a[q] = (FULL || 8 * q + 4 * h < d) ? *reinterpret_cast<const float4 *>(tile_ptr + off + 8 * q) : f4_zero();
-            } else {
-                // planes 2, 1, 0 — the order in which the pipelined block re-loads them: the compiler sizes the
-                // s_waitcnt before each MFMA for the worse of the two ways into the block, and with the planes in
-                // storage order here it waited for all but the last 3 loads at the top of every block (+25 % time)
-                const float4 *pk = packed + (int64_t)t * 12 * kWave + lane;
-#pragma unroll
-                for (int pl = 2; pl >= 0; --pl)
-#pragma unroll
-                    for (int st = 0; st < 4; ++st) a[pl * 4 + st] = pk[(pl * 4 + st) * kWave];
-            }
+            for (int q = 0; q < D / 8; ++q)
+                buf[q] = (FULL || 8 * q + 4 * h < A.d) ? *reinterpret_cast<const float4 *>(tile_ptr + off + 32 * q) : f4_zero();
         };
-        // MODE 1: the six plane products, smallest first: (item plane, user plane)
-        constexpr int kTermA[6] = {2, 1, 0, 1, 0, 0};
-        constexpr int kTermB[6] = {0, 1, 2, 0, 1, 0};
-        // the whole chain of one tile, nothing interleaved (prologue of a piece)
-        auto chain_plain = [&](f32x16 &acc) {
+        auto load_a = [&](int t) { load_into(a, t); };
+        // the chains of one tile, nothing interleaved (prologue of a piece)
+        auto chain_plain = [&](f32x16 (&acc)[NG]) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-            if constexpr (MODE == 0) {
+            for (int g = 0; g < NG; ++g)
 #pragma unroll
-                for (int q = 0; q < D / 8; ++q) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bfrag[4 * q + 0], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bfrag[4 * q + 1], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bfrag[4 * q + 2], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bfrag[4 * q + 3], acc, 0, 0, 0);
+                for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+#pragma unroll
+            for (int q = 0; q < D / 8; ++q) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bfrag[g][4 * q + 0], acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bfrag[g][4 * q + 1], acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bfrag[g][4 * q + 2], acc[g], 0, 0, 0);
+                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bfrag[g][4 * q + 3], acc[g], 0, 0, 0);
                 }
-            } else {
-#pragma unroll
-                for (int tm = 0; tm < 6; ++tm)
-#pragma unroll
-                    for (int st = 0; st < 4; ++st)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[kTermA[tm] * 4 + st]), as_bf16x8(ub[kTermB[tm]][st]), acc, 0, 0, 0);
             }
         };
 
         // ---- the parts of a tile's bookkeeping ------------------------------------------------------
-        // masks of tile t on its scores (rare events, branches): ragged end, exclusion cursor, banned items
-        auto mask_tile = [&](f32x16 &acc, int tile_base) {
-            // rows past the end of the piece: NaN = "already examined", never a candidate
+        // Masks of a tile (ragged end of the piece, banned items, the users' exclusion cursors) never touch the
+        // accumulators: they are collected as one bit per item in exm[g], already shifted so that bit
+        // (r & 3) + 8 (r >> 2) belongs to register r of this lane, and are honoured when a row is staged (a masked
+        // row goes in as -inf, so it can only fill a list that has fewer than k real entries).  A masked item with a
+        // high score costs one needless look at its quad, nothing else.  mflag (wave-uniform): some exm is non-zero.
+        auto build_masks = [&](int tile, int tile_base) {
+#ifdef IGCN_TOPK_STATS
+            const unsigned long long t_m = IGCN_CLOCK();
+#endif
+            if (mflag) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) exm[g] = 0u;
+                mflag = false;
+            }
             if (tile_base + 32 > item_hi) {                        // ragged last tile (wave-uniform)
-                asm volatile("; ragged tile");                     // (a real branch: the common path skips all of this)
+                const unsigned beyond = item_hi > tile_base ? ~0u << (item_hi - tile_base) : ~0u;
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (tile_base + row_of(r, h) >= item_hi) acc[r] = kNaN;
+                for (int g = 0; g < NG; ++g) exm[g] |= beyond >> (4 * h);
+                mflag = true;
             }
-            if (excl_rowptr) {
+            if (A.banned_bits) {
+                const unsigned bm = A.banned_bits[tile];          // wave-uniform: one scalar load per tile
+                if (bm) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) exm[g] |= bm >> (4 * h);
+                    mflag = true;
+                }
+            }
+            if (A.excl_rowptr) {
                 const int tile_end = tile_base + 32;
-                while (true) {
-                    const bool need = ex_next < tile_end;
-                    if (!__any(need)) break;
-                    if (need) {
-                        const int rl = ex_next - tile_base;          // 0..31
-                        if (((rl >> 2) & 1) == h) {
-                            const int rr = (rl & 3) + 4 * (rl >> 3);
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[r] = (r == rr) ? -INFINITY : acc[r];
-                        }
-                        ++ex_pos;
-                        ex_next = ex_after;
-                        ex_after = ex_pos + 1 < ex_end ? ex_ptr[ex_pos + 1] : kIdxNone;
+                for (int g = 0; g < NG; ++g) {
+                    bool need = ex_next[g] < tile_end;
+                    if (__any(need)) {
+                        mflag = true;
+                        do {
+                            if (need) {
+                                exm[g] |= (1u << (ex_next[g] - tile_base)) >> (4 * h);
+                                ++ex_pos[g];
+                                ex_next[g] = ex_after[g];
+                                ex_after[g] = ex_pos[g] + 1 < ex_end[g] ? ex_ptr[g][ex_pos[g] + 1] : kIdxNone;
+                            }
+                            need = ex_next[g] < tile_end;
+                        } while (__any(need));
                     }
                 }
             }
-            if (banned) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int it = tile_base + 8 * g + 4 * h + c;
-                        if (it < item_hi && banned[it]) acc[4 * g + c] = -INFINITY;
-                    }
-                }
-            }
-        };
-        // candidates of a tile -> staging slots, straight-line (predicated LDS writes, no branches), so
-        // that it can be scheduled between the MFMAs of the NEXT tile's chain: while the matrix pipe of
-        // a SIMD works on a wave's MFMA, the only instructions that issue are that same wave's own
-        // independent ones (scripts/probes/mfma_valu_overlap_probe.hip).  Returns whether a lane had a
-        // candidate but no free slot (those scores stay unmarked for stage_rows_slow).
-        // One row of the fast staging: write (score, item id) to the lane's next free staging slot; a
-        // candidate then advances the slot counter.  No branch, no select on the address: slots past
-        // `cap` all map to one spare slot.  A lane that ran past it lost candidates; the caller then
-        // discards this tile's staged entries and redoes the tile the slow way.
-        unsigned int *const stage32 = reinterpret_cast<unsigned int *>(stage);
-        const unsigned stage_base = (unsigned)(uintptr_t)stage;  // LDS byte address of this lane's first staging slot
-        auto stage_row_fast = [&](float sc, int item, int &slot) {
-            // 5 vector instructions and one LDS write per row (everything a wave issues besides MFMAs costs
-            // matrix-pipe time on this chip, scripts/probes/mfma_shadow_probe.hip): clamp, address, item id,
-            // compare, add-with-carry.  The store is written as ds_write2_b32 by hand: the compiler would
-            // build a register pair with a move for ds_write_b64.  flush() waits for these stores itself.
-#ifdef IGCN_X_NOSTAGE
-            if (sc == 12345.f) slot += item;
-#else
-            const unsigned w = stage_base + (unsigned)(slot < cap ? slot : cap) * (unsigned)(kWave * 8);
-            asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" : : "v"(w), "v"(sc), "v"(item) : "memory");
-            slot += sc >= thr ? 1 : 0;
-            asm volatile("" : "+v"(slot));                       // one add-with-carry per row, no re-association
+#ifdef IGCN_TOPK_STATS
+            asm volatile("" : : "v"(exm[0]) : "memory");
+            st_10 += IGCN_CLOCK() - t_m;
 #endif
         };
-        // the same with flushes in between, for a tile that overflowed some lane's staging slots
-        auto stage_rows_slow = [&](f32x16 &acc, int tile_base) {
-            bool full;
-            do {
+        // One part of the selection of group g, quad q4 (rows 4 q4 .. 4 q4 + 3 of the lane): s = 0, 1 fold the
+        // quad's maximum, s = 2 compares it with the user's threshold into a wave-wide mask (scalar registers).
+        float qmax[NG];
+        unsigned long long qmask[NG][kQuad];
+#ifdef IGCN_X_NOSELECT
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float sc = acc[r];
-                    const bool take = sc >= thr;
-                    if (__any(take)) {                           // a row without candidates costs a compare and a branch
-                        asm volatile("; row with candidates");
-                        if (take && cnt < cap) {
-                            stage[cnt * kWave] = ((unsigned long long)(unsigned int)(tile_base + row_of(r, h)) << 32) | __float_as_uint(sc);
-                            ++cnt;
-                            acc[r] = kNaN;
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int q4 = 0; q4 < kQuad; ++q4) qmask[g][q4] = 0ull;
+#endif
+        auto select_part = [&](const f32x16 &cur, int g, int q4, int s) {
+            if (s == 0) qmax[g] = vmax3(cur[4 * q4], cur[4 * q4 + 1], cur[4 * q4 + 2]);
+            else if (s == 1) qmax[g] = vmax2(qmax[g], cur[4 * q4 + 3]);
+            else qmask[g][q4] = __builtin_amdgcn_fcmpf(qmax[g], thr[g], 3 /* oge */);
+        };
+        // The four rows of a quad that holds a candidate -> staging: (score, item id) goes to the lane's next free
+        // staging slot whether it is a candidate or not; a candidate then advances the slot counter.  No branch.
+        // The store is written as ds_write2_b32 by hand: the compiler would build a register pair with a move
+        // for ds_write_b64.  flush() waits for these stores itself.  The caller has made sure of 4 free slots.
+        auto stage_quad = [&](const f32x16 &cur, int g, int q4, int item_h, bool masks) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                float sc = cur[4 * q4 + rr];
+                if (masks && ((exm[g] >> (8 * q4 + rr)) & 1u)) sc = -INFINITY;
+                const int item = item_h + 8 * q4 + rr;
+                const unsigned w = stage_addr[g] + ((unsigned)cnt[g] << 9);
+                asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" : : "v"(w), "v"(sc), "v"(item) : "memory");
+                cnt[g] += sc >= thr[g] ? 1 : 0;
+            }
+        };
+        // after a tile's selection: the quads with candidates, in order, each behind a scalar branch on its mask,
+        // draining the staging lists first whenever some lane has fewer than 4 free slots
+        auto stage_hits = [&](f32x16 (&cur)[NG], int tile_base) {
+            IGCN_STAT(0, 1);
+#ifdef IGCN_TOPK_STATS
+            const unsigned long long t_hits = IGCN_CLOCK();
+#endif
+#ifdef IGCN_X_NOHITS
+            if (tile_base != 0x7fffff00) return;                 // developer ablation build (never shipped)
+#endif
+            unsigned long long any = 0ull;
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int q4 = 0; q4 < kQuad; ++q4) any |= qmask[g][q4];
+            if (!any) return;
+            IGCN_STAT(1, 1);
+            if (prio_boost) __builtin_amdgcn_s_setprio(3);
+            const int item_h = tile_base + 4 * h;
+            auto run = [&](auto masks_c) {
+                constexpr bool masks = decltype(masks_c)::value;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                    for (int q4 = 0; q4 < kQuad; ++q4) {
+                        if (qmask[g][q4]) {
+                            IGCN_STAT(2, 1);
+#ifdef IGCN_X_NOFLUSH
+                            cnt[g] = cnt[g] > cap - 4 ? cap - 4 : cnt[g];        // developer ablation: wrong results, no drain
+#else
+                            if (__any(cnt[g] > cap - 4)) flush();
+#endif
+                            stage_quad(cur[g], g, q4, item_h, masks);
                         }
                     }
                 }
-                full = __any(cnt >= cap);                        // a full lane may have left candidates behind
-                if (full) flush();
-            } while (full);
+            };
+            if (mflag) run(std::true_type{}); else run(std::false_type{});
+            if (prio_boost) set_base_priority(prio_slot);
+#ifdef IGCN_TOPK_STATS
+            asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(cnt[0]) : "memory");
+            st_8 += IGCN_CLOCK() - t_hits;
+#endif
         };
-        // One step of the software pipeline: `cur` holds the raw scores of tile t, a[] the A operand of
-        // tile t+1.  The chain of tile t+1 (into `nxt`), the loads of tile t+2 (each a[q] as soon as the
-        // chain has consumed it) and the staging of tile t's candidates are ONE basic block.
-        auto tile_step = [&](f32x16 &cur, f32x16 &nxt, int tile) {
+        // One step of the software pipeline: `cur` holds the raw scores of tile t, a[] the A operand of tile
+        // t+1.  The chains of tile t+1 (into `nxt`), the loads of tile t+2 (each a[q] as soon as the chains have
+        // consumed it) and the selection of tile t are ONE basic block, its schedule written out by hand and
+        // pinned (sched_barrier after every MFMA).
+        auto tile_step = [&](f32x16 (&cur)[NG], f32x16 (&nxt)[NG], float4 (&ause)[D / 8], float4 (&aload)[D / 8], int tile) {
             const int tile_base = tile * 32;
-            mask_tile(cur, tile_base);
-            const int item_h = tile_base + 4 * h;
-            int slot = cnt;
+            build_masks(tile, tile_base);
+            constexpr int kSlots = (D / 2) * NG;                  // MFMAs of the block
+            constexpr int kParts = 3 * kQuad * NG;                // selection instructions of the block
+            constexpr int kFirst = 4;                             // the first ones wait until the previous block's MFMAs have long retired
             if (tile + 1 < tin1) {
-                const float *tile_ptr = nullptr; int off = 0;
-                if constexpr (MODE == 0) tile_addr(tile + 2 < tin1 ? tile + 2 : tin1 - 1, tile_ptr, off);   // (re-reads the last tile at the end)
+                const char *tile_ptr = nullptr; unsigned off = 0;
+                tile_addr(tile + 2 < tin1 ? tile + 2 : tin1 - 1, tile_ptr, off);   // (re-reads the last tile at the end)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) nxt[r] = 0.f;
-                // The schedule is written out by hand and pinned (sched_barrier after every MFMA): each MFMA of
-                // the next tile's chain is followed by its share of this tile's 16 staging rows, and every
-                // a[q] is re-loaded for the tile after next as soon as its four MFMAs have issued.
-                if constexpr (MODE == 1) {
-                    // 24 bf16 MFMAs; a staging row after each of the first 16 (the bf16 MFMA, unlike the fp32 one,
-                    // has a shadow of ~5 vector instructions: scripts/probes/mfma_bf16_shadow_probe.hip); every
-                    // item plane register is re-loaded for the tile after next right after its last use
-                    const float4 *pk = packed + (int64_t)(tile + 2 < tin1 ? tile + 2 : tin1 - 1) * 12 * kWave + lane;
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int g = 0; g < NG; ++g)
 #pragma unroll
-                    for (int tm = 0; tm < 6; ++tm) {
+                    for (int r = 0; r < 16; ++r) nxt[g][r] = 0.f;
+                if constexpr (kTwoBuffers) {
 #pragma unroll
-                        for (int st = 0; st < 4; ++st) {
-                            const int m = tm * 4 + st;
-                            const int ai = kTermA[tm] * 4 + st;
-                            nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[ai]), as_bf16x8(ub[kTermB[tm]][st]), nxt, 0, 0, 0);
-                            if (m < 16) stage_row_fast(cur[m], item_h + row_of(m, 0), slot);
+                    for (int q = 0; q < D / 8; ++q)
+                        aload[q] = (FULL || 8 * q + 4 * h < A.d) ? *reinterpret_cast<const float4 *>(tile_ptr + off + 32 * q) : f4_zero();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < D / 8; ++q) {
+                    const float4 aq = ause[q];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float av = c == 0 ? aq.x : c == 1 ? aq.y : c == 2 ? aq.z : aq.w;
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) {
+                            nxt[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bfrag[g][4 * q + c], nxt[g], 0, 0, 0);
+                            const int slot = (4 * q + c) * NG + g;
+#ifndef IGCN_X_NOSELECT
+                            if (slot >= kFirst) {
+                                const int p0 = (slot - kFirst) * kParts / (kSlots - kFirst);
+                                const int p1 = (slot - kFirst + 1) * kParts / (kSlots - kFirst);
+#pragma unroll
+                                for (int p = 0; p < kParts; ++p)
+                                    if (p >= p0 && p < p1) {
+                                        const int pg = p % NG, pp = p / NG;
+                                        select_part(cur[pg], pg, pp / 3, pp % 3);
+                                    }
+                            }
+#endif
 #ifndef IGCN_X_NOLOADA
-                            if (tm == 0 || tm == 3 || tm == 5) a[ai] = pk[ai * kWave];   // last use of planes 2, 1, 0
+                            if (!kTwoBuffers && c == 3 && g == NG - 1)
+                                aload[q] = (FULL || 8 * q + 4 * h < A.d) ? *reinterpret_cast<const float4 *>(tile_ptr + off + 32 * q) : f4_zero();
 #endif
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
-                } else {
-                constexpr int RPG = 128 / D;                     // staging rows per group of four MFMAs (D = 64: 2)
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < D / 8; ++q) {
-                    const float4 aq = a[q];
-                    nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(aq.x, bfrag[4 * q + 0], nxt, 0, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < (RPG + 3) / 4; ++i)
-                        if (RPG * q + i < 16 && i < RPG) stage_row_fast(cur[RPG * q + i], item_h + row_of(RPG * q + i, 0), slot);
-                    __builtin_amdgcn_sched_barrier(0);
-                    nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(aq.y, bfrag[4 * q + 1], nxt, 0, 0, 0);
-#pragma unroll
-                    for (int i = (RPG + 3) / 4; i < (RPG + 1) / 2; ++i)
-                        if (i < RPG) stage_row_fast(cur[RPG * q + i], item_h + row_of(RPG * q + i, 0), slot);
-                    __builtin_amdgcn_sched_barrier(0);
-                    nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(aq.z, bfrag[4 * q + 2], nxt, 0, 0, 0);
-#pragma unroll
-                    for (int i = (RPG + 1) / 2; i < (3 * RPG + 3) / 4; ++i)
-                        if (i < RPG) stage_row_fast(cur[RPG * q + i], item_h + row_of(RPG * q + i, 0), slot);
-                    __builtin_amdgcn_sched_barrier(0);
-                    nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(aq.w, bfrag[4 * q + 3], nxt, 0, 0, 0);
-#pragma unroll
-                    for (int i = (3 * RPG + 3) / 4; i < RPG; ++i)
-                        stage_row_fast(cur[RPG * q + i], item_h + row_of(RPG * q + i, 0), slot);
-                    a[q] = (FULL || 8 * q + 4 * h < d) ? *reinterpret_cast<const float4 *>(tile_ptr + off + 8 * q) : f4_zero();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
                 }
             } else {
+                // last tile of the piece: no chain to hide behind; the MFMA results must have landed (the compiler
+                // does not see the hand-written instructions' operands as MFMA results)
+                asm volatile("s_nop 15\n\ts_nop 15" : : : "memory");
 #pragma unroll
-                for (int r = 0; r < 16; ++r) stage_row_fast(cur[r], item_h + row_of(r, 0), slot);
+                for (int p = 0; p < kParts; ++p) {
+                    const int pg = p % NG, pp = p / NG;
+                    select_part(cur[pg], pg, pp / 3, pp % 3);
+                }
             }
-            if (__any(slot > cap)) {
-                asm volatile("; staging overflow");
-                flush();                                         // cnt still excludes this tile's entries
-                stage_rows_slow(cur, tile_base);
-            } else {
-                cnt = slot;
-                if (__any(cnt >= cap)) flush();
-            }
-#ifdef IGCN_TOPK_TRACE
-            ++tr_tiles;
-#endif
+            stage_hits(cur, tile_base);
         };
 
         // prologue: scores of the first tile, A operand of the second
-        f32x16 acc_a, acc_b;
+        f32x16 acc_a[NG], acc_b[NG];
         load_a(tin0);
         chain_plain(acc_a);
         if (tin0 + 1 < tin1) load_a(tin0 + 1);
         for (int tile = tin0; tile < tin1; tile += 2) {
-            tile_step(acc_a, acc_b, tile);
-            if (tile + 1 < tin1) tile_step(acc_b, acc_a, tile + 1);
+            if constexpr (kTwoBuffers) {
+                tile_step(acc_a, acc_b, a, a2, tile);
+                if (tile + 1 < tin1) tile_step(acc_b, acc_a, a2, a, tile + 1);
+            } else {
+                tile_step(acc_a, acc_b, a, a, tile);
+                if (tile + 1 < tin1) tile_step(acc_b, acc_a, a, a, tile + 1);
+            }
         }
         flush();
 
-        // ---- emit: heapsort each lane's list in place (best first), then either merge the two lanes
-        // of a user into the output or hand both lists to the merge kernel ------------------------
+        // ---- emit: every owner lane heapsorts its user's list in place (best first) and writes it to the
+        // output, or to the workspace when the user's sweep was cut into pieces ----------------------
         for (int n = k - 1; n > 0; --n) {
             const unsigned long long last = heap[n * kWave];
             heap[n * kWave] = heap[0];                           // current minimum goes to the end
             heap_replace_root(heap, n, last);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (direct) {
-            if (h == 0 && user_ok) {
-                const unsigned long long *pheap = heap + 32;     // partner lane (l + 32), same wave
-                int i0 = 0, i1 = 0;
-                unsigned long long k0 = heap[0], k1 = pheap[0];
+        const int64_t b_own = group * UPW + lane;                // owner lane l keeps user l of the wave-group
+        if (owner && b_own < A.batch) {
+            if (direct) {
                 for (int r = 0; r < k; ++r) {
-                    unsigned long long best;
-                    if (k0 >= k1) { best = k0; ++i0; k0 = i0 < k ? heap[i0 * kWave] : 0ull; }
-                    else          { best = k1; ++i1; k1 = i1 < k ? pheap[i1 * kWave] : 0ull; }
-                    out_idx[b * k + r] = best ? key_item(best) : -1;
-                    out_val[b * k + r] = best ? key_score(best) : -INFINITY;
+                    const unsigned long long key = heap[r * kWave];
+                    A.out_idx[b_own * k + r] = key ? key_item(key) : -1;
+                    A.out_val[b_own * k + r] = key ? key_score(key) : -INFINITY;
                 }
-            }
-        } else if (user_ok) {
-            const int64_t slot = ((b - n_full * 32) * (2 * p_max) + 2 * pidx + h) * k;
-            for (int r = 0; r < k; ++r) {
-                const unsigned long long key = heap[r * kWave];
-                ws_val[slot + r] = key ? key_score(key) : -INFINITY;
-                ws_idx[slot + r] = key ? key_item(key) : kIdxNone;
+            } else {
+                const int64_t slot = ((b_own - n_full * UPW) * A.p_max + pidx) * k;
+                for (int r = 0; r < k; ++r) {
+                    const unsigned long long key = heap[r * kWave];
+                    A.ws_val[slot + r] = key ? key_score(key) : -INFINITY;
+                    A.ws_idx[slot + r] = key ? key_item(key) : kIdxNone;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
-#ifdef IGCN_TOPK_TRACE
-    if (lane == 0) {
-        atomicAdd(&g_topk_trace[0], tr_load); atomicAdd(&g_topk_trace[1], tr_chain);
-        atomicAdd(&g_topk_trace[2], tr_mask); atomicAdd(&g_topk_trace[3], tr_sel);
-        atomicAdd(&g_topk_trace[4], trace_clock(0) - tr_begin); atomicAdd(&g_topk_trace[5], tr_tiles);
-        atomicAdd(&g_topk_trace[6], 1ull);
-        unsigned long long tr_rt_end;
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr_rt_end) : : "memory");
-        atomicAdd(&g_topk_trace[7], tr_rt_end - tr_rt_begin);      // wave lifetime in 100 MHz ticks
-        if (blockIdx.x < 8192) {
-            g_topk_wave_times[4 * blockIdx.x] = tr_rt_begin; g_topk_wave_times[4 * blockIdx.x + 1] = tr_rt_end;
-            g_topk_wave_times[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
-            g_topk_wave_times[4 * blockIdx.x + 3] = 0;
+#ifdef IGCN_TOPK_STATS
+    {
+        // st_5 is per lane (staged candidates this owner lane drained): sum over the wave
+        unsigned long long c5 = st_5;
+        for (int off = 32; off > 0; off >>= 1) c5 += __shfl_xor(c5, off);
+        if (lane == 0) {
+            atomicAdd(&g_topk_stats[0], st_0); atomicAdd(&g_topk_stats[1], st_1); atomicAdd(&g_topk_stats[2], st_2);
+            atomicAdd(&g_topk_stats[3], st_3); atomicAdd(&g_topk_stats[4], st_4); atomicAdd(&g_topk_stats[5], c5);
+            atomicAdd(&g_topk_stats[6], 1ull);
+            atomicAdd(&g_topk_stats[7], st_7); atomicAdd(&g_topk_stats[8], st_8);
+            atomicAdd(&g_topk_stats[9], IGCN_CLOCK() - st_begin); atomicAdd(&g_topk_stats[10], st_10);
+            atomicAdd(&g_topk_stats[11], __builtin_amdgcn_s_memrealtime() - st_rt_begin);   // 100 MHz ticks
+            if (blockIdx.x < 4096) {
+                g_topk_wave_times[3 * blockIdx.x] = st_rt_begin;
+                g_topk_wave_times[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+                g_topk_wave_times[3 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+            }
         }
     }
 #endif
 }
 
-// One wave per user of the groups that were cut: lane = one (piece, lane half) list, already
-// best-first; k rounds of a wave-wide arg-best over the heads.
+// One wave per user of the groups that were cut: lane = one piece's list, already best-first; k rounds of a
+// wave-wide arg-best over the heads.
 __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restrict__ ws_val, const int32_t *__restrict__ ws_idx,
                                                             int64_t first_user, int64_t batch, int n_tiles, int64_t run,
-                                                            int p_max, int k,
+                                                            int p_max, int k, int upw,
                                                             int64_t *__restrict__ out_idx, float *__restrict__ out_val)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t rb = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
     const int64_t b = first_user + rb;
     if (b >= batch) return;
-    const int64_t rg = rb / 32;
-    const int n_splits = 2 * (int)((((rg + 1) * n_tiles - 1) / run) - (rg * n_tiles) / run + 1);
-    const float *v = ws_val + (rb * (2 * p_max) + lane) * k;
-    const int32_t *ix = ws_idx + (rb * (2 * p_max) + lane) * k;
+    const int64_t rg = rb / upw;
+    const int n_lists = (int)((((rg + 1) * n_tiles - 1) / run) - (rg * n_tiles) / run + 1);
+    const bool live = lane < n_lists;
+    const float *v = ws_val + (rb * p_max + (live ? lane : 0)) * k;
+    const int32_t *ix = ws_idx + (rb * p_max + (live ? lane : 0)) * k;
     int cur = 0;
     float hv = -INFINITY;
     int hi = kIdxNone;
-    if (lane < n_splits) { hv = v[0]; hi = ix[0]; }
+    if (live) { hv = v[0]; hi = ix[0]; }
     for (int r = 0; r < k; ++r) {
         float bv = hv;
         int bi = hi, bl = lane;
@@ -702,10 +717,25 @@ __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restr
             if (ranks_before(ov, oi, bv, bi) || (ov == bv && oi == bi && ol < bl)) { bv = ov; bi = oi; bl = ol; }
         }
         if (lane == 0) { out_idx[b * k + r] = bi == kIdxNone ? -1 : bi; out_val[b * k + r] = bv; }
-        if (lane == bl && lane < n_splits) {
+        if (lane == bl && live) {
             ++cur;
             if (cur < k) { hv = v[cur]; hi = ix[cur]; } else { hv = -INFINITY; hi = kIdxNone; }
         }
+    }
+}
+
+// banned uint8 [n_items] -> one bit per item, one 32-bit word per 32-item tile
+__global__ __launch_bounds__(kBlock) void topk_pack_banned_kernel(const uint8_t *__restrict__ banned, int64_t n_items, int n_tiles,
+                                                                  uint32_t *__restrict__ bits)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t pair = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);     // a wave packs two tiles
+    const int64_t item = pair * kWave + lane;
+    const bool b = item < n_items && banned[item] != 0;
+    const unsigned long long m = __ballot(b);
+    if (lane == 0) {
+        if (2 * pair < n_tiles) bits[2 * pair] = (uint32_t)m;
+        if (2 * pair + 1 < n_tiles) bits[2 * pair + 1] = (uint32_t)(m >> 32);
     }
 }
 
@@ -727,34 +757,31 @@ __global__ void hit_matrix_kernel(const int64_t *__restrict__ rec, int64_t n_use
     hit[i] = (lo < end && eval_col[lo] == item) ? 1.f : 0.f;
 }
 
-template <int D, bool FULL, int MODE = 0>
-static int launch_topk(const TopkPlan &p, hipStream_t st,
-                       const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
-                       const float *item_rows, int64_t ldi, int64_t n_items, int d,
-                       const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned, int k,
-                       int64_t *out_idx, float *out_val, float *ws_val, int32_t *ws_idx, const float4 *packed = nullptr)
+template <int D, int NG, bool FULL>
+static int launch_topk(const TopkPlan &p, hipStream_t st, const TopkArgs &args)
 {
-    auto kern = score_topk_kernel<D, FULL, MODE>;
+    auto kern = score_topk_kernel<D, NG, FULL>;
     static bool configured = false;
-    if (!configured && p.lds_bytes > 48 * 1024) {
+    if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)(64 * 1024));
+                                           (int)(160 * 1024));
         if (e != hipSuccess) return (int)e;
         configured = true;
     }
     if (p.units >= ((int64_t)1 << 31)) return IGCN_E_SHAPE;
-    const int stagger = env_int("IGCN_TOPK_STAGGER", 0, 1, 1);                          // developer knob
-    hipLaunchKernelGGL(kern, dim3((unsigned)p.units), dim3(kWave), p.lds_bytes, st, user_rows, ldu, user_ids, batch,
-                       item_rows, ldi, n_items, d, excl_rowptr, excl_col, banned, k, p.cap, p.n_tiles, p.n_whole,
-                       p.rest_tiles, p.run, p.p_max, stagger, out_idx, out_val, ws_val, ws_idx, packed);
+    hipLaunchKernelGGL(kern, dim3((unsigned)p.units), dim3(kWave), p.lds_bytes, st, args);
     return launch_status();
 }
 
 // users whose lists come back in pieces (rows of the workspace)
 static inline int64_t topk_rest_users(const TopkPlan &p, int64_t batch) {
     if (p.p_max <= 1) return 0;
-    const int64_t first = p.n_whole * p.units * 32;
+    const int64_t first = p.n_whole * p.units * 32 * p.ng;
     return batch > first ? batch - first : 0;
+}
+// the partial lists (fp32 score + int32 id per entry), rounded up so that what follows stays aligned
+static inline int64_t topk_merge_bytes(const TopkPlan &p, int64_t batch, int32_t k) {
+    return (topk_rest_users(p, batch) * p.p_max * k * 8 + 255) / 256 * 256;
 }
 
 }  // namespace igcn
@@ -765,7 +792,7 @@ extern "C" int64_t igcn_score_topk_workspace_bytes(int64_t batch, int64_t n_item
 {
     TopkPlan p;
     if (topk_make_plan(batch, n_items, d, k, &p) != IGCN_OK) return -1;
-    return topk_rest_users(p, batch) * 2 * p.p_max * k * 8;
+    return topk_merge_bytes(p, batch, k) + (int64_t)p.n_tiles * 4;       // + the banned items as one word per tile
 }
 
 extern "C" int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
@@ -781,104 +808,60 @@ extern "C" int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const in
     if (ldu < d || ldi < d || ldu % 4 || ldi % 4 || n_items >= ((int64_t)1 << 31) - 64 || ldi > (1 << 20)) return IGCN_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(user_rows) | reinterpret_cast<uintptr_t>(item_rows)) % 16) return IGCN_E_ALIGN;
     const int64_t rest_users = topk_rest_users(p, batch);
-    if (rest_users > 0 && !workspace) return IGCN_E_NULL;
+    if ((rest_users > 0 || banned) && !workspace) return IGCN_E_NULL;
+    if (workspace && reinterpret_cast<uintptr_t>(workspace) % 8) return IGCN_E_ALIGN;
     hipStream_t st = static_cast<hipStream_t>(stream);
     float *ws_val = static_cast<float *>(workspace);
-    int32_t *ws_idx = reinterpret_cast<int32_t *>(ws_val ? ws_val + rest_users * 2 * p.p_max * k : nullptr);
+    int32_t *ws_idx = reinterpret_cast<int32_t *>(ws_val ? ws_val + rest_users * p.p_max * k : nullptr);
+    uint32_t *banned_bits = nullptr;
+    if (banned) {
+        banned_bits = reinterpret_cast<uint32_t *>(static_cast<char *>(workspace) + topk_merge_bytes(p, batch, k));
+        const int64_t pairs = ((int64_t)p.n_tiles + 1) / 2;
+        hipLaunchKernelGGL(topk_pack_banned_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(kBlock), 0, st, banned, n_items,
+                           p.n_tiles, banned_bits);
+        rc = launch_status();
+        if (rc != IGCN_OK) return rc;
+    }
+    TopkArgs a{};
+    a.user_rows = user_rows; a.ldu = ldu; a.user_ids = user_ids; a.batch = batch;
+    a.item_rows = item_rows; a.ldi = ldi; a.n_items = n_items; a.d = (int)d;
+    a.excl_rowptr = excl_rowptr; a.excl_col = excl_col; a.banned_bits = banned_bits;
+    a.k = (int)k; a.cap = p.cap; a.n_tiles = p.n_tiles; a.p_max = p.p_max;
+    const int stagger = tuning_get(IGCN_TUNE_TOPK_STAGGER);
+    a.stagger = stagger < 0 ? 3 : stagger;                        // bit 0: base priority by wave slot, bit 1: boost in the slow path
+    a.n_whole = p.n_whole; a.rest_tiles = p.rest_tiles; a.run = p.run;
+    a.out_idx = out_idx; a.out_val = out_val; a.ws_val = ws_val; a.ws_idx = ws_idx;
 
-#define IGCN_TOPK_CASE(DD)                                                                                        \
-    rc = (d == DD ? launch_topk<DD, true> : launch_topk<DD, false>)(                                             \
-        p, st, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, (int)d, excl_rowptr, excl_col, banned,   \
-        (int)k, out_idx, out_val, ws_val, ws_idx, nullptr)
     switch (p.d_pad) {
-    case 16: IGCN_TOPK_CASE(16); break;
-    case 32: IGCN_TOPK_CASE(32); break;
-    case 64: IGCN_TOPK_CASE(64); break;
-    default: IGCN_TOPK_CASE(128); break;
+    case 16: rc = d == 16 ? launch_topk<16, 2, true>(p, st, a) : launch_topk<16, 2, false>(p, st, a); break;
+    case 32: rc = d == 32 ? launch_topk<32, 2, true>(p, st, a) : launch_topk<32, 2, false>(p, st, a); break;
+    case 64: rc = d == 64 ? launch_topk<64, 2, true>(p, st, a) : launch_topk<64, 2, false>(p, st, a); break;
+    default: rc = d == 128 ? launch_topk<128, 1, true>(p, st, a) : launch_topk<128, 1, false>(p, st, a); break;
     }
-#undef IGCN_TOPK_CASE
     if (rc != IGCN_OK) return rc;
     if (rest_users > 0) {
         const int64_t blocks = (rest_users + 3) / 4;
         hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, ws_val, ws_idx,
-                           p.n_whole * p.units * 32, batch, p.n_tiles, p.run, p.p_max, (int)k, out_idx, out_val);
+                           p.n_whole * p.units * 32 * p.ng, batch, p.n_tiles, p.run, p.p_max, (int)k, 32 * p.ng, out_idx, out_val);
         rc = launch_status();
     }
     return rc;
 }
 
-// ---- the same evaluation with the products on the bf16 matrix cores (exact 3-way bf16 split of both operands,
-// 6 of the 9 plane products, fp32 accumulation): fp32-grade scores (products to 2^-23), ~2.5x the throughput, but
-// not the bit pattern of the fp32 fmaf chain.  d = 64 only.  Workspace = merge lists + the packed item planes.
-static inline int64_t topk_split_packed_bytes(int64_t n_items) { return (n_items + 31) / 32 * 12 * kWave * 16; }
-
-extern "C" int64_t igcn_score_topk_bf16x3_workspace_bytes(int64_t batch, int64_t n_items, int32_t d, int32_t k)
-{
-    if (d != 64) return -1;
-    TopkPlan p;
-    if (topk_make_plan(batch, n_items, d, k, &p) != IGCN_OK) return -1;
-    const int64_t merge = (topk_rest_users(p, batch) * 2 * p.p_max * k * 8 + 255) / 256 * 256;
-    return merge + topk_split_packed_bytes(n_items);
-}
-
-extern "C" int igcn_score_topk_bf16x3_f32(const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
-                                          const float *item_rows, int64_t ldi, int64_t n_items, int32_t d,
-                                          const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned,
-                                          int32_t k, int64_t *out_idx, float *out_val, void *workspace, void *stream)
-{
-    if (!user_rows || !item_rows || !out_idx || !out_val || !workspace) return IGCN_E_NULL;
-    if ((excl_rowptr == nullptr) != (excl_col == nullptr)) return IGCN_E_NULL;
-    if (d != 64) return IGCN_E_SHAPE;
-    TopkPlan p;
-    int rc = topk_make_plan(batch, n_items, d, k, &p);
-    if (rc != IGCN_OK) return rc;
-    if (ldu < d || ldi < d || ldu % 4 || ldi % 4 || n_items >= ((int64_t)1 << 31) - 64 || ldi > (1 << 20)) return IGCN_E_SHAPE;
-    if ((reinterpret_cast<uintptr_t>(user_rows) | reinterpret_cast<uintptr_t>(item_rows) | reinterpret_cast<uintptr_t>(workspace)) % 16)
-        return IGCN_E_ALIGN;
-    const int64_t rest_users = topk_rest_users(p, batch);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    float *ws_val = static_cast<float *>(workspace);
-    int32_t *ws_idx = reinterpret_cast<int32_t *>(ws_val + rest_users * 2 * p.p_max * k);
-    const int64_t merge_bytes = (rest_users * 2 * p.p_max * k * 8 + 255) / 256 * 256;
-    float4 *packed = reinterpret_cast<float4 *>(static_cast<char *>(workspace) + merge_bytes);
-
-    const int64_t threads = (int64_t)p.n_tiles * 4 * kWave;
-    hipLaunchKernelGGL(topk_pack_items_kernel, dim3((unsigned)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                       item_rows, ldi, n_items, p.n_tiles, packed);
-    rc = launch_status();
-    if (rc != IGCN_OK) return rc;
-    rc = launch_topk<64, true, 1>(p, st, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, (int)d, excl_rowptr, excl_col,
-                                  banned, (int)k, out_idx, out_val, ws_val, ws_idx, packed);
-    if (rc != IGCN_OK) return rc;
-    if (rest_users > 0) {
-        const int64_t blocks = (rest_users + 3) / 4;
-        hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, ws_val, ws_idx,
-                           p.n_whole * p.units * 32, batch, p.n_tiles, p.run, p.p_max, (int)k, out_idx, out_val);
-        rc = launch_status();
-    }
-    return rc;
-}
-
-#ifdef IGCN_TOPK_TRACE
+#ifdef IGCN_TOPK_STATS
 extern "C" int igcn_debug_topk_wave_times(unsigned long long *host, int n_waves)
 {
     hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipMemcpyFromSymbol(host, HIP_SYMBOL(igcn::g_topk_wave_times), (size_t)n_waves * 32);
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(host, HIP_SYMBOL(igcn::g_topk_wave_times), (size_t)n_waves * 24);
     return (int)e;
 }
-extern "C" int igcn_debug_topk_occupancy(int lds_bytes)
-{
-    int n = -1;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, igcn::score_topk_kernel<64, true, 0>, 64, (size_t)lds_bytes);
-    return e == hipSuccess ? n : -(int)e;
-}
-extern "C" int igcn_debug_topk_trace(unsigned long long *host8, int reset)
+extern "C" int igcn_debug_topk_stats(unsigned long long *host8, int reset)
 {
     hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess && host8) e = hipMemcpyFromSymbol(host8, HIP_SYMBOL(igcn::g_topk_trace), 64);
+    if (e == hipSuccess && host8) e = hipMemcpyFromSymbol(host8, HIP_SYMBOL(igcn::g_topk_stats), 96);
     if (e == hipSuccess && reset) {
-        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(igcn::g_topk_trace), z, 64);
+        const unsigned long long z[12] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(igcn::g_topk_stats), z, 96);
     }
     return (int)e;
 }

@@ -29,6 +29,7 @@
 //     power-law load, few enough to amortise the per-wave set-up — and never just
 //     above what is resident at once (see resident_blocks_per_cu below).
 #include <stdlib.h>
+#include <string.h>
 #include "common.h"
 
 namespace igcn {
@@ -392,12 +393,15 @@ __global__ void csr_row_pow_kernel(const int64_t *__restrict__ rowptr, const flo
     }
 }
 
-// Developer tuning knobs (environment, read per call): IGCN_SPMM_BLOCKS_PER_CU, IGCN_SPMM_MULTIROW.
+int g_tuning[IGCN_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1};
+
+// Developer tuning knobs (igcn_set_tuning): spmm_blocks_per_cu, spmm_multirow.
 struct SpmmTuning { int blocks_per_cu; int multirow; };
 static SpmmTuning tuning() {
-    SpmmTuning v{0, 1};                                       // 0 = resident_blocks_per_cu() of the kernel variant
-    if (const char *e = getenv("IGCN_SPMM_BLOCKS_PER_CU")) { int x = atoi(e); if (x >= 1 && x <= 4096) v.blocks_per_cu = x; }
-    if (const char *e = getenv("IGCN_SPMM_MULTIROW")) v.multirow = atoi(e) != 0;
+    SpmmTuning v{0, 1};                                       // 0 = sized by rows per wave
+    const int b = tuning_get(IGCN_TUNE_SPMM_BLOCKS_PER_CU), m = tuning_get(IGCN_TUNE_SPMM_MULTIROW);
+    if (b >= 1 && b <= 4096) v.blocks_per_cu = b;
+    if (m >= 0) v.multirow = m != 0;
     return v;
 }
 
@@ -658,6 +662,16 @@ extern "C" int igcn_debug_spmm_wave_times(unsigned long long *host, int n_waves)
 #endif
 
 extern "C" int igcn_abi_version(void) { return IGCN_ABI_VERSION; }
+
+extern "C" int igcn_set_tuning(const char *name, int32_t value)
+{
+    static const char *const names[IGCN_TUNE_COUNT] = {"spmm_blocks_per_cu", "spmm_multirow", "topk_slots",
+                                                       "topk_waves_per_cu", "topk_cap", "topk_stagger"};
+    if (!name) return IGCN_E_NULL;
+    for (int i = 0; i < IGCN_TUNE_COUNT; ++i)
+        if (strcmp(name, names[i]) == 0) { g_tuning[i] = value < 0 ? -1 : value; return IGCN_OK; }
+    return IGCN_E_RANGE;
+}
 
 extern "C" const char *igcn_error_string(int code)
 {

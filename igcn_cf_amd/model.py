@@ -88,13 +88,8 @@ class BasicModel(nn.Module):
         """Top-k item ids per user (best first), masked by the exclusion CSR and the
         banned mask: predict -> mask -> topk of trainer.py:147-163, fused."""
         user_rows, item_rows = self.score_tables()
-        # config key 'eval_precision': 'fp32' (default, the exact fp32 contraction) or 'bf16x3' (d = 64: fp32-grade
-        # scores from an exact 3-way bf16 split on the bf16 matrix cores, faster; see igcn_score_topk_bf16x3_f32)
-        precision = self.config.get('eval_precision', 'fp32')
-        if precision == 'bf16x3' and item_rows.shape[1] != 64:
-            precision = 'fp32'
         idx, _ = ops.score_topk(user_rows, item_rows, k, user_ids=users.contiguous(), excl_rowptr=excl_rowptr,
-                                excl_col=excl_col, banned=banned, precision=precision)
+                                excl_col=excl_col, banned=banned)
         return idx
 
     def _cached_rep(self, key, compute):

@@ -259,16 +259,9 @@ def bpr_loss_terms(u_tab, p_tab, l2u_tab, l2p_tab, w, users, pos, neg, item_offs
     return BprLossFn.apply(u_tab, p_tab, l2u_tab, l2p_tab, w, users, pos, neg, item_offset, l2_item_offset, reduce_fn)
 
 
-def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_col=None, banned=None, batch=None,
-               precision='fp32'):
+def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_col=None, banned=None, batch=None):
     """Top-k item ids (best first) and scores for each user row; masked items are
-    never returned unless fewer than k unmasked items exist (igcn_score_topk_f32).
-
-    precision='bf16x3' (d = 64 only): igcn_score_topk_bf16x3_f32 — exact 3-way bf16 split of both operands on the
-    bf16 matrix cores, fp32 accumulation; fp32-grade scores at ~2.5x the speed, but not the fp32 fmaf chain bit
-    for bit (near-ties may rank differently).  The default is the exact fp32 path."""
-    if precision not in ('fp32', 'bf16x3'):
-        raise _lib.IgcnError("precision must be 'fp32' or 'bf16x3'")
+    never returned unless fewer than k unmasked items exist (igcn_score_topk_f32)."""
     _require_gpu_f32(user_rows, 'user_rows')
     _require_gpu_f32(item_rows, 'item_rows')
     if user_ids is not None:
@@ -294,23 +287,18 @@ def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_co
     if banned is not None and (banned.dtype != torch.uint8 or banned.numel() != n_items or not banned.is_cuda):
         raise _lib.IgcnError('banned must be uint8 [n_items] on the GPU')
     L = _lib.lib()
-    split = precision == 'bf16x3'
-    if split and d != 64:
-        raise _lib.IgcnError("precision='bf16x3' is built for embedding width 64 (got %d)" % d)
-    ws_bytes = (L.igcn_score_topk_bf16x3_workspace_bytes if split else L.igcn_score_topk_workspace_bytes)(B, n_items, d, k)
+    ws_bytes = L.igcn_score_topk_workspace_bytes(B, n_items, d, k)
     if ws_bytes < 0:
         raise _lib.IgcnError('unsupported top-k shape: batch=%d n_items=%d d=%d k=%d (need d%%4==0, d<=128, '
                              'k<=%d, k<=n_items)' % (B, n_items, d, k, _lib.MAX_TOPK))
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=item_rows.device)
     out_idx = torch.empty((B, k), dtype=torch.int64, device=item_rows.device)
     out_val = torch.empty((B, k), dtype=torch.float32, device=item_rows.device)
-    entry = L.igcn_score_topk_bf16x3_f32 if split else L.igcn_score_topk_f32
-    _lib.check(entry(
+    _lib.check(L.igcn_score_topk_f32(
         user_rows.data_ptr(), user_rows.stride(0), _lib.ptr(user_ids), B,
         item_rows.data_ptr(), item_rows.stride(0), n_items, d,
         _lib.ptr(excl_rowptr), _lib.ptr(excl_col), _lib.ptr(banned), k,
-        out_idx.data_ptr(), out_val.data_ptr(), ws.data_ptr(), _lib.current_stream()),
-        'igcn_score_topk_bf16x3_f32' if split else 'igcn_score_topk_f32')
+        out_idx.data_ptr(), out_val.data_ptr(), ws.data_ptr(), _lib.current_stream()), 'igcn_score_topk_f32')
     return out_idx, out_val
 
 

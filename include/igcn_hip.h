@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IGCN_ABI_VERSION 2
+#define IGCN_ABI_VERSION 3
 
 #define IGCN_OK            0
 #define IGCN_E_NULL       -1   /* a required pointer is NULL               */
@@ -33,10 +33,16 @@ extern "C" {
 #define IGCN_E_NO_DEVICE  -5   /* no HIP device is available               */
 
 #define IGCN_MAX_ADDS      8   /* epilogue addends of igcn_spmm_csr_f32     */
-#define IGCN_MAX_TOPK     64   /* k of igcn_score_topk_f32                  */
+#define IGCN_MAX_TOPK    256   /* k of igcn_score_topk_f32                  */
 
 int         igcn_abi_version(void);
 const char *igcn_error_string(int code);
+
+/* Developer / test knobs of the launch heuristics (no reference counterpart).  name: "spmm_blocks_per_cu",
+ * "spmm_multirow", "topk_slots", "topk_waves_per_cu", "topk_cap", "topk_stagger"; value < 0 restores the library
+ * default.  Results never depend on them (tests/test_spmm_gpu.py::test_launch_shape_does_not_change_results).
+ * Not thread-safe against concurrent launches.  Returns IGCN_E_RANGE for an unknown name. */
+int igcn_set_tuning(const char *name, int32_t value);
 
 /* One piece of a long CSR row (a "row segment"): nonzeros [start, start+len)
  * of row `row`, whose partial sum goes to partial[slot].  Built once per graph
@@ -195,28 +201,16 @@ int igcn_bpr_bwd_f32(const float *u_tab, const float *p_tab, const float *n_tab,
  *   out_val[b, 0..k) = their scores (-inf for masked fill-ins).
  * user_ids int64 [B] or NULL (then row b of user_rows is user b);
  * excl_rowptr int64 / excl_col int32 may be NULL; banned uint8 [n_items] or NULL.
- * d <= 128, d % 4 == 0; k <= IGCN_MAX_TOPK and k <= n_items.
- * workspace: igcn_score_topk_workspace_bytes(B, n_items, d, k) bytes (partial
- * lists of the item-range splits that fill the chip when B is small). */
+ * d <= 128, d % 4 == 0; k <= IGCN_MAX_TOPK and k <= n_items (k <= 24 runs 8 waves per CU; the heaps of a
+ * larger k take more of the CU's LDS and fewer waves are resident: 4 up to 56, 2 up to 120, 1 above).
+ * workspace (8-byte aligned): igcn_score_topk_workspace_bytes(B, n_items, d, k) bytes (partial lists of the
+ * item-range splits that fill the chip when B is small + the banned items packed one bit each). */
 int64_t igcn_score_topk_workspace_bytes(int64_t batch, int64_t n_items, int32_t d, int32_t k);
 int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
                         const float *item_rows, int64_t ldi, int64_t n_items, int32_t d,
                         const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned,
                         int32_t k, int64_t *out_idx, float *out_val,
                         void *workspace, void *stream);
-
-/* igcn_score_topk_f32 with the products on the bf16 matrix cores: both operands are split EXACTLY into three
- * bf16 planes (v = h0 + h1 + h2 up to 2^-24 |v|), 6 of the 9 plane products are accumulated in fp32.  Scores are
- * fp32-grade (each product good to 2^-23 — the order of the rounding of an fp32 dot product) but are not the
- * bit pattern of the fp32 fmaf chain, so the ranking can differ from igcn_score_topk_f32 where two scores are
- * within fp32 rounding of each other.  About 2.5x the throughput.  d must be 64 (IGCN_E_SHAPE otherwise);
- * workspace (16-byte aligned, never NULL): igcn_score_topk_bf16x3_workspace_bytes — merge lists + the item table
- * re-packed per call as bf16 planes.  Same masks, same tie rule, same outputs. */
-int64_t igcn_score_topk_bf16x3_workspace_bytes(int64_t batch, int64_t n_items, int32_t d, int32_t k);
-int igcn_score_topk_bf16x3_f32(const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
-                               const float *item_rows, int64_t ldi, int64_t n_items, int32_t d,
-                               const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned,
-                               int32_t k, int64_t *out_idx, float *out_val, void *workspace, void *stream);
 
 /* hit[u, j] = 1 if rec[u, j] is in eval_col[eval_rowptr[u]..eval_rowptr[u+1])
  * (sorted ascending), else 0: the membership loop of trainer.py:111-115.

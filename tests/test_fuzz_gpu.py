@@ -50,7 +50,8 @@ def test_spmm_fuzz_shapes_degrees_and_plans():
         assert err < 1e-4, (case, n_rows, n_cols, d, style, lt, sl, err)
 
 
-def test_score_topk_fuzz(monkeypatch):
+def test_score_topk_fuzz():
+    from igcn_cf_amd import _lib
     from igcn_cf_amd.ops import score_topk
     rng = np.random.default_rng(77)
     for case in range(60):
@@ -60,9 +61,9 @@ def test_score_topk_fuzz(monkeypatch):
         k = int(rng.integers(1, min(n_items, 64) + 1))
         if case % 3 == 1:
             # few wave slots: every wave sweeps whole groups AND a run of the leftover groups' tiles (+ merge)
-            monkeypatch.setenv('IGCN_TOPK_SLOTS', str(int(rng.integers(1, 8))))
+            _lib.set_tuning('topk_slots', int(rng.integers(1, 8)))
         else:
-            monkeypatch.delenv('IGCN_TOPK_SLOTS', raising=False)
+            _lib.set_tuning('topk_slots', None)
         U = rng.integers(-4, 5, size=(n_users, d)).astype(np.float32)             # exact dot products
         I = rng.integers(-4, 5, size=(n_items, d)).astype(np.float32)
         scores = U @ I.T

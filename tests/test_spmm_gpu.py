@@ -296,7 +296,7 @@ def test_device_csr_utilities_match_host_builders():
     assert e.transposed_view().shape == (7, 10) and int(e.transposed_view().rowptr.sum()) == 0
 
 
-def test_launch_shape_does_not_change_results(monkeypatch):
+def test_launch_shape_does_not_change_results():
     """The nnz hint and the developer grid knob only change how rows are dealt to waves: outputs are
     bit-identical (each row is summed by one wave in storage order whatever the grid is)."""
     import ctypes as C
@@ -310,10 +310,13 @@ def test_launch_shape_does_not_change_results(monkeypatch):
     csr = CsrMatrix(rowptr, col, val, (n_rows, n_cols), 'cuda')
     x = torch.randn(n_cols, d, device='cuda')
     ref = spmm(csr, x)
-    for bpc in ('1', '7', '64', '4096'):
-        monkeypatch.setenv('IGCN_SPMM_BLOCKS_PER_CU', bpc)
+    for bpc in (1, 7, 64, 4096):
+        _lib.set_tuning('spmm_blocks_per_cu', bpc)
         assert torch.equal(spmm(csr, x), ref)
-    monkeypatch.delenv('IGCN_SPMM_BLOCKS_PER_CU')
+    _lib.set_tuning('spmm_blocks_per_cu', None)
+    _lib.set_tuning('spmm_multirow', 0)                 # one row per wave: other lane groups, so another summation order
+    assert _rel_err(spmm(csr, x).cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    _lib.set_tuning('spmm_multirow', None)
     for nnz_hint in (0, 1, 10 ** 12):                                   # unknown / absurdly light / absurdly heavy rows
         y = torch.empty_like(ref)
         nul = (C.c_void_p * 1)()
