@@ -3,34 +3,33 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json: "propagation edges/sec + eval users/sec, Amazon-book
-dim=64"): LightGCN, 3 layers, d = 64, fp32, on the seeded Amazon-book-like
-synthetic split (109 730 users x 96 421 items, ~2.2 M train pairs); at N > 1 the
-graph is N x that size (weak scaling) and the embedding COLUMNS are sharded: every rank
-holds the whole CSR and d/N columns, so the K-layer pass needs no exchange
-(igcn_cf_amd/dist.py: ColumnShardedLightGCN).  The north_star's row-sharded pass with an RCCL
-all-gather per half-layer (RowShardedPropagator) is timed in the same run -> extras.
+Workload (BASELINE.json: "propagation edges/sec + eval users/sec, Amazon-book dim=64"; configs[3]):
+LightGCN, 3 layers, d = 64, fp32, on the seeded Amazon-book-like synthetic split (109 730 users x
+96 421 items, ~2.2 M train pairs) — the SAME graph at every N (strong scaling).  At N > 1 the rows of
+A_hat, of the embeddings and of the outputs are sharded over the ranks (nnz-balanced user and item
+blocks, igcn_cf_amd/dist.py: RowShardedPropagator) and every layer's input is exchanged by an RCCL
+all-gather over xGMI, as BASELINE.json's north_star describes; the embedding-column sharding that
+needs no exchange is timed next to it (extras.column_sharded).
 
-A STEP is one K-layer propagation pass over the whole graph (LightGCN.get_rep,
-model.py:96-106 = 3 SpMM launches with the layer mean fused in the last).  Inputs are resident in HBM before the timed
-region.  value = edges/s = steps * n_layers * nnz(A_hat) / time (whole job).
-Also reported (outside `value`): full-evaluation users/s (propagate once + fused
-score/mask/top-20 over every user) and the full training step (sample + forward
-+ BPR + backward + Adam).
+A STEP is one K-layer propagation pass over the whole graph (LightGCN.get_rep, model.py:96-106): at
+N = 1 three SpMM launches with the layer mean fused in the last; at N > 1 the X_0 exchange, K local
+SpMMs and K - 1 all-gathers.  Inputs are resident in HBM before the timed region.
+value = edges/s = steps * n_layers * nnz(A_hat) / time (whole job, max over ranks).
+Also reported (outside `value`): full-evaluation users/s (propagate once + fused score/mask/top-20 over
+every user) and the full training step (sample + forward + BPR + backward + Adam).
 
-roofline: the dominant kernel is spmm_csr_multirow_kernel<16,2,false>; `achieved` =
-algorithmic bytes per launch (nnz*(8+4d) + N*(4d+4)) / average
-launch duration measured with HIP events over the timed region.  The 52.8 MB operand of this
-workload lives in the 256 MiB Infinity Cache, so the 8 TB/s HBM roof does not bind it; `peak` is
-therefore the roof that does, MEASURED IN THIS RUN: a row-structure-free gather + FMA + store
-kernel over the same index stream (igcn_cf_amd/csrc/roof_probe.hip), expressed in the same
-algorithmic bytes/s, and `frac` = achieved / peak <= 1.  The figure against the HBM spec is kept
-as `frac_of_hbm_spec` (not a bound).  The HBM-bound leg — one GPU's 1/8 row share of BASELINE
-config 5 (125 M nonzeros against a 12 M x 128 operand = 6.1 GB, kernel
-spmm_csr_rows_kernel<32,false>) — is timed in the same run: extras.roofline_hbm_bound, against
-the 8 TB/s HBM peak.
-cpu_baseline (rank 0, N = 1): the C restatement of the path (oracle/oracle_c.c,
-kind "port") on all host cores, on the same graph, bounded to ~10-30 s.
+roofline: the dominant kernel is spmm_csr_multirow_kernel<16,2,false>; `achieved` = algorithmic bytes
+per launch (nnz*(8+4d) + N*(4d+4)) / average launch duration measured with HIP events
+over the timed region.  The 52.8 MB operand of this workload lives in the 256 MiB Infinity Cache, so the
+8 TB/s HBM roof does not bind it; `peak` is therefore the roof that does, MEASURED IN THIS RUN: a
+row-structure-free gather + FMA + store kernel over the same index stream
+(igcn_cf_amd/csrc/roof_probe.hip), expressed in the same algorithmic bytes/s, and `frac` =
+achieved / peak <= 1.  The figure against the HBM spec is kept as `frac_of_hbm_spec` (not a bound).
+The HBM-bound leg — one GPU's 1/8 row share of BASELINE config 5 (125 M nonzeros against a 12 M x 128
+operand = 6.1 GB, kernel spmm_csr_rows_kernel<32,false>) — is timed in the same run:
+extras.roofline_hbm_bound, against the 8 TB/s HBM peak.
+cpu_baseline (rank 0, N = 1): the C restatement of the path (oracle/oracle_c.c, kind "port") on all
+host cores, on the same graph, bounded to ~10-30 s.
 """
 import argparse
 import json
@@ -62,6 +61,10 @@ def parse():
 
 def main():
     args = parse()
+    # stdout carries ONE JSON line: whatever native libraries print there (the RCCL version banner) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -74,7 +77,7 @@ def main():
     device = torch.device('cuda', local_rank)
     import torch.distributed as dist
     sharded = world > 1 or os.environ.get('IGCN_FORCE_DIST') == '1'     # the latter: RCCL smoke of the sharded path at P=1
-    if world > 1 or sharded:
+    if sharded:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
@@ -83,10 +86,7 @@ def main():
     from igcn_cf_amd.graph import CsrMatrix, normalized_adjacency_host
     from igcn_cf_amd import ops
 
-    base = SyntheticDataset.PRESETS[args.preset]
-    cfg = {'name': 'SyntheticDataset', 'n_users': base['n_users'] * world, 'n_items': base['n_items'] * world,
-           'n_inter': base['n_inter'] * world, 'seed': 2021, 'device': device}
-    ds = SyntheticDataset(cfg)
+    ds = SyntheticDataset({'name': 'SyntheticDataset', 'preset': args.preset, 'seed': 2021, 'device': device})
     n = ds.n_users + ds.n_items
     d, K = args.dim, args.layers
     rowptr, col, val = normalized_adjacency_host(ds.train_array, ds.n_users, ds.n_items)
@@ -99,30 +99,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def job_max(seconds):
+        if not sharded:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     if not sharded:
         csr = CsrMatrix(rowptr, col, val, (n, n), device)
         x0 = emb_host.to(device)
         step = lambda: ops.propagate_mean(csr, x0, K)
-        launches_per_step = K
+        local_nnz, local_rows, launches_per_step = nnz, n, K
     else:
-        # N > 1.  Primary mode: embedding-COLUMN sharding (every rank: whole CSR, d/N columns, no exchange
-        # inside the K-layer pass).  The row-sharded pass of the north_star (all-gather per half-layer) is
-        # timed next to it and reported in extras.
         from igcn_cf_amd.dist import RowShardedPropagator
-        dl = d // world
-        csr = CsrMatrix(rowptr, col, val, (n, n), device)
-        x0 = emb_host[:, rank * dl:(rank + 1) * dl].contiguous().to(device)
-        step = lambda: ops.propagate_mean(csr, x0, K)
-        launches_per_step = K
         prop = RowShardedPropagator(None, ds.n_users, ds.n_items, K, rank, world, device, adjacency=(rowptr, col, val))
         L = prop.layout
         (ulo, uhi), (ilo, ihi) = L.user_rows(rank), L.item_rows(rank)
         eu = emb_host[ulo:uhi].to(device)
         ei = emb_host[ds.n_users + ilo: ds.n_users + ihi].to(device)
 
-        def row_step():                                                   # exchange X_0, then the sharded pass
+        def step():                                                       # exchange X_0, then the sharded pass
             prop.load_local_embedding(eu, ei)
             return prop.propagate()
+        local_nnz, local_rows, launches_per_step = prop.local_nnz, L.block, K * (1 if prop.exchange == 'fused' else 2)
 
     for _ in range(args.warmup):
         step()
@@ -134,128 +134,145 @@ def main():
         step()
     e1.record()
     barrier_sync()
-    wall = time.perf_counter() - t0
+    wall = job_max(time.perf_counter() - t0)
     dev_ms = e0.elapsed_time(e1)
-    if sharded:
-        t = torch.tensor([wall], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-
-    row_sharded = None
-    if sharded:                                                           # the north_star's row-sharded pass, same graph
-        n_row = max(5, args.steps // 10)
-        for _ in range(3):
-            row_step()
-        barrier_sync()
-        t1 = time.perf_counter()
-        for _ in range(n_row):
-            row_step()
-        barrier_sync()
-        tr = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
-        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
-        row_sharded = {'ms_per_step': float(tr.item()) * 1e3 / n_row, 'edges_per_s': n_row * K * nnz / float(tr.item()),
-                       'steps': n_row}
-
-    sharded_eval = None
-    if sharded and not args.no_extras:
-        # evaluation at N > 1: gather the column slices of the final representation once, then every rank
-        # scores its block of users against all items (fused score / mask / top-20; train lists masked)
-        from igcn_cf_amd.trainer import _csr_to_device
-        rp_h, col_h = ds.csr('train', sort=True)
-        ub = (ds.n_users + world - 1) // world
-        ulo, uhi = rank * ub, min((rank + 1) * ub, ds.n_users)
-        excl_rp, excl_col = _csr_to_device(rp_h, col_h, device)
-        my_users = torch.arange(ulo, uhi, dtype=torch.int64, device=device)
-
-        def eval_once():
-            rep_slice = ops.propagate_mean(csr, x0, K)
-            parts = torch.empty((world * n, dl), dtype=torch.float32, device=device)
-            dist.all_gather_into_tensor(parts, rep_slice.contiguous())
-            full = parts.view(world, n, dl).permute(1, 0, 2).reshape(n, d).contiguous()
-            return ops.score_topk(full, full[ds.n_users:], 20, user_ids=my_users, excl_rowptr=excl_rp, excl_col=excl_col)
-        eval_once()
-        barrier_sync()
-        t2 = time.perf_counter()
-        for _ in range(2):
-            eval_once()
-        barrier_sync()
-        te = torch.tensor([time.perf_counter() - t2], dtype=torch.float64, device=device)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        sharded_eval = {'eval_ms': float(te.item()) * 1e3 / 2, 'eval_users_per_s': 2 * ds.n_users / float(te.item()),
-                        'n_users': ds.n_users, 'n_items': ds.n_items,
-                        'eval_mfma_tflops_all_gpus': 2.0 * ds.n_users * ds.n_items * d / (float(te.item()) / 2) / 1e12,
-                        'note': 'weak scaling grows users AND items with N: scoring work per evaluation grows as N^2, '
-                                'so users/s stays level while the aggregate TFLOP/s scales with N'}
 
     edges = args.steps * K * nnz
     value = edges / wall
+    if not sharded:
+        parallelism = 'single GPU'
+    else:
+        parallelism = ('rows of A_hat / embeddings / outputs sharded over %d ranks (nnz-balanced user and item blocks), exchange '
+                       '"%s": X_0 exchange + %d RCCL all-gather(s) per pass over xGMI' %
+                       (world, prop.exchange, (K - 1) * (1 if prop.exchange == 'fused' else 2)))
     out = {
         'metric': 'propagation edges/sec (3-layer LightGCN get_rep, Amazon-book-like, dim=64)',
         'value': value, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': wall * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'ms_per_step': wall * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'LightGCN %d-layer d=%d propagation on synthetic %s-like x%d (users=%d items=%d nnz(A_hat)=%d)'
-                               % (K, d, args.preset, world, ds.n_users, ds.n_items, nnz),
-                   'preset': args.preset, 'nnz': nnz, 'd': d, 'n_layers': K,
-                   'parallelism': 'single GPU' if not sharded else
-                   'embedding-column sharding x%d: replicated CSR, d/%d = %d columns per rank, no exchange inside the pass '
-                   '(row-sharded + RCCL all-gather variant in extras)' % (world, world, d // world)},
+        'config': {'workload': 'LightGCN %d-layer d=%d propagation on synthetic %s-like (users=%d items=%d nnz(A_hat)=%d), the same '
+                               'graph at every N' % (K, d, args.preset, ds.n_users, ds.n_items, nnz),
+                   'preset': args.preset, 'nnz': nnz, 'd': d, 'n_layers': K, 'parallelism': parallelism},
     }
 
     # ---- roofline of the dominant kernel (per launch, this rank) ----------------------------------
-    dcols = d if not sharded else d // world                              # embedding columns this rank carries
-    b_alg = nnz * (8 + 4 * dcols) + n * (4 * dcols + 4)
-    b_min = nnz * 8 + n * (8 * dcols + 4)
-    ms_launch = dev_ms / (args.steps * launches_per_step)
-    ach = b_alg / ms_launch / 1e6
-    x_mb = n * dcols * 4 / 1e6
-    kernel_name = ('spmm_csr_multirow_kernel<%d,%d,false>' % (max(1, dcols // 4), 2 if dcols >= 32 else 4)) if dcols <= 64 \
-        else 'spmm_csr_rows_kernel<%d,false>' % (dcols // 4)
-    roof = {'bound': 'hbm', 'kernel': kernel_name, 'achieved': ach, 'unit': 'GB/s',
-            'algorithmic_bytes_per_launch': b_alg, 'compulsory_bytes_per_launch': b_min, 'avg_launch_ms': ms_launch,
-            'frac_of_hbm_spec': ach / HBM_PEAK_GBPS, 'hbm_spec_GBps': HBM_PEAK_GBPS,
-            'frac_of_compulsory': b_min / b_alg,
-            'avg_launch_note': 'HIP events over the timed region / launches: one igcn_spmm_csr_f32 call = the main kernel + the '
-                               'long-row reduce kernel (~5 us) + the launch gap'}
+    b_alg = local_nnz * (8 + 4 * d) + local_rows * (4 * d + 4)
+    b_min = local_nnz * 8 + (n + local_rows) * 4 * d + local_rows * 4
+    kernel_name = ('spmm_csr_multirow_kernel<%d,%d,false>' % (max(1, d // 4), 2 if d >= 32 else 4)) if d <= 64 \
+        else 'spmm_csr_rows_kernel<%d,false>' % (d // 4)
     if not sharded:
-        copy_gbps = measured_copy_GBps(device)
-        g = gather_roof(device, csr.col, csr.val, x0, n, dcols)
-        # same units as `achieved`: the algorithmic rate this SpMM would have at the bare-gather speed
-        peak = b_alg / g['best_ms'] / 1e6
-        roof.update({'peak': peak, 'frac': ach / peak, 'hbm_copy_measured_GBps': copy_gbps,
-                     'peak_source': 'measured in this run: row-structure-free gather+FMA+store kernel over the SAME col/val '
-                                    'stream and operand (roof_probe.hip), best of %d grids' % len(g['same_stream_ms']),
-                     'gather_roof': g,
-                     'note': 'X (%.1f MB) fits the 256 MiB Infinity Cache: the HBM roof (8 TB/s) does not bind this workload '
-                             '(frac_of_hbm_spec may exceed 1); peak/frac use the measured cache-resident gather roof; the '
-                             'HBM-bound leg is extras.roofline_hbm_bound' % x_mb})
-        t = stored_traffic(kernel_name, args.preset, nnz, dcols)
+        ms_launch = dev_ms / (args.steps * launches_per_step)
+        launch_note = ('HIP events over the timed region / launches: one igcn_spmm_csr_f32 call = the main kernel + the '
+                       'long-row reduce kernel (~5 us) + the launch gap')
+        g = gather_roof(device, csr.col, csr.val, x0, n, d)
+    else:
+        # the timed region holds collectives: the local product is timed on its own, same operands, same stream
+        local_csr = prop.csr if prop.exchange == 'fused' else prop.csr_u
+        own, rep = prop._buffers(d)
+        y = own[1] if prop.exchange == 'fused' else prop._part(own[1], 'u')
+        ms_launch = time_ms(lambda: ops.spmm(local_csr, rep[0], out=y), 50, 5)
+        if prop.exchange != 'fused':
+            b_alg = local_csr.nnz * (8 + 4 * d) + L.bu * (4 * d + 4)
+        launch_note = 'HIP events around 50 back-to-back launches of the rank-local product (the timed region also holds the collectives)'
+        g = gather_roof(device, local_csr.col, local_csr.val, rep[0], y.shape[0], d)
+    ach = b_alg / ms_launch / 1e6
+    x_mb = n * d * 4 / 1e6
+    peak = b_alg / g['best_ms'] / 1e6       # same units as `achieved`: the algorithmic rate this SpMM would have at the bare-gather speed
+    roof = {'bound': 'hbm', 'kernel': kernel_name, 'achieved': ach, 'peak': peak, 'unit': 'GB/s', 'frac': ach / peak,
+            'algorithmic_bytes_per_launch': b_alg, 'compulsory_bytes_per_launch': b_min, 'avg_launch_ms': ms_launch,
+            'avg_launch_note': launch_note, 'frac_of_hbm_spec': ach / HBM_PEAK_GBPS, 'hbm_spec_GBps': HBM_PEAK_GBPS,
+            'frac_of_compulsory': b_min / b_alg,
+            'peak_source': 'measured in this run: row-structure-free gather+FMA+store kernel over the SAME col/val stream and '
+                           'operand (roof_probe.hip), best of %d grids' % len(g['same_stream_ms']),
+            'gather_roof': g,
+            'note': ('rank 0 of %d; ' % world if sharded else '') +
+                    'X (%.1f MB) fits the 256 MiB Infinity Cache: the HBM roof (8 TB/s) does not bind this workload '
+                    '(frac_of_hbm_spec may exceed 1); peak/frac use the measured cache-resident gather roof; the HBM-bound leg '
+                    'is extras.roofline_hbm_bound (N = 1 runs)' % x_mb}
+    if not sharded:
+        roof['hbm_copy_measured_GBps'] = measured_copy_GBps(device)
+        t = stored_traffic(kernel_name, args.preset, nnz, d)
         roof['traffic'] = t['bytes'] if t else None
         roof['traffic_source'] = t['source'] if t else 'no PMC pass on file for this kernel/workload'
     else:
-        roof.update({'peak': HBM_PEAK_GBPS, 'frac': ach / HBM_PEAK_GBPS, 'traffic': None, 'note': 'rank 0 of %d' % world})
+        roof['traffic'] = None
     out['roofline'] = roof
 
     extras = {}
+    if sharded and not args.no_extras:
+        extras = sharded_side_measurements(ds, device, d, K, rank, world, rowptr, col, val, emb_host, barrier_sync, job_max)
     if not sharded and not args.no_extras:
         extras = side_measurements(ds, device, d, K)
     if not sharded and not args.no_hbm_leg:
         del csr, x0
         torch.cuda.empty_cache()
         extras['roofline_hbm_bound'] = hbm_bound_leg(device)
-    if row_sharded is not None:
-        extras['row_sharded_allgather'] = row_sharded
-    if sharded_eval is not None:
-        extras['user_sharded_eval'] = sharded_eval
     out['extras'] = extras
 
     if not sharded and rank == 0 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(rowptr, col, val, emb_host.numpy(), K, nnz, ds.n_users)
 
-    if rank == 0:
-        print(json.dumps(out))
     if sharded:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(json_fd, 1)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def sharded_side_measurements(ds, device, d, K, rank, world, rowptr, col, val, emb_host, barrier_sync, job_max):
+    """N > 1, same fixed graph: the no-exchange embedding-column sharding, the row-sharded training step and the
+    user-sharded evaluation."""
+    import torch.distributed as dist
+    from igcn_cf_amd import ops
+    from igcn_cf_amd.dist import ShardedLightGCN
+    from igcn_cf_amd.graph import CsrMatrix
+    from igcn_cf_amd.trainer import DeviceSampler, _merge_sorted_csr
+    res = {}
+    n = ds.n_users + ds.n_items
+    nnz = int(rowptr[-1])
+
+    def timed(fn, reps, warm):
+        for _ in range(warm):
+            fn()
+        barrier_sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        barrier_sync()
+        return job_max(time.perf_counter() - t0) / reps
+
+    if d % world == 0:
+        dl = d // world
+        csr = CsrMatrix(rowptr, col, val, (n, n), device)
+        xs = emb_host[:, rank * dl:(rank + 1) * dl].contiguous().to(device)
+        sec = timed(lambda: ops.propagate_mean(csr, xs, K), 200, 20)
+        res['column_sharded'] = {'ms_per_step': sec * 1e3, 'edges_per_s': K * nnz / sec,
+                                 'note': 'same graph, replicated CSR, d/%d = %d embedding columns per rank, no exchange inside the pass '
+                                         '(scoring then needs one all-reduce of 3*B partial dots per training step)' % (world, dl)}
+        del csr, xs
+    model = ShardedLightGCN(ds, d, K, rank, world, device, full_embedding=emb_host, adjacency=(rowptr, col, val))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    sampler = DeviceSampler(ds, device, 2021)                      # the same seed on every rank: identical batches
+    batches = [b for _, b in zip(range(40), sampler.epoch_batches(2048))]
+    it = iter(batches * 4)
+
+    def train_step():
+        users, pos, neg = next(it).t().contiguous().unbind(0)
+        terms = model.bpr_loss_terms(users, pos, neg)
+        loss = terms[0] + 1e-5 * terms[1]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    sec = timed(train_step, 30, 5)
+    res['row_sharded_train_step_ms'] = sec * 1e3
+    excl = _merge_sorted_csr(ds.csr('train', sort=True), ds.csr('val', sort=True))
+    sec = timed(lambda: model.recommend_local(20, excl), 3, 1)
+    res['user_sharded_eval'] = {'eval_ms': sec * 1e3, 'eval_users_per_s': ds.n_users / sec,
+                                'eval_mfma_tflops_all_gpus': 2.0 * ds.n_users * ds.n_items * d / sec / 1e12,
+                                'note': 'sharded propagation, one all-gather of the item rows, then every rank scores the users it '
+                                        'owns against all items (fused score / mask / top-20, train+val lists masked)'}
+    return res
 
 
 def time_ms(fn, reps, warm):

@@ -1,25 +1,33 @@
-"""Row-sharded propagation across the GPUs of one node (one process per GPU,
+"""Row-sharded propagation and training across the GPUs of one node (one process per GPU,
 torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).
 
 Not in the reference (single process, single device — SURVEY.md section 2.1); this is
 the scheme BASELINE.json's north_star asks for at Amazon-book scale and above:
 
-* the user set and the item set are each cut into P equal contiguous blocks
-  (padded); rank r owns user block r and item block r: those rows of A_hat as
-  local CSR (global, padded column ids), of the embeddings and of the outputs;
-* every layer input X_l is replicated (the all-gather target); a rank computes
-  its own rows of X_{l+1} straight into its slot of the next replicated buffer
-  and the slots are exchanged with an in-place all-gather;
-* the graph is bipartite: user rows read only item embeddings and vice versa.
-  Each layer is therefore two half-steps, and the order of the halves alternates
-  from layer to layer (users,items / items,users / ...), so that every
-  all-gather runs under the SpMM of the other half — no half-step ever waits
-  for a collective that was issued immediately before it;
-* the layer mean is the epilogue of the last local SpMM, on owned rows only.
+* the user set and the item set are each cut into P contiguous blocks balanced by NONZEROS
+  (ShardLayout.balanced: boundaries from the prefix sums of the row pointers; power-law item
+  degrees make equal row counts unequal work); rank r owns user block r and item block r:
+  those rows of A_hat as local CSR (padded global column ids), of the embeddings, of every
+  layer's output, of the gradients and of the optimizer state;
+* every layer input X_l is replicated (the all-gather target).  Two replicated buffers are
+  used in turn; the rows a rank computes go to its own [rows, d] buffer of that layer (the
+  layer mean needs them again) and from there into the other ranks' replicated buffers;
+* exchange, chosen by size:
+  - 'fused' (the replicated operand is small, latency decides — Amazon-book: 52.8 MB): padded
+    layout [rank 0: users, items | rank 1: users, items | ...], ONE local SpMM over the
+    rank's user and item rows and ONE all-gather per layer;
+  - 'halves' (the operand is GBs, bandwidth decides — BASELINE config 5): padded layout
+    [all user blocks | all item blocks]; the graph is bipartite (user rows read only item
+    embeddings and vice versa), so a layer is two half-steps whose order alternates from
+    layer to layer and every all-gather runs under the SpMM of the other half;
+* the layer mean is the epilogue of the last local SpMM, on owned rows only;
+* a training step needs 3 B rows of the result (and of the raw embeddings): they are exchanged
+  as ONE all-reduce of a [3 B, 2 d] buffer in which every rank fills the rows it owns
+  (x + 0 is exact), never the full tables.
 
-`spmm_fn` is the local product; the product path uses the HIP kernel
-(ops.spmm).  The CPU tests inject a checker implementation to exercise the
-partitioning / exchange logic under gloo with world_size 2.
+`spmm_fn` is the local product; the product path uses the HIP kernel (ops.spmm).  The CPU
+tests inject a checker implementation to exercise the partitioning / exchange logic under
+gloo with world_size 2.  Nothing here has run on more than one physical GPU yet.
 """
 import numpy as np
 import torch
@@ -27,51 +35,99 @@ import torch.distributed as dist
 
 from .graph import normalized_adjacency_host
 
+FUSED_EXCHANGE_MAX_BYTES = 128 << 20       # replicated operand (at d = 64) up to which one all-gather per layer is used
 
-def block_size(n, world):
-    return (n + world - 1) // world
+
+def _dist_on():
+    return dist.is_available() and dist.is_initialized()
 
 
 class ShardLayout:
-    """Padded global layout [P*bu user rows ; P*bi item rows]."""
+    """Contiguous user / item blocks per rank and the padded layout of the replicated buffers.
 
-    def __init__(self, n_users, n_items, world):
-        self.n_users, self.n_items, self.world = n_users, n_items, world
-        self.bu, self.bi = block_size(n_users, world), block_size(n_items, world)
+    user_bounds / item_bounds: int64 [world + 1] block boundaries (default: equal row counts).
+    bu / bi: padded block sizes (the largest block).  fused: see the module docstring."""
+
+    def __init__(self, n_users, n_items, world, user_bounds=None, item_bounds=None, fused=False):
+        self.n_users, self.n_items, self.world, self.fused = int(n_users), int(n_items), int(world), bool(fused)
+        eq = lambda n: np.minimum(np.arange(world + 1, dtype=np.int64) * ((n + world - 1) // world), n)
+        self.user_bounds = eq(self.n_users) if user_bounds is None else np.asarray(user_bounds, dtype=np.int64)
+        self.item_bounds = eq(self.n_items) if item_bounds is None else np.asarray(item_bounds, dtype=np.int64)
+        for bnd, n in ((self.user_bounds, self.n_users), (self.item_bounds, self.n_items)):
+            if bnd.shape != (world + 1,) or bnd[0] != 0 or bnd[-1] != n or np.any(np.diff(bnd) < 0):
+                raise ValueError('block boundaries must rise from 0 to the section size')
+        self.bu = max(1, int(np.diff(self.user_bounds).max()))
+        self.bi = max(1, int(np.diff(self.item_bounds).max()))
         self.pu, self.pi = self.bu * world, self.bi * world          # padded section sizes
         self.n_pad = self.pu + self.pi
+        self.block = self.bu + self.bi                                # rows a rank owns (padded)
 
-    def pad_index(self, node):
-        """global node id (users first, then items) -> row in the padded layout."""
-        node = np.asarray(node, dtype=np.int64)
-        return np.where(node < self.n_users, node, node - self.n_users + self.pu)
+    @classmethod
+    def balanced(cls, rowptr, n_users, n_items, world, fused=False):
+        """Blocks with (nearly) equal nonzeros, separately within the user and the item range."""
+        rowptr = np.asarray(rowptr, dtype=np.int64)
+
+        def cut(lo, hi):
+            nnz = rowptr[lo:hi + 1] - rowptr[lo]
+            targets = nnz[-1] * np.arange(1, world, dtype=np.float64) / world
+            inner = np.searchsorted(nnz, targets, side='left')
+            return np.concatenate([[0], np.clip(inner, 0, hi - lo), [hi - lo]]).astype(np.int64)
+        ub, ib = cut(0, n_users), cut(n_users, n_users + n_items)
+        return cls(n_users, n_items, world, np.maximum.accumulate(ub), np.maximum.accumulate(ib), fused)
 
     def user_rows(self, rank):
-        lo = rank * self.bu
-        return lo, min(lo + self.bu, self.n_users)
+        return int(self.user_bounds[rank]), int(self.user_bounds[rank + 1])
 
     def item_rows(self, rank):
-        lo = rank * self.bi
-        return lo, min(lo + self.bi, self.n_items)
+        return int(self.item_bounds[rank]), int(self.item_bounds[rank + 1])
+
+    def owner(self, node):
+        """(rank, row inside the rank's padded block [bu users ; bi items]) of global node ids."""
+        node = np.asarray(node, dtype=np.int64)
+        is_item = node >= self.n_users
+        it = np.where(is_item, node - self.n_users, 0)
+        us = np.where(is_item, 0, node)
+        ru = np.searchsorted(self.user_bounds, us, side='right') - 1
+        ri = np.searchsorted(self.item_bounds, it, side='right') - 1
+        ru, ri = np.minimum(ru, self.world - 1), np.minimum(ri, self.world - 1)
+        rank = np.where(is_item, ri, ru)
+        local = np.where(is_item, self.bu + it - self.item_bounds[ri], us - self.user_bounds[ru])
+        return rank, local
+
+    def pad_index(self, node):
+        """global node id (users first, then items) -> row in the padded replicated layout."""
+        rank, local = self.owner(node)
+        if self.fused:
+            return rank * self.block + local
+        is_item = np.asarray(node, dtype=np.int64) >= self.n_users
+        return np.where(is_item, self.pu + rank * self.bi + (local - self.bu), rank * self.bu + local)
 
 
 def local_blocks_host(rowptr, col, val, layout, rank):
-    """Rows of the global CSR owned by `rank`, as two CSR blocks (user rows,
-    item rows) of exactly bu / bi rows (padding rows empty), padded column ids."""
+    """Rows of the global CSR owned by `rank`, as two CSR blocks (user rows, item rows) of
+    exactly bu / bi rows (padding rows empty), padded column ids."""
     out = []
     for (lo, hi), nb, base in ((layout.user_rows(rank), layout.bu, 0),
                                (layout.item_rows(rank), layout.bi, layout.n_users)):
-        s, e = rowptr[base + lo], rowptr[base + max(hi, lo)]
+        s, e = rowptr[base + lo], rowptr[base + hi]
         rp = np.full(nb + 1, e - s, dtype=np.int64)
-        rp[:max(hi - lo, 0) + 1] = rowptr[base + lo: base + max(hi, lo) + 1] - s
+        rp[:hi - lo + 1] = rowptr[base + lo: base + hi + 1] - s
         out.append((rp, layout.pad_index(col[s:e]).astype(np.int32), val[s:e].copy()))
     return out
 
 
 class RowShardedPropagator:
     def __init__(self, train_array, n_users, n_items, n_layers, rank, world, device, group=None,
-                 spmm_fn=None, csr_factory=None, adjacency=None):
-        self.layout = ShardLayout(n_users, n_items, world)
+                 spmm_fn=None, csr_factory=None, adjacency=None, exchange=None, balance=True):
+        rowptr, col, val = adjacency if adjacency is not None else normalized_adjacency_host(train_array, n_users, n_items)
+        if exchange is None:
+            exchange = 'fused' if (n_users + n_items) * 256 <= FUSED_EXCHANGE_MAX_BYTES else 'halves'
+        if exchange not in ('fused', 'halves'):
+            raise ValueError("exchange must be 'fused' or 'halves'")
+        self.exchange = exchange
+        fused = exchange == 'fused'
+        self.layout = ShardLayout.balanced(rowptr, n_users, n_items, world, fused) if balance else \
+            ShardLayout(n_users, n_items, world, fused=fused)
         self.n_layers, self.rank, self.world, self.group = n_layers, rank, world, group
         self.device = torch.device(device)
         if spmm_fn is None:
@@ -81,72 +137,84 @@ class RowShardedPropagator:
             from .graph import CsrMatrix
             csr_factory = lambda rp, c, v, shape: CsrMatrix(rp, c, v, shape, self.device)
         self.spmm = spmm_fn
-        rowptr, col, val = adjacency if adjacency is not None else normalized_adjacency_host(train_array, n_users, n_items)
         (urp, ucol, uval), (irp, icol, ival) = local_blocks_host(rowptr, col, val, self.layout, rank)
         L = self.layout
         self.local_nnz = int(urp[-1] + irp[-1])
         self.global_nnz = int(rowptr[-1])
-        self.csr_u = csr_factory(urp, ucol, uval, (L.bu, L.n_pad))
-        self.csr_i = csr_factory(irp, icol, ival, (L.bi, L.n_pad))
-        self._bufs = None
+        if fused:                                        # one matrix: the rank's user rows, then its item rows
+            rp = np.concatenate([urp, irp[1:] + urp[-1]])
+            self.csr = csr_factory(rp, np.concatenate([ucol, icol]), np.concatenate([uval, ival]), (L.block, L.n_pad))
+        else:
+            self.csr_u = csr_factory(urp, ucol, uval, (L.bu, L.n_pad))
+            self.csr_i = csr_factory(irp, icol, ival, (L.bi, L.n_pad))
+        self._d = None
 
     # ---- buffers -----------------------------------------------------------------
     def _buffers(self, d):
-        if self._bufs is None or self._bufs[0].shape[1] != d:
-            L = self.layout
-            self._bufs = [torch.zeros((L.n_pad, d), dtype=torch.float32, device=self.device)
-                          for _ in range(max(self.n_layers, 1))]
-            self._rep_u = torch.empty((L.bu, d), dtype=torch.float32, device=self.device)
-            self._rep_i = torch.empty((L.bi, d), dtype=torch.float32, device=self.device)
-        return self._bufs
+        """own[l]: this rank's rows of X_l ([block, d]; user rows first), l = 0..K; rep[0..1]: the two
+        replicated buffers used in turn."""
+        if self._d != d:
+            L, K = self.layout, self.n_layers
+            z = lambda rows: torch.zeros((rows, d), dtype=torch.float32, device=self.device)
+            self._own = [z(L.block) for _ in range(K + 1)]
+            self._rep = [z(L.n_pad) for _ in range(2 if K > 1 else 1)]
+            self._d = d
+        return self._own, self._rep
 
-    def _slot(self, buf, part):
+    def _part(self, own, part):
         L = self.layout
-        if part == 'u':
-            return buf[self.rank * L.bu:(self.rank + 1) * L.bu]
-        return buf[L.pu + self.rank * L.bi: L.pu + (self.rank + 1) * L.bi]
+        return own[:L.bu] if part == 'u' else own[L.bu:]
 
-    def _section(self, buf, part):
+    def _section(self, rep, part):
         L = self.layout
-        return buf[:L.pu] if part == 'u' else buf[L.pu:]
+        return rep[:L.pu] if part == 'u' else rep[L.pu:]
 
-    def _allgather(self, buf, part):
-        if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
+    def _allgather(self, out, inp, async_op):
+        if not _dist_on():
+            out.copy_(inp)                               # one rank without a process group
             return None
-        return dist.all_gather_into_tensor(self._section(buf, part), self._slot(buf, part), group=self.group,
-                                           async_op=True)
+        return dist.all_gather_into_tensor(out, inp, group=self.group, async_op=async_op)
 
     def load_local_embedding(self, emb_u_local, emb_i_local):
-        """Owned rows of the layer-0 embeddings -> slot of X_0, then exchange X_0."""
+        """Owned rows of the layer-0 embeddings -> own[0], then exchange X_0 into rep[0]."""
         d = emb_u_local.shape[1]
-        x0 = self._buffers(d)[0]
-        su, si = self._slot(x0, 'u'), self._slot(x0, 'i')
-        su.zero_(); si.zero_()
-        su[:emb_u_local.shape[0]].copy_(emb_u_local)
-        si[:emb_i_local.shape[0]].copy_(emb_i_local)
-        for w in (self._allgather(x0, 'u'), self._allgather(x0, 'i')):
-            if w is not None:
-                w.wait()
-        return x0
+        own, rep = self._buffers(d)
+        L = self.layout
+        own[0].zero_()
+        own[0][:emb_u_local.shape[0]].copy_(emb_u_local)
+        own[0][L.bu:L.bu + emb_i_local.shape[0]].copy_(emb_i_local)
+        if self.exchange == 'fused':
+            self._allgather(rep[0], own[0], False)
+        else:
+            ws = [self._allgather(self._section(rep[0], p), self._part(own[0], p), True) for p in ('u', 'i')]
+            for w in ws:
+                if w is not None:
+                    w.wait()
+        return rep[0]
 
     # ---- the sharded K-layer pass -------------------------------------------------
-    def propagate(self, x0=None):
-        """mean(X_0..X_K) on the owned rows: (rep_users [bu, d], rep_items [bi, d]).
-        `x0`: replicated padded layer-0 buffer (default: the one filled by
-        load_local_embedding)."""
-        bufs = self._buffers(x0.shape[1] if x0 is not None else self._bufs[0].shape[1])
-        if x0 is not None and x0.data_ptr() != bufs[0].data_ptr():
-            bufs[0].copy_(x0)
-        K = self.n_layers
+    def propagate(self):
+        """mean(X_0..X_K) on the owned rows: (rep_users [bu, d], rep_items [bi, d]) — views of one
+        [block, d] buffer that the next call overwrites.  X_0 is what load_local_embedding left."""
+        own, rep = self._buffers(self._d)
+        K, L = self.n_layers, self.layout
         s = 1.0 / (K + 1)
         if K == 0:
-            return self._slot(bufs[0], 'u').clone(), self._slot(bufs[0], 'i').clone()
+            return self._part(own[0], 'u'), self._part(own[0], 'i')
+        if self.exchange == 'fused':
+            for l in range(K):
+                src = rep[l % 2]
+                if l == K - 1:
+                    self.spmm(self.csr, src, out=own[K], adds=own[:K], out_scale=s, add_scale=s)
+                else:
+                    self.spmm(self.csr, src, out=own[l + 1])
+                    self._allgather(rep[(l + 1) % 2], own[l + 1], False)
+            return self._part(own[K], 'u'), self._part(own[K], 'i')
         pending = {}                                     # (layer, part) -> in-flight all-gather
         csr = {'u': self.csr_u, 'i': self.csr_i}
-        rep = {'u': self._rep_u, 'i': self._rep_i}
         for l in range(K):
             last = l == K - 1
-            src = bufs[l]
+            src = rep[l % 2]
             order = ('u', 'i') if l % 2 == 0 else ('i', 'u')
             for part in order:
                 other = 'i' if part == 'u' else 'u'
@@ -154,30 +222,31 @@ class RowShardedPropagator:
                 if w is not None:
                     w.wait()
                 if last:
-                    adds = [self._slot(bufs[j], part) for j in range(K)]
-                    self.spmm(csr[part], src, out=rep[part], adds=adds, out_scale=s, add_scale=s)
+                    self.spmm(csr[part], src, out=self._part(own[K], part), adds=[self._part(o, part) for o in own[:K]],
+                              out_scale=s, add_scale=s)
                 else:
-                    dst = bufs[l + 1]
-                    self.spmm(csr[part], src, out=self._slot(dst, part))
-                    pending[(l + 1, part)] = self._allgather(dst, part)
+                    # the half of X_{l+1} computed here is read by the OTHER half of layer l+1; the replicated buffer
+                    # it goes to was last read by layer l-1, whose two halves are done
+                    self.spmm(csr[part], src, out=self._part(own[l + 1], part))
+                    pending[(l + 1, part)] = self._allgather(self._section(rep[(l + 1) % 2], part),
+                                                             self._part(own[l + 1], part), True)
         for w in pending.values():                        # nothing should be left; be safe
             if w is not None:
                 w.wait()
-        return rep['u'], rep['i']
+        return self._part(own[K], 'u'), self._part(own[K], 'i')
 
     def gather_full_rep(self, rep_u, rep_i):
-        """Replicated [n_users + n_items, d] from the owned blocks (used once per
-        evaluation: scoring shards by user and needs every item row)."""
+        """Replicated [n_users + n_items, d] in the ORIGINAL node order from the owned blocks (evaluation:
+        scoring shards by user and needs every item row)."""
         L = self.layout
         d = rep_u.shape[1]
         full_u = torch.empty((L.pu, d), dtype=torch.float32, device=self.device)
         full_i = torch.empty((L.pi, d), dtype=torch.float32, device=self.device)
-        if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
-            full_u.copy_(rep_u); full_i.copy_(rep_i)
-        else:
-            dist.all_gather_into_tensor(full_u, rep_u.contiguous(), group=self.group)
-            dist.all_gather_into_tensor(full_i, rep_i.contiguous(), group=self.group)
-        return torch.cat([full_u[:L.n_users], full_i[:L.n_items]], dim=0)
+        self._allgather(full_u, rep_u.contiguous(), False)
+        self._allgather(full_i, rep_i.contiguous(), False)
+        parts = [full_u[r * L.bu: r * L.bu + (L.user_bounds[r + 1] - L.user_bounds[r])] for r in range(L.world)]
+        parts += [full_i[r * L.bi: r * L.bi + (L.item_bounds[r + 1] - L.item_bounds[r])] for r in range(L.world)]
+        return torch.cat(parts, dim=0)
 
 
 # ---------------------------------------------------------------------------------------
@@ -203,48 +272,107 @@ class _ShardedPropagateFn(torch.autograd.Function):
         return gu.clone(), gi.clone(), None
 
 
-class _GatherRowsFn(torch.autograd.Function):
-    """Owned blocks -> replicated [n_users + n_items, d].  Every rank evaluates the
-    SAME full batch on the replicated rows, so each rank's gradient w.r.t. the
-    replicated tensor is already the total: the backward pass just keeps the rows
-    this rank owns (no reduce-scatter needed)."""
+class _BatchRowsFn(torch.autograd.Function):
+    """Rows `ids` (global node ids, any owner) of several row-sharded tables -> replicated [M, d] each.
+
+    Every rank writes the rows it owns into a zero [M, sum d] buffer and ONE all-reduce (sum) completes it
+    — M = 3 B rows per training step instead of the whole table.  Every rank evaluates the same batch on
+    the replicated rows, so each rank's gradient w.r.t. them is already the total: the backward pass adds
+    the rows a rank owns into its local gradient tables (duplicate ids add up), no communication."""
 
     @staticmethod
-    def forward(ctx, blk_u, blk_i, prop):
-        ctx.prop = prop
-        ctx.nu, ctx.ni = blk_u.shape[0], blk_i.shape[0]
-        return prop.gather_full_rep(blk_u.detach(), blk_i.detach())
+    def forward(ctx, prop, ids, *tables_ui):
+        L, rank = prop.layout, prop.rank
+        if ids.is_cuda:
+            owner, local = _owner_device(L, ids)
+        else:
+            o, l = L.owner(ids.numpy())
+            owner, local = torch.from_numpy(o), torch.from_numpy(l)
+        sel = torch.nonzero(owner == rank, as_tuple=False).flatten()
+        loc = local[sel]
+        n_tab = len(tables_ui) // 2
+        widths = [tables_ui[2 * t].shape[1] for t in range(n_tab)]
+        buf = torch.zeros((ids.numel(), sum(widths)), dtype=torch.float32, device=tables_ui[0].device)
+        c0 = 0
+        for t in range(n_tab):
+            tu, ti = tables_ui[2 * t].detach(), tables_ui[2 * t + 1].detach()
+            is_item = loc >= L.bu
+            rows = torch.where(is_item[:, None], ti[(loc - L.bu).clamp(min=0, max=max(ti.shape[0] - 1, 0))],
+                               tu[loc.clamp(max=max(tu.shape[0] - 1, 0))])
+            buf[sel, c0:c0 + widths[t]] = rows
+            c0 += widths[t]
+        if _dist_on():
+            dist.all_reduce(buf, group=prop.group)
+        ctx.sel, ctx.loc, ctx.bu, ctx.widths = sel, loc, L.bu, widths
+        ctx.shapes = [t.shape for t in tables_ui]
+        outs, c0 = [], 0
+        for w in widths:
+            outs.append(buf[:, c0:c0 + w])
+            c0 += w
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, g_full):
-        L, r = ctx.prop.layout, ctx.prop.rank
-        (ulo, uhi), (ilo, ihi) = L.user_rows(r), L.item_rows(r)
-        gu = g_full.new_zeros((ctx.nu, g_full.shape[1]))
-        gi = g_full.new_zeros((ctx.ni, g_full.shape[1]))
-        if uhi > ulo:
-            gu[:uhi - ulo] = g_full[ulo:uhi]
-        if ihi > ilo:
-            gi[:ihi - ilo] = g_full[L.n_users + ilo: L.n_users + ihi]
-        return gu, gi, None
+    def backward(ctx, *grads):
+        sel, loc, bu = ctx.sel, ctx.loc, ctx.bu
+        is_item = loc >= bu
+        su, si = sel[~is_item], sel[is_item]
+        lu, li = loc[~is_item], loc[is_item] - bu
+        out = []
+        for t, g in enumerate(grads):
+            gu = g.new_zeros(ctx.shapes[2 * t])
+            gi = g.new_zeros(ctx.shapes[2 * t + 1])
+            if g is not None:
+                gu.index_add_(0, lu, g[su])
+                gi.index_add_(0, li, g[si])
+            out += [gu, gi]
+        return (None, None, *out)
+
+
+def _owner_device(L, ids):
+    """ShardLayout.owner on the device (ids int64 on the GPU): (rank, local row) tensors."""
+    dev = ids.device
+    cache = getattr(L, '_dev_bounds', None)
+    if cache is None or cache[0].device != dev:
+        cache = (torch.from_numpy(L.user_bounds).to(dev), torch.from_numpy(L.item_bounds).to(dev))
+        L._dev_bounds = cache
+    ub, ib = cache
+    is_item = ids >= L.n_users
+    it = torch.where(is_item, ids - L.n_users, torch.zeros_like(ids))
+    us = torch.where(is_item, torch.zeros_like(ids), ids)
+    ru = (torch.searchsorted(ub, us, right=True) - 1).clamp(max=L.world - 1)
+    ri = (torch.searchsorted(ib, it, right=True) - 1).clamp(max=L.world - 1)
+    rank = torch.where(is_item, ri, ru)
+    local = torch.where(is_item, L.bu + it - ib[ri], us - ub[ru])
+    return rank, local
+
+
+def _compact_bpr_terms(rows_rep, rows_emb, batch):
+    """The fused BPR kernel on the exchanged rows: [users | positives | negatives], B rows each."""
+    from . import ops
+    idx = torch.arange(batch, dtype=torch.int64, device=rows_rep.device)
+    rr, re = rows_rep.contiguous(), rows_emb.contiguous()
+    return ops.bpr_loss_terms(rr, rr, re, re, None, idx, idx, idx + batch, batch, batch)
 
 
 class ShardedLightGCN(torch.nn.Module):
     """LightGCN (model.py:75-123) with the embedding table, its gradient and the
     optimizer state row-sharded over the ranks.  One step:
-      X_0 exchange + K sharded half-layer passes  ->  owned rows of rep
-      one all-gather of rep (and of E for the L2 term, model.py:110-113)
-      the full batch's fused BPR loss on every rank (identical batch: same sampler seed)
-      backward: owned rows of d loss / d rep  ->  the same sharded pass  ->  d loss / d E (owned rows)
+      X_0 exchange + K sharded layers                ->  owned rows of rep
+      ONE all-reduce of the 3 B batch rows of rep and of E (model.py:110-116 reads nothing else)
+      the batch's fused BPR loss on every rank (identical batch: same sampler seed)
+      backward: owned batch rows of d loss / d rep   ->  the same sharded pass  ->  d loss / d E (owned rows)
       Adam on the owned rows.
-    `loss_fn(rep_full, emb_full, users, pos, neg, n_users) -> tensor[2]` defaults to the
-    fused HIP kernel (ops.bpr_loss_terms); the CPU tests inject a torch one."""
+    `loss_fn(rows_rep [3B, d], rows_emb [3B, d], B) -> tensor[2]` (rows: users, positives, negatives) defaults
+    to the fused HIP kernel; the CPU tests inject a torch one."""
 
     def __init__(self, dataset, embedding_size, n_layers, rank, world, device, group=None, seed=2021,
-                 spmm_fn=None, csr_factory=None, loss_fn=None, full_embedding=None):
+                 spmm_fn=None, csr_factory=None, loss_fn=None, full_embedding=None, exchange=None, balance=True,
+                 adjacency=None):
         super().__init__()
         self.n_users, self.n_items, self.n_layers = dataset.n_users, dataset.n_items, n_layers
         self.prop = RowShardedPropagator(dataset.train_array, dataset.n_users, dataset.n_items, n_layers, rank, world,
-                                         device, group=group, spmm_fn=spmm_fn, csr_factory=csr_factory)
+                                         device, group=group, spmm_fn=spmm_fn, csr_factory=csr_factory, exchange=exchange,
+                                         balance=balance, adjacency=adjacency)
         L = self.prop.layout
         (ulo, uhi), (ilo, ihi) = L.user_rows(rank), L.item_rows(rank)
         if full_embedding is None:                       # normal_(std=0.1), model.py:82 — same table on every rank
@@ -252,27 +380,48 @@ class ShardedLightGCN(torch.nn.Module):
             full_embedding = torch.randn(self.n_users + self.n_items, embedding_size, generator=g) * 0.1
         eu = torch.zeros(L.bu, embedding_size)
         ei = torch.zeros(L.bi, embedding_size)
-        eu[:max(uhi - ulo, 0)] = full_embedding[ulo:uhi]
-        ei[:max(ihi - ilo, 0)] = full_embedding[self.n_users + ilo: self.n_users + ihi]
+        eu[:uhi - ulo] = full_embedding[ulo:uhi]
+        ei[:ihi - ilo] = full_embedding[self.n_users + ilo: self.n_users + ihi]
         self.emb_users = torch.nn.Parameter(eu.to(device))
         self.emb_items = torch.nn.Parameter(ei.to(device))
-        if loss_fn is None:
-            from . import ops
-            loss_fn = lambda rep, emb, u, p, n, nu: ops.bpr_loss_terms(rep, rep, emb, emb, None, u, p, n, nu, nu)
-        self.loss_fn = loss_fn
+        self.loss_fn = loss_fn if loss_fn is not None else _compact_bpr_terms
 
     def get_rep_local(self):
         return _ShardedPropagateFn.apply(self.emb_users, self.emb_items, self.prop)
 
     def bpr_loss_terms(self, users, pos_items, neg_items):
         ru, ri = self.get_rep_local()
-        rep_full = _GatherRowsFn.apply(ru, ri, self.prop)
-        emb_full = _GatherRowsFn.apply(self.emb_users, self.emb_items, self.prop)
-        return self.loss_fn(rep_full, emb_full, users, pos_items, neg_items, self.n_users)
+        ids = torch.cat([users, self.n_users + pos_items, self.n_users + neg_items])
+        rows_rep, rows_emb = _BatchRowsFn.apply(self.prop, ids, ru, ri, self.emb_users, self.emb_items)
+        return self.loss_fn(rows_rep, rows_emb, users.numel())
 
     def full_embedding(self):
         with torch.no_grad():
             return self.prop.gather_full_rep(self.emb_users.detach(), self.emb_items.detach())
+
+    def recommend_local(self, k, excl=None):
+        """Top-k item ids for the users THIS rank owns (global user ids [ulo, uhi)): the item rows of the
+        representation are gathered once, every rank scores its own users against all of them (no collective
+        in the scoring loop).  excl: host CSR (rowptr, col) of masked items over ALL users, or None."""
+        from . import ops
+        L, rank = self.prop.layout, self.prop.rank
+        with torch.no_grad():
+            ru, ri = self.get_rep_local()
+            d = ri.shape[1]
+            full_i = torch.empty((L.pi, d), dtype=torch.float32, device=ri.device)
+            self.prop._allgather(full_i, ri.contiguous(), False)
+            items = torch.cat([full_i[r * L.bi: r * L.bi + (L.item_bounds[r + 1] - L.item_bounds[r])] for r in range(L.world)])
+            ulo, uhi = L.user_rows(rank)
+            if uhi == ulo:
+                return torch.empty((0, k), dtype=torch.int64, device=ri.device)
+            rp = cl = None
+            if excl is not None:
+                rowptr, col = excl
+                s, e = int(rowptr[ulo]), int(rowptr[uhi])
+                rp = torch.from_numpy(np.ascontiguousarray(rowptr[ulo:uhi + 1] - s, dtype=np.int64)).to(ri.device)
+                cl = torch.from_numpy(np.ascontiguousarray(col[s:e], dtype=np.int32)).to(ri.device)
+            idx, _ = ops.score_topk(ru[:uhi - ulo].contiguous(), items.contiguous(), k, excl_rowptr=rp, excl_col=cl)
+            return idx
 
 
 # ---------------------------------------------------------------------------------------

@@ -33,26 +33,32 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, train_array, nu, ni, emb, n_layers, ret):
+def _worker(rank, world, port, train_array, nu, ni, emb, n_layers, exchange, balance, ret):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from igcn_cf_amd.dist import RowShardedPropagator
         prop = RowShardedPropagator(train_array, nu, ni, n_layers, rank, world, 'cpu', spmm_fn=cpu_spmm,
-                                    csr_factory=lambda rp, c, v, shape: CpuCsr(rp, c, v, shape))
+                                    csr_factory=lambda rp, c, v, shape: CpuCsr(rp, c, v, shape), exchange=exchange,
+                                    balance=balance)
         L = prop.layout
         (ulo, uhi), (ilo, ihi) = L.user_rows(rank), L.item_rows(rank)
         prop.load_local_embedding(torch.from_numpy(emb[ulo:uhi]), torch.from_numpy(emb[nu + ilo:nu + ihi]))
         ru, ri = prop.propagate()
         full = prop.gather_full_rep(ru, ri)
         ret[rank] = (ru[:uhi - ulo].numpy().copy(), ri[:ihi - ilo].numpy().copy(), full.numpy().copy(),
-                     prop.local_nnz, prop.global_nnz)
+                     prop.local_nnz, prop.global_nnz, (ulo, uhi, ilo, ihi))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('n_layers', [1, 2, 3, 4])
-def test_row_sharded_propagation_equals_unsharded(golden, n_layers):
+@pytest.mark.parametrize('n_layers,exchange,balance', [(1, 'halves', True), (2, 'halves', False), (3, 'halves', True),
+                                                       (4, 'halves', True), (1, 'fused', True), (3, 'fused', True),
+                                                       (4, 'fused', False)])
+def test_row_sharded_propagation_equals_unsharded(golden, n_layers, exchange, balance):
+    """Both exchanges (one all-gather per layer on the interleaved layout / two overlapped half-layer gathers),
+    equal-row and nnz-balanced (unequal, padded) blocks, 1-4 layers: owned rows and the gathered table equal the
+    unsharded oracle."""
     nu, ni = int(golden['n_users']), int(golden['n_items'])
     ta = golden['train_array']
     rng = np.random.default_rng(0)
@@ -61,25 +67,24 @@ def test_row_sharded_propagation_equals_unsharded(golden, n_layers):
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ta, nu, ni, emb, n_layers, ret), nprocs=world, join=True)
-    from igcn_cf_amd.dist import ShardLayout
-    L = ShardLayout(nu, ni, world)
-    nnz = 0
+    mp.spawn(_worker, args=(world, _free_port(), ta, nu, ni, emb, n_layers, exchange, balance, ret), nprocs=world, join=True)
+    nnz, users_seen, items_seen = 0, 0, 0
     for r in range(world):
-        ru, ri, full, lnnz, gnnz = ret[r]
-        (ulo, uhi), (ilo, ihi) = L.user_rows(r), L.item_rows(r)
+        ru, ri, full, lnnz, gnnz, (ulo, uhi, ilo, ihi) = ret[r]
+        users_seen += uhi - ulo
+        items_seen += ihi - ilo
         np.testing.assert_allclose(ru, ref[ulo:uhi], rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(ri, ref[nu + ilo:nu + ihi], rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(full, ref, rtol=1e-5, atol=1e-7)
         nnz += lnnz
-    assert nnz == gnnz                                   # every edge owned exactly once
+    assert nnz == gnnz and users_seen == nu and items_seen == ni          # every edge / node owned exactly once
 
 
-def test_shard_layout_padding():
+def test_shard_layout_padding_and_balance():
     from igcn_cf_amd.dist import ShardLayout, local_blocks_host
-    L = ShardLayout(5, 3, 4)                              # blocks of 2 users / 1 item, ranks with empty tails
+    L = ShardLayout(5, 3, 4)                              # equal-row blocks of 2 users / 1 item, ranks with empty tails
     assert (L.bu, L.bi, L.pu, L.pi) == (2, 1, 8, 4)
-    assert L.user_rows(2) == (4, 5) and L.user_rows(3) == (6, 5) and L.item_rows(3) == (3, 3)
+    assert L.user_rows(2) == (4, 5) and L.user_rows(3) == (5, 5) and L.item_rows(3) == (3, 3)
     np.testing.assert_array_equal(L.pad_index([0, 4, 5, 7]), [0, 4, 8, 10])
     rowptr = np.arange(9, dtype=np.int64)                 # one entry per row
     col = np.array([5, 6, 7, 5, 6, 0, 1, 2], dtype=np.int32)
@@ -88,6 +93,29 @@ def test_shard_layout_padding():
     assert urp.tolist() == [0, 0, 0] and irp.tolist() == [0, 0]          # rank 3 owns padding only
     (urp, ucol, _), (irp, icol, _) = local_blocks_host(rowptr, col, val, L, 2)
     assert urp.tolist() == [0, 1, 1] and ucol.tolist() == [9] and irp.tolist() == [0, 1] and icol.tolist() == [2]
+    # interleaved layout of the fused exchange: [rank 0: 2 users, 1 item | rank 1: ... ]
+    F = ShardLayout(5, 3, 4, fused=True)
+    np.testing.assert_array_equal(F.pad_index([0, 1, 2, 4, 5, 6, 7]), [0, 1, 3, 6, 2, 5, 8])
+    # nnz-balanced blocks on a power-law graph: row counts differ, nonzeros per block nearly equal
+    rng = np.random.default_rng(0)
+    nu, ni, P = 4000, 3000, 8
+    deg_u = rng.integers(5, 30, nu)
+    deg_i = np.maximum((rng.pareto(1.1, ni) * 8).astype(np.int64), 1)
+    rowptr = np.concatenate([[0], np.cumsum(np.concatenate([deg_u, deg_i]))]).astype(np.int64)
+    B = ShardLayout.balanced(rowptr, nu, ni, P)
+    E = ShardLayout(nu, ni, P)
+    def spread(L, lo_of, base):
+        nnz = [rowptr[base + lo_of(r)[1]] - rowptr[base + lo_of(r)[0]] for r in range(P)]
+        return max(nnz) / (sum(nnz) / P)
+    assert spread(B, B.item_rows, nu) < spread(E, E.item_rows, nu) and spread(B, B.item_rows, nu) < 1.6       # one huge row can outweigh a block
+    assert spread(B, B.user_rows, 0) < 1.02
+    assert len({B.item_rows(r)[1] - B.item_rows(r)[0] for r in range(P)}) > 1       # unequal row counts
+    rank, local = B.owner(np.arange(nu + ni))
+    for r in range(P):                                                               # owner() inverts the block maps
+        (ulo, uhi), (ilo, ihi) = B.user_rows(r), B.item_rows(r)
+        assert np.all(rank[ulo:uhi] == r) and np.all(rank[nu + ilo:nu + ihi] == r)
+        np.testing.assert_array_equal(local[ulo:uhi], np.arange(uhi - ulo))
+        np.testing.assert_array_equal(local[nu + ilo:nu + ihi], B.bu + np.arange(ihi - ilo))
 
 
 # ---- sharded training step (forward + backward + Adam) vs the same step unsharded ----------------
@@ -100,7 +128,14 @@ def torch_bpr_terms(rep, emb, users, pos, neg, n_users):
     return torch.stack([bpr, l2])
 
 
-def _train_worker(rank, world, port, path, emb, batch, n_layers, ret):
+def torch_bpr_terms_rows(rows_rep, rows_emb, B):
+    """The same on the exchanged batch rows [users | positives | negatives] (dist.ShardedLightGCN's loss_fn)."""
+    ur, pr, nr = rows_rep[:B], rows_rep[B:2 * B], rows_rep[2 * B:]
+    bpr = torch.nn.functional.softplus((ur * nr).sum(1) - (ur * pr).sum(1)).mean()
+    return torch.stack([bpr, (rows_emb ** 2).sum(1).view(3, B).sum(0).mean()])
+
+
+def _train_worker(rank, world, port, path, emb, batch, n_layers, exchange, ret):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -108,8 +143,8 @@ def _train_worker(rank, world, port, path, emb, batch, n_layers, ret):
         from igcn_cf_amd.dist import ShardedLightGCN
         ds = ProcessedDataset({'name': 'ProcessedDataset', 'path': path, 'device': 'cpu'})
         model = ShardedLightGCN(ds, emb.shape[1], n_layers, rank, world, 'cpu', spmm_fn=cpu_spmm,
-                                csr_factory=lambda rp, c, v, shape: CpuCsr(rp, c, v, shape), loss_fn=torch_bpr_terms,
-                                full_embedding=torch.from_numpy(emb))
+                                csr_factory=lambda rp, c, v, shape: CpuCsr(rp, c, v, shape), loss_fn=torch_bpr_terms_rows,
+                                full_embedding=torch.from_numpy(emb), exchange=exchange)
         opt = torch.optim.Adam(model.parameters(), lr=1e-2)
         b = torch.from_numpy(batch)
         losses = []
@@ -123,7 +158,10 @@ def _train_worker(rank, world, port, path, emb, batch, n_layers, ret):
         dist.destroy_process_group()
 
 
-def test_sharded_training_step_equals_unsharded(golden):
+@pytest.mark.parametrize('exchange', ['fused', 'halves'])
+def test_sharded_training_step_equals_unsharded(golden, exchange):
+    """Two Adam steps of the row-sharded model (nnz-balanced unequal blocks, batch rows exchanged by one
+    all-reduce, duplicate ids in the batch) against the same steps on the dense unsharded chain."""
     nu, ni = int(golden['n_users']), int(golden['n_items'])
     ta = golden['train_array']
     n_layers = 3
@@ -149,7 +187,7 @@ def test_sharded_training_step_equals_unsharded(golden):
         ref_losses.append(float(loss))
     world = 2
     ret = mp.Manager().dict()
-    mp.spawn(_train_worker, args=(world, _free_port(), golden['path'], emb, batch, n_layers, ret), nprocs=world, join=True)
+    mp.spawn(_train_worker, args=(world, _free_port(), golden['path'], emb, batch, n_layers, exchange, ret), nprocs=world, join=True)
     for r in range(world):
         losses, full = ret[r]
         np.testing.assert_allclose(losses, ref_losses, rtol=1e-5)
