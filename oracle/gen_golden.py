@@ -104,6 +104,79 @@ class RecordingModel(torch.nn.Module):
         self.anneal_calls += 1
 
 
+# scripted training runs: (n_epochs, max_patience, val_interval, validation NDCG@topks[0] per validation)
+TRAIN_SCRIPTS = [
+    (12, 3, 1, [0.10, 0.12, 0.11, 0.13, 0.13, 0.12, 0.125, 0.11, 0.2, 0.3, 0.1, 0.1]),     # stops early at patience 3
+    (7, 4, 2, [0.30, 0.20, 0.25]),                                                          # val every 2nd epoch, runs out
+    (5, 50, 1, [0.01, 0.02, 0.03, 0.04, 0.05]),                                             # improves every epoch
+]
+
+
+class ScriptedModel(torch.nn.Module):
+    """Input to the reference trainer: records save / load, writes a real (tiny) file so os.remove works."""
+
+    def __init__(self, events, trainable=True):
+        super().__init__()
+        self.name, self.trainable, self.events = 'Scripted', trainable, events
+
+    def save(self, path):
+        self.events.append('save ' + os.path.basename(path))
+        open(path, 'w').close()
+
+    def load(self, path):
+        self.events.append('load ' + os.path.basename(path))
+
+
+def run_train_script(trainer_cls, dataset, script, trainable=True, workdir=None):
+    """Runs trainer_cls.train() with scripted epochs; returns (events, returned value, epochs run).  Shared by the
+    generator (reference trainer) and — re-stated — by tests/test_host_cpu.py (this package's trainer)."""
+    n_epochs, patience, interval, ndcgs = script
+    events = []
+    model = ScriptedModel(events, trainable)
+
+    class Scripted(trainer_cls):
+        def train_one_epoch(self_inner):
+            events.append('epoch %d' % self_inner.epoch)
+            return 1.0 / (1 + self_inner.epoch)
+
+        def eval(self_inner, val_or_test, banned_items=None):
+            events.append('eval ' + val_or_test)
+            v = ndcgs[min(self_inner._n_val, len(ndcgs) - 1)] if val_or_test == 'val' else 0.5
+            if val_or_test == 'val':
+                self_inner._n_val += 1
+            m = {name: {k: np.float64(v) for k in self_inner.topks} for name in ('Precision', 'Recall', 'NDCG')}
+            return 'scripted ', m
+    cfg = {'name': 'Scripted', 'dataset': dataset, 'model': model, 'topks': [5, 10], 'device': 'cpu', 'n_epochs': n_epochs,
+           'max_patience': patience, 'val_interval': interval, 'test_batch_size': 7}
+    cwd = os.getcwd()
+    os.chdir(workdir)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr = Scripted(cfg)
+            tr._n_val = 0
+            ret = tr.train(verbose=True)
+        left = sorted(os.listdir('checkpoints')) if os.path.isdir('checkpoints') else []
+    finally:
+        os.chdir(cwd)
+    return events, float(ret), left
+
+
+def train_protocol_fixture(ref_trainer, ds):
+    import tempfile
+    g = {}
+    for j, script in enumerate(TRAIN_SCRIPTS):
+        with tempfile.TemporaryDirectory() as tmp:
+            events, ret, left = run_train_script(ref_trainer.BasicTrainer, ds, script, True, tmp)
+        g['train%d_script' % j] = np.array(list(script[:3]) + list(script[3]), dtype=np.float64)
+        g['train%d_events' % j] = np.array(events)
+        g['train%d_return' % j] = np.float64(ret)
+        g['train%d_checkpoints_left' % j] = np.array(left)
+    with tempfile.TemporaryDirectory() as tmp:                        # a non-trainable model is only validated
+        events, ret, left = run_train_script(ref_trainer.BasicTrainer, ds, TRAIN_SCRIPTS[0], False, tmp)
+    g['train_nontrainable_events'], g['train_nontrainable_return'] = np.array(events), np.float64(ret)
+    return g
+
+
 def main():
     sys.path.insert(0, REF)
     with contextlib.redirect_stdout(io.StringIO()):
@@ -112,6 +185,15 @@ def main():
         import trainer as ref_trainer      # noqa: E402
     os.makedirs(OUT, exist_ok=True)
     quiet = contextlib.redirect_stdout(io.StringIO())
+    import importlib.util
+
+    def load_script(rel):                  # the dataset scripts live in directories without __init__.py
+        spec = importlib.util.spec_from_file_location(rel.replace('/', '_')[:-3], os.path.join(REF, rel))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    ref_dropui = load_script('run/dropui/dataset_dropui.py')
+    ref_dropit = load_script('run/dropit/dataset_dropit.py')
 
     toys = {'toy_a': make_toy('toy_a', 30, 20, 11, quirks=False),
             'toy_b': make_toy('toy_b', 300, 200, 12, quirks=True)}
@@ -257,6 +339,26 @@ def main():
         g['igcn_rep1'] = model.rep.detach().numpy().copy()
         g['igcn_emb1'] = model.embedding.weight.detach().numpy().copy()
         g['igcn_w1'] = model.w.detach().numpy().copy()
+
+        # run/dropui/dataset_dropui.py:7-29 resize_dataset and run/dropit/dataset_dropit.py:6-9 dropit_dataset, each
+        # followed by BasicDataset.output_dataset (dataset.py:40-44, :133-137): the three text files ARE the fixture
+        for tag, fn, ratio in (('dropui', ref_dropui.resize_dataset, 0.8), ('dropit', ref_dropit.dropit_dataset, 0.8),
+                               ('dropui_half', ref_dropui.resize_dataset, 0.5)):
+            with quiet:
+                fresh = ref_dataset.get_dataset({'name': 'ProcessedDataset', 'path': path, 'device': 'cpu'})
+            fn(fresh, ratio)
+            out_dir = os.path.join(OUT, name + '_' + tag)
+            if os.path.isdir(out_dir):
+                for f in os.listdir(out_dir):
+                    os.remove(os.path.join(out_dir, f))
+            else:
+                os.makedirs(out_dir)
+            fresh.output_dataset(out_dir)
+            g['%s_n_users' % tag], g['%s_n_items' % tag] = fresh.n_users, fresh.n_items
+
+        # BasicTrainer.train protocol (trainer.py:57-107) with scripted epochs: what is evaluated when, which
+        # checkpoints are written / removed / re-loaded, when training stops, what is returned
+        g.update(train_protocol_fixture(ref_trainer, ds))
 
         np.savez_compressed(os.path.join(OUT, name + '.npz'), **g)
         print('wrote', name, 'n_users', ds.n_users, 'n_items', ds.n_items, 'train pairs', len(ds))

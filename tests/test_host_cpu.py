@@ -271,3 +271,94 @@ def test_batch_seeds_are_mixed():
     assert (diffs > 8).all()
     flips = [bin(a ^ b).count('1') for a, b in zip(seeds[:-1], seeds[1:])]
     assert 24 < np.mean(flips) < 40                                      # ~32 of 64 bits change per step
+
+
+@pytest.mark.parametrize('tag,ratio', [('dropui', 0.8), ('dropit', 0.8), ('dropui_half', 0.5)])
+def test_derived_datasets_match_reference_files(golden, tmp_path, tag, ratio):
+    """resize_dataset (run/dropui/dataset_dropui.py:7-29) / dropit_dataset (run/dropit/dataset_dropit.py:6-9) followed by
+    output_dataset (dataset.py:40-44, :133-137): byte-identical to the three files the reference itself wrote
+    (fixtures tests/golden/<toy>_<tag>/, generated by oracle/gen_golden.py from the imported reference)."""
+    from igcn_cf_amd.dataset import ProcessedDataset, dropit_dataset, resize_dataset
+    ds = ProcessedDataset({'name': 'ProcessedDataset', 'path': golden['path'], 'device': 'cpu'})
+    derived = (dropit_dataset if tag == 'dropit' else resize_dataset)(ds, ratio)
+    assert (derived.n_users, derived.n_items) == (int(golden[tag + '_n_users']), int(golden[tag + '_n_items']))
+    derived.output_dataset(str(tmp_path / tag))
+    for f in ('train.txt', 'val.txt', 'test.txt'):
+        want = open(os.path.join(golden['path'] + '_' + tag, f), 'rb').read()
+        assert open(str(tmp_path / tag / f), 'rb').read() == want, (tag, f)
+    # the source dataset is left as it was (the reference edits it in place; here a new dataset is returned)
+    assert ds.n_users == int(golden['n_users']) and len(ds) == int(golden['len'])
+
+
+def _run_train_script(dataset, script, trainable, workdir):
+    """BasicTrainer.train() of THIS package under the scripted epochs of oracle/gen_golden.py:run_train_script."""
+    import contextlib
+    import io
+    import torch
+    from igcn_cf_amd.trainer import BasicTrainer
+    n_epochs, patience, interval, ndcgs = script
+    events = []
+
+    class Model(torch.nn.Module):
+        name = 'Scripted'
+
+        def __init__(self):
+            super().__init__()
+            self.trainable = trainable
+
+        def save(self, path):
+            events.append('save ' + os.path.basename(path))
+            open(path, 'w').close()
+
+        def load(self, path):
+            events.append('load ' + os.path.basename(path))
+
+    class Scripted(BasicTrainer):
+        def train_one_epoch(self):
+            events.append('epoch %d' % self.epoch)
+            return 1.0 / (1 + self.epoch)
+
+        def eval(self, val_or_test, banned_items=None):
+            events.append('eval ' + val_or_test)
+            v = ndcgs[min(self._n_val, len(ndcgs) - 1)] if val_or_test == 'val' else 0.5
+            if val_or_test == 'val':
+                self._n_val += 1
+            return 'scripted ', {name: {k: np.float64(v) for k in self.topks} for name in ('Precision', 'Recall', 'NDCG')}
+    cfg = {'name': 'Scripted', 'dataset': dataset, 'model': Model(), 'topks': [5, 10], 'device': 'cpu', 'n_epochs': n_epochs,
+           'max_patience': patience, 'val_interval': interval, 'test_batch_size': 7}
+    cwd = os.getcwd()
+    os.chdir(workdir)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            tr = Scripted(cfg)
+            tr._n_val = 0
+            ret = tr.train(verbose=True)
+        left = sorted(os.listdir('checkpoints')) if os.path.isdir('checkpoints') else []
+    finally:
+        os.chdir(cwd)
+    return events, float(ret), left
+
+
+def test_train_protocol_matches_reference(golden, tmp_path):
+    """BasicTrainer.train (trainer.py:57-107): per-epoch train evaluation, validation every val_interval epochs,
+    best-NDCG checkpoint naming / replacement, patience, reload of the best checkpoint, return value — the event
+    sequences the reference's own BasicTrainer produced under the same scripted epochs."""
+    from igcn_cf_amd.dataset import ProcessedDataset
+    ds = ProcessedDataset({'name': 'ProcessedDataset', 'path': golden['path'], 'device': 'cpu'})
+    j = 0
+    while 'train%d_script' % j in golden:
+        sc = golden['train%d_script' % j]
+        script = (int(sc[0]), int(sc[1]), int(sc[2]), [float(v) for v in sc[3:]])
+        work = tmp_path / ('run%d' % j)
+        work.mkdir()
+        events, ret, left = _run_train_script(ds, script, True, str(work))
+        assert events == [str(e) for e in golden['train%d_events' % j]], j
+        assert ret == float(golden['train%d_return' % j])
+        assert left == [str(f) for f in golden['train%d_checkpoints_left' % j]]
+        j += 1
+    assert j == 3
+    sc = golden['train0_script']
+    work = tmp_path / 'nontrainable'
+    work.mkdir()
+    events, ret, _ = _run_train_script(ds, (int(sc[0]), int(sc[1]), int(sc[2]), [float(v) for v in sc[3:]]), False, str(work))
+    assert events == [str(e) for e in golden['train_nontrainable_events']] and ret == float(golden['train_nontrainable_return'])
