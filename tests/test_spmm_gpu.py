@@ -326,3 +326,36 @@ def test_launch_shape_does_not_change_results():
                                           _lib.ptr(csr.partial(d)), csr.long_threshold, None, 0, 1.0, None, 0, nnz_hint,
                                           torch.cuda.current_stream().cuda_stream)
         assert rc == 0 and torch.equal(y, ref)
+
+
+def test_config5_rank_shard_hbm_bound_variant():
+    """BASELINE config 5 (10 M users x 2 M items x 500 M edges, d = 128, 8 GPUs): ONE rank's share under row
+    sharding — 1.5 M rows, 125 M nonzeros against the full replicated 12 M x 128 operand (6.1 GB, far beyond the
+    Infinity Cache) — through igcn_spmm_csr_f32 (kernel spmm_csr_rows_kernel<32,false>, the HBM-bound variant):
+    256 sampled rows against float64, and <Y, A X> = <A^T Y, X> with the device-built transposed view."""
+    from igcn_cf_amd.graph import CsrMatrix
+    from igcn_cf_amd.ops import spmm
+    d, n_cols, n_rows, nnz_target = 128, 12_000_000, 1_500_000, 125_000_000
+    g = torch.Generator(device='cuda').manual_seed(5)
+    w = torch.exp(torch.randn(n_rows, device='cuda', generator=g))
+    deg = torch.clamp((w / w.sum() * nnz_target).round().long(), min=1)
+    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device='cuda')
+    torch.cumsum(deg, 0, out=rowptr[1:])
+    nnz = int(rowptr[-1].item())
+    col = torch.randint(0, n_cols, (nnz,), device='cuda', generator=g, dtype=torch.int32)
+    val = torch.rand(nnz, device='cuda', generator=g) * 0.1
+    csr = CsrMatrix.from_device(rowptr, col, val, (n_rows, n_cols))
+    assert csr.n_long > 0                                               # log-normal rows: the long-row pass is exercised too
+    x = torch.randn(n_cols, d, device='cuda', generator=g) * 0.1
+    y = spmm(csr, x)
+    rows = torch.randint(0, n_rows, (256,), device='cuda', generator=g).tolist()
+    for r in rows:
+        s, e = int(rowptr[r]), int(rowptr[r + 1])
+        ref = (x[col[s:e].long()].double() * val[s:e].double()[:, None]).sum(0)
+        assert float((y[r].double() - ref).abs().max() / (ref.abs().max() + 1e-30)) < 1e-4, r
+    # adjoint identity on the transposed view (values = ones there: fold A's values into the test through val = None)
+    ones = CsrMatrix.from_device(rowptr, col, None, (n_rows, n_cols))
+    yt = torch.randn(n_rows, d, device='cuda', generator=g)
+    lhs = (spmm(ones, x).double() * yt.double()).sum().item()
+    rhs = (spmm(ones.transposed_view(), yt).double() * x.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
