@@ -395,6 +395,37 @@ def hbm_bound_leg(device, reps=5):
             'frac_of_measured_gather_roof': gr['best_ms'] / ms, 'gather_roof_ms': gr['best_ms']}
 
 
+def train_step_ms(trainer, steps, warm):
+    trainer.model.train()
+    it = trainer.sampler.epoch_node_batches(trainer.batch_size, trainer.model.n_users)
+    for _ in range(warm):
+        trainer.node_step(next(it))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        trainer.node_step(next(it))
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3 / steps
+
+
+def small_graph_steps(device, d, K):
+    """BASELINE config 2 (LightGCN on the Gowalla-like split): the step is launch-bound there, so it is also timed as
+    ONE captured HIP graph per step (trainer config 'hip_graph')."""
+    from igcn_cf_amd import config as cfg
+    from igcn_cf_amd.dataset import get_dataset
+    from igcn_cf_amd.model import get_model
+    from igcn_cf_amd.trainer import get_trainer
+    ds_cfg, m_cfg, t_cfg = cfg.get_synthetic_config(device, 'gowalla')[1]
+    ds = get_dataset(ds_cfg)
+    out = {'workload': 'LightGCN %d-layer d=%d on the Gowalla-like split (users=%d items=%d), B=2048' % (K, d, ds.n_users, ds.n_items)}
+    for key, hip_graph in (('train_step_ms_eager', False), ('train_step_ms_hip_graph', True)):
+        torch.manual_seed(2021)
+        model = get_model(dict(m_cfg, embedding_size=d, n_layers=K), ds)
+        trainer = get_trainer(dict(t_cfg, hip_graph=hip_graph), ds, model)
+        out[key] = train_step_ms(trainer, 100, 10)
+    return out
+
+
 def side_measurements(ds, device, d, K):
     """Full evaluation (users/s) and full training step (ms) on the same workload."""
     from igcn_cf_amd.model import get_model
@@ -405,18 +436,10 @@ def side_measurements(ds, device, d, K):
                            'n_epochs': 1, 'batch_size': 2048, 'dataloader_num_workers': 0, 'test_batch_size': 512,
                            'topks': [20]}, ds, model)
     res = {}
-    # training step: sample + forward + fused BPR + backward + Adam
-    model.train()
-    batches = [b for _, b in zip(range(30), trainer.sampler.epoch_batches(2048))]
-    for b in batches[:5]:
-        trainer.bpr_step(b)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for b in batches[5:]:
-        trainer.bpr_step(b)
-    torch.cuda.synchronize()
-    res['train_step_ms'] = (time.perf_counter() - t0) * 1e3 / len(batches[5:])
+    # training step: sample + forward + fused BPR + backward + Adam (the loop of BPRTrainer.train_one_epoch)
+    res['train_step_ms'] = train_step_ms(trainer, 30, 5)
     res['train_step_edges_per_s_fwd_bwd'] = 2 * K * model.norm_adj.nnz / (res['train_step_ms'] / 1e3)
+    res['launch_bound_config'] = small_graph_steps(device, d, K)
     # evaluation: propagate once + fused score/mask/top-20 for every user (device part of trainer.eval)
     model.eval()
     trainer.recommend_all('test')

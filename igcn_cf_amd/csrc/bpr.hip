@@ -134,9 +134,53 @@ __global__ __launch_bounds__(kBlock) void bpr_bwd_kernel(
     }
 }
 
+// dst[ids[i]] += scale * src[ids[i]] (float atomics: an id may occur several times); one wave per id
+__global__ __launch_bounds__(kBlock) void rows_scaled_add_kernel(float *__restrict__ dst, int64_t ldd, const float *__restrict__ src,
+                                                                 int64_t lds, const int64_t *__restrict__ ids, int64_t n, int d,
+                                                                 const float *__restrict__ scale_dev, float scale_host)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t i = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int64_t r = ids[i];
+    const float sc = scale_dev ? scale_host * scale_dev[0] : scale_host;
+    for (int j = lane; j < d; j += kWave) atomicAdd(dst + r * ldd + j, sc * src[r * lds + j]);
+}
+
+__global__ __launch_bounds__(kBlock) void rows_zero_kernel(float *__restrict__ dst, int64_t ldd, const int64_t *__restrict__ ids,
+                                                           int64_t n, int d)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t i = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int64_t r = ids[i];
+    for (int j = lane; j < d; j += kWave) dst[r * ldd + j] = 0.f;
+}
+
 }  // namespace igcn
 
 using namespace igcn;
+
+extern "C" int igcn_rows_scaled_add_f32(float *dst, int64_t ldd, const float *src, int64_t lds, const int64_t *ids, int64_t n,
+                                        int32_t d, const float *scale_dev, float scale_host, void *stream)
+{
+    if (!dst || !src || !ids) return IGCN_E_NULL;
+    if (n < 0 || d < 1 || ldd < d || lds < d) return IGCN_E_SHAPE;
+    if (n == 0) return IGCN_OK;
+    hipLaunchKernelGGL(rows_scaled_add_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       dst, ldd, src, lds, ids, n, (int)d, scale_dev, scale_host);
+    return launch_status();
+}
+
+extern "C" int igcn_rows_zero_f32(float *dst, int64_t ldd, const int64_t *ids, int64_t n, int32_t d, void *stream)
+{
+    if (!dst || !ids) return IGCN_E_NULL;
+    if (n < 0 || d < 1 || ldd < d) return IGCN_E_SHAPE;
+    if (n == 0) return IGCN_OK;
+    hipLaunchKernelGGL(rows_zero_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       dst, ldd, ids, n, (int)d);
+    return launch_status();
+}
 
 static int bpr_check(const float *u, const float *p, const float *n, int64_t ld,
                      const float *a, const float *b, const float *c, int64_t ld2,

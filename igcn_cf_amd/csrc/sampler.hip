@@ -19,7 +19,7 @@ __device__ __forceinline__ int64_t uniform_below(uint64_t counter, uint32_t s0, 
 
 __global__ void bpr_sample_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                   const int32_t *__restrict__ nonempty, int64_t n_nonempty, int64_t n_items,
-                                  int64_t batch, uint32_t s0, uint32_t s1, int64_t *__restrict__ out)
+                                  int64_t batch, uint32_t s0, uint32_t s1, int64_t *__restrict__ out, int64_t soa_item_offset)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= batch) return;
@@ -37,9 +37,15 @@ __global__ void bpr_sample_kernel(const int64_t *__restrict__ rowptr, const int3
         }
         if (!(lo < hi0 && col[lo] == neg)) break;
     }
-    out[3 * i + 0] = user;
-    out[3 * i + 1] = pos;
-    out[3 * i + 2] = neg;
+    if (soa_item_offset < 0) {                         // [batch, 3] triplets (what a DataLoader batch looks like)
+        out[3 * i + 0] = user;
+        out[3 * i + 1] = pos;
+        out[3 * i + 2] = neg;
+    } else {                                           // [3, batch] node ids: users, offset + positives, offset + negatives
+        out[i] = user;
+        out[batch + i] = soa_item_offset + pos;
+        out[2 * batch + i] = soa_item_offset + neg;
+    }
 }
 
 }  // namespace igcn
@@ -55,6 +61,19 @@ extern "C" int igcn_bpr_sample(const int64_t *train_rowptr, const int32_t *train
     if (batch == 0) return IGCN_OK;
     hipLaunchKernelGGL(bpr_sample_kernel, dim3((unsigned)((batch + kBlock - 1) / kBlock)), dim3(kBlock), 0,
                        static_cast<hipStream_t>(stream), train_rowptr, train_col, nonempty_users, n_nonempty, n_items,
-                       batch, (uint32_t)seed, (uint32_t)(seed >> 32), out);
+                       batch, (uint32_t)seed, (uint32_t)(seed >> 32), out, (int64_t)-1);
+    return launch_status();
+}
+
+extern "C" int igcn_bpr_sample_nodes(const int64_t *train_rowptr, const int32_t *train_col,
+                                     const int32_t *nonempty_users, int64_t n_nonempty, int64_t n_items,
+                                     int64_t batch, uint64_t seed, int64_t item_offset, int64_t *out, void *stream)
+{
+    if (!train_rowptr || !train_col || !nonempty_users || !out) return IGCN_E_NULL;
+    if (n_nonempty < 1 || n_items < 1 || batch < 0 || item_offset < 0) return IGCN_E_SHAPE;
+    if (batch == 0) return IGCN_OK;
+    hipLaunchKernelGGL(bpr_sample_kernel, dim3((unsigned)((batch + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), train_rowptr, train_col, nonempty_users, n_nonempty, n_items,
+                       batch, (uint32_t)seed, (uint32_t)(seed >> 32), out, item_offset);
     return launch_status();
 }

@@ -59,6 +59,7 @@ class BasicModel(nn.Module):
         # set by dist.column_shard_model: this model holds d/P embedding columns and the partial dots of a
         # loss are summed over the ranks with this function (an all-reduce)
         self.slice_reduce_fn = None
+        self._batch_grads = ops.BatchGradTable()
 
     def predict(self, users):
         raise NotImplementedError
@@ -170,9 +171,17 @@ class LightGCN(BasicModel):
         return (*(rep[i] for i in idx), _sq_norms(*(raw[i] for i in idx)))
 
     def bpr_loss_terms(self, users, pos_items, neg_items):
-        rep, e = self.get_rep(self._batch_rows(users, pos_items, neg_items)), self.embedding.weight
-        return ops.bpr_loss_terms(rep, rep, e, e, None, users, pos_items, neg_items, self.n_users, self.n_users,
-                                  reduce_fn=self.slice_reduce_fn)
+        if self.slice_reduce_fn is not None:             # embedding-column slice: partial dots + all-reduce
+            rep, e = self.get_rep(self._batch_rows(users, pos_items, neg_items)), self.embedding.weight
+            return ops.bpr_loss_terms(rep, rep, e, e, None, users, pos_items, neg_items, self.n_users, self.n_users,
+                                      reduce_fn=self.slice_reduce_fn)
+        return self.bpr_loss_terms_nodes(torch.cat([users, self.n_users + pos_items, self.n_users + neg_items]))
+
+    def bpr_loss_terms_nodes(self, nodes):
+        """The same from the node ids of the batch, int64 [3 B] = users | n_users + positives | n_users + negatives
+        (what ops.bpr_sample_nodes draws): one fused autograd node, row-sparse gradients."""
+        return ops.graph_bpr_terms(self.embedding.weight, self.norm_adj, self.norm_adj, self.n_layers, nodes, 'raw',
+                                   self._batch_grads, self.config.get('prune_propagation', True))
 
     def predict(self, users):
         rep = self.get_rep()
@@ -297,9 +306,21 @@ class IGCN(BasicModel):
         return (*rows, _sq_norms(*rows))
 
     def bpr_loss_terms(self, users, pos_items, neg_items):
-        rep = self.get_rep(self._batch_rows(users, pos_items, neg_items))
-        return ops.bpr_loss_terms(rep, rep, rep, rep, None, users, pos_items, neg_items, self.n_users, self.n_users,
-                                  reduce_fn=self.slice_reduce_fn)
+        if self.slice_reduce_fn is not None:
+            rep = self.get_rep(self._batch_rows(users, pos_items, neg_items))
+            return ops.bpr_loss_terms(rep, rep, rep, rep, None, users, pos_items, neg_items, self.n_users, self.n_users,
+                                      reduce_fn=self.slice_reduce_fn)
+        return self.bpr_loss_terms_nodes(torch.cat([users, self.n_users + pos_items, self.n_users + neg_items]))
+
+    def bpr_loss_terms_nodes(self, nodes):
+        """As LightGCN.bpr_loss_terms_nodes; the L2 term is taken on the propagated rows (model.py:297-298)."""
+        keep_prob, seed = self._dropout_args()
+        x0 = self.inductive_rep_layer(self.feat_mat, keep_prob, seed)
+        return ops.graph_bpr_terms(x0, self.norm_adj, self.norm_adj, self._prop_layers(), nodes, 'rep', self._batch_grads,
+                                   self.config.get('prune_propagation', True))
+
+    def _prop_layers(self):
+        return self.n_layers
 
     def aux_loss(self, users, pos_items, neg_items):
         """Self-enhanced auxiliary BPR loss on the raw template rows, weighted by w
@@ -329,6 +350,9 @@ class IGCN(BasicModel):
 
 class IMF(IGCN):
     """INMO-MF, model.py:536-543: the template layer without propagation."""
+
+    def _prop_layers(self):
+        return 0
 
     def _compute_rep(self, needed_rows=None):
         keep_prob, seed = self._dropout_args()

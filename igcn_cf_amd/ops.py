@@ -151,6 +151,90 @@ class FeatureLayerFn(torch.autograd.Function):
                     seed=ctx.seed), None, None, None, None, None
 
 
+class BatchGradTable:
+    """The dense [N, d] table a training step's row-sparse batch gradients are scattered into before the propagation
+    backward gathers from it.  It is all zeros between steps: a step adds into <= 3 B rows and puts exactly those rows
+    back to zero afterwards (igcn_rows_zero_f32), instead of allocating and zero-filling N x d floats per step."""
+
+    def __init__(self):
+        self._t = None
+
+    def get(self, like):
+        if self._t is None or self._t.shape != like.shape or self._t.device != like.device:
+            self._t = torch.zeros_like(like)
+        return self._t
+
+
+class GraphBprFn(torch.autograd.Function):
+    """The differentiable part of one BPR step of a graph model as ONE autograd node (model.py:108-116 / :293-299 +
+    trainer.py:238-243): K-layer propagation pruned to what the batch reads, row gathers, dots, softplus, L2.
+
+    forward(x0, csr, csr_t, n_layers, nodes [3 B] = users | n_users + positives | n_users + negatives, l2_on,
+            table: BatchGradTable, prune) -> tensor [2] = (mean softplus(neg - pos), mean l2_norm_sq)
+    l2_on = 'raw': the L2 term reads the rows of x0 (LightGCN, model.py:110-113); 'rep': the propagated rows (IGCN).
+    backward: batch gradients -> the persistent zero table (float atomics, 256-B row segments), K SpMMs (Horner), the
+    L2 rows of 'raw' added straight into the result, the table's rows put back to zero."""
+
+    @staticmethod
+    def forward(ctx, x0, csr, csr_t, n_layers, nodes, l2_on, table, prune):
+        _require_gpu_f32(x0, 'x0')
+        _require_i64(nodes, 'nodes')
+        if nodes.numel() % 3 or not x0.is_contiguous():
+            raise _lib.IgcnError('nodes must hold 3 * B ids and x0 must be contiguous')
+        B, d = nodes.numel() // 3, x0.shape[1]
+        xd = x0.detach()
+        masks = mark_rows(csr, nodes) if prune and n_layers > 0 else None
+        rep = propagate_mean(csr, xd, n_layers, masks=masks)
+        l2t = xd if l2_on == 'raw' else rep
+        users, pos, neg = nodes[:B], nodes[B:2 * B], nodes[2 * B:]
+        out = torch.empty(2, dtype=torch.float32, device=x0.device)
+        work = torch.empty(3 * B, dtype=torch.float32, device=x0.device)
+        _lib.check(_lib.lib().igcn_bpr_fwd_f32(
+            rep.data_ptr(), rep.data_ptr(), rep.data_ptr(), rep.stride(0), l2t.data_ptr(), l2t.data_ptr(), l2t.data_ptr(),
+            l2t.stride(0), users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B, d, None, out.data_ptr(), work.data_ptr(),
+            _lib.current_stream()), 'igcn_bpr_fwd_f32')
+        ctx.state = (xd, rep, csr_t, n_layers, nodes, l2_on, table, masks, work)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        xd, rep, csr_t, n_layers, nodes, l2_on, table, masks, work = ctx.state
+        B, d = nodes.numel() // 3, rep.shape[1]
+        users, pos, neg = nodes[:B], nodes[B:2 * B], nodes[2 * B:]
+        g = g_out.contiguous().float()
+        gt = table.get(rep)
+        on_rep = l2_on == 'rep'
+        rp, gp = rep.data_ptr(), gt.data_ptr()
+        _lib.check(_lib.lib().igcn_bpr_bwd_f32(
+            rp, rp, rp, rep.stride(0), rp if on_rep else None, rp if on_rep else None, rp if on_rep else None, rep.stride(0),
+            users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B, d, None, work.data_ptr(), g.data_ptr(),
+            gp, gp, gp, gp if on_rep else None, gp if on_rep else None, gp if on_rep else None, None,
+            _lib.current_stream()), 'igcn_bpr_bwd_f32')
+        grad = propagate_mean_backward(csr_t, gt, n_layers, masks=masks)
+        if not on_rep:                                   # d/dx0 of mean_b |x0[row]|^2 * g_out[1], row by row
+            _lib.check(_lib.lib().igcn_rows_scaled_add_f32(grad.data_ptr(), grad.stride(0), xd.data_ptr(), xd.stride(0),
+                                                           nodes.data_ptr(), 3 * B, d, g[1:].data_ptr(), 2.0 / B,
+                                                           _lib.current_stream()), 'igcn_rows_scaled_add_f32')
+        _lib.check(_lib.lib().igcn_rows_zero_f32(gp, gt.stride(0), nodes.data_ptr(), 3 * B, d, _lib.current_stream()),
+                   'igcn_rows_zero_f32')
+        return grad, None, None, None, None, None, None, None
+
+
+def graph_bpr_terms(x0, csr, csr_t, n_layers, nodes, l2_on, table, prune=True):
+    return GraphBprFn.apply(x0, csr, csr_t, n_layers, nodes, l2_on, table, prune)
+
+
+def bpr_sample_nodes(train_rowptr, train_col, nonempty_users, n_items, batch, seed, item_offset):
+    """int64 [3 * batch] node ids of the draws of bpr_sample(seed): users | item_offset + positives | item_offset +
+    negatives (igcn_bpr_sample_nodes)."""
+    _require_i64(train_rowptr, 'train_rowptr')
+    out = torch.empty(3 * batch, dtype=torch.int64, device=train_rowptr.device)
+    _lib.check(_lib.lib().igcn_bpr_sample_nodes(train_rowptr.data_ptr(), train_col.data_ptr(), nonempty_users.data_ptr(),
+                                                nonempty_users.numel(), n_items, batch, int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                                int(item_offset), out.data_ptr(), _lib.current_stream()), 'igcn_bpr_sample_nodes')
+    return out
+
+
 def _require_i64(t, name):
     if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.int64 and t.is_contiguous()):
         raise _lib.IgcnError('%s must be a contiguous int64 tensor on the GPU' % name)

@@ -108,6 +108,18 @@ class DeviceSampler:
             self.calls += 1
             yield ops.bpr_sample(self.rowptr, self.col, self.nonempty, self.n_items, b, batch_seed(self.seed, self.calls))
 
+    def epoch_node_batches(self, batch_size, item_offset):
+        """The same draws as epoch_batches (same seeds), each as int64 [3 * b] NODE ids: users | item_offset +
+        positives | item_offset + negatives — what a graph model's bpr_loss_terms_nodes takes, with no transpose,
+        offset add or concatenation per step."""
+        left = self.length
+        while left > 0:
+            b = min(batch_size, left)
+            left -= b
+            self.calls += 1
+            yield ops.bpr_sample_nodes(self.rowptr, self.col, self.nonempty, self.n_items, b,
+                                       batch_seed(self.seed, self.calls), item_offset)
+
 
 class BasicTrainer:
     def __init__(self, trainer_config):
@@ -135,6 +147,8 @@ class BasicTrainer:
         kw = {}
         if opt is Adam and self.config.get('fused_optimizer', True):
             kw['fused'] = True             # same update rule, one kernel over all parameters
+            if self.config.get('hip_graph', False):
+                kw['capturable'] = True    # the step count lives on the device, so the step can sit in a HIP graph
         self.opt = opt(self.model.parameters(), lr=self.config['lr'], **kw)
 
     def train_one_epoch(self):
@@ -375,22 +389,58 @@ class BPRTrainer(BasicTrainer):
         self.sampler = DeviceSampler(self.dataset, self.device, trainer_config.get('seed', 2021))
         self.initialize_optimizer()
         self.l2_reg = trainer_config['l2_reg']
+        self._graph = None
 
     def bpr_step(self, inputs):
         """One optimisation step on an int64 [B, 3] batch; returns the loss tensor."""
         users, pos_items, neg_items = inputs.t().contiguous().unbind(0)          # one transpose, three row views
-        terms = self.model.bpr_loss_terms(users, pos_items, neg_items)
+        return self._optimise(self.model.bpr_loss_terms(users, pos_items, neg_items))
+
+    def _optimise(self, terms):
         loss = terms[0] + self.l2_reg * terms[1]
         self.opt.zero_grad()
         loss.backward()
         self.opt.step()
         return loss.detach()
 
+    def node_step(self, nodes):
+        """One optimisation step on the node ids of a batch (DeviceSampler.epoch_node_batches).  With the trainer
+        config key 'hip_graph': True, full-size batches replay ONE captured HIP graph (forward, backward and the
+        fused Adam step: ~35 launches become one) — what a launch-bound small graph needs."""
+        if not self.config.get('hip_graph', False) or nodes.numel() != 3 * self.batch_size:
+            return self._optimise(self.model.bpr_loss_terms_nodes(nodes))
+        if self._graph is None:
+            self._capture(nodes)
+        self._static_nodes.copy_(nodes)
+        self._graph.replay()
+        return self._static_loss.clone()
+
+    def _capture(self, nodes):
+        self._static_nodes = nodes.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                    # warm-up off the capture: lazy initialisation, workspaces
+            for _ in range(3):
+                self._optimise(self.model.bpr_loss_terms_nodes(self._static_nodes))
+        torch.cuda.current_stream().wait_stream(side)
+        self.opt.zero_grad(set_to_none=True)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            terms = self.model.bpr_loss_terms_nodes(self._static_nodes)
+            loss = terms[0] + self.l2_reg * terms[1]
+            loss.backward()
+            self.opt.step()
+            self._static_loss = loss.detach()
+
     def train_one_epoch(self):
         losses = AverageMeter()
         pending = []
-        for inputs in self.sampler.epoch_batches(self.batch_size):
-            pending.append((self.bpr_step(inputs), inputs.shape[0]))
+        if hasattr(self.model, 'bpr_loss_terms_nodes') and self.model.slice_reduce_fn is None:
+            for nodes in self.sampler.epoch_node_batches(self.batch_size, self.model.n_users):
+                pending.append((self.node_step(nodes), nodes.shape[0] // 3))
+        else:
+            for inputs in self.sampler.epoch_batches(self.batch_size):
+                pending.append((self.bpr_step(inputs), inputs.shape[0]))
         for loss, n in pending:               # one host sync per epoch, not per step (trainer.py:247)
             losses.update(loss.item(), n)
         return losses.avg
@@ -413,7 +463,12 @@ class IGCNTrainer(BasicTrainer):
 
     def igcn_step(self, inputs, aux_inputs):
         users, pos_items, neg_items = inputs.t().contiguous().unbind(0)
-        terms = self.model.bpr_loss_terms(users, pos_items, neg_items)
+        return self._igcn_optimise(self.model.bpr_loss_terms(users, pos_items, neg_items), aux_inputs)
+
+    def igcn_node_step(self, nodes, aux_inputs):
+        return self._igcn_optimise(self.model.bpr_loss_terms_nodes(nodes), aux_inputs)
+
+    def _igcn_optimise(self, terms, aux_inputs):
         a_users, a_pos, a_neg = aux_inputs.t().contiguous().unbind(0)
         aux_loss = self.model.aux_loss(a_users, a_pos, a_neg)
         loss = terms[0] + self.l2_reg * terms[1] + self.aux_reg * aux_loss
@@ -425,9 +480,14 @@ class IGCNTrainer(BasicTrainer):
     def train_one_epoch(self):
         losses = AverageMeter()
         pending = []
-        for inputs, aux_inputs in zip(self.sampler.epoch_batches(self.batch_size),
-                                      self.aux_sampler.epoch_batches(self.batch_size)):
-            pending.append((self.igcn_step(inputs, aux_inputs), inputs.shape[0]))
+        if self.model.slice_reduce_fn is None:
+            for nodes, aux_inputs in zip(self.sampler.epoch_node_batches(self.batch_size, self.model.n_users),
+                                         self.aux_sampler.epoch_batches(self.batch_size)):
+                pending.append((self.igcn_node_step(nodes, aux_inputs), nodes.shape[0] // 3))
+        else:
+            for inputs, aux_inputs in zip(self.sampler.epoch_batches(self.batch_size),
+                                          self.aux_sampler.epoch_batches(self.batch_size)):
+                pending.append((self.igcn_step(inputs, aux_inputs), inputs.shape[0]))
         for loss, n in pending:
             losses.update(loss.item(), n)
         self.model.feat_mat_anneal()

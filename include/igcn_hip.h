@@ -228,6 +228,21 @@ int igcn_bpr_sample(const int64_t *train_rowptr, const int32_t *train_col,
                     const int32_t *nonempty_users, int64_t n_nonempty, int64_t n_items,
                     int64_t batch, uint64_t seed, int64_t *out, void *stream);
 
+/* The same draws as igcn_bpr_sample(seed), written as the NODE ids a graph model gathers (model.py:110-115):
+ * out [3, batch] = users | item_offset + positives | item_offset + negatives (item_offset = n_users). */
+int igcn_bpr_sample_nodes(const int64_t *train_rowptr, const int32_t *train_col,
+                          const int32_t *nonempty_users, int64_t n_nonempty, int64_t n_items,
+                          int64_t batch, uint64_t seed, int64_t item_offset, int64_t *out, void *stream);
+
+/* Row-sparse helpers of the training step's backward pass (trainer.py:244-246: loss.backward()).
+ *  igcn_rows_scaled_add_f32: dst[ids[i]] += scale_host * (scale_dev ? *scale_dev : 1) * src[ids[i]] for i < n, float
+ *  atomics (an id may repeat) — the gradient of the L2 term on the raw embedding rows (model.py:110-113) added to the
+ *  dense gradient the propagation backward produced, instead of a second dense table and a dense add.
+ *  igcn_rows_zero_f32: dst[ids[i]] = 0 — puts the persistent batch-gradient table back to zero after a step. */
+int igcn_rows_scaled_add_f32(float *dst, int64_t ldd, const float *src, int64_t lds, const int64_t *ids, int64_t n,
+                             int32_t d, const float *scale_dev, float scale_host, void *stream);
+int igcn_rows_zero_f32(float *dst, int64_t ldd, const int64_t *ids, int64_t n, int32_t d, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

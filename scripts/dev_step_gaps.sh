@@ -20,8 +20,8 @@ print('steps 40  wall_us/step %.1f  gpu_busy_us/step %.1f  kernels/step %.1f  id
 import collections
 agg = collections.defaultdict(lambda: [0, 0])
 for s, e, n in seg:
-    k = n.split('(')[0].replace('void ', '').replace('igcn::', '')[:60]
+    k = n.split('(')[0].replace('void ', '').replace('igcn::', '')[:90]
     agg[k][0] += e - s; agg[k][1] += 1
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:14]:
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:30]:
     print('  %-62s %7.1f us/step  %5.1f calls/step' % (k, v[0] / 40e3, v[1] / 40))
 PY

@@ -508,3 +508,42 @@ def test_column_sharded_lightgcn_class_world1_matches_plain(golden):
     (la[0] + 0.01 * la[1]).backward(); (lb[0] + 0.01 * lb[1]).backward()
     assert torch.allclose(plain.embedding.weight.grad, col.emb.grad, rtol=1e-5, atol=1e-9)
     assert torch.equal(col.full_embedding().cpu(), emb0)
+
+
+def test_node_batches_fused_step_and_hip_graph(golden):
+    """The trainers' fast path: (1) epoch_node_batches draws the same triplets as epoch_batches, as node ids;
+    (2) the persistent batch-gradient table is all zeros again after a step; (3) a LightGCN trained through ONE captured
+    HIP graph per step (config 'hip_graph') follows the eager trajectory (same batches, same fused Adam)."""
+    from igcn_cf_amd.model import get_model
+    from igcn_cf_amd.trainer import DeviceSampler, get_trainer
+    ds = _dataset(golden)
+    a, b = DeviceSampler(ds, 'cuda', seed=5), DeviceSampler(ds, 'cuda', seed=5)
+    for t3, nodes in zip(a.epoch_batches(64), b.epoch_node_batches(64, ds.n_users)):
+        B = t3.shape[0]
+        assert torch.equal(nodes[:B], t3[:, 0]) and torch.equal(nodes[B:2 * B], ds.n_users + t3[:, 1])
+        assert torch.equal(nodes[2 * B:], ds.n_users + t3[:, 2])
+    tcfg = {'name': 'BPRTrainer', 'optimizer': 'Adam', 'lr': 1e-2, 'l2_reg': 1e-3, 'device': 'cuda', 'n_epochs': 1,
+            'batch_size': 32, 'dataloader_num_workers': 0, 'test_batch_size': 64, 'topks': [5], 'seed': 9}
+    finals, losses = [], []
+    for hip_graph in (False, True):
+        torch.manual_seed(3)
+        model = get_model({'name': 'LightGCN', 'embedding_size': 64, 'n_layers': 3, 'device': 'cuda'}, ds)
+        trainer = get_trainer(dict(tcfg, hip_graph=hip_graph), ds, model)
+        model.train()
+        if hip_graph:                                    # the capture's warm-up steps must not move the comparison's start
+            w0 = model.embedding.weight.detach().clone()
+            nodes0 = next(iter(DeviceSampler(ds, 'cuda', seed=77).epoch_node_batches(32, ds.n_users)))
+            trainer._capture(nodes0)
+            with torch.no_grad():
+                model.embedding.weight.copy_(w0)
+            for st in trainer.opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        losses.append(trainer.train_one_epoch())
+        assert float(model._batch_grads.get(model.embedding.weight).abs().max()) == 0.0
+        finals.append(model.embedding.weight.detach().cpu().numpy().copy())
+        assert (trainer._graph is not None) == hip_graph
+    assert abs(losses[0] - losses[1]) < 1e-5
+    # float atomics order the batch gradients differently from run to run: Adam turns that into rounding-level noise
+    assert np.abs(finals[0] - finals[1]).max() < 5e-3 and np.mean(np.abs(finals[0] - finals[1]) > 1e-5) < 2e-2
