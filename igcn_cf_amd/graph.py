@@ -122,6 +122,66 @@ def feature_matrix_host(train_array, n_users, n_items, user_map=None, item_map=N
     return rowptr, col, row_sum, shape
 
 
+def _csr_from_keys_device(key, n_rows, n_cols):
+    """Row-major sorted CSR with duplicates counted, from int64 keys = row * n_cols + col on the device:
+    (rowptr int64 [n_rows + 1], col int32, count float32) — the device form of coo_to_csr_host for unit values."""
+    ukey, counts = torch.unique(key, sorted=True, return_counts=True)
+    row = torch.div(ukey, n_cols, rounding_mode='floor')
+    col = (ukey - row * n_cols).to(torch.int32)
+    rowptr = torch.empty(n_rows + 1, dtype=torch.int64, device=key.device)
+    _lib.check(_lib.lib().igcn_csr_from_sorted_coo(row.data_ptr(), row.numel(), n_rows, rowptr.data_ptr(), _lib.current_stream()),
+               'igcn_csr_from_sorted_coo')
+    return rowptr, row, col, counts.to(torch.float32)
+
+
+def normalized_adjacency_device(train_array, n_users, n_items, device):
+    """normalized_adjacency_host built in HBM (the graph-swap path of the inductive update, run/dropui/igcn_dropui.py:
+    26-35, rebuilds the graph on a live model): one sort of the 2 T keys on the GPU instead of host argsorts.  Values
+    are BIT-IDENTICAL to the host builder / model.py:85-94: degrees are small integers, so D^-1/2 comes from a table of
+    numpy float32 powers, and the two float32 products are taken in the reference's order."""
+    ta = torch.from_numpy(np.ascontiguousarray(np.asarray(train_array, dtype=np.int64).reshape(-1, 2))).to(device)
+    n = n_users + n_items
+    users, items = ta[:, 0], ta[:, 1] + n_users
+    key = torch.cat([users * n + items, items * n + users])
+    rowptr, row, col, val = _csr_from_keys_device(key, n, n)
+    degree = torch.zeros(n, dtype=torch.float32, device=device).index_add_(0, row, val).clamp_(min=1.)
+    max_deg = int(degree.max().item()) if n else 1
+    table = np.power(np.maximum(np.arange(max_deg + 1, dtype=np.float32), np.float32(1.)), np.float32(-0.5)).astype(np.float32)
+    d_inv = torch.from_numpy(table).to(device)[degree.to(torch.int64)]
+    val = (d_inv[row] * val) * d_inv[col.to(torch.int64)]
+    return CsrMatrix.from_device(rowptr, col, val, (n, n))
+
+
+def feature_matrix_device(train_array, n_users, n_items, user_map, item_map, device):
+    """feature_matrix_host built in HBM: (CsrMatrix F with implicit unit values, row_sum float32 tensor)."""
+    ta = torch.from_numpy(np.ascontiguousarray(np.asarray(train_array, dtype=np.int64).reshape(-1, 2))).to(device)
+    users, items = ta[:, 0], ta[:, 1]
+
+    def lut(mapping, n):
+        if mapping is None:
+            return torch.arange(n, dtype=torch.int64, device=device), n
+        t = np.full(n, -1, dtype=np.int64)
+        if len(mapping):
+            k = np.fromiter(mapping.keys(), dtype=np.int64, count=len(mapping))
+            v = np.fromiter(mapping.values(), dtype=np.int64, count=len(mapping))
+            keep = k < n
+            t[k[keep]] = v[keep]
+        return torch.from_numpy(t).to(device), len(mapping)
+    u_lut, user_dim = lut(user_map, n_users)
+    i_lut, item_dim = lut(item_map, n_items)
+    it, ut = i_lut[items], u_lut[users]
+    m_i, m_u = it >= 0, ut >= 0
+    n_cols = user_dim + item_dim + 2
+    ar_u = torch.arange(n_users, dtype=torch.int64, device=device)
+    ar_i = torch.arange(n_items, dtype=torch.int64, device=device)
+    key = torch.cat([users[m_i] * n_cols + (user_dim + it[m_i]), (n_users + items[m_u]) * n_cols + ut[m_u],
+                     ar_u * n_cols + (user_dim + item_dim), (n_users + ar_i) * n_cols + (user_dim + item_dim + 1)])
+    n_rows = n_users + n_items
+    rowptr, row, col, val = _csr_from_keys_device(key, n_rows, n_cols)
+    row_sum = torch.zeros(n_rows, dtype=torch.float32, device=device).index_add_(0, row, val)
+    return CsrMatrix.from_device(rowptr, col, None, (n_rows, n_cols)), row_sum
+
+
 def graph_rank_nodes(dataset, ranking_metric):
     """Template ranking for feature_ratio < 1 (utils.py:94-123): 'degree' = row sums
     of A, 'sort' / 'greedy' = column sums of the row-L1-normalised A.  Returns

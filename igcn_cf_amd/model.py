@@ -28,7 +28,7 @@ import torch.nn as nn
 from torch.nn.init import normal_
 
 from . import _lib, ops
-from .graph import (CsrMatrix, feature_matrix_host, graph_rank_nodes, normalized_adjacency_host)
+from .graph import (feature_matrix_device, graph_rank_nodes, normalized_adjacency_device)
 
 
 def get_model(config, dataset):
@@ -143,10 +143,8 @@ class LightGCN(BasicModel):
         self.to(device=self.device)
 
     def generate_graph(self, dataset):
-        """A_hat = D^-1/2 A D^-1/2 as device CSR (model.py:85-94)."""
-        n = dataset.n_users + dataset.n_items
-        rowptr, col, val = normalized_adjacency_host(dataset.train_array, dataset.n_users, dataset.n_items)
-        return CsrMatrix(rowptr, col, val, (n, n), self.device)
+        """A_hat = D^-1/2 A D^-1/2 as device CSR (model.py:85-94), built in HBM."""
+        return normalized_adjacency_device(dataset.train_array, dataset.n_users, dataset.n_items, self.device)
 
     def get_rep(self, needed_rows=None):
         """needed_rows: ids of the only rows the caller will read (training batches); the
@@ -265,10 +263,10 @@ class IGCN(BasicModel):
             item_map = {int(i): idx for idx, i in enumerate(core_items)}
         else:
             user_map, item_map = self.user_map, self.item_map
-        rowptr, col, row_sum, shape = feature_matrix_host(dataset.train_array, self.n_users, self.n_items,
-                                                          user_map, item_map)
-        feat = CsrMatrix(rowptr, col, None, shape, self.device, keep_host=True)
-        return feat, user_map, item_map, torch.from_numpy(row_sum).to(self.device)
+        full = not is_updating and self.feature_ratio >= 1.      # every node its own template: identity maps
+        feat, row_sum = feature_matrix_device(dataset.train_array, self.n_users, self.n_items,
+                                              None if full else user_map, None if full else item_map, self.device)
+        return feat, user_map, item_map, row_sum
 
     def inductive_rep_layer(self, feat_mat, keep_prob=1., seed=0):
         """X0 = dropout(F) @ T (model.py:423-432; no padding tensor is needed)."""

@@ -71,6 +71,24 @@ def _csr_to_device(rowptr, col, device):
             torch.from_numpy(np.ascontiguousarray(col, dtype=np.int32)).to(device))
 
 
+def _sorted_csr_device(csrs, n_items, device):
+    """Per-user union (as a multiset) of one or more host CSR lists (any order inside a user), each user's items
+    sorted ascending, as device arrays (rowptr int64, col int32): the sort runs on the GPU (one torch.sort of
+    user * n_items + item keys), not as a host lexsort per evaluation stage."""
+    n = len(csrs[0][0]) - 1
+    counts = sum(torch.from_numpy(np.diff(rp).astype(np.int64)) for rp, _ in csrs)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64)
+    torch.cumsum(counts, 0, out=rowptr[1:])
+    keys = []
+    users = torch.arange(n, dtype=torch.int64, device=device)
+    for rp, col in csrs:
+        lens = torch.from_numpy(np.diff(rp).astype(np.int64)).to(device)
+        c = torch.from_numpy(np.ascontiguousarray(col, dtype=np.int64)).to(device)
+        keys.append(torch.repeat_interleave(users, lens) * n_items + c)
+    key = torch.sort(torch.cat(keys) if len(keys) > 1 else keys[0]).values
+    return rowptr.to(device), (key % n_items).to(torch.int32)
+
+
 def _merge_sorted_csr(a, b):
     """Per-user union (as a multiset) of two CSR lists, each row sorted ascending."""
     (rp_a, col_a), (rp_b, col_b) = a, b
@@ -89,8 +107,8 @@ class DeviceSampler:
     DataLoader over BasicDataset.__getitem__, trainer.py:226-227)."""
 
     def __init__(self, dataset, device, seed):
-        rowptr, col = dataset.csr('train', sort=True)
-        self.rowptr, self.col = _csr_to_device(rowptr, col, device)
+        rowptr, col = dataset.csr('train', sort=False)
+        self.rowptr, self.col = _sorted_csr_device([(rowptr, col)], dataset.n_items, device)
         nonempty = np.flatnonzero(np.diff(rowptr) > 0).astype(np.int32)
         self.nonempty = torch.from_numpy(nonempty).to(device)
         self.n_items = dataset.n_items
@@ -278,8 +296,7 @@ class BasicTrainer:
         split's version changed.  In-place edits of the lists need dataset.invalidate(split)."""
         key = ('eval', val_or_test) + self._split_version(val_or_test)
         if self._excl_cache.get('eval_key') != key or None in key:
-            rowptr, col = self.dataset.csr(val_or_test, sort=True)
-            rp, cl = _csr_to_device(rowptr, col, self.device)
+            rp, cl = _sorted_csr_device([self.dataset.csr(val_or_test, sort=False)], self.dataset.n_items, self.device)
             self._excl_cache['eval_key'] = key
             self._excl_cache['eval_val'] = (rp, cl, (rp[1:] - rp[:-1]).contiguous())
         return self._excl_cache['eval_val']
@@ -303,11 +320,11 @@ class BasicTrainer:
             return None, None
         key = ('excl', val_or_test) + self._split_version('train', 'val')
         if self._excl_cache.get('excl_key_' + val_or_test) != key or None in key:
-            excl = self.dataset.csr('train', sort=True)
+            lists = [self.dataset.csr('train', sort=False)]
             if val_or_test == 'test':
-                excl = _merge_sorted_csr(excl, self.dataset.csr('val', sort=True))
+                lists.append(self.dataset.csr('val', sort=False))
             self._excl_cache['excl_key_' + val_or_test] = key
-            self._excl_cache['excl_val_' + val_or_test] = _csr_to_device(excl[0], excl[1], self.device)
+            self._excl_cache['excl_val_' + val_or_test] = _sorted_csr_device(lists, self.dataset.n_items, self.device)
         return self._excl_cache['excl_val_' + val_or_test]
 
     def recommend_all(self, val_or_test, banned_items=None):
@@ -326,11 +343,12 @@ class BasicTrainer:
                 out.append(self.model.recommend(users, k, excl_rowptr, excl_col, banned))
         return torch.cat(out, dim=0) if len(out) > 1 else out[0]
 
-    def eval(self, val_or_test, banned_items=None):
-        """trainer.py:140-177; returns (results string, metrics dict)."""
+    def eval(self, val_or_test, banned_items=None, _eval_lists=None):
+        """trainer.py:140-177; returns (results string, metrics dict).  _eval_lists (internal): device CSR
+        (rowptr, sorted items, lengths) evaluated instead of the dataset's lists of that stage."""
         self.model.eval()
         rec = self.recommend_all(val_or_test, banned_items)
-        rp, cl, lens = self._eval_lists_device(val_or_test)    # eval lists may have been edited in place
+        rp, cl, lens = _eval_lists if _eval_lists is not None else self._eval_lists_device(val_or_test)
         hit = ops.hit_matrix(rec.contiguous(), rp, cl)
         if self.config.get('host_metrics', False):
             metrics = self._metrics_from_hits(hit.cpu().numpy(), lens.cpu().numpy().astype(np.int32))
@@ -348,36 +366,34 @@ class BasicTrainer:
         graph was extended by users >= n_old_users and items >= n_old_items: every combination the
         paper reports of {all, old, new} users x {all, old, new} items.  A user outside the evaluated
         user set gets an empty test list; for an item subset the test lists are filtered to it and
-        the other items are banned from the recommendations.  The dataset's test lists are restored
-        afterwards."""
+        the other items are banned from the recommendations.  The reference edits dataset.test_data in place
+        and restores it; here the six filtered lists are cut from the test CSR on the device and the dataset is
+        never touched."""
         n_users, n_items = self.dataset.n_users, self.dataset.n_items
-        original = self.dataset.test_data
+        rp, cl, _ = self._eval_lists_device('test')
+        user_of = torch.repeat_interleave(torch.arange(n_users, device=self.device), rp[1:] - rp[:-1])
         old_items = np.arange(n_old_items)
         new_items = np.arange(n_old_items, n_items)
-        #  label                     evaluated users              kept items  banned items
+        #  label                     evaluated users (lo, hi)    kept items  banned items
         variants = [
-            ('All users and all items', range(n_users),               None,  None),
-            ('Old users and all items', range(n_old_users),           None,  None),
-            ('New users and all items', range(n_old_users, n_users),  None,  None),
-            ('All users and old items', range(n_users),               'old', new_items),
-            ('All users and new items', range(n_users),               'new', old_items),
-            ('Old users and old items', range(n_old_users),           'old', new_items),
+            ('All users and all items', (0, n_users),               None,  None),
+            ('Old users and all items', (0, n_old_users),           None,  None),
+            ('New users and all items', (n_old_users, n_users),     None,  None),
+            ('All users and old items', (0, n_users),               'old', new_items),
+            ('All users and new items', (0, n_users),               'new', old_items),
+            ('Old users and old items', (0, n_old_users),           'old', new_items),
         ]
-        try:
-            for label, users, keep, banned in variants:
-                lists = [[] for _ in range(n_users)]
-                for u in users:
-                    items = original[u]
-                    if keep == 'old':
-                        items = [i for i in items if i < n_old_items]
-                    elif keep == 'new':
-                        items = [i for i in items if i >= n_old_items]
-                    lists[u] = list(items)
-                self.dataset.test_data = lists
-                summary, _ = self.eval('test', banned_items=banned)
-                print(f'{label} result. {summary}')
-        finally:
-            self.dataset.test_data = original
+        for label, (ulo, uhi), keep, banned in variants:
+            m = (user_of >= ulo) & (user_of < uhi)
+            if keep == 'old':
+                m &= cl < n_old_items
+            elif keep == 'new':
+                m &= cl >= n_old_items
+            lens = torch.bincount(user_of[m], minlength=n_users)
+            frp = torch.zeros(n_users + 1, dtype=torch.int64, device=self.device)
+            torch.cumsum(lens, 0, out=frp[1:])
+            summary, _ = self.eval('test', banned_items=banned, _eval_lists=(frp, cl[m].contiguous(), lens))
+            print(f'{label} result. {summary}')
 
 
 class BPRTrainer(BasicTrainer):

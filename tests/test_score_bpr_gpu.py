@@ -179,15 +179,16 @@ def test_inductive_eval_golden(golden, capsys):
     got = []
     orig = tr.eval
 
-    def spy(stage, banned_items=None):
-        res = orig(stage, banned_items=banned_items)
-        got.append((tr.last_rec_items.cpu().numpy(), res[1], [list(x) for x in ds.test_data]))
+    def spy(stage, banned_items=None, _eval_lists=None):
+        res = orig(stage, banned_items=banned_items, _eval_lists=_eval_lists)
+        rp, cl = _eval_lists[0].cpu().numpy(), _eval_lists[1].cpu().numpy()      # the masked test lists of this variant
+        got.append((tr.last_rec_items.cpu().numpy(), res[1], [cl[rp[u]:rp[u + 1]].tolist() for u in range(ds.n_users)]))
         return res
     tr.eval = spy
     test_before = [list(x) for x in ds.test_data]
     n_old_users, n_old_items = (int(v) for v in golden['ind_n_old'])
     tr.inductive_eval(n_old_users, n_old_items)
-    assert len(got) == 6 and [list(x) for x in ds.test_data] == test_before      # test lists restored
+    assert len(got) == 6 and [list(x) for x in ds.test_data] == test_before      # the dataset's lists are never touched
     assert 'Old users and old items result.' in capsys.readouterr().out
     lists = _lists(golden)
     ex, _, _ = _excl_csr(lists, 'test')

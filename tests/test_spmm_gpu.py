@@ -359,3 +359,30 @@ def test_config5_rank_shard_hbm_bound_variant():
     lhs = (spmm(ones, x).double() * yt.double()).sum().item()
     rhs = (spmm(ones.transposed_view(), yt).double() * x.double()).sum().item()
     assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+
+
+def test_device_graph_builders_are_bit_identical_to_the_host_ones(golden):
+    """normalized_adjacency_device / feature_matrix_device (what the models build their graphs with, in HBM) against
+    the host builders that are pinned to the reference-run fixtures: same structure, bit-identical values, on the golden
+    toys (duplicate pairs, empty users, partial template maps) and on a 5000 x 4000 synthetic split."""
+    from igcn_cf_amd.dataset import ProcessedDataset, SyntheticDataset
+    from igcn_cf_amd.graph import (feature_matrix_device, feature_matrix_host, normalized_adjacency_device,
+                                   normalized_adjacency_host)
+    cases = [ProcessedDataset({'name': 'ProcessedDataset', 'path': golden['path'], 'device': 'cuda'}),
+             SyntheticDataset({'name': 'SyntheticDataset', 'n_users': 5000, 'n_items': 4000, 'n_inter': 150000, 'zipf_q': 0.})]
+    for ds in cases:
+        nu, ni = ds.n_users, ds.n_items
+        rp, col, val = normalized_adjacency_host(ds.train_array, nu, ni)
+        a = normalized_adjacency_device(ds.train_array, nu, ni, 'cuda')
+        np.testing.assert_array_equal(a.rowptr.cpu().numpy(), rp)
+        np.testing.assert_array_equal(a.col.cpu().numpy(), col)
+        np.testing.assert_array_equal(a.val.cpu().numpy(), val)                 # bit-exact, not allclose
+        half_u = {int(u): j for j, u in enumerate(range(0, nu, 2))}
+        third_i = {int(i): j for j, i in enumerate(range(1, ni, 3))}
+        for um, im in ((None, None), (half_u, third_i)):
+            frp, fcol, frow_sum, shape = feature_matrix_host(ds.train_array, nu, ni, um, im)
+            f, row_sum = feature_matrix_device(ds.train_array, nu, ni, um, im, 'cuda')
+            assert f.shape == shape and f.val is None
+            np.testing.assert_array_equal(f.rowptr.cpu().numpy(), frp)
+            np.testing.assert_array_equal(f.col.cpu().numpy(), fcol)
+            np.testing.assert_array_equal(row_sum.cpu().numpy(), frow_sum)
