@@ -13,7 +13,7 @@ def find(d, suffix):
 
 
 def short(name):
-    name = name.replace('igcn::', '')
+    name = name.replace('igcn::', '').replace('(anonymous namespace)::', '')
     return name.split('(')[0][:90]
 
 
@@ -22,13 +22,21 @@ def main():
     src = os.path.join('gpurun_out', 'prof_' + tag)
     os.makedirs('profiles', exist_ok=True)
     lines = []
-    ks = find(os.path.join(src, 'kt'), 'kernel_stats.csv')
-    if ks:
-        lines.append('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline')
+    for sub, cmd, top in (('kt', 'bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras --no-hbm-leg  (the headline workload alone: '
+                                 'the SpMM average below is that of the timed launches)', 8),
+                          ('kt_full', 'bench.py --steps 100 --warmup 10 --no-cpu-baseline  (with eval, train step, HBM-bound leg, '
+                                      'Gowalla-size step: the SpMM kernel name now also covers masked and small-graph launches)', 24)):
+        ks = find(os.path.join(src, sub), 'kernel_stats.csv')
+        if not ks:
+            continue
+        lines.append('# rocprofv3 --kernel-trace --stats -- python3 ' + cmd)
         lines.append('%-92s %8s %12s %10s %7s' % ('kernel', 'calls', 'total_us', 'avg_us', 'pct'))
-        for r in csv.DictReader(open(ks)):
+        for j, r in enumerate(csv.DictReader(open(ks))):
+            if j >= top:
+                break
             lines.append('%-92s %8s %12.1f %10.2f %7s' % (short(r['Name']), r['Calls'], float(r['TotalDurationNs']) / 1e3,
                                                           float(r['AverageNs']) / 1e3, r['Percentage']))
+        lines.append('')
     pmc = {}
     for key, sub in (('FETCH_SIZE', 'pmc_fetch'), ('WRITE_SIZE', 'pmc_write'), ('TCC_HIT_sum', 'pmc_l2'), ('TCC_MISS_sum', 'pmc_l2')):
         f = find(os.path.join(src, sub), 'counter_collection.csv')
