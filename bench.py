@@ -107,7 +107,7 @@ def main():
         return float(t.item())
 
     if not sharded:
-        csr = CsrMatrix(rowptr, col, val, (n, n), device)
+        csr = CsrMatrix(rowptr, col, val, (n, n), device, order_blocks=[0, ds.n_users, n])
         x0 = emb_host.to(device)
         step = lambda: ops.propagate_mean(csr, x0, K)
         local_nnz, local_rows, launches_per_step = nnz, n, K
@@ -244,7 +244,7 @@ def sharded_side_measurements(ds, device, d, K, rank, world, rowptr, col, val, e
 
     if d % world == 0:
         dl = d // world
-        csr = CsrMatrix(rowptr, col, val, (n, n), device)
+        csr = CsrMatrix(rowptr, col, val, (n, n), device, order_blocks=[0, ds.n_users, n])
         xs = emb_host[:, rank * dl:(rank + 1) * dl].contiguous().to(device)
         sec = timed(lambda: ops.propagate_mean(csr, xs, K), 200, 20)
         res['column_sharded'] = {'ms_per_step': sec * 1e3, 'edges_per_s': K * nnz / sec,

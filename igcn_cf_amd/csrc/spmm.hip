@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
     int64_t n_rows, int d, SpmmEpilogue ep, SpmmDropout dr,
     const igcn_row_segment *__restrict__ segments, int64_t n_segments,
     float *__restrict__ partial, int long_threshold,
-    const uint8_t *__restrict__ row_mask, int masked_rows_zero)
+    const uint8_t *__restrict__ row_mask, int masked_rows_zero, const int32_t *__restrict__ row_order)
 {
     constexpr int G = kWave / LPR;           // source rows per gather instruction
     const int lane = threadIdx.x & (kWave - 1);
@@ -84,9 +84,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
     unsigned long long tr_rows = 0, tr_nnz = 0, tr_chunks = 0;
 #endif
 
-    for (int64_t v = wave0; v < n_virtual; v += n_waves) {
+    for (int64_t vv = wave0; vv < n_virtual; vv += n_waves) {
         int64_t start, end, dst;
         bool to_partial;
+        const int64_t v = row_order ? (int64_t)row_order[vv] : vv;
         if (v < n_rows) {
             start = rowptr[v];
             end = rowptr[v + 1];
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
     int64_t n_rows, int d, SpmmEpilogue ep, SpmmDropout dr,
     const igcn_row_segment *__restrict__ segments, int64_t n_segments,
     float *__restrict__ partial, int long_threshold,
-    const uint8_t *__restrict__ row_mask, int masked_rows_zero)
+    const uint8_t *__restrict__ row_mask, int masked_rows_zero, const int32_t *__restrict__ row_order)
 {
     constexpr int S = kWave / R;             // lanes of a sub-wave
     constexpr int G = S / LPR;               // source rows per gather instruction and sub-wave
@@ -213,7 +214,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
     const int64_t n_virtual = n_rows + n_segments;
 
     for (int64_t vb = wave0 * R; vb < n_virtual; vb += n_waves * R) {
-        const int64_t v = vb + lane / S;                          // this sub-wave's virtual row
+        const int64_t vv = vb + lane / S;                         // this sub-wave's virtual row
+        const int64_t v = (row_order && vv < n_virtual) ? (int64_t)row_order[vv] : vv;
         // kind: 0 nothing, 1 ordinary row -> y, 2 row segment -> partial, 3 masked row that must read as zero
         int64_t start = 0, dst = 0;
         int len = 0, kind = 0;
@@ -441,7 +443,7 @@ static int launch_rows(bool dropout, int64_t blocks, hipStream_t st,
                        float *y, int64_t ldy, int64_t n_rows, int d, const SpmmEpilogue &ep, const SpmmDropout &dr,
                        const igcn_row_segment *segments, int64_t n_segments, float *partial, int long_threshold,
                        const igcn_long_row *long_rows, int64_t n_long, const uint8_t *row_mask, int masked_rows_zero,
-                       int64_t nnz)
+                       int64_t nnz, const int32_t *row_order)
 {
     // Grid: `blocks` on entry = one wave per row.  Fewer, longer-lived waves amortise the per-wave set-up;
     // many short ones let the hardware dispatcher even out the load (a power-law graph deals very
@@ -477,17 +479,17 @@ static int launch_rows(bool dropout, int64_t blocks, hipStream_t st,
         if constexpr (R > 1) {
             if (dropout)
                 hipLaunchKernelGGL((spmm_csr_multirow_kernel<LPR, R, true>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y,
-                                   ldy, n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero);
+                                   ldy, n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order);
             else
                 hipLaunchKernelGGL((spmm_csr_multirow_kernel<LPR, R, false>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y,
-                                   ldy, n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero);
+                                   ldy, n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order);
         }
     } else if (dropout)
         hipLaunchKernelGGL((spmm_csr_rows_kernel<LPR, true>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
-                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero);
+                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order);
     else
         hipLaunchKernelGGL((spmm_csr_rows_kernel<LPR, false>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
-                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero);
+                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order);
     int rc = launch_status();
     if (rc != IGCN_OK) return rc;
     if (n_long > 0) {
@@ -560,7 +562,7 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
                                  float *partial, int32_t long_threshold,
                                  const int32_t *edge_id, uint64_t seed, float keep_prob,
                                  const uint8_t *row_mask, int32_t masked_rows_zero,
-                                 int64_t nnz, void *stream)
+                                 int64_t nnz, const int32_t *row_order, void *stream)
 {
     if (!rowptr || !x || !y) return IGCN_E_NULL;
     if (n_rows < 0 || n_cols < 0 || d < 1 || d > 256 || ldx < d || ldy < d) return IGCN_E_SHAPE;
@@ -606,7 +608,7 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
     for (int i = 0; i < n_adds && vec; ++i) vec = reinterpret_cast<uintptr_t>(ep.add[i]) % 16 == 0;
     if (n_segments > 0 && (reinterpret_cast<uintptr_t>(partial) % 16 != 0)) return IGCN_E_ALIGN;
     if (!vec) {
-        if (n_segments > 0 || row_mask) return IGCN_E_ALIGN;   // plan / row masks need the vector path
+        if (n_segments > 0 || row_mask || row_order) return IGCN_E_ALIGN;   // plan / row masks / row order need the vector path
         hipLaunchKernelGGL(spmm_csr_scalar_kernel, scalar_grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
                            n_rows, (int)d, ep, dr, dropout);
         return launch_status();
@@ -614,7 +616,7 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
 #define IGCN_SPMM_CASE(L)                                                                                         \
     return launch_rows<L>(dropout, blocks, st, rowptr, col, val, x, ldx, y, ldy, n_rows, (int)d, ep, dr, segments,  \
                           n_segments, partial, (int)long_threshold, long_rows, n_long_rows, row_mask, (int)masked_rows_zero, \
-                          nnz)
+                          nnz, row_order)
     const int q = d / 4;
     if (q <= 1) IGCN_SPMM_CASE(1);
     if (q <= 2) IGCN_SPMM_CASE(2);

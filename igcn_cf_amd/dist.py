@@ -135,7 +135,7 @@ class RowShardedPropagator:
             spmm_fn = ops.spmm
         if csr_factory is None:
             from .graph import CsrMatrix
-            csr_factory = lambda rp, c, v, shape: CsrMatrix(rp, c, v, shape, self.device)
+            csr_factory = lambda rp, c, v, shape, blocks=None: CsrMatrix(rp, c, v, shape, self.device, order_blocks=blocks)
         self.spmm = spmm_fn
         (urp, ucol, uval), (irp, icol, ival) = local_blocks_host(rowptr, col, val, self.layout, rank)
         L = self.layout
@@ -143,11 +143,19 @@ class RowShardedPropagator:
         self.global_nnz = int(rowptr[-1])
         if fused:                                        # one matrix: the rank's user rows, then its item rows
             rp = np.concatenate([urp, irp[1:] + urp[-1]])
-            self.csr = csr_factory(rp, np.concatenate([ucol, icol]), np.concatenate([uval, ival]), (L.block, L.n_pad))
+            self.csr = self._make_csr(csr_factory, rp, np.concatenate([ucol, icol]), np.concatenate([uval, ival]),
+                                      (L.block, L.n_pad), [0, L.bu, L.block])
         else:
-            self.csr_u = csr_factory(urp, ucol, uval, (L.bu, L.n_pad))
-            self.csr_i = csr_factory(irp, icol, ival, (L.bi, L.n_pad))
+            self.csr_u = self._make_csr(csr_factory, urp, ucol, uval, (L.bu, L.n_pad), [0, L.bu])
+            self.csr_i = self._make_csr(csr_factory, irp, icol, ival, (L.bi, L.n_pad), [0, L.bi])
         self._d = None
+
+    @staticmethod
+    def _make_csr(factory, rp, col, val, shape, blocks):
+        try:
+            return factory(rp, col, val, shape, blocks)          # rows dealt to the waves by length inside each phase
+        except TypeError:
+            return factory(rp, col, val, shape)                  # injected 4-argument factories (CPU tests)
 
     # ---- buffers -----------------------------------------------------------------
     def _buffers(self, d):

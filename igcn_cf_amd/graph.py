@@ -149,7 +149,7 @@ def normalized_adjacency_device(train_array, n_users, n_items, device):
     table = np.power(np.maximum(np.arange(max_deg + 1, dtype=np.float32), np.float32(1.)), np.float32(-0.5)).astype(np.float32)
     d_inv = torch.from_numpy(table).to(device)[degree.to(torch.int64)]
     val = (d_inv[row] * val) * d_inv[col.to(torch.int64)]
-    return CsrMatrix.from_device(rowptr, col, val, (n, n))
+    return CsrMatrix.from_device(rowptr, col, val, (n, n), order_blocks=[0, n_users, n])
 
 
 def feature_matrix_device(train_array, n_users, n_items, user_map, item_map, device):
@@ -179,7 +179,9 @@ def feature_matrix_device(train_array, n_users, n_items, user_map, item_map, dev
     n_rows = n_users + n_items
     rowptr, row, col, val = _csr_from_keys_device(key, n_rows, n_cols)
     row_sum = torch.zeros(n_rows, dtype=torch.float32, device=device).index_add_(0, row, val)
-    return CsrMatrix.from_device(rowptr, col, None, (n_rows, n_cols)), row_sum
+    f = CsrMatrix.from_device(rowptr, col, None, (n_rows, n_cols), order_blocks=[0, n_users, n_rows])
+    f.transposed_order_blocks = [0, user_dim, user_dim + item_dim, n_cols]
+    return f, row_sum
 
 
 def graph_rank_nodes(dataset, ranking_metric):
@@ -211,7 +213,7 @@ class CsrMatrix:
     ones), edge_id int32 [nnz] or None."""
 
     def __init__(self, rowptr, col, val, shape, device, edge_id=None,
-                 long_threshold=LONG_THRESHOLD, segment_len=SEGMENT_LEN, keep_host=False):
+                 long_threshold=LONG_THRESHOLD, segment_len=SEGMENT_LEN, keep_host=False, order_blocks=None):
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
         col = np.ascontiguousarray(col, dtype=np.int32)
         self.shape = (int(shape[0]), int(shape[1]))
@@ -229,13 +231,15 @@ class CsrMatrix:
             torch.from_numpy(np.ascontiguousarray(edge_id, dtype=np.int32)).to(self.device)
         self.long_threshold = int(long_threshold)
         self.segment_len = int(segment_len)
+        self.order_blocks = order_blocks
         self._build_plan()
         self._partial = {}
         self._col_host = col if keep_host else None
         self._transposed = None
 
     @classmethod
-    def from_device(cls, rowptr, col, val, shape, edge_id=None, long_threshold=LONG_THRESHOLD, segment_len=SEGMENT_LEN):
+    def from_device(cls, rowptr, col, val, shape, edge_id=None, long_threshold=LONG_THRESHOLD, segment_len=SEGMENT_LEN,
+                    order_blocks=None):
         """Wrap CSR arrays that already live in HBM (int64 rowptr, int32 col, float32 val or None);
         only rowptr is copied to the host, for the long-row schedule."""
         self = cls.__new__(cls)
@@ -247,6 +251,7 @@ class CsrMatrix:
         if self.rowptr_host.shape[0] != self.shape[0] + 1 or self.rowptr_host[-1] != self.nnz:
             raise ValueError('inconsistent CSR arrays')
         self.long_threshold, self.segment_len = int(long_threshold), int(segment_len)
+        self.order_blocks = order_blocks
         self._build_plan()
         self._partial = {}
         self._col_host = None
@@ -270,7 +275,8 @@ class CsrMatrix:
                                                 t_rowptr.data_ptr(), _lib.ptr(t_col), _lib.ptr(edge_id), ws.data_ptr(),
                                                 _lib.current_stream()), 'igcn_csr_transpose')
                 self._transposed = CsrMatrix.from_device(t_rowptr, t_col, None, (self.shape[1], self.shape[0]), edge_id=edge_id,
-                                                         long_threshold=self.long_threshold, segment_len=self.segment_len)
+                                                         long_threshold=self.long_threshold, segment_len=self.segment_len,
+                                                         order_blocks=getattr(self, 'transposed_order_blocks', None))
             else:
                 col = self._col_host if self._col_host is not None else self.col.cpu().numpy()
                 self._transposed = CsrMatrix.transposed(self.rowptr_host, col, self.shape, self.device,
@@ -285,6 +291,7 @@ class CsrMatrix:
                                                self.segment_len, C.byref(n_long), C.byref(n_seg)), 'spmm_plan_count')
         self.n_long, self.n_segments = int(n_long.value), int(n_seg.value)
         self.long_rows = self.segments = None
+        sg = None
         if self.n_long:
             lr = np.zeros(self.n_long, dtype=_lib.LONG_ROW_DTYPE)
             sg = np.zeros(self.n_segments, dtype=_lib.ROW_SEGMENT_DTYPE)
@@ -293,6 +300,24 @@ class CsrMatrix:
                                                   sg.ctypes.data, self.n_segments), 'spmm_plan_fill')
             self.long_rows = torch.from_numpy(lr.view(np.uint8)).to(self.device)
             self.segments = torch.from_numpy(sg.view(np.uint8)).to(self.device)
+        # The order in which rows and long-row segments are dealt to the waves.  Inside each block of rows (for A_hat:
+        # the user rows, then the item rows, so that the launch still gathers from one table at a time): first the
+        # segments of the block's long rows — the heaviest work items start first instead of forming the kernel's
+        # tail — then the block's rows by descending length, so that the rows a wave works on together and the
+        # waves next to it carry equal work.
+        self.row_order = None
+        if self.order_blocks is not None and self.shape[0] > 0:
+            n_rows = self.shape[0]
+            lens = np.diff(self.rowptr_host)
+            seg_row = sg['row'].astype(np.int64) if self.n_long else np.zeros(0, dtype=np.int64)
+            pieces = []
+            bounds = list(self.order_blocks)
+            for lo, hi in zip(bounds[:-1], bounds[1:]):
+                pieces.append(n_rows + np.flatnonzero((seg_row >= lo) & (seg_row < hi)))
+                pieces.append(lo + np.argsort(-lens[lo:hi], kind='stable'))
+            order = np.concatenate(pieces).astype(np.int32)
+            assert order.shape[0] == n_rows + self.n_segments
+            self.row_order = torch.from_numpy(order).to(self.device)
 
     def partial(self, d):
         """Workspace for the partial sums of long-row segments (n_segments x d)."""

@@ -107,7 +107,12 @@ int igcn_spmm_plan_fill_host(const int64_t *rowptr_host, int64_t n_rows,
  * and the layer before it — and by symmetry the first backward hop — shrink to
  * the batch rows / their neighbourhood; see igcn_mark_rows);
  * nnz = rowptr[n_rows] as the caller knows it (it sizes the launch: the heavier the rows, the fewer
- * of them a wave is given; <= 0 = unknown, a mean degree of 21 is assumed). */
+ * of them a wave is given; <= 0 = unknown, a mean degree of 21 is assumed);
+ * row_order int32 [n_rows + n_segments] or NULL: the order in which rows (entries < n_rows) and row segments
+ * (n_rows + segment index) are dealt to the waves — a permutation of 0..n_rows+n_segments-1, e.g. per phase of a
+ * bipartite matrix the segments of its long rows first, then its rows by descending length, so that heavy work
+ * starts first and the rows a wave works on together carry equal work; it changes which wave computes what, not
+ * the result. */
 int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val,
                       const float *x, int64_t ldx, float *y, int64_t ldy,
                       int64_t n_rows, int64_t n_cols, int32_t d,
@@ -118,7 +123,7 @@ int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *va
                       float *partial, int32_t long_threshold,
                       const int32_t *edge_id, uint64_t seed, float keep_prob,
                       const uint8_t *row_mask, int32_t masked_rows_zero,
-                      int64_t nnz, void *stream);
+                      int64_t nnz, const int32_t *row_order, void *stream);
 
 /* Row masks for igcn_spmm_csr_f32.  mask1[ids[i] + offsets...] = 1 for every listed row;
  * when rowptr/col are given, mask2[r] = 1 for every listed row r and every column
