@@ -50,8 +50,12 @@ SIGNATURES = {
     'igcn_hit_matrix': (C.c_int, [vp, C.c_int64, C.c_int32, vp, vp, vp, vp]),
     'igcn_bpr_sample': (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, vp, vp]),
     'igcn_bpr_sample_nodes': (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, vp, vp]),
-    'igcn_rows_scaled_add_f32': (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int32, vp, C.c_float, vp]),
-    'igcn_rows_zero_f32': (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.c_int32, vp]),
+    'igcn_rows_finish_f32': (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int32, vp, C.c_float, vp]),
+    'igcn_bpr_loss_f32': (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, vp, C.c_int64, vp, vp, vp,
+                                    C.c_int64, C.c_int32, vp, C.c_float, vp, vp, vp]),
+    'igcn_bpr_loss_bwd_f32': (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, vp, C.c_int64, vp, vp, vp,
+                                        C.c_int64, C.c_int32, vp, vp, vp, C.c_float,
+                                        vp, vp, vp, vp, vp, vp, vp, vp]),
 }
 
 _handle = None

@@ -90,7 +90,7 @@ __global__ void bpr_finish_kernel(const float *__restrict__ dots, int64_t batch,
 
 // loss_out[0] = mean(work[B..2B)), loss_out[1] = mean(work[2B..3B)); one block, fixed order.
 __global__ __launch_bounds__(kBlock) void bpr_reduce_kernel(const float *__restrict__ work, int64_t batch,
-                                                            float *__restrict__ loss_out)
+                                                            float *__restrict__ loss_out, float l2_weight = 0.f, int write3 = 0)
 {
     __shared__ float sm[2][kBlock];
     float a = 0.f, c = 0.f;
@@ -101,7 +101,11 @@ __global__ __launch_bounds__(kBlock) void bpr_reduce_kernel(const float *__restr
         if ((int)threadIdx.x < s) { sm[0][threadIdx.x] += sm[0][threadIdx.x + s]; sm[1][threadIdx.x] += sm[1][threadIdx.x + s]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { loss_out[0] = sm[0][0] / (float)batch; loss_out[1] = sm[1][0] / (float)batch; }
+    if (threadIdx.x == 0) {
+        const float a0 = sm[0][0] / (float)batch, a1 = sm[1][0] / (float)batch;
+        loss_out[0] = a0; loss_out[1] = a1;
+        if (write3) loss_out[2] = a0 + l2_weight * a1;       // the training loss of trainer.py:242 in the same launch
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void bpr_bwd_kernel(
@@ -110,15 +114,16 @@ __global__ __launch_bounds__(kBlock) void bpr_bwd_kernel(
     const int64_t *__restrict__ users, const int64_t *__restrict__ pos, const int64_t *__restrict__ neg,
     int64_t batch, int d, const float *__restrict__ w, const float *__restrict__ work, const float *__restrict__ g_out,
     float *__restrict__ gu, float *__restrict__ gp, float *__restrict__ gn,
-    float *__restrict__ g2u, float *__restrict__ g2p, float *__restrict__ g2n, float *__restrict__ gw)
+    float *__restrict__ g2u, float *__restrict__ g2p, float *__restrict__ g2n, float *__restrict__ gw,
+    int g_len = 2, float s0 = 1.f, float s1 = 1.f)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t b = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
     if (b >= batch) return;
     const int64_t iu = users[b], ip = pos[b], in = neg[b];
     const float inv_b = 1.f / (float)batch;
-    const float c = g_out[0] * work[b] * inv_b;       // d loss / d (neg_b - pos_b)
-    const float c2 = 2.f * g_out[1] * inv_b;
+    const float c = g_out[0] * s0 * work[b] * inv_b;  // d loss / d (neg_b - pos_b)
+    const float c2 = 2.f * g_out[g_len > 1 ? 1 : 0] * s1 * inv_b;
     for (int j = lane; j < d; j += kWave) {
         const float u = u_tab[iu * ld + j], p = p_tab[ip * ld + j], n = n_tab[in * ld + j];
         const float wj = w ? w[j] : 1.f;
@@ -134,51 +139,39 @@ __global__ __launch_bounds__(kBlock) void bpr_bwd_kernel(
     }
 }
 
-// dst[ids[i]] += scale * src[ids[i]] (float atomics: an id may occur several times); one wave per id
-__global__ __launch_bounds__(kBlock) void rows_scaled_add_kernel(float *__restrict__ dst, int64_t ldd, const float *__restrict__ src,
-                                                                 int64_t lds, const int64_t *__restrict__ ids, int64_t n, int d,
-                                                                 const float *__restrict__ scale_dev, float scale_host)
+// The row-sparse tail of a training step's backward pass, one wave per id: dst[ids[i]] += scale * src[ids[i]]
+// (float atomics: an id may occur several times) and / or zero_tab[ids[i]] = 0.
+__global__ __launch_bounds__(kBlock) void rows_finish_kernel(float *__restrict__ dst, int64_t ldd, const float *__restrict__ src,
+                                                             int64_t lds, float *__restrict__ zero_tab, int64_t ldz,
+                                                             const int64_t *__restrict__ ids, int64_t n, int d,
+                                                             const float *__restrict__ scale_dev, float scale_host)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t i = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
     if (i >= n) return;
     const int64_t r = ids[i];
-    const float sc = scale_dev ? scale_host * scale_dev[0] : scale_host;
-    for (int j = lane; j < d; j += kWave) atomicAdd(dst + r * ldd + j, sc * src[r * lds + j]);
-}
-
-__global__ __launch_bounds__(kBlock) void rows_zero_kernel(float *__restrict__ dst, int64_t ldd, const int64_t *__restrict__ ids,
-                                                           int64_t n, int d)
-{
-    const int lane = threadIdx.x & (kWave - 1);
-    const int64_t i = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-    if (i >= n) return;
-    const int64_t r = ids[i];
-    for (int j = lane; j < d; j += kWave) dst[r * ldd + j] = 0.f;
+    if (dst) {
+        const float sc = scale_dev ? scale_host * scale_dev[0] : scale_host;
+        for (int j = lane; j < d; j += kWave) atomicAdd(dst + r * ldd + j, sc * src[r * lds + j]);
+    }
+    if (zero_tab)
+        for (int j = lane; j < d; j += kWave) zero_tab[r * ldz + j] = 0.f;
 }
 
 }  // namespace igcn
 
 using namespace igcn;
 
-extern "C" int igcn_rows_scaled_add_f32(float *dst, int64_t ldd, const float *src, int64_t lds, const int64_t *ids, int64_t n,
-                                        int32_t d, const float *scale_dev, float scale_host, void *stream)
+extern "C" int igcn_rows_finish_f32(float *dst, int64_t ldd, const float *src, int64_t lds, float *zero_tab, int64_t ldz,
+                                    const int64_t *ids, int64_t n, int32_t d, const float *scale_dev, float scale_host,
+                                    void *stream)
 {
-    if (!dst || !src || !ids) return IGCN_E_NULL;
-    if (n < 0 || d < 1 || ldd < d || lds < d) return IGCN_E_SHAPE;
+    if (!ids || (!dst && !zero_tab) || (dst && !src)) return IGCN_E_NULL;
+    if (n < 0 || d < 1 || (dst && (ldd < d || lds < d)) || (zero_tab && ldz < d)) return IGCN_E_SHAPE;
+    if (dst && zero_tab == dst) return IGCN_E_RANGE;
     if (n == 0) return IGCN_OK;
-    hipLaunchKernelGGL(rows_scaled_add_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                       dst, ldd, src, lds, ids, n, (int)d, scale_dev, scale_host);
-    return launch_status();
-}
-
-extern "C" int igcn_rows_zero_f32(float *dst, int64_t ldd, const int64_t *ids, int64_t n, int32_t d, void *stream)
-{
-    if (!dst || !ids) return IGCN_E_NULL;
-    if (n < 0 || d < 1 || ldd < d) return IGCN_E_SHAPE;
-    if (n == 0) return IGCN_OK;
-    hipLaunchKernelGGL(rows_zero_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                       dst, ldd, ids, n, (int)d);
+    hipLaunchKernelGGL(rows_finish_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       dst, ldd, src, lds, zero_tab, ldz, ids, n, (int)d, scale_dev, scale_host);
     return launch_status();
 }
 
@@ -213,6 +206,25 @@ extern "C" int igcn_bpr_fwd_f32(const float *u_tab, const float *p_tab, const fl
     return launch_status();
 }
 
+extern "C" int igcn_bpr_loss_f32(const float *u_tab, const float *p_tab, const float *n_tab, int64_t ld,
+                                 const float *l2_u_tab, const float *l2_p_tab, const float *l2_n_tab, int64_t ld_l2,
+                                 const int64_t *users, const int64_t *pos, const int64_t *neg,
+                                 int64_t batch, int32_t d, const float *w, float l2_weight,
+                                 float *loss_out3, float *work, void *stream)
+{
+    int rc = bpr_check(u_tab, p_tab, n_tab, ld, l2_u_tab, l2_p_tab, l2_n_tab, ld_l2, users, pos, neg, batch, d);
+    if (rc != IGCN_OK) return rc;
+    if (!loss_out3 || !work) return IGCN_E_NULL;
+    if (batch == 0) return IGCN_E_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(bpr_fwd_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(kBlock), 0, st, u_tab, p_tab, n_tab, ld,
+                       l2_u_tab, l2_p_tab, l2_n_tab, ld_l2, users, pos, neg, batch, (int)d, w, work);
+    rc = launch_status();
+    if (rc != IGCN_OK) return rc;
+    hipLaunchKernelGGL(bpr_reduce_kernel, dim3(1), dim3(kBlock), 0, st, work, batch, loss_out3, l2_weight, 1);
+    return launch_status();
+}
+
 extern "C" int igcn_bpr_dots_f32(const float *u_tab, const float *p_tab, const float *n_tab, int64_t ld,
                                  const float *l2_u_tab, const float *l2_p_tab, const float *l2_n_tab, int64_t ld_l2,
                                  const int64_t *users, const int64_t *pos, const int64_t *neg,
@@ -240,13 +252,13 @@ extern "C" int igcn_bpr_finish_f32(const float *dots, int64_t batch, float *loss
     return launch_status();
 }
 
-extern "C" int igcn_bpr_bwd_f32(const float *u_tab, const float *p_tab, const float *n_tab, int64_t ld,
-                                const float *l2_u_tab, const float *l2_p_tab, const float *l2_n_tab, int64_t ld_l2,
-                                const int64_t *users, const int64_t *pos, const int64_t *neg,
-                                int64_t batch, int32_t d, const float *w, const float *work, const float *g_out,
-                                float *gu_tab, float *gp_tab, float *gn_tab,
-                                float *gl2_u_tab, float *gl2_p_tab, float *gl2_n_tab,
-                                float *gw_out, void *stream)
+static int bpr_bwd_launch(const float *u_tab, const float *p_tab, const float *n_tab, int64_t ld,
+                          const float *l2_u_tab, const float *l2_p_tab, const float *l2_n_tab, int64_t ld_l2,
+                          const int64_t *users, const int64_t *pos, const int64_t *neg,
+                          int64_t batch, int32_t d, const float *w, const float *work, const float *g_out,
+                          float *gu_tab, float *gp_tab, float *gn_tab,
+                          float *gl2_u_tab, float *gl2_p_tab, float *gl2_n_tab,
+                          float *gw_out, int g_len, float s0, float s1, void *stream)
 {
     int rc = bpr_check(u_tab, p_tab, n_tab, ld, l2_u_tab, l2_p_tab, l2_n_tab, ld_l2, users, pos, neg, batch, d);
     if (rc != IGCN_OK) return rc;
@@ -259,6 +271,31 @@ extern "C" int igcn_bpr_bwd_f32(const float *u_tab, const float *p_tab, const fl
     const int64_t blocks = (batch + 3) / 4;
     hipLaunchKernelGGL(bpr_bwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
                        u_tab, p_tab, n_tab, ld, l2_u_tab, l2_p_tab, l2_n_tab, ld_l2, users, pos, neg, batch, (int)d, w,
-                       work, g_out, gu_tab, gp_tab, gn_tab, gl2_u_tab, gl2_p_tab, gl2_n_tab, gw_out);
+                       work, g_out, gu_tab, gp_tab, gn_tab, gl2_u_tab, gl2_p_tab, gl2_n_tab, gw_out, g_len, s0, s1);
     return launch_status();
+}
+
+extern "C" int igcn_bpr_bwd_f32(const float *u_tab, const float *p_tab, const float *n_tab, int64_t ld,
+                                const float *l2_u_tab, const float *l2_p_tab, const float *l2_n_tab, int64_t ld_l2,
+                                const int64_t *users, const int64_t *pos, const int64_t *neg,
+                                int64_t batch, int32_t d, const float *w, const float *work, const float *g_out,
+                                float *gu_tab, float *gp_tab, float *gn_tab,
+                                float *gl2_u_tab, float *gl2_p_tab, float *gl2_n_tab,
+                                float *gw_out, void *stream)
+{
+    return bpr_bwd_launch(u_tab, p_tab, n_tab, ld, l2_u_tab, l2_p_tab, l2_n_tab, ld_l2, users, pos, neg, batch, d, w, work, g_out,
+                          gu_tab, gp_tab, gn_tab, gl2_u_tab, gl2_p_tab, gl2_n_tab, gw_out, 2, 1.f, 1.f, stream);
+}
+
+extern "C" int igcn_bpr_loss_bwd_f32(const float *u_tab, const float *p_tab, const float *n_tab, int64_t ld,
+                                     const float *l2_u_tab, const float *l2_p_tab, const float *l2_n_tab, int64_t ld_l2,
+                                     const int64_t *users, const int64_t *pos, const int64_t *neg,
+                                     int64_t batch, int32_t d, const float *w, const float *work, const float *g_loss,
+                                     float l2_weight,
+                                     float *gu_tab, float *gp_tab, float *gn_tab,
+                                     float *gl2_u_tab, float *gl2_p_tab, float *gl2_n_tab,
+                                     float *gw_out, void *stream)
+{
+    return bpr_bwd_launch(u_tab, p_tab, n_tab, ld, l2_u_tab, l2_p_tab, l2_n_tab, ld_l2, users, pos, neg, batch, d, w, work, g_loss,
+                          gu_tab, gp_tab, gn_tab, gl2_u_tab, gl2_p_tab, gl2_n_tab, gw_out, 1, 1.f, l2_weight, stream);
 }

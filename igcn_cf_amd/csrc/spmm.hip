@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
     const int64_t n_virtual = n_rows + n_segments;
 
     for (int64_t vb = wave0 * R; vb < n_virtual; vb += n_waves * R) {
-        const int64_t vv = vb + lane / S;                         // this sub-wave's virtual row
+        const int64_t vv = vb + lane / S;                         // this sub-wave's entry of the dealing order
         const int64_t v = (row_order && vv < n_virtual) ? (int64_t)row_order[vv] : vv;
         // kind: 0 nothing, 1 ordinary row -> y, 2 row segment -> partial, 3 masked row that must read as zero
         int64_t start = 0, dst = 0;

@@ -181,6 +181,11 @@ class LightGCN(BasicModel):
         return ops.graph_bpr_terms(self.embedding.weight, self.norm_adj, self.norm_adj, self.n_layers, nodes, 'raw',
                                    self._batch_grads, self.config.get('prune_propagation', True))
 
+    def bpr_loss_nodes(self, nodes, l2_reg):
+        """The scalar training loss of trainer.py:242 (bpr + l2_reg * mean l2_norm_sq) as one differentiable tensor."""
+        return ops.graph_bpr_terms(self.embedding.weight, self.norm_adj, self.norm_adj, self.n_layers, nodes, 'raw',
+                                   self._batch_grads, self.config.get('prune_propagation', True), l2_reg)
+
     def predict(self, users):
         rep = self.get_rep()
         return torch.mm(rep[users, :], rep[self.n_users:, :].t())
@@ -316,6 +321,12 @@ class IGCN(BasicModel):
         x0 = self.inductive_rep_layer(self.feat_mat, keep_prob, seed)
         return ops.graph_bpr_terms(x0, self.norm_adj, self.norm_adj, self._prop_layers(), nodes, 'rep', self._batch_grads,
                                    self.config.get('prune_propagation', True))
+
+    def bpr_loss_nodes(self, nodes, l2_reg):
+        keep_prob, seed = self._dropout_args()
+        x0 = self.inductive_rep_layer(self.feat_mat, keep_prob, seed)
+        return ops.graph_bpr_terms(x0, self.norm_adj, self.norm_adj, self._prop_layers(), nodes, 'rep', self._batch_grads,
+                                   self.config.get('prune_propagation', True), l2_reg)
 
     def _prop_layers(self):
         return self.n_layers

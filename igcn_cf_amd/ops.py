@@ -69,7 +69,7 @@ def mark_rows(csr: CsrMatrix, ids, with_neighbours=True):
     return masks[0], masks[1]
 
 
-def propagate_mean(csr: CsrMatrix, x0, n_layers, row_scale_last=None, masks=None):
+def propagate_mean(csr: CsrMatrix, x0, n_layers, row_scale_last=None, masks=None, zero_masked=True):
     """mean(X_0..X_K), X_{l+1} = csr @ X_l — the layer loop + stack/mean of
     model.py:101-105.  The mean is the epilogue of the last SpMM (no stack).
 
@@ -87,7 +87,7 @@ def propagate_mean(csr: CsrMatrix, x0, n_layers, row_scale_last=None, masks=None
     for l in range(n_layers):
         if l == n_layers - 1:
             y = spmm(csr, layers[-1], adds=layers, out_scale=s, add_scale=s, row_scale=row_scale_last,
-                     row_mask=masks[0] if masks else None, masked_rows_zero=True)
+                     row_mask=masks[0] if masks else None, masked_rows_zero=zero_masked)
         elif l == n_layers - 2 and masks:
             y = spmm(csr, layers[-1], row_mask=masks[1], masked_rows_zero=False)
         else:
@@ -170,13 +170,15 @@ class GraphBprFn(torch.autograd.Function):
     trainer.py:238-243): K-layer propagation pruned to what the batch reads, row gathers, dots, softplus, L2.
 
     forward(x0, csr, csr_t, n_layers, nodes [3 B] = users | n_users + positives | n_users + negatives, l2_on,
-            table: BatchGradTable, prune) -> tensor [2] = (mean softplus(neg - pos), mean l2_norm_sq)
+            table: BatchGradTable, prune, l2_reg)
+      l2_reg None  -> tensor [2] = (mean softplus(neg - pos), mean l2_norm_sq)
+      l2_reg float -> the scalar training loss bpr + l2_reg * l2 (trainer.py:242), computed inside the reduce kernel
     l2_on = 'raw': the L2 term reads the rows of x0 (LightGCN, model.py:110-113); 'rep': the propagated rows (IGCN).
-    backward: batch gradients -> the persistent zero table (float atomics, 256-B row segments), K SpMMs (Horner), the
-    L2 rows of 'raw' added straight into the result, the table's rows put back to zero."""
+    backward: batch gradients -> the persistent zero table (float atomics, 256-B row segments), K SpMMs (Horner), then
+    ONE launch adds the L2 rows of 'raw' straight into the result and puts the table's rows back to zero."""
 
     @staticmethod
-    def forward(ctx, x0, csr, csr_t, n_layers, nodes, l2_on, table, prune):
+    def forward(ctx, x0, csr, csr_t, n_layers, nodes, l2_on, table, prune, l2_reg):
         _require_gpu_f32(x0, 'x0')
         _require_i64(nodes, 'nodes')
         if nodes.numel() % 3 or not x0.is_contiguous():
@@ -184,44 +186,48 @@ class GraphBprFn(torch.autograd.Function):
         B, d = nodes.numel() // 3, x0.shape[1]
         xd = x0.detach()
         masks = mark_rows(csr, nodes) if prune and n_layers > 0 else None
-        rep = propagate_mean(csr, xd, n_layers, masks=masks)
+        # only the batch rows of the result are read (by the kernels below): the rest is left unwritten
+        rep = propagate_mean(csr, xd, n_layers, masks=masks, zero_masked=False)
         l2t = xd if l2_on == 'raw' else rep
         users, pos, neg = nodes[:B], nodes[B:2 * B], nodes[2 * B:]
-        out = torch.empty(2, dtype=torch.float32, device=x0.device)
+        out = torch.empty(3, dtype=torch.float32, device=x0.device)
         work = torch.empty(3 * B, dtype=torch.float32, device=x0.device)
-        _lib.check(_lib.lib().igcn_bpr_fwd_f32(
+        _lib.check(_lib.lib().igcn_bpr_loss_f32(
             rep.data_ptr(), rep.data_ptr(), rep.data_ptr(), rep.stride(0), l2t.data_ptr(), l2t.data_ptr(), l2t.data_ptr(),
-            l2t.stride(0), users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B, d, None, out.data_ptr(), work.data_ptr(),
-            _lib.current_stream()), 'igcn_bpr_fwd_f32')
-        ctx.state = (xd, rep, csr_t, n_layers, nodes, l2_on, table, masks, work)
-        return out
+            l2t.stride(0), users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B, d, None,
+            0.0 if l2_reg is None else float(l2_reg), out.data_ptr(), work.data_ptr(), _lib.current_stream()), 'igcn_bpr_loss_f32')
+        ctx.state = (xd, rep, csr_t, n_layers, nodes, l2_on, table, masks, work, l2_reg)
+        return out[:2] if l2_reg is None else out[2]
 
     @staticmethod
     def backward(ctx, g_out):
-        xd, rep, csr_t, n_layers, nodes, l2_on, table, masks, work = ctx.state
+        xd, rep, csr_t, n_layers, nodes, l2_on, table, masks, work, l2_reg = ctx.state
         B, d = nodes.numel() // 3, rep.shape[1]
         users, pos, neg = nodes[:B], nodes[B:2 * B], nodes[2 * B:]
         g = g_out.contiguous().float()
         gt = table.get(rep)
         on_rep = l2_on == 'rep'
         rp, gp = rep.data_ptr(), gt.data_ptr()
-        _lib.check(_lib.lib().igcn_bpr_bwd_f32(
-            rp, rp, rp, rep.stride(0), rp if on_rep else None, rp if on_rep else None, rp if on_rep else None, rep.stride(0),
-            users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B, d, None, work.data_ptr(), g.data_ptr(),
-            gp, gp, gp, gp if on_rep else None, gp if on_rep else None, gp if on_rep else None, None,
-            _lib.current_stream()), 'igcn_bpr_bwd_f32')
+        l2p, g2p = (rp, gp) if on_rep else (None, None)
+        common = (rp, rp, rp, rep.stride(0), l2p, l2p, l2p, rep.stride(0), users.data_ptr(), pos.data_ptr(), neg.data_ptr(),
+                  B, d, None, work.data_ptr(), g.data_ptr())
+        grads = (gp, gp, gp, g2p, g2p, g2p, None, _lib.current_stream())
+        if l2_reg is None:
+            _lib.check(_lib.lib().igcn_bpr_bwd_f32(*common, *grads), 'igcn_bpr_bwd_f32')
+            l2_dev, l2_host = g[1:], 2.0 / B
+        else:
+            _lib.check(_lib.lib().igcn_bpr_loss_bwd_f32(*common, float(l2_reg), *grads), 'igcn_bpr_loss_bwd_f32')
+            l2_dev, l2_host = g, 2.0 * float(l2_reg) / B
         grad = propagate_mean_backward(csr_t, gt, n_layers, masks=masks)
-        if not on_rep:                                   # d/dx0 of mean_b |x0[row]|^2 * g_out[1], row by row
-            _lib.check(_lib.lib().igcn_rows_scaled_add_f32(grad.data_ptr(), grad.stride(0), xd.data_ptr(), xd.stride(0),
-                                                           nodes.data_ptr(), 3 * B, d, g[1:].data_ptr(), 2.0 / B,
-                                                           _lib.current_stream()), 'igcn_rows_scaled_add_f32')
-        _lib.check(_lib.lib().igcn_rows_zero_f32(gp, gt.stride(0), nodes.data_ptr(), 3 * B, d, _lib.current_stream()),
-                   'igcn_rows_zero_f32')
-        return grad, None, None, None, None, None, None, None
+        raw = not on_rep                                 # d/dx0 of mean_b |x0[row]|^2, row by row, into the dense result
+        _lib.check(_lib.lib().igcn_rows_finish_f32(grad.data_ptr() if raw else None, grad.stride(0), xd.data_ptr() if raw else None,
+                                                   xd.stride(0), gp, gt.stride(0), nodes.data_ptr(), 3 * B, d,
+                                                   l2_dev.data_ptr(), l2_host, _lib.current_stream()), 'igcn_rows_finish_f32')
+        return grad, None, None, None, None, None, None, None, None
 
 
-def graph_bpr_terms(x0, csr, csr_t, n_layers, nodes, l2_on, table, prune=True):
-    return GraphBprFn.apply(x0, csr, csr_t, n_layers, nodes, l2_on, table, prune)
+def graph_bpr_terms(x0, csr, csr_t, n_layers, nodes, l2_on, table, prune=True, l2_reg=None):
+    return GraphBprFn.apply(x0, csr, csr_t, n_layers, nodes, l2_on, table, prune, l2_reg)
 
 
 def bpr_sample_nodes(train_rowptr, train_col, nonempty_users, n_items, batch, seed, item_offset):

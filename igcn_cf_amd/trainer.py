@@ -413,7 +413,9 @@ class BPRTrainer(BasicTrainer):
         return self._optimise(self.model.bpr_loss_terms(users, pos_items, neg_items))
 
     def _optimise(self, terms):
-        loss = terms[0] + self.l2_reg * terms[1]
+        return self._optimise_loss(terms[0] + self.l2_reg * terms[1])
+
+    def _optimise_loss(self, loss):
         self.opt.zero_grad()
         loss.backward()
         self.opt.step()
@@ -424,7 +426,7 @@ class BPRTrainer(BasicTrainer):
         config key 'hip_graph': True, full-size batches replay ONE captured HIP graph (forward, backward and the
         fused Adam step: ~35 launches become one) — what a launch-bound small graph needs."""
         if not self.config.get('hip_graph', False) or nodes.numel() != 3 * self.batch_size:
-            return self._optimise(self.model.bpr_loss_terms_nodes(nodes))
+            return self._optimise_loss(self.model.bpr_loss_nodes(nodes, self.l2_reg))
         if self._graph is None:
             self._capture(nodes)
         self._static_nodes.copy_(nodes)
@@ -437,13 +439,12 @@ class BPRTrainer(BasicTrainer):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                    # warm-up off the capture: lazy initialisation, workspaces
             for _ in range(3):
-                self._optimise(self.model.bpr_loss_terms_nodes(self._static_nodes))
+                self._optimise_loss(self.model.bpr_loss_nodes(self._static_nodes, self.l2_reg))
         torch.cuda.current_stream().wait_stream(side)
         self.opt.zero_grad(set_to_none=True)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
-            terms = self.model.bpr_loss_terms_nodes(self._static_nodes)
-            loss = terms[0] + self.l2_reg * terms[1]
+            loss = self.model.bpr_loss_nodes(self._static_nodes, self.l2_reg)
             loss.backward()
             self.opt.step()
             self._static_loss = loss.detach()
@@ -482,12 +483,14 @@ class IGCNTrainer(BasicTrainer):
         return self._igcn_optimise(self.model.bpr_loss_terms(users, pos_items, neg_items), aux_inputs)
 
     def igcn_node_step(self, nodes, aux_inputs):
-        return self._igcn_optimise(self.model.bpr_loss_terms_nodes(nodes), aux_inputs)
+        return self._igcn_optimise(None, aux_inputs, self.model.bpr_loss_nodes(nodes, self.l2_reg))
 
-    def _igcn_optimise(self, terms, aux_inputs):
+    def _igcn_optimise(self, terms, aux_inputs, main_loss=None):
         a_users, a_pos, a_neg = aux_inputs.t().contiguous().unbind(0)
         aux_loss = self.model.aux_loss(a_users, a_pos, a_neg)
-        loss = terms[0] + self.l2_reg * terms[1] + self.aux_reg * aux_loss
+        if main_loss is None:
+            main_loss = terms[0] + self.l2_reg * terms[1]
+        loss = main_loss + self.aux_reg * aux_loss
         self.opt.zero_grad()
         loss.backward()
         self.opt.step()

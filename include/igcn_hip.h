@@ -239,14 +239,31 @@ int igcn_bpr_sample_nodes(const int64_t *train_rowptr, const int32_t *train_col,
                           const int32_t *nonempty_users, int64_t n_nonempty, int64_t n_items,
                           int64_t batch, uint64_t seed, int64_t item_offset, int64_t *out, void *stream);
 
-/* Row-sparse helpers of the training step's backward pass (trainer.py:244-246: loss.backward()).
- *  igcn_rows_scaled_add_f32: dst[ids[i]] += scale_host * (scale_dev ? *scale_dev : 1) * src[ids[i]] for i < n, float
- *  atomics (an id may repeat) — the gradient of the L2 term on the raw embedding rows (model.py:110-113) added to the
- *  dense gradient the propagation backward produced, instead of a second dense table and a dense add.
- *  igcn_rows_zero_f32: dst[ids[i]] = 0 — puts the persistent batch-gradient table back to zero after a step. */
-int igcn_rows_scaled_add_f32(float *dst, int64_t ldd, const float *src, int64_t lds, const int64_t *ids, int64_t n,
-                             int32_t d, const float *scale_dev, float scale_host, void *stream);
-int igcn_rows_zero_f32(float *dst, int64_t ldd, const int64_t *ids, int64_t n, int32_t d, void *stream);
+/* igcn_bpr_fwd_f32 / igcn_bpr_bwd_f32 for a caller that wants the training loss itself (trainer.py:242:
+ * loss = bpr + l2_reg * mean l2_norm_sq) as ONE differentiable scalar — no elementwise launches between the kernels:
+ * loss_out3[0..1] as igcn_bpr_fwd_f32, loss_out3[2] = loss_out3[0] + l2_weight * loss_out3[1];
+ * the backward takes g_loss = d total / d loss_out3[2] (DEVICE pointer to one float) and the same l2_weight. */
+int igcn_bpr_loss_f32(const float *u_tab, const float *p_tab, const float *n_tab, int64_t ld,
+                      const float *l2_u_tab, const float *l2_p_tab, const float *l2_n_tab, int64_t ld_l2,
+                      const int64_t *users, const int64_t *pos, const int64_t *neg,
+                      int64_t batch, int32_t d, const float *w, float l2_weight,
+                      float *loss_out3, float *work, void *stream);
+int igcn_bpr_loss_bwd_f32(const float *u_tab, const float *p_tab, const float *n_tab, int64_t ld,
+                          const float *l2_u_tab, const float *l2_p_tab, const float *l2_n_tab, int64_t ld_l2,
+                          const int64_t *users, const int64_t *pos, const int64_t *neg,
+                          int64_t batch, int32_t d, const float *w, const float *work, const float *g_loss,
+                          float l2_weight,
+                          float *gu_tab, float *gp_tab, float *gn_tab,
+                          float *gl2_u_tab, float *gl2_p_tab, float *gl2_n_tab,
+                          float *gw_out, void *stream);
+
+/* The row-sparse tail of a training step's backward pass (trainer.py:244-246: loss.backward()), one launch:
+ *  dst != NULL: dst[ids[i]] += scale_host * (scale_dev ? *scale_dev : 1) * src[ids[i]] for i < n, float atomics (an id may
+ *  repeat) — the gradient of the L2 term on the raw embedding rows (model.py:110-113) added to the dense gradient the
+ *  propagation backward produced, instead of a second dense table and a dense add;
+ *  zero_tab != NULL: zero_tab[ids[i]] = 0 — puts the persistent batch-gradient table back to zero after a step. */
+int igcn_rows_finish_f32(float *dst, int64_t ldd, const float *src, int64_t lds, float *zero_tab, int64_t ldz,
+                         const int64_t *ids, int64_t n, int32_t d, const float *scale_dev, float scale_host, void *stream);
 
 #ifdef __cplusplus
 }

@@ -24,4 +24,8 @@ for s, e, n in seg:
     agg[k][0] += e - s; agg[k][1] += 1
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:30]:
     print('  %-62s %7.1f us/step  %5.1f calls/step' % (k, v[0] / 40e3, v[1] / 40))
+print('--- one step: start_us  duration_us  kernel')
+t0 = rows[marks[-2]][0]
+for s_, e_, n_ in rows[marks[-2]:marks[-1]]:
+    print('%8.1f %7.1f  %s' % ((s_ - t0) / 1e3, (e_ - s_) / 1e3, n_.replace('void ', '').replace('igcn::', '').replace('at::native::', '')[:80]))
 PY

@@ -15,8 +15,8 @@ torch.manual_seed(2021)
 model = get_model(m_cfg, ds)
 trainer = get_trainer(t_cfg, ds, model)
 model.train()
-its = [b for _, b in zip(range(60), trainer.sampler.epoch_batches(2048))]
-aux = [b for _, b in zip(range(60), trainer.aux_sampler.epoch_batches(2048))] if hasattr(trainer, 'aux_sampler') else None
-for i in range(60):
-    trainer.igcn_step(its[i], aux[i]) if aux else trainer.bpr_step(its[i])
+its = trainer.sampler.epoch_node_batches(2048, model.n_users)
+aux = trainer.aux_sampler.epoch_batches(2048) if hasattr(trainer, 'aux_sampler') else None
+for i in range(60):                               # the loop of train_one_epoch
+    trainer.igcn_node_step(next(its), next(aux)) if aux else trainer.node_step(next(its))
 torch.cuda.synchronize()
