@@ -373,7 +373,7 @@ def hbm_bound_leg(device, reps=5):
     nnz = int(rowptr[-1].item())
     col = torch.randint(0, n_cols, (nnz,), device=device, generator=g, dtype=torch.int32)
     val = torch.rand(nnz, device=device, generator=g) * 0.1
-    csr = CsrMatrix.from_device(rowptr, col, val, (n_rows, n_cols))
+    csr = CsrMatrix.from_device(rowptr, col, val, (n_rows, n_cols), order_blocks=[0, n_rows])
     x = torch.randn(n_cols, d, device=device, generator=g) * 0.1
     y = torch.empty(n_rows, d, device=device)
     ms = min(time_ms(lambda: ops.spmm(csr, x, out=y), reps, 2) for _ in range(2))

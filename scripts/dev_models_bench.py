@@ -1,5 +1,6 @@
 """Developer: per-model train-step / eval timings on the synthetic presets (configs 1-4 of BASELINE.json)."""
 import json
+import os
 import sys
 import time
 
@@ -13,7 +14,10 @@ from igcn_cf_amd.trainer import get_trainer
 
 
 def main():
-    for preset, index in (('gowalla', 0), ('gowalla', 1), ('yelp', 2), ('yelp', 6), ('amazon', 1), ('amazon', 2)):
+    cases = (('gowalla', 0), ('gowalla', 1), ('yelp', 2), ('yelp', 6), ('amazon', 1), ('amazon', 2))
+    if os.environ.get('CASES'):                      # e.g. CASES=yelp:2,yelp:6
+        cases = tuple((c.split(':')[0], int(c.split(':')[1])) for c in os.environ['CASES'].split(','))
+    for preset, index in cases:
         ds_cfg, m_cfg, t_cfg = cfg.get_synthetic_config(torch.device('cuda'), preset)[index]
         t0 = time.time()
         ds = get_dataset(ds_cfg)
@@ -25,9 +29,14 @@ def main():
         torch.cuda.synchronize()
         t_build = time.time() - t0
         model.train()
-        its = [b for _, b in zip(range(40), trainer.sampler.epoch_batches(2048))]
+        graph_model = hasattr(model, 'bpr_loss_nodes')
+        its = [b for _, b in zip(range(40), trainer.sampler.epoch_node_batches(2048, ds.n_users) if graph_model
+                                 else trainer.sampler.epoch_batches(2048))]
         aux = [b for _, b in zip(range(40), trainer.aux_sampler.epoch_batches(2048))] if hasattr(trainer, 'aux_sampler') else None
-        step = (lambda i: trainer.igcn_step(its[i], aux[i])) if aux else (lambda i: trainer.bpr_step(its[i]))
+        if aux:
+            step = lambda i: trainer.igcn_node_step(its[i], aux[i])
+        else:
+            step = (lambda i: trainer.node_step(its[i])) if graph_model else (lambda i: trainer.bpr_step(its[i]))
         for i in range(5):
             step(i)
         torch.cuda.synchronize()

@@ -29,12 +29,20 @@ rank_i = np.empty(ni, dtype=np.int64); rank_i[pi] = np.arange(ni)
 first_hot = np.full(nu, ni, dtype=np.int64)
 np.minimum.at(first_hot, ta[:, 0], rank_i[ta[:, 1]])
 variants['items_by_degree_users_by_hottest_item'] = relabel(np.argsort(first_hot, kind='stable'), pi)
+try:                                     # reverse Cuthill-McKee on the bipartite graph (bandwidth-reducing order)
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    a = sp.coo_matrix((np.ones(len(ta)), (ta[:, 0], ta[:, 1] + nu)), shape=(nu + ni, nu + ni)).tocsr()
+    perm = reverse_cuthill_mckee((a + a.T).tocsr(), symmetric_mode=True)
+    variants['reverse_cuthill_mckee'] = relabel(perm[perm < nu], perm[perm >= nu] - nu)
+except Exception as e:
+    print('rcm skipped', repr(e))
 variants['random'] = relabel(np.random.default_rng(0).permutation(nu), np.random.default_rng(1).permutation(ni))
 
 mats = {}
 for name, arr in variants.items():
     rowptr, col, val = normalized_adjacency_host(arr, nu, ni)
-    mats[name] = CsrMatrix(rowptr, col, val, (nu + ni, nu + ni), 'cuda')
+    mats[name] = CsrMatrix(rowptr, col, val, (nu + ni, nu + ni), 'cuda', order_blocks=[0, nu, nu + ni])
 x = torch.randn(nu + ni, 64, device='cuda') * 0.1
 y = torch.empty_like(x)
 res = {k: [] for k in mats}

@@ -5,7 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/step_gaps
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -- python3 $REPO/scripts/dev_step_profile.py amazon 1 > $OUT/kt.log 2>&1 || { tail -5 $OUT/kt.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -- python3 $REPO/scripts/dev_step_profile.py ${PRESET:-amazon} ${INDEX:-1} > $OUT/kt.log 2>&1 || { tail -5 $OUT/kt.log; exit 1; }
 python3 - <<PY
 import csv, glob
 f = glob.glob('$OUT/kt/**/*kernel_trace.csv', recursive=True)[0]
