@@ -73,6 +73,11 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs the MI355X (no CPU fallback for the product path)')
+    # IGCN_BENCH_ONE_GPU=1: rehearsal of the N > 1 code path on a 1-GPU box — every rank on cuda:0, exchange over
+    # gloo (staged through the host).  Exercises the launch / sharding / exchange code; its timings mean nothing.
+    rehearsal = os.environ.get('IGCN_BENCH_ONE_GPU') == '1'
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     import torch.distributed as dist
@@ -80,7 +85,10 @@ def main():
     if sharded:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     from igcn_cf_amd.dataset import SyntheticDataset
     from igcn_cf_amd.graph import CsrMatrix, normalized_adjacency_host
@@ -145,6 +153,8 @@ def main():
         parallelism = ('rows of A_hat / embeddings / outputs sharded over %d ranks (nnz-balanced user and item blocks), exchange '
                        '"%s": X_0 exchange + %d RCCL all-gather(s) per pass over xGMI' %
                        (world, prop.exchange, (K - 1) * (1 if prop.exchange == 'fused' else 2)))
+        if rehearsal:
+            parallelism += ' — REHEARSAL: all ranks on one GPU, exchange over gloo; timings are not measurements'
     out = {
         'metric': 'propagation edges/sec (3-layer LightGCN get_rep, Amazon-book-like, dim=64)',
         'value': value, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
