@@ -25,6 +25,7 @@ import torch
 from torch.optim import SGD, Adam  # noqa: F401  (resolved by name, trainer.py:43-45)
 
 from . import ops
+from ._lib import MAX_TOPK
 from .dataset import AuxiliaryDataset
 
 
@@ -146,6 +147,11 @@ class BasicTrainer:
         self.dataset = trainer_config['dataset']
         self.model = trainer_config['model']
         self.topks = trainer_config['topks']
+        # limits of the fused scorer (csrc/score_topk.hip), checked here rather than at the first eval
+        d = getattr(self.model, 'embedding_size', None)
+        if max(self.topks) > MAX_TOPK or (d is not None and (d % 4 or d > 128)):
+            raise ValueError('fused score/top-k kernel: needs max(topks) <= %d and embedding_size %% 4 == 0, <= 128 '
+                             '(got topks=%s, embedding_size=%s)' % (MAX_TOPK, self.topks, d))
         self.device = torch.device(trainer_config['device'])
         self.n_epochs = trainer_config['n_epochs']
         self.max_patience = trainer_config.get('max_patience', 50)

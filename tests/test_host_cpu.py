@@ -362,3 +362,22 @@ def test_train_protocol_matches_reference(golden, tmp_path):
     work.mkdir()
     events, ret, _ = _run_train_script(ds, (int(sc[0]), int(sc[1]), int(sc[2]), [float(v) for v in sc[3:]]), False, str(work))
     assert events == [str(e) for e in golden['train_nontrainable_events']] and ret == float(golden['train_nontrainable_return'])
+
+
+def test_trainer_constructor_states_the_scorer_limits():
+    """max(topks) beyond IGCN_MAX_TOPK or an embedding size the fused scorer cannot take fails at construction,
+    with the limits in the message (the reference accepts any topks: trainer.py:30, :163)."""
+    import torch
+    from igcn_cf_amd._lib import MAX_TOPK
+    from igcn_cf_amd.trainer import BasicTrainer
+
+    class Model(torch.nn.Module):
+        name, trainable = 'M', False
+        embedding_size = 64
+    cfg = {'name': 'BasicTrainer', 'dataset': None, 'model': Model(), 'topks': [20, MAX_TOPK], 'device': 'cpu', 'n_epochs': 1}
+    BasicTrainer(cfg)
+    with pytest.raises(ValueError, match='max\\(topks\\) <= %d' % MAX_TOPK):
+        BasicTrainer(dict(cfg, topks=[MAX_TOPK + 1]))
+    m = Model(); m.embedding_size = 192
+    with pytest.raises(ValueError, match='embedding_size'):
+        BasicTrainer(dict(cfg, model=m))
