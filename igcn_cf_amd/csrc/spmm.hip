@@ -41,6 +41,7 @@ struct SpmmEpilogue {
     float add_scale;
     const float *row_scale;
     const float *col_scale;
+    const uint8_t *col_mask;   // source rows known to be zero are not gathered
 };
 
 struct SpmmDropout {
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
                 c = col[p];
                 w = val ? val[p] : 1.f;
                 if (ep.col_scale) w *= ep.col_scale[c];
+                if (ep.col_mask && !ep.col_mask[c]) w = 0.f;
                 if (DROPOUT) {
                     const uint64_t e = dr.edge_id ? (uint64_t)(uint32_t)dr.edge_id[p] : (uint64_t)p;
                     w = hash_counter(e, dr.s0, dr.s1) < dr.keep_below ? w / dr.keep_prob : 0.f;
@@ -133,12 +135,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
                 int c0 = __shfl(c, k + g), c1 = __shfl(c, k + G + g), c2 = __shfl(c, k + 2 * G + g), c3 = __shfl(c, k + 3 * G + g);
                 float w0 = __shfl(w, k + g), w1 = __shfl(w, k + G + g), w2 = __shfl(w, k + 2 * G + g), w3 = __shfl(w, k + 3 * G + g);
                 float4 x0 = f4_zero(), x1 = f4_zero(), x2 = f4_zero(), x3 = f4_zero();
-                if (lane_on) {
-                    x0 = *reinterpret_cast<const float4 *>(x + (int64_t)c0 * ldx + 4 * t);
-                    x1 = *reinterpret_cast<const float4 *>(x + (int64_t)c1 * ldx + 4 * t);
-                    x2 = *reinterpret_cast<const float4 *>(x + (int64_t)c2 * ldx + 4 * t);
-                    x3 = *reinterpret_cast<const float4 *>(x + (int64_t)c3 * ldx + 4 * t);
-                }
+                // an edge of weight zero (dropped out, or its source row masked as zero) is not gathered
+                if (lane_on && w0 != 0.f) x0 = *reinterpret_cast<const float4 *>(x + (int64_t)c0 * ldx + 4 * t);
+                if (lane_on && w1 != 0.f) x1 = *reinterpret_cast<const float4 *>(x + (int64_t)c1 * ldx + 4 * t);
+                if (lane_on && w2 != 0.f) x2 = *reinterpret_cast<const float4 *>(x + (int64_t)c2 * ldx + 4 * t);
+                if (lane_on && w3 != 0.f) x3 = *reinterpret_cast<const float4 *>(x + (int64_t)c3 * ldx + 4 * t);
                 f4_fma(acc, w0, x0); f4_fma(acc, w1, x1); f4_fma(acc, w2, x2); f4_fma(acc, w3, x3);
             }
             // tail: one gather instruction per step, groups past the end masked off
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
                 const int src = k + g;
                 const int cc = __shfl(c, src);
                 const float ww = __shfl(w, src);
-                if (lane_on && src < cnt) {
+                if (lane_on && src < cnt && ww != 0.f) {
                     const float4 xv = *reinterpret_cast<const float4 *>(x + (int64_t)cc * ldx + 4 * t);
                     f4_fma(acc, ww, xv);
                 }
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
                 c = col[p];
                 w = val ? val[p] : 1.f;
                 if (ep.col_scale) w *= ep.col_scale[c];
+                if (ep.col_mask && !ep.col_mask[c]) w = 0.f;
                 if (DROPOUT) {
                     const uint64_t e = dr.edge_id ? (uint64_t)(uint32_t)dr.edge_id[p] : (uint64_t)p;
                     w = hash_counter(e, dr.s0, dr.s1) < dr.keep_below ? w / dr.keep_prob : 0.f;
@@ -257,10 +259,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
                 const float w0 = __shfl(w, sub_base + (s0 & (S - 1))), w1 = __shfl(w, sub_base + (s1 & (S - 1)));
                 const float w2 = __shfl(w, sub_base + (s2 & (S - 1))), w3 = __shfl(w, sub_base + (s3 & (S - 1)));
                 float4 x0 = f4_zero(), x1 = f4_zero(), x2 = f4_zero(), x3 = f4_zero();
-                if (lane_on && s0 < cnt) x0 = *reinterpret_cast<const float4 *>(x + (int64_t)c0 * ldx + 4 * t);
-                if (lane_on && s1 < cnt) x1 = *reinterpret_cast<const float4 *>(x + (int64_t)c1 * ldx + 4 * t);
-                if (lane_on && s2 < cnt) x2 = *reinterpret_cast<const float4 *>(x + (int64_t)c2 * ldx + 4 * t);
-                if (lane_on && s3 < cnt) x3 = *reinterpret_cast<const float4 *>(x + (int64_t)c3 * ldx + 4 * t);
+                // an edge of weight zero (dropped out, or its source row masked as zero) is not gathered
+                if (lane_on && s0 < cnt && w0 != 0.f) x0 = *reinterpret_cast<const float4 *>(x + (int64_t)c0 * ldx + 4 * t);
+                if (lane_on && s1 < cnt && w1 != 0.f) x1 = *reinterpret_cast<const float4 *>(x + (int64_t)c1 * ldx + 4 * t);
+                if (lane_on && s2 < cnt && w2 != 0.f) x2 = *reinterpret_cast<const float4 *>(x + (int64_t)c2 * ldx + 4 * t);
+                if (lane_on && s3 < cnt && w3 != 0.f) x3 = *reinterpret_cast<const float4 *>(x + (int64_t)c3 * ldx + 4 * t);
                 if (s0 < cnt) f4_fma(acc, w0, x0);
                 if (s1 < cnt) f4_fma(acc, w1, x1);
                 if (s2 < cnt) f4_fma(acc, w2, x2);
@@ -362,6 +365,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_scalar_kernel(
             for (int64_t p = start; p < end; ++p) {
                 float w = val ? val[p] : 1.f;
                 if (ep.col_scale) w *= ep.col_scale[col[p]];
+                if (ep.col_mask && !ep.col_mask[col[p]]) w = 0.f;
                 if (dropout) {
                     const uint64_t e = dr.edge_id ? (uint64_t)(uint32_t)dr.edge_id[p] : (uint64_t)p;
                     w = hash_counter(e, dr.s0, dr.s1) < dr.keep_below ? w / dr.keep_prob : 0.f;
@@ -562,7 +566,7 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
                                  float *partial, int32_t long_threshold,
                                  const int32_t *edge_id, uint64_t seed, float keep_prob,
                                  const uint8_t *row_mask, int32_t masked_rows_zero,
-                                 int64_t nnz, const int32_t *row_order, void *stream)
+                                 int64_t nnz, const int32_t *row_order, const uint8_t *col_mask, void *stream)
 {
     if (!rowptr || !x || !y) return IGCN_E_NULL;
     if (n_rows < 0 || n_cols < 0 || d < 1 || d > 256 || ldx < d || ldy < d) return IGCN_E_SHAPE;
@@ -586,6 +590,7 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
     ep.add_scale = add_scale;
     ep.row_scale = row_scale;
     ep.col_scale = col_scale;
+    ep.col_mask = col_mask;
 
     const bool dropout = keep_prob < 1.f;
     SpmmDropout dr{};

@@ -20,8 +20,9 @@ def _require_gpu_f32(t, name):
 
 
 def spmm(csr: CsrMatrix, x, out=None, adds=(), out_scale=1.0, add_scale=1.0, row_scale=None, col_scale=None,
-         keep_prob=1.0, seed=0, row_mask=None, masked_rows_zero=False):
-    """out = (out_scale * csr @ x + add_scale * sum(adds)) * row_scale  (see igcn_spmm_csr_f32)."""
+         keep_prob=1.0, seed=0, row_mask=None, masked_rows_zero=False, col_mask=None):
+    """out = (out_scale * csr @ x + add_scale * sum(adds)) * row_scale  (see igcn_spmm_csr_f32).
+    col_mask uint8 [n_cols]: rows of x with col_mask == 0 are all zero and are not read."""
     _require_gpu_f32(x, 'x')
     n_rows, n_cols = csr.shape
     if x.shape[0] < n_cols:
@@ -42,6 +43,8 @@ def spmm(csr: CsrMatrix, x, out=None, adds=(), out_scale=1.0, add_scale=1.0, row
         raise _lib.IgcnError('row_scale must be float32 [n_rows] on the GPU')
     if row_mask is not None and (row_mask.dtype != torch.uint8 or row_mask.numel() < n_rows or not row_mask.is_cuda):
         raise _lib.IgcnError('row_mask must be uint8 [n_rows] on the GPU')
+    if col_mask is not None and (col_mask.dtype != torch.uint8 or col_mask.numel() < n_cols or not col_mask.is_cuda):
+        raise _lib.IgcnError('col_mask must be uint8 [n_cols] on the GPU')
     if col_scale is not None and (col_scale.dtype != torch.float32 or col_scale.numel() < n_cols or not col_scale.is_cuda):
         raise _lib.IgcnError('col_scale must be float32 [n_cols] on the GPU')
     add_ptrs = (C.c_void_p * max(1, len(adds)))(*[a.data_ptr() for a in adds])
@@ -53,7 +56,7 @@ def spmm(csr: CsrMatrix, x, out=None, adds=(), out_scale=1.0, add_scale=1.0, row
         _lib.ptr(csr.long_rows), csr.n_long, _lib.ptr(csr.segments), csr.n_segments, _lib.ptr(partial),
         csr.long_threshold, _lib.ptr(csr.edge_id), int(seed) & 0xFFFFFFFFFFFFFFFF, float(keep_prob),
         _lib.ptr(row_mask), 1 if masked_rows_zero else 0, csr.nnz, _lib.ptr(csr.row_order),
-        _lib.current_stream()), 'igcn_spmm_csr_f32')
+        _lib.ptr(col_mask), _lib.current_stream()), 'igcn_spmm_csr_f32')
     return out
 
 
@@ -100,7 +103,9 @@ def propagate_mean_backward(csr_t: CsrMatrix, grad, n_layers, row_scale=None, ma
     """d/dX_0 of propagate_mean:  s * sum_l (M^T)^l g  by Horner's rule,
     G <- s*g + M^T G, K times — one SpMM per layer with the add fused.
     row_scale (optional) multiplies the final rows (used by the INMO path).
-    With masks (g is zero outside masks[0]) the first hop is non-zero only on masks[1]."""
+    With masks (g is zero outside masks[0]) the first hop is non-zero only on masks[1]: it is computed for those
+    rows alone and gathers only the rows of g in masks[0]; the second hop gathers only the rows in masks[1]
+    (about 70 % of the rows at B = 2048 on the Amazon-like graph: 124 -> 116 us)."""
     s = 1.0 / (n_layers + 1)
     if n_layers == 0:
         return grad.clone()
@@ -110,10 +115,12 @@ def propagate_mean_backward(csr_t: CsrMatrix, grad, n_layers, row_scale=None, ma
         last = l == n_layers - 1
         rs = row_scale if last else None
         if cur is None:
+            # rows outside masks[1] are zero: written as zeros only when this hop is the result, else never read
             cur = spmm(csr_t, g, adds=[g], out_scale=s, add_scale=s, row_scale=rs,
-                       row_mask=masks[1] if masks else None, masked_rows_zero=True)
+                       row_mask=masks[1] if masks else None, masked_rows_zero=last, col_mask=masks[0] if masks else None)
         else:
-            cur = spmm(csr_t, cur, adds=[g], out_scale=1.0, add_scale=s, row_scale=rs)
+            cur = spmm(csr_t, cur, adds=[g], out_scale=1.0, add_scale=s, row_scale=rs,
+                       col_mask=masks[1] if masks and l == 1 else None)
     return cur
 
 

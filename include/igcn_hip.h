@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IGCN_ABI_VERSION 3
+#define IGCN_ABI_VERSION 4
 
 #define IGCN_OK            0
 #define IGCN_E_NULL       -1   /* a required pointer is NULL               */
@@ -112,7 +112,10 @@ int igcn_spmm_plan_fill_host(const int64_t *rowptr_host, int64_t n_rows,
  * (n_rows + segment index) are dealt to the waves — a permutation of 0..n_rows+n_segments-1, e.g. per phase of a
  * bipartite matrix the segments of its long rows first, then its rows by descending length, so that heavy work
  * starts first and the rows a wave works on together carry equal work; it changes which wave computes what, not
- * the result. */
+ * the result;
+ * col_mask uint8 [n_cols] or NULL: rows of X the caller knows to be all zero (col_mask[c] == 0) are not read —
+ * the first backward hops of a training step, whose operand is non-zero on the batch rows / their neighbourhood
+ * only.  Edges whose weight comes out zero (masked here, or dropped out) issue no gather at all. */
 int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val,
                       const float *x, int64_t ldx, float *y, int64_t ldy,
                       int64_t n_rows, int64_t n_cols, int32_t d,
@@ -123,7 +126,7 @@ int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *va
                       float *partial, int32_t long_threshold,
                       const int32_t *edge_id, uint64_t seed, float keep_prob,
                       const uint8_t *row_mask, int32_t masked_rows_zero,
-                      int64_t nnz, const int32_t *row_order, void *stream);
+                      int64_t nnz, const int32_t *row_order, const uint8_t *col_mask, void *stream);
 
 /* Row masks for igcn_spmm_csr_f32.  mask1[ids[i] + offsets...] = 1 for every listed row;
  * when rowptr/col are given, mask2[r] = 1 for every listed row r and every column
