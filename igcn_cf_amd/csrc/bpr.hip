@@ -118,25 +118,37 @@ __global__ __launch_bounds__(kBlock) void bpr_bwd_kernel(
     int g_len = 2, float s0 = 1.f, float s1 = 1.f)
 {
     const int lane = threadIdx.x & (kWave - 1);
-    const int64_t b = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-    if (b >= batch) return;
-    const int64_t iu = users[b], ip = pos[b], in = neg[b];
+    const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
     const float inv_b = 1.f / (float)batch;
-    const float c = g_out[0] * s0 * work[b] * inv_b;  // d loss / d (neg_b - pos_b)
-    const float c2 = 2.f * g_out[g_len > 1 ? 1 : 0] * s1 * inv_b;
-    for (int j = lane; j < d; j += kWave) {
-        const float u = u_tab[iu * ld + j], p = p_tab[ip * ld + j], n = n_tab[in * ld + j];
-        const float wj = w ? w[j] : 1.f;
-        atomicAdd(gu + iu * ld + j, c * (n - p) * wj);
-        atomicAdd(gp + ip * ld + j, -c * u * wj);
-        atomicAdd(gn + in * ld + j, c * u * wj);
-        if (gw) atomicAdd(gw + j, c * u * (n - p));
-        if (l2u && g2u) {
-            atomicAdd(g2u + iu * ld2 + j, c2 * l2u[iu * ld2 + j]);
-            atomicAdd(g2p + ip * ld2 + j, c2 * l2p[ip * ld2 + j]);
-            atomicAdd(g2n + in * ld2 + j, c2 * l2n[in * ld2 + j]);
+    // d loss / d w: every triplet adds to the same d floats — kept in registers across the wave's triplets (the launch
+    // uses a small grid then) and added once per wave (columns lane, lane + 64, ... up to 256; beyond: straight atomics)
+    float gw_acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t b = wave; b < batch; b += n_waves) {
+        const int64_t iu = users[b], ip = pos[b], in = neg[b];
+        const float c = g_out[0] * s0 * work[b] * inv_b;  // d loss / d (neg_b - pos_b)
+        const float c2 = 2.f * g_out[g_len > 1 ? 1 : 0] * s1 * inv_b;
+        for (int j = lane, q = 0; j < d; j += kWave, ++q) {
+            const float u = u_tab[iu * ld + j], p = p_tab[ip * ld + j], n = n_tab[in * ld + j];
+            const float wj = w ? w[j] : 1.f;
+            atomicAdd(gu + iu * ld + j, c * (n - p) * wj);
+            atomicAdd(gp + ip * ld + j, -c * u * wj);
+            atomicAdd(gn + in * ld + j, c * u * wj);
+            if (gw) {
+                if (q < 4) gw_acc[q] += c * u * (n - p);
+                else atomicAdd(gw + j, c * u * (n - p));
+            }
+            if (l2u && g2u) {
+                atomicAdd(g2u + iu * ld2 + j, c2 * l2u[iu * ld2 + j]);
+                atomicAdd(g2p + ip * ld2 + j, c2 * l2p[ip * ld2 + j]);
+                atomicAdd(g2n + in * ld2 + j, c2 * l2n[in * ld2 + j]);
+            }
         }
     }
+    if (gw)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (lane + q * kWave < d) atomicAdd(gw + lane + q * kWave, gw_acc[q]);
 }
 
 // The row-sparse tail of a training step's backward pass, one wave per id: dst[ids[i]] += scale * src[ids[i]]
@@ -268,7 +280,8 @@ static int bpr_bwd_launch(const float *u_tab, const float *p_tab, const float *n
     if (n_g2 == 3 && !l2_u_tab) return IGCN_E_NULL;
     if (gw_out && !w) return IGCN_E_NULL;
     if (batch == 0) return IGCN_E_SHAPE;
-    const int64_t blocks = (batch + 3) / 4;
+    int64_t blocks = (batch + 3) / 4;
+    if (gw_out && blocks > 64) blocks = 64;      // a few triplets per wave: d loss / d w is added once per wave, not once per triplet
     hipLaunchKernelGGL(bpr_bwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
                        u_tab, p_tab, n_tab, ld, l2_u_tab, l2_p_tab, l2_n_tab, ld_l2, users, pos, neg, batch, (int)d, w,
                        work, g_out, gu_tab, gp_tab, gn_tab, gl2_u_tab, gl2_p_tab, gl2_n_tab, gw_out, g_len, s0, s1);
