@@ -478,7 +478,8 @@ def inductive_update_timing(ds, device, d, K):
                 'first_full_eval_s': t4 - t3, 'update_plus_eval_s': t4 - t0, 'six_inductive_evals_s': t5 - t4,
                 'old_users': small.n_users, 'old_items': small.n_items, 'users': ds.n_users, 'items': ds.n_items,
                 'reference_published_s': 3.4,
-                'note': 'host numpy builds the CSR arrays (graph.py), everything else runs on the device; the published 3.4 s '
+                'note': 'graph and feature CSRs are built in HBM (graph.py *_device builders, bit-identical to the host ones); '
+                        'trainer_setup_s is the host side of the device sampler / exclusion lists; the published 3.4 s '
                         '(run/plot.py:200) is the authors\' figure on their GPU and real Amazon-book, quoted for orientation only'})
     return out
 
