@@ -724,6 +724,50 @@ __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restr
     }
 }
 
+// The same merge with one LANE per user, for plans that cut a group's sweep into at most P pieces (the usual
+// case: 2-3): the lane keeps the heads of its user's lists in registers and emits the best of them k times.  A wave
+// per user spends 18 cross-lane operations per output on 2-3 live lanes; this one spends P compares.
+template <int P>
+__global__ __launch_bounds__(kBlock) void topk_merge_lanes_kernel(const float *__restrict__ ws_val, const int32_t *__restrict__ ws_idx,
+                                                                  int64_t first_user, int64_t batch, int n_tiles, int64_t run,
+                                                                  int p_max, int k, int upw,
+                                                                  int64_t *__restrict__ out_idx, float *__restrict__ out_val)
+{
+    const int64_t rb = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t b = first_user + rb;
+    if (b >= batch) return;
+    const int64_t rg = rb / upw;
+    const int n_lists = (int)((((rg + 1) * n_tiles - 1) / run) - (rg * n_tiles) / run + 1);
+    const float *v = ws_val + rb * p_max * k;
+    const int32_t *ix = ws_idx + rb * p_max * k;
+    float hv[P];
+    int hi[P], cur[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const bool live = q < n_lists;
+        hv[q] = live ? v[q * k] : -INFINITY;
+        hi[q] = live ? ix[q * k] : kIdxNone;
+        cur[q] = 0;
+    }
+    for (int r = 0; r < k; ++r) {
+        float bv = hv[0];
+        int bi = hi[0], bq = 0;
+#pragma unroll
+        for (int q = 1; q < P; ++q)
+            if (ranks_before(hv[q], hi[q], bv, bi)) { bv = hv[q]; bi = hi[q]; bq = q; }    // ties: the lower list wins
+        out_idx[b * k + r] = bi == kIdxNone ? -1 : bi;
+        out_val[b * k + r] = bv;
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+            if (q == bq && q < n_lists) {
+                ++cur[q];
+                const bool more = cur[q] < k;
+                hv[q] = more ? v[q * k + cur[q]] : -INFINITY;
+                hi[q] = more ? ix[q * k + cur[q]] : kIdxNone;
+            }
+    }
+}
+
 // banned uint8 [n_items] -> one bit per item, one 32-bit word per 32-item tile
 __global__ __launch_bounds__(kBlock) void topk_pack_banned_kernel(const uint8_t *__restrict__ banned, int64_t n_items, int n_tiles,
                                                                   uint32_t *__restrict__ bits)
@@ -840,9 +884,16 @@ extern "C" int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const in
     }
     if (rc != IGCN_OK) return rc;
     if (rest_users > 0) {
-        const int64_t blocks = (rest_users + 3) / 4;
-        hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, ws_val, ws_idx,
-                           p.n_whole * p.units * 32 * p.ng, batch, p.n_tiles, p.run, p.p_max, (int)k, 32 * p.ng, out_idx, out_val);
+        const int64_t first = p.n_whole * p.units * 32 * p.ng;
+        if (p.p_max <= 4)
+            hipLaunchKernelGGL(topk_merge_lanes_kernel<4>, dim3((unsigned)((rest_users + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                               ws_val, ws_idx, first, batch, p.n_tiles, p.run, p.p_max, (int)k, 32 * p.ng, out_idx, out_val);
+        else if (p.p_max <= 8)
+            hipLaunchKernelGGL(topk_merge_lanes_kernel<8>, dim3((unsigned)((rest_users + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                               ws_val, ws_idx, first, batch, p.n_tiles, p.run, p.p_max, (int)k, 32 * p.ng, out_idx, out_val);
+        else
+            hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)((rest_users + 3) / 4)), dim3(kBlock), 0, st, ws_val, ws_idx,
+                               first, batch, p.n_tiles, p.run, p.p_max, (int)k, 32 * p.ng, out_idx, out_val);
         rc = launch_status();
     }
     return rc;
