@@ -46,6 +46,8 @@ struct SpmmEpilogue {
 
 struct SpmmDropout {
     const int32_t *edge_id;
+    const uint32_t *seed_words;   // the seed in device memory (low word, high word) instead of s0 / s1: a launch captured
+                                  // in a HIP graph then drops different edges at every replay
     uint32_t s0, s1;
     uint32_t keep_below;   // keep iff hash < keep_below
     float keep_prob;
@@ -80,6 +82,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
     const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)));
     const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
     const int64_t n_virtual = n_rows + n_segments;
+    const uint32_t seed0 = DROPOUT && dr.seed_words ? dr.seed_words[0] : dr.s0;
+    const uint32_t seed1 = DROPOUT && dr.seed_words ? dr.seed_words[1] : dr.s1;
 #ifdef IGCN_SPMM_TRACE
     const unsigned long long tr_begin = spmm_realtime();
     unsigned long long tr_rows = 0, tr_nnz = 0, tr_chunks = 0;
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
                 if (ep.col_mask && !ep.col_mask[c]) w = 0.f;
                 if (DROPOUT) {
                     const uint64_t e = dr.edge_id ? (uint64_t)(uint32_t)dr.edge_id[p] : (uint64_t)p;
-                    w = hash_counter(e, dr.s0, dr.s1) < dr.keep_below ? w / dr.keep_prob : 0.f;
+                    w = hash_counter(e, seed0, seed1) < dr.keep_below ? w / dr.keep_prob : 0.f;
                 }
             }
             int k = 0;
@@ -213,6 +217,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
     const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)));
     const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
     const int64_t n_virtual = n_rows + n_segments;
+    const uint32_t seed0 = DROPOUT && dr.seed_words ? dr.seed_words[0] : dr.s0;
+    const uint32_t seed1 = DROPOUT && dr.seed_words ? dr.seed_words[1] : dr.s1;
 
     for (int64_t vb = wave0 * R; vb < n_virtual; vb += n_waves * R) {
         const int64_t vv = vb + lane / S;                         // this sub-wave's entry of the dealing order
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
                 if (ep.col_mask && !ep.col_mask[c]) w = 0.f;
                 if (DROPOUT) {
                     const uint64_t e = dr.edge_id ? (uint64_t)(uint32_t)dr.edge_id[p] : (uint64_t)p;
-                    w = hash_counter(e, dr.s0, dr.s1) < dr.keep_below ? w / dr.keep_prob : 0.f;
+                    w = hash_counter(e, seed0, seed1) < dr.keep_below ? w / dr.keep_prob : 0.f;
                 }
             }
             // 4 gather instructions in flight; a group past the end of its row takes no part
@@ -357,6 +363,8 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_scalar_kernel(
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t wave0 = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
+    const uint32_t seed0 = dropout && dr.seed_words ? dr.seed_words[0] : dr.s0;
+    const uint32_t seed1 = dropout && dr.seed_words ? dr.seed_words[1] : dr.s1;
     for (int64_t r = wave0; r < n_rows; r += n_waves) {
         const int64_t start = rowptr[r], end = rowptr[r + 1];
         for (int j0 = 0; j0 < d; j0 += kWave) {
@@ -368,7 +376,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_scalar_kernel(
                 if (ep.col_mask && !ep.col_mask[col[p]]) w = 0.f;
                 if (dropout) {
                     const uint64_t e = dr.edge_id ? (uint64_t)(uint32_t)dr.edge_id[p] : (uint64_t)p;
-                    w = hash_counter(e, dr.s0, dr.s1) < dr.keep_below ? w / dr.keep_prob : 0.f;
+                    w = hash_counter(e, seed0, seed1) < dr.keep_below ? w / dr.keep_prob : 0.f;
                 }
                 if (j < d) acc = fmaf(w, x[(int64_t)col[p] * ldx + j], acc);
             }
@@ -566,7 +574,8 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
                                  float *partial, int32_t long_threshold,
                                  const int32_t *edge_id, uint64_t seed, float keep_prob,
                                  const uint8_t *row_mask, int32_t masked_rows_zero,
-                                 int64_t nnz, const int32_t *row_order, const uint8_t *col_mask, void *stream)
+                                 int64_t nnz, const int32_t *row_order, const uint8_t *col_mask,
+                                 const uint64_t *seed_dev, void *stream)
 {
     if (!rowptr || !x || !y) return IGCN_E_NULL;
     if (n_rows < 0 || n_cols < 0 || d < 1 || d > 256 || ldx < d || ldy < d) return IGCN_E_SHAPE;
@@ -597,6 +606,7 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
     dr.edge_id = edge_id;
     dr.s0 = (uint32_t)seed;
     dr.s1 = (uint32_t)(seed >> 32);
+    dr.seed_words = reinterpret_cast<const uint32_t *>(seed_dev);
     double kb = (double)keep_prob * 4294967296.0;
     dr.keep_below = kb >= 4294967295.0 ? 4294967295u : (uint32_t)kb;
     dr.keep_prob = keep_prob;

@@ -212,6 +212,7 @@ class IGCN(BasicModel):
         normal_(self.embedding.weight, std=0.1)
         self.to(device=self.device)
         self._drop_calls = 0
+        self._seed_dev = None
 
     # feat_mat may be re-assigned on a live model (run/dropui/igcn_dropui.py:28-32)
     @property
@@ -229,7 +230,9 @@ class IGCN(BasicModel):
         one scale per ROW — the kernel applies it in its epilogue, the matrix
         structure is never rebuilt."""
         n_rows = self.feat_mat.shape[0]
-        scale = torch.empty(n_rows, dtype=torch.float32, device=self.device)
+        scale = getattr(self, '_feat_scale', None)
+        if scale is None or scale.numel() != n_rows:       # else rewritten in place: a captured HIP graph keeps reading it
+            scale = torch.empty(n_rows, dtype=torch.float32, device=self.device)
         expo = (self.alpha - 1.) / 2. - 0.5
         _lib.check(_lib.lib().igcn_csr_row_pow_f32(self.feat_mat.rowptr.data_ptr(), self.row_sum.data_ptr(), expo,
                                                    None, scale.data_ptr(), n_rows, _lib.current_stream()),
@@ -285,7 +288,20 @@ class IGCN(BasicModel):
         hash of (seed, edge id) drawn per call from torch's CPU generator."""
         if not self.training or self.dropout <= 0.:
             return 1., 0
+        if self._seed_dev is not None:                      # set by advance_dropout_seed(), read by the kernels
+            return 1. - self.dropout, self._seed_dev
         return 1. - self.dropout, int(torch.randint(0, 2 ** 62, (1,)).item())
+
+    def use_device_seed(self):
+        """Keep the dropout seed in device memory (a step captured in a HIP graph must not bake it in as a launch
+        argument); the trainer then calls advance_dropout_seed() once before every step."""
+        if self._seed_dev is None:
+            self._seed_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+
+    def advance_dropout_seed(self):
+        """The next seed of the same CPU-generator sequence _dropout_args draws from, written to the device."""
+        if self._seed_dev is not None and self.training and self.dropout > 0.:
+            self._seed_dev.fill_(int(torch.randint(0, 2 ** 62, (1,)).item()))
 
     def _compute_rep(self, needed_rows=None):
         keep_prob, seed = self._dropout_args()
@@ -296,7 +312,7 @@ class IGCN(BasicModel):
         if needed_rows is not None and self.training:
             return self._compute_rep(needed_rows)
         w = self.embedding.weight
-        key = (w._version, id(self.norm_adj), id(self.feat_mat), id(self._feat_scale), w.data_ptr())
+        key = (w._version, id(self.norm_adj), id(self.feat_mat), w.data_ptr())     # anneal / feat_mat swap drop the cache themselves
         return self._cached_rep(key, self._compute_rep)
 
     _batch_rows = LightGCN._batch_rows

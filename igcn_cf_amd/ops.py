@@ -22,7 +22,8 @@ def _require_gpu_f32(t, name):
 def spmm(csr: CsrMatrix, x, out=None, adds=(), out_scale=1.0, add_scale=1.0, row_scale=None, col_scale=None,
          keep_prob=1.0, seed=0, row_mask=None, masked_rows_zero=False, col_mask=None):
     """out = (out_scale * csr @ x + add_scale * sum(adds)) * row_scale  (see igcn_spmm_csr_f32).
-    col_mask uint8 [n_cols]: rows of x with col_mask == 0 are all zero and are not read."""
+    col_mask uint8 [n_cols]: rows of x with col_mask == 0 are all zero and are not read.
+    seed: an int, or a one-element int64 tensor on the GPU (read by the kernel: HIP-graph replays see its current value)."""
     _require_gpu_f32(x, 'x')
     n_rows, n_cols = csr.shape
     if x.shape[0] < n_cols:
@@ -49,6 +50,11 @@ def spmm(csr: CsrMatrix, x, out=None, adds=(), out_scale=1.0, add_scale=1.0, row
         raise _lib.IgcnError('col_scale must be float32 [n_cols] on the GPU')
     add_ptrs = (C.c_void_p * max(1, len(adds)))(*[a.data_ptr() for a in adds])
     partial = csr.partial(d)
+    seed_dev = None
+    if isinstance(seed, torch.Tensor):
+        if seed.dtype != torch.int64 or seed.numel() != 1 or not seed.is_cuda:
+            raise _lib.IgcnError('a device seed must be a one-element int64 tensor on the GPU')
+        seed_dev, seed = seed, 0
     _lib.check(_lib.lib().igcn_spmm_csr_f32(
         csr.rowptr.data_ptr(), csr.col.data_ptr(), _lib.ptr(csr.val),
         x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0),
@@ -56,7 +62,7 @@ def spmm(csr: CsrMatrix, x, out=None, adds=(), out_scale=1.0, add_scale=1.0, row
         _lib.ptr(csr.long_rows), csr.n_long, _lib.ptr(csr.segments), csr.n_segments, _lib.ptr(partial),
         csr.long_threshold, _lib.ptr(csr.edge_id), int(seed) & 0xFFFFFFFFFFFFFFFF, float(keep_prob),
         _lib.ptr(row_mask), 1 if masked_rows_zero else 0, csr.nnz, _lib.ptr(csr.row_order),
-        _lib.ptr(col_mask), _lib.current_stream()), 'igcn_spmm_csr_f32')
+        _lib.ptr(col_mask), _lib.ptr(seed_dev), _lib.current_stream()), 'igcn_spmm_csr_f32')
     return out
 
 

@@ -171,9 +171,78 @@ class BasicTrainer:
         kw = {}
         if opt is Adam and self.config.get('fused_optimizer', True):
             kw['fused'] = True             # same update rule, one kernel over all parameters
-            if self.config.get('hip_graph', False):
+            if self.config.get('hip_graph', True):
                 kw['capturable'] = True    # the step count lives on the device, so the step can sit in a HIP graph
         self.opt = opt(self.model.parameters(), lr=self.config['lr'], **kw)
+
+    # ---- one optimisation step as ONE captured HIP graph (config key 'hip_graph', default True) -----------------
+    def _graph_wanted(self):
+        return bool(self.config.get('hip_graph', True)) and not getattr(self, '_graph_failed', False)
+
+    def _graph_key(self):
+        m = self.model                       # a swapped graph / feature matrix / optimizer means new pointers: capture again
+        return (id(getattr(m, 'norm_adj', None)), id(getattr(m, 'feat_mat', None)), id(self.opt), self.batch_size)
+
+    def _graph_step(self, inputs, loss_fn):
+        """Replays the captured step on `inputs` (tensors copied into the static buffers the graph reads); captures
+        it first when there is none for the current model state.  Returns the loss tensor, or None when capture is not
+        possible here (the caller then runs the step eagerly — same kernels, launched one by one)."""
+        key = self._graph_key()
+        if getattr(self, '_graph', None) is None or self._graph_for != key:
+            try:
+                self._capture_step(inputs, loss_fn)
+                self._graph_for = key
+            except Exception as e:           # e.g. an optimizer that cannot be captured
+                self._graph, self._graph_failed = None, True
+                print('hip_graph: capture failed (%r); steps are launched eagerly' % (e,), file=sys.stderr)
+                return None
+        for st, t in zip(self._static_inputs, inputs):
+            st.copy_(t)
+        self._graph.replay()
+        return self._static_loss.clone()
+
+    def _capture_step(self, inputs, loss_fn):
+        """Warm-up steps (lazy initialisation, workspaces) on a side stream, then the capture.  The warm-up is made
+        invisible: parameters, optimizer state, the CPU generator the dropout seeds come from and the device seed are
+        put back, so a run with hip_graph follows the run without it."""
+        self._static_inputs = [t.clone() for t in inputs]
+        params = [p for g in self.opt.param_groups for p in g['params']]
+        saved_p = [p.detach().clone() for p in params]
+        saved_s = {id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.opt.state[p].items()}
+                   for p in params if p in self.opt.state}
+        rng = torch.get_rng_state()
+        seed_dev = getattr(self.model, '_seed_dev', None)
+        saved_seed = seed_dev.clone() if seed_dev is not None else None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                if hasattr(self.model, 'advance_dropout_seed'):
+                    self.model.advance_dropout_seed()
+                loss = loss_fn(*self._static_inputs)
+                self.opt.zero_grad()
+                loss.backward()
+                self.opt.step()
+                del loss                      # no autograd graph of the warm-up (its AccumulateGrad nodes) outlives it
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.no_grad():
+            for p, sp in zip(params, saved_p):
+                p.copy_(sp)
+            for p in params:
+                for k, v in self.opt.state[p].items():
+                    if torch.is_tensor(v):
+                        old = saved_s.get(id(p), {}).get(k)
+                        v.copy_(old) if old is not None else v.zero_()
+            if saved_seed is not None:
+                seed_dev.copy_(saved_seed)
+        torch.set_rng_state(rng)
+        self.opt.zero_grad(set_to_none=True)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            loss = loss_fn(*self._static_inputs)
+            loss.backward()
+            self.opt.step()
+            self._static_loss = loss.detach()
 
     def train_one_epoch(self):
         raise NotImplementedError
@@ -428,32 +497,16 @@ class BPRTrainer(BasicTrainer):
         return loss.detach()
 
     def node_step(self, nodes):
-        """One optimisation step on the node ids of a batch (DeviceSampler.epoch_node_batches).  With the trainer
-        config key 'hip_graph': True, full-size batches replay ONE captured HIP graph (forward, backward and the
-        fused Adam step: ~35 launches become one) — what a launch-bound small graph needs."""
-        if not self.config.get('hip_graph', False) or nodes.numel() != 3 * self.batch_size:
-            return self._optimise_loss(self.model.bpr_loss_nodes(nodes, self.l2_reg))
-        if self._graph is None:
-            self._capture(nodes)
-        self._static_nodes.copy_(nodes)
-        self._graph.replay()
-        return self._static_loss.clone()
-
-    def _capture(self, nodes):
-        self._static_nodes = nodes.clone()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                    # warm-up off the capture: lazy initialisation, workspaces
-            for _ in range(3):
-                self._optimise_loss(self.model.bpr_loss_nodes(self._static_nodes, self.l2_reg))
-        torch.cuda.current_stream().wait_stream(side)
-        self.opt.zero_grad(set_to_none=True)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            loss = self.model.bpr_loss_nodes(self._static_nodes, self.l2_reg)
-            loss.backward()
-            self.opt.step()
-            self._static_loss = loss.detach()
+        """One optimisation step on the node ids of a batch (DeviceSampler.epoch_node_batches).  Full-size batches
+        replay ONE captured HIP graph (forward, backward and the fused Adam step: 22 launches become one) unless the
+        trainer config says 'hip_graph': False — what a launch-bound step needs (Gowalla-size LightGCN, IMF: -20...-25 %);
+        a GPU-bound step pays ~1 % for the copies into the static buffers (profiles/r02j_*)."""
+        loss_fn = lambda n: self.model.bpr_loss_nodes(n, self.l2_reg)
+        if self._graph_wanted() and nodes.numel() == 3 * self.batch_size:
+            loss = self._graph_step((nodes,), loss_fn)
+            if loss is not None:
+                return loss
+        return self._optimise_loss(loss_fn(nodes))
 
     def train_one_epoch(self):
         losses = AverageMeter()
@@ -483,13 +536,30 @@ class IGCNTrainer(BasicTrainer):
         self.initialize_optimizer()
         self.l2_reg = trainer_config['l2_reg']
         self.aux_reg = trainer_config['aux_reg']
+        self._graph = None
 
     def igcn_step(self, inputs, aux_inputs):
         users, pos_items, neg_items = inputs.t().contiguous().unbind(0)
         return self._igcn_optimise(self.model.bpr_loss_terms(users, pos_items, neg_items), aux_inputs)
 
     def igcn_node_step(self, nodes, aux_inputs):
+        """One step on node-id batches.  Full-size batches replay ONE captured HIP graph (both losses, backward, fused
+        Adam) unless the config says 'hip_graph': False; the dropout seed then lives in device memory
+        (IGCN.use_device_seed) and is advanced before every step, captured or not — the same sequence of seeds as
+        the eager path draws."""
+        graph = self._graph_wanted()
+        if graph:
+            self.model.use_device_seed()
+        self.model.advance_dropout_seed()
+        if graph and nodes.numel() == 3 * self.batch_size and aux_inputs.shape[0] == self.batch_size:
+            loss = self._graph_step((nodes, aux_inputs), self._igcn_loss)
+            if loss is not None:
+                return loss
         return self._igcn_optimise(None, aux_inputs, self.model.bpr_loss_nodes(nodes, self.l2_reg))
+
+    def _igcn_loss(self, nodes, aux_inputs):
+        a_users, a_pos, a_neg = aux_inputs.t().contiguous().unbind(0)
+        return self.model.bpr_loss_nodes(nodes, self.l2_reg) + self.aux_reg * self.model.aux_loss(a_users, a_pos, a_neg)
 
     def _igcn_optimise(self, terms, aux_inputs, main_loss=None):
         a_users, a_pos, a_neg = aux_inputs.t().contiguous().unbind(0)

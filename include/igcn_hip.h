@@ -115,7 +115,9 @@ int igcn_spmm_plan_fill_host(const int64_t *rowptr_host, int64_t n_rows,
  * the result;
  * col_mask uint8 [n_cols] or NULL: rows of X the caller knows to be all zero (col_mask[c] == 0) are not read —
  * the first backward hops of a training step, whose operand is non-zero on the batch rows / their neighbourhood
- * only.  Edges whose weight comes out zero (masked here, or dropped out) issue no gather at all. */
+ * only.  Edges whose weight comes out zero (masked here, or dropped out) issue no gather at all;
+ * seed_dev: NULL, or the dropout seed in device memory (overrides `seed`): a launch captured in a HIP graph reads it
+ * at every replay, so the caller changes the dropped edges by writing 8 bytes, not by re-capturing. */
 int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val,
                       const float *x, int64_t ldx, float *y, int64_t ldy,
                       int64_t n_rows, int64_t n_cols, int32_t d,
@@ -126,7 +128,8 @@ int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *va
                       float *partial, int32_t long_threshold,
                       const int32_t *edge_id, uint64_t seed, float keep_prob,
                       const uint8_t *row_mask, int32_t masked_rows_zero,
-                      int64_t nnz, const int32_t *row_order, const uint8_t *col_mask, void *stream);
+                      int64_t nnz, const int32_t *row_order, const uint8_t *col_mask,
+                      const uint64_t *seed_dev, void *stream);
 
 /* Row masks for igcn_spmm_csr_f32.  mask1[ids[i] + offsets...] = 1 for every listed row;
  * when rowptr/col are given, mask2[r] = 1 for every listed row r and every column

@@ -19,6 +19,8 @@ def main():
         cases = tuple((c.split(':')[0], int(c.split(':')[1])) for c in os.environ['CASES'].split(','))
     for preset, index in cases:
         ds_cfg, m_cfg, t_cfg = cfg.get_synthetic_config(torch.device('cuda'), preset)[index]
+        if os.environ.get('HIP_GRAPH') == '0':           # graph models: launch the step's kernels one by one
+            t_cfg = dict(t_cfg, hip_graph=False)
         t0 = time.time()
         ds = get_dataset(ds_cfg)
         t_ds = time.time() - t0
@@ -52,7 +54,7 @@ def main():
         model._rep_cache = None
         _, metrics = trainer.eval('test')
         ms_eval = (time.time() - t0) * 1e3
-        print(json.dumps(dict(preset=preset, model=m_cfg['name'], n_users=ds.n_users, n_items=ds.n_items, train_pairs=len(ds),
+        print(json.dumps(dict(preset=preset, model=m_cfg['name'], hip_graph=bool(t_cfg.get('hip_graph', True)), n_users=ds.n_users, n_items=ds.n_items, train_pairs=len(ds),
                               dataset_s=round(t_ds, 2), build_s=round(t_build, 2), train_step_ms=round(ms_step, 3),
                               steps_per_epoch=-(-len(ds) // 2048), epoch_train_s=round(ms_step * (-(-len(ds) // 2048)) / 1e3, 3),
                               eval_test_ms=round(ms_eval, 1), recall20=float(metrics['Recall'][20]))), flush=True)

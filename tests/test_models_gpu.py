@@ -513,7 +513,8 @@ def test_column_sharded_lightgcn_class_world1_matches_plain(golden):
 def test_node_batches_fused_step_and_hip_graph(golden):
     """The trainers' fast path: (1) epoch_node_batches draws the same triplets as epoch_batches, as node ids;
     (2) the persistent batch-gradient table is all zeros again after a step; (3) a LightGCN trained through ONE captured
-    HIP graph per step (config 'hip_graph') follows the eager trajectory (same batches, same fused Adam)."""
+    HIP graph per step (config 'hip_graph', the default) follows the eager trajectory (same batches, same fused Adam;
+    the capture's warm-up steps are undone, so the run starts where the eager one does)."""
     from igcn_cf_amd.model import get_model
     from igcn_cf_amd.trainer import DeviceSampler, get_trainer
     ds = _dataset(golden)
@@ -530,16 +531,6 @@ def test_node_batches_fused_step_and_hip_graph(golden):
         model = get_model({'name': 'LightGCN', 'embedding_size': 64, 'n_layers': 3, 'device': 'cuda'}, ds)
         trainer = get_trainer(dict(tcfg, hip_graph=hip_graph), ds, model)
         model.train()
-        if hip_graph:                                    # the capture's warm-up steps must not move the comparison's start
-            w0 = model.embedding.weight.detach().clone()
-            nodes0 = next(iter(DeviceSampler(ds, 'cuda', seed=77).epoch_node_batches(32, ds.n_users)))
-            trainer._capture(nodes0)
-            with torch.no_grad():
-                model.embedding.weight.copy_(w0)
-            for st in trainer.opt.state.values():
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        v.zero_()
         losses.append(trainer.train_one_epoch())
         assert float(model._batch_grads.get(model.embedding.weight).abs().max()) == 0.0
         finals.append(model.embedding.weight.detach().cpu().numpy().copy())
@@ -547,3 +538,42 @@ def test_node_batches_fused_step_and_hip_graph(golden):
     assert abs(losses[0] - losses[1]) < 1e-5
     # float atomics order the batch gradients differently from run to run: Adam turns that into rounding-level noise
     assert np.abs(finals[0] - finals[1]).max() < 5e-3 and np.mean(np.abs(finals[0] - finals[1]) > 1e-5) < 2e-2
+
+
+@pytest.mark.parametrize('name,dropout', [('IGCN', 0.3), ('IMF', 0.0)])
+def test_igcn_step_as_one_hip_graph_follows_the_eager_trajectory(golden, name, dropout):
+    """IGCNTrainer with config 'hip_graph': both losses, backward and Adam replayed as ONE captured graph per step.
+    The dropout seed is read from device memory (a new mask every replay, the same sequence of seeds as the eager
+    path draws), the annealed feature values are rewritten in place between epochs: two epochs follow the eager run."""
+    from igcn_cf_amd.model import get_model
+    from igcn_cf_amd.trainer import DeviceSampler, get_trainer
+    ds = _dataset(golden)
+    mcfg = {'name': name, 'embedding_size': 64, 'n_layers': 2, 'device': 'cuda', 'dropout': dropout, 'feature_ratio': 1.}
+    tcfg = {'name': 'IGCNTrainer', 'optimizer': 'Adam', 'lr': 1e-2, 'l2_reg': 1e-3, 'aux_reg': 0.01, 'device': 'cuda',
+            'n_epochs': 2, 'batch_size': 32, 'dataloader_num_workers': 0, 'test_batch_size': 64, 'topks': [5], 'seed': 9}
+    finals, losses, reps = [], [], []
+    for hip_graph in (False, True):
+        torch.manual_seed(3)
+        model = get_model(dict(mcfg), ds)
+        trainer = get_trainer(dict(tcfg, hip_graph=hip_graph), ds, model)
+        model.train()
+        torch.manual_seed(11)                            # the dropout seeds of both runs come from this stream
+        seeds_seen = set()
+        ep = []
+        for _ in range(2):
+            ep.append(trainer.train_one_epoch())
+            if model._seed_dev is not None:
+                seeds_seen.add(int(model._seed_dev.item()))
+        losses.append(ep)
+        assert (trainer._graph is not None) == hip_graph
+        if hip_graph and dropout > 0:
+            assert len(seeds_seen) == 2 and 0 not in seeds_seen          # the device seed moved between the epochs
+        finals.append({k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()})
+        model.eval()
+        with torch.no_grad():
+            reps.append(model.get_rep().cpu().numpy().copy())
+    assert np.allclose(losses[0], losses[1], atol=2e-5)
+    for k in finals[0]:                                  # float atomics order the batch gradients differently from run to run
+        diff = np.abs(finals[0][k] - finals[1][k])
+        assert diff.max() < 5e-3 and np.mean(diff > 1e-5) < 2e-2, k
+    assert np.abs(reps[0] - reps[1]).max() < 5e-3

@@ -197,7 +197,7 @@ def test_c_abi_error_codes_without_launch():
 
     def call(rowptr_p, x_p, y_p, d=64, ldx=64, n_adds=0, keep=1.0, n_rows=8):
         return L.igcn_spmm_csr_f32(rowptr_p, col.data_ptr(), None, x_p, ldx, y_p, 64, n_rows, 8, d, 1.0, nul, n_adds, 1.0,
-                                   None, None, None, 0, None, 0, None, 256, None, 0, keep, None, 0, 0, None, None, None)
+                                   None, None, None, 0, None, 0, None, 256, None, 0, keep, None, 0, 0, None, None, None, None)
     assert call(None, x.data_ptr(), y.data_ptr()) == -1                       # IGCN_E_NULL
     assert call(rowptr.data_ptr(), x.data_ptr(), y.data_ptr(), d=0) == -2     # IGCN_E_SHAPE
     assert call(rowptr.data_ptr(), x.data_ptr(), y.data_ptr(), d=300) == -2
@@ -329,7 +329,7 @@ def test_launch_shape_does_not_change_results():
         rc = _lib.lib().igcn_spmm_csr_f32(csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.val.data_ptr(), x.data_ptr(), d,
                                           y.data_ptr(), d, n_rows, n_cols, d, 1.0, nul, 0, 0.0, None, None,
                                           _lib.ptr(csr.long_rows), csr.n_long, _lib.ptr(csr.segments), csr.n_segments,
-                                          _lib.ptr(csr.partial(d)), csr.long_threshold, None, 0, 1.0, None, 0, nnz_hint, None, None,
+                                          _lib.ptr(csr.partial(d)), csr.long_threshold, None, 0, 1.0, None, 0, nnz_hint, None, None, None,
                                           torch.cuda.current_stream().cuda_stream)
         assert rc == 0 and torch.equal(y, ref)
     # a row order (rows dealt to the waves by descending length inside two blocks) changes who computes a row, not the result
