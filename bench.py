@@ -479,7 +479,7 @@ def inductive_update_timing(ds, device, d, K):
                 'old_users': small.n_users, 'old_items': small.n_items, 'users': ds.n_users, 'items': ds.n_items,
                 'reference_published_s': 3.4,
                 'note': 'graph and feature CSRs are built in HBM (graph.py *_device builders, bit-identical to the host ones); '
-                        'trainer_setup_s is the host side of the device sampler / exclusion lists; the published 3.4 s '
+                        'samplers / the re-indexed auxiliary dataset are built on first training use, not for an evaluation; the published 3.4 s '
                         '(run/plot.py:200) is the authors\' figure on their GPU and real Amazon-book, quoted for orientation only'})
     return out
 

@@ -16,6 +16,7 @@ run on the device:
 Baseline trainers outside the hot path (IDCFTrainer, BCETrainer, MLTrainer) are
 out of scope.
 """
+import functools
 import os
 import sys
 import time
@@ -477,10 +478,14 @@ class BPRTrainer(BasicTrainer):
     def __init__(self, trainer_config):
         super().__init__(trainer_config)
         self.batch_size = trainer_config['batch_size']
-        self.sampler = DeviceSampler(self.dataset, self.device, trainer_config.get('seed', 2021))
         self.initialize_optimizer()
         self.l2_reg = trainer_config['l2_reg']
         self._graph = None
+
+    @functools.cached_property
+    def sampler(self):
+        """Built on first use: a trainer made only to evaluate (the inductive scripts) never pays for it."""
+        return DeviceSampler(self.dataset, self.device, self.config.get('seed', 2021))
 
     def bpr_step(self, inputs):
         """One optimisation step on an int64 [B, 3] batch; returns the loss tensor."""
@@ -529,14 +534,24 @@ class IGCNTrainer(BasicTrainer):
     def __init__(self, trainer_config):
         super().__init__(trainer_config)
         self.batch_size = trainer_config['batch_size']
-        seed = trainer_config.get('seed', 2021)
-        self.sampler = DeviceSampler(self.dataset, self.device, seed)
-        self.aux_dataset = AuxiliaryDataset(self.dataset, self.model.user_map, self.model.item_map)
-        self.aux_sampler = DeviceSampler(self.aux_dataset, self.device, seed + 1)
         self.initialize_optimizer()
         self.l2_reg = trainer_config['l2_reg']
         self.aux_reg = trainer_config['aux_reg']
         self._graph = None
+
+    # samplers and the re-indexed auxiliary dataset (dataset.py:258-273) are built on first use: the inductive
+    # scripts make an IGCNTrainer only to evaluate (run/dropui/igcn_dropui.py:33-35)
+    @functools.cached_property
+    def sampler(self):
+        return DeviceSampler(self.dataset, self.device, self.config.get('seed', 2021))
+
+    @functools.cached_property
+    def aux_dataset(self):
+        return AuxiliaryDataset(self.dataset, self.model.user_map, self.model.item_map)
+
+    @functools.cached_property
+    def aux_sampler(self):
+        return DeviceSampler(self.aux_dataset, self.device, self.config.get('seed', 2021) + 1)
 
     def igcn_step(self, inputs, aux_inputs):
         users, pos_items, neg_items = inputs.t().contiguous().unbind(0)
