@@ -46,17 +46,17 @@ def _worker(rank, world, port, path, emb, batch, n_layers, exchange, k, excl, re
             terms = model.bpr_loss_terms(b[:, 0].contiguous(), b[:, 1].contiguous(), b[:, 2].contiguous())
             loss = terms[0] + 1e-2 * terms[1]
             opt.zero_grad(); loss.backward(); opt.step()
-            losses.append(float(loss))
+            losses.append(float(loss.detach()))
         ret[rank] = (rep0, rec, losses, model.full_embedding().cpu().numpy().copy(), (ulo, uhi, ilo, ihi), model.prop.exchange)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,exchange', [(2, 'halves'), (3, 'fused')])
-def test_row_sharded_product_path_ranks_share_one_gpu(golden, world, exchange):
+@pytest.mark.parametrize('world,exchange,d', [(2, 'halves', 16), (3, 'fused', 16), (2, 'halves', 128)])
+def test_row_sharded_product_path_ranks_share_one_gpu(golden, world, exchange, d):
     nu, ni = int(golden['n_users']), int(golden['n_items'])
     ta = golden['train_array']
-    n_layers, d, k = 3, 16, 5
+    n_layers, k = 3, 5          # d = 128: the one-row-per-wave SpMM variant and the exchange BASELINE config 5 uses
     rng = np.random.default_rng(3)
     emb = (rng.standard_normal((nu + ni, d)) * 0.1).astype(np.float32)
     batch = np.stack([rng.integers(0, nu, 96), rng.integers(0, ni, 96), rng.integers(0, ni, 96)], axis=1).astype(np.int64)
@@ -89,7 +89,7 @@ def test_row_sharded_product_path_ranks_share_one_gpu(golden, world, exchange):
         l2 = ((e[b[:, 0]] ** 2).sum(1) + (e[nu + b[:, 1]] ** 2).sum(1) + (e[nu + b[:, 2]] ** 2).sum(1)).mean()
         loss = torch.nn.functional.softplus((ur * nr).sum(1) - (ur * pr).sum(1)).mean() + 1e-2 * l2
         opt.zero_grad(); loss.backward(); opt.step()
-        ref_losses.append(float(loss))
+        ref_losses.append(float(loss.detach()))
 
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), golden['path'], emb, batch, n_layers, exchange, k,
@@ -101,7 +101,8 @@ def test_row_sharded_product_path_ranks_share_one_gpu(golden, world, exchange):
         np.testing.assert_allclose(ru, rep_ref[ulo:uhi], rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(ri, rep_ref[nu + ilo:nu + ihi], rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(losses, ref_losses, rtol=1e-5)
-        np.testing.assert_allclose(full, e.detach().numpy(), rtol=1e-4, atol=1e-6)
+        # two Adam steps: an update is lr * m / sqrt(v), so rounding-level gradient differences show at the 1e-5 level
+        np.testing.assert_allclose(full, e.detach().numpy(), rtol=1e-4, atol=2e-5)
         assert rec.shape == (uhi - ulo, k)
         for j, u in enumerate(range(ulo, uhi)):                              # same score multiset as the float64 ranking
             want = np.sort(scores[u])[::-1][:k]

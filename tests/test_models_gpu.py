@@ -577,3 +577,40 @@ def test_igcn_step_as_one_hip_graph_follows_the_eager_trajectory(golden, name, d
         diff = np.abs(finals[0][k] - finals[1][k])
         assert diff.max() < 5e-3 and np.mean(diff > 1e-5) < 2e-2, k
     assert np.abs(reps[0] - reps[1]).max() < 5e-3
+
+
+def test_captured_step_is_recaptured_when_the_graph_is_swapped(golden):
+    """A step captured as a HIP graph holds pointers into the model's CSR: assigning a new norm_adj (the inductive
+    protocol, run/dropui/igcn_dropui.py:28-32) must make the next step capture again and train on the new graph —
+    the captured run keeps following the eagerly launched one."""
+    from igcn_cf_amd.graph import CsrMatrix, normalized_adjacency_host
+    from igcn_cf_amd.model import get_model
+    from igcn_cf_amd.trainer import get_trainer
+    ds = _dataset(golden)
+    tcfg = {'name': 'BPRTrainer', 'optimizer': 'Adam', 'lr': 1e-2, 'l2_reg': 1e-3, 'device': 'cuda', 'n_epochs': 1,
+            'batch_size': 32, 'dataloader_num_workers': 0, 'test_batch_size': 64, 'topks': [5], 'seed': 9}
+    n = ds.n_users + ds.n_items
+    half = CsrMatrix(*normalized_adjacency_host(ds.train_array[::2], ds.n_users, ds.n_items), (n, n), 'cuda')
+    runs = []
+    for hip_graph in (True, False):
+        torch.manual_seed(3)
+        model = get_model({'name': 'LightGCN', 'embedding_size': 32, 'n_layers': 2, 'device': 'cuda'}, ds)
+        trainer = get_trainer(dict(tcfg, hip_graph=hip_graph), ds, model)
+        model.train()
+        batches = [b for _, b in zip(range(3), trainer.sampler.epoch_node_batches(32, ds.n_users))]
+        losses = [float(trainer.node_step(batches[0])), float(trainer.node_step(batches[1]))]
+        first = trainer._graph
+        assert (first is not None) == hip_graph
+        model.norm_adj = half
+        losses.append(float(trainer.node_step(batches[2])))
+        if hip_graph:
+            assert trainer._graph is not first                       # new pointers: captured again
+            second = trainer._graph
+            trainer.node_step(batches[2])
+            assert trainer._graph is second                          # same state: replayed
+        else:
+            trainer.node_step(batches[2])
+        runs.append((losses, model.embedding.weight.detach().cpu().numpy().copy()))
+    assert np.allclose(runs[0][0], runs[1][0], atol=2e-5)
+    diff = np.abs(runs[0][1] - runs[1][1])
+    assert diff.max() < 5e-3 and np.mean(diff > 1e-5) < 2e-2

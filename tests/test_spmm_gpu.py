@@ -396,3 +396,33 @@ def test_device_graph_builders_are_bit_identical_to_the_host_ones(golden):
             np.testing.assert_array_equal(f.rowptr.cpu().numpy(), frp)
             np.testing.assert_array_equal(f.col.cpu().numpy(), fcol)
             np.testing.assert_array_equal(row_sum.cpu().numpy(), frow_sum)
+
+
+def test_dropout_seed_from_device_memory_matches_the_launch_argument():
+    """seed_dev (ABI v4): the same 64-bit seed read from device memory drops the same edges as when it is passed as a
+    launch argument — on the matrix and on its transposed view (edge ids) — and a new value written there changes
+    the mask without any new binding (what a captured HIP graph replays)."""
+    from igcn_cf_amd import _lib
+    from igcn_cf_amd.graph import CsrMatrix
+    from igcn_cf_amd.ops import spmm
+    rng = np.random.default_rng(5)
+    n_rows, n_cols, d = 700, 500, 64
+    dense = (rng.random((n_rows, n_cols)) < 0.05)
+    row, col = np.nonzero(dense)
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(row, minlength=n_rows))]).astype(np.int64)
+    csr = CsrMatrix(rowptr, col.astype(np.int32), None, (n_rows, n_cols), 'cuda')
+    x = torch.randn(n_cols, d, device='cuda')
+    g = torch.randn(n_rows, d, device='cuda')
+    csr_t = csr.transposed_view()
+    seed_dev = torch.zeros(1, dtype=torch.int64, device='cuda')
+    outs = []
+    for seed in (123456789012345, 987654321):
+        seed_dev.fill_(seed)
+        a = spmm(csr, x, keep_prob=0.6, seed=seed)
+        b = spmm(csr, x, keep_prob=0.6, seed=seed_dev)
+        assert torch.equal(a, b)
+        assert torch.equal(spmm(csr_t, g, keep_prob=0.6, seed=seed), spmm(csr_t, g, keep_prob=0.6, seed=seed_dev))
+        outs.append(b)
+    assert not torch.equal(outs[0], outs[1])
+    with pytest.raises(_lib.IgcnError):
+        spmm(csr, x, keep_prob=0.6, seed=torch.zeros(1, dtype=torch.int32, device='cuda'))
