@@ -51,6 +51,10 @@ SIGNATURES = {
     'igcn_bpr_sample': (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, vp, vp]),
     'igcn_bpr_sample_nodes': (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, vp, vp]),
     'igcn_rows_finish_f32': (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int32, vp, C.c_float, vp]),
+    'igcn_owned_rows_gather_f32': (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                             vp, C.c_int64, vp, C.c_int64, C.c_int32, vp, C.c_int64, vp]),
+    'igcn_owned_rows_scatter_add_f32': (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                                  vp, C.c_int64, C.c_int32, vp, C.c_int64, vp, C.c_int64, vp]),
     'igcn_bpr_loss_f32': (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, vp, C.c_int64, vp, vp, vp,
                                     C.c_int64, C.c_int32, vp, C.c_float, vp, vp, vp]),
     'igcn_bpr_loss_bwd_f32': (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, vp, C.c_int64, vp, vp, vp,

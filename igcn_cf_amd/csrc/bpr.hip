@@ -170,6 +170,40 @@ __global__ __launch_bounds__(kBlock) void rows_finish_kernel(float *__restrict__
         for (int j = lane; j < d; j += kWave) zero_tab[r * ldz + j] = 0.f;
 }
 
+
+// Row-sharded training (igcn_cf_amd/dist.py): of the batch's node ids, a rank owns the users in [ulo, uhi) and the
+// items (id - n_users) in [ilo, ihi).  One wave per id.
+__global__ __launch_bounds__(kBlock) void owned_rows_gather_kernel(
+    const int64_t *__restrict__ ids, int64_t n, int64_t n_users, int64_t ulo, int64_t uhi, int64_t ilo, int64_t ihi,
+    const float *__restrict__ tab_u, int64_t ld_u, const float *__restrict__ tab_i, int64_t ld_i, int d,
+    float *__restrict__ out, int64_t ld_out)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t i = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int64_t id = ids[i];
+    const float *src = nullptr;
+    if (id < n_users) { if (id >= ulo && id < uhi) src = tab_u + (id - ulo) * ld_u; }
+    else { const int64_t it = id - n_users; if (it >= ilo && it < ihi) src = tab_i + (it - ilo) * ld_i; }
+    for (int j = lane; j < d; j += kWave) out[i * ld_out + j] = src ? src[j] : 0.f;      // rows of other ranks: zero (x + 0 is exact)
+}
+
+__global__ __launch_bounds__(kBlock) void owned_rows_scatter_add_kernel(
+    const int64_t *__restrict__ ids, int64_t n, int64_t n_users, int64_t ulo, int64_t uhi, int64_t ilo, int64_t ihi,
+    const float *__restrict__ g, int64_t ld_g, int d,
+    float *__restrict__ gu, int64_t ld_gu, float *__restrict__ gi, int64_t ld_gi)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t i = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int64_t id = ids[i];
+    float *dst = nullptr;
+    if (id < n_users) { if (id >= ulo && id < uhi) dst = gu + (id - ulo) * ld_gu; }
+    else { const int64_t it = id - n_users; if (it >= ilo && it < ihi) dst = gi + (it - ilo) * ld_gi; }
+    if (!dst) return;
+    for (int j = lane; j < d; j += kWave) atomicAdd(dst + j, g[i * ld_g + j]);            // an id may occur several times
+}
+
 }  // namespace igcn
 
 using namespace igcn;
@@ -311,4 +345,28 @@ extern "C" int igcn_bpr_loss_bwd_f32(const float *u_tab, const float *p_tab, con
 {
     return bpr_bwd_launch(u_tab, p_tab, n_tab, ld, l2_u_tab, l2_p_tab, l2_n_tab, ld_l2, users, pos, neg, batch, d, w, work, g_loss,
                           gu_tab, gp_tab, gn_tab, gl2_u_tab, gl2_p_tab, gl2_n_tab, gw_out, 1, 1.f, l2_weight, stream);
+}
+
+extern "C" int igcn_owned_rows_gather_f32(const int64_t *ids, int64_t n, int64_t n_users, int64_t ulo, int64_t uhi,
+                                          int64_t ilo, int64_t ihi, const float *tab_u, int64_t ld_u,
+                                          const float *tab_i, int64_t ld_i, int32_t d, float *out, int64_t ld_out, void *stream)
+{
+    if (!ids || !out || (uhi > ulo && !tab_u) || (ihi > ilo && !tab_i)) return IGCN_E_NULL;
+    if (n < 0 || d < 1 || ld_out < d || (tab_u && ld_u < d) || (tab_i && ld_i < d) || uhi < ulo || ihi < ilo) return IGCN_E_SHAPE;
+    if (n == 0) return IGCN_OK;
+    hipLaunchKernelGGL(owned_rows_gather_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       ids, n, n_users, ulo, uhi, ilo, ihi, tab_u, ld_u, tab_i, ld_i, (int)d, out, ld_out);
+    return launch_status();
+}
+
+extern "C" int igcn_owned_rows_scatter_add_f32(const int64_t *ids, int64_t n, int64_t n_users, int64_t ulo, int64_t uhi,
+                                               int64_t ilo, int64_t ihi, const float *g, int64_t ld_g, int32_t d,
+                                               float *gu, int64_t ld_gu, float *gi, int64_t ld_gi, void *stream)
+{
+    if (!ids || !g || (uhi > ulo && !gu) || (ihi > ilo && !gi)) return IGCN_E_NULL;
+    if (n < 0 || d < 1 || ld_g < d || (gu && ld_gu < d) || (gi && ld_gi < d) || uhi < ulo || ihi < ilo) return IGCN_E_SHAPE;
+    if (n == 0) return IGCN_OK;
+    hipLaunchKernelGGL(owned_rows_scatter_add_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), ids, n, n_users, ulo, uhi, ilo, ihi, g, ld_g, (int)d, gu, ld_gu, gi, ld_gi);
+    return launch_status();
 }

@@ -291,28 +291,41 @@ class _BatchRowsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, prop, ids, *tables_ui):
         L, rank = prop.layout, prop.rank
-        if ids.is_cuda:
-            owner, local = _owner_device(L, ids)
-        else:
-            o, l = L.owner(ids.numpy())
-            owner, local = torch.from_numpy(o), torch.from_numpy(l)
-        sel = torch.nonzero(owner == rank, as_tuple=False).flatten()
-        loc = local[sel]
         n_tab = len(tables_ui) // 2
         widths = [tables_ui[2 * t].shape[1] for t in range(n_tab)]
-        buf = torch.zeros((ids.numel(), sum(widths)), dtype=torch.float32, device=tables_ui[0].device)
-        c0 = 0
-        for t in range(n_tab):
-            tu, ti = tables_ui[2 * t].detach(), tables_ui[2 * t + 1].detach()
-            is_item = loc >= L.bu
-            rows = torch.where(is_item[:, None], ti[(loc - L.bu).clamp(min=0, max=max(ti.shape[0] - 1, 0))],
-                               tu[loc.clamp(max=max(tu.shape[0] - 1, 0))])
-            buf[sel, c0:c0 + widths[t]] = rows
-            c0 += widths[t]
+        ctx.widths, ctx.shapes = widths, [t.shape for t in tables_ui]
+        ctx.device_path = ids.is_cuda
+        if ids.is_cuda:
+            # two launches per table pair, no host round trip: the rank's own rows, zeros elsewhere
+            from . import _lib
+            (ulo, uhi), (ilo, ihi) = L.user_rows(rank), L.item_rows(rank)
+            ctx.ids, ctx.bounds = ids, (L.n_users, ulo, uhi, ilo, ihi)
+            buf = torch.empty((ids.numel(), sum(widths)), dtype=torch.float32, device=ids.device)
+            c0 = 0
+            for t in range(n_tab):
+                tu, ti = tables_ui[2 * t].detach(), tables_ui[2 * t + 1].detach()
+                _lib.check(_lib.lib().igcn_owned_rows_gather_f32(
+                    ids.data_ptr(), ids.numel(), L.n_users, ulo, uhi, ilo, ihi, tu.data_ptr(), tu.stride(0), ti.data_ptr(),
+                    ti.stride(0), widths[t], buf.data_ptr() + 4 * c0, buf.stride(0), _lib.current_stream()),
+                    'igcn_owned_rows_gather_f32')
+                c0 += widths[t]
+        else:                                            # host tensors: the CPU tests of the exchange logic
+            o, l = L.owner(ids.numpy())
+            owner, local = torch.from_numpy(o), torch.from_numpy(l)
+            sel = torch.nonzero(owner == rank, as_tuple=False).flatten()
+            loc = local[sel]
+            buf = torch.zeros((ids.numel(), sum(widths)), dtype=torch.float32, device=tables_ui[0].device)
+            c0 = 0
+            for t in range(n_tab):
+                tu, ti = tables_ui[2 * t].detach(), tables_ui[2 * t + 1].detach()
+                is_item = loc >= L.bu
+                rows = torch.where(is_item[:, None], ti[(loc - L.bu).clamp(min=0, max=max(ti.shape[0] - 1, 0))],
+                                   tu[loc.clamp(max=max(tu.shape[0] - 1, 0))])
+                buf[sel, c0:c0 + widths[t]] = rows
+                c0 += widths[t]
+            ctx.sel, ctx.loc, ctx.bu = sel, loc, L.bu
         if _dist_on():
             dist.all_reduce(buf, group=prop.group)
-        ctx.sel, ctx.loc, ctx.bu, ctx.widths = sel, loc, L.bu, widths
-        ctx.shapes = [t.shape for t in tables_ui]
         outs, c0 = [], 0
         for w in widths:
             outs.append(buf[:, c0:c0 + w])
@@ -321,11 +334,26 @@ class _BatchRowsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        out = []
+        if ctx.device_path:
+            from . import _lib
+            n_users, ulo, uhi, ilo, ihi = ctx.bounds
+            for t, g in enumerate(grads):
+                gu = torch.zeros(ctx.shapes[2 * t], dtype=torch.float32, device=ctx.ids.device)
+                gi = torch.zeros(ctx.shapes[2 * t + 1], dtype=torch.float32, device=ctx.ids.device)
+                if g is not None:
+                    if g.stride(1) != 1:
+                        g = g.contiguous()
+                    _lib.check(_lib.lib().igcn_owned_rows_scatter_add_f32(
+                        ctx.ids.data_ptr(), ctx.ids.numel(), n_users, ulo, uhi, ilo, ihi, g.data_ptr(), g.stride(0),
+                        ctx.widths[t], gu.data_ptr(), gu.stride(0), gi.data_ptr(), gi.stride(0), _lib.current_stream()),
+                        'igcn_owned_rows_scatter_add_f32')
+                out += [gu, gi]
+            return (None, None, *out)
         sel, loc, bu = ctx.sel, ctx.loc, ctx.bu
         is_item = loc >= bu
         su, si = sel[~is_item], sel[is_item]
         lu, li = loc[~is_item], loc[is_item] - bu
-        out = []
         for t, g in enumerate(grads):
             gu = g.new_zeros(ctx.shapes[2 * t])
             gi = g.new_zeros(ctx.shapes[2 * t + 1])
@@ -334,24 +362,6 @@ class _BatchRowsFn(torch.autograd.Function):
                 gi.index_add_(0, li, g[si])
             out += [gu, gi]
         return (None, None, *out)
-
-
-def _owner_device(L, ids):
-    """ShardLayout.owner on the device (ids int64 on the GPU): (rank, local row) tensors."""
-    dev = ids.device
-    cache = getattr(L, '_dev_bounds', None)
-    if cache is None or cache[0].device != dev:
-        cache = (torch.from_numpy(L.user_bounds).to(dev), torch.from_numpy(L.item_bounds).to(dev))
-        L._dev_bounds = cache
-    ub, ib = cache
-    is_item = ids >= L.n_users
-    it = torch.where(is_item, ids - L.n_users, torch.zeros_like(ids))
-    us = torch.where(is_item, torch.zeros_like(ids), ids)
-    ru = (torch.searchsorted(ub, us, right=True) - 1).clamp(max=L.world - 1)
-    ri = (torch.searchsorted(ib, it, right=True) - 1).clamp(max=L.world - 1)
-    rank = torch.where(is_item, ri, ru)
-    local = torch.where(is_item, L.bu + it - ib[ri], us - ub[ru])
-    return rank, local
 
 
 def _compact_bpr_terms(rows_rep, rows_emb, batch):

@@ -271,6 +271,18 @@ int igcn_bpr_loss_bwd_f32(const float *u_tab, const float *p_tab, const float *n
 int igcn_rows_finish_f32(float *dst, int64_t ldd, const float *src, int64_t lds, float *zero_tab, int64_t ldz,
                          const int64_t *ids, int64_t n, int32_t d, const float *scale_dev, float scale_host, void *stream);
 
+/* Row-sharded multi-GPU training (igcn_cf_amd/dist.py; not in the reference, which is single-device): of the n node ids
+ * of a batch (users < n_users <= items) this rank owns the users in [ulo, uhi) and the items (id - n_users) in
+ * [ilo, ihi).  gather: out[i, 0:d] = the owned row of tab_u / tab_i (local row = id - ulo / item - ilo), zeros for
+ * ids of other ranks — every rank fills its rows and ONE all-reduce completes the [n, d] block.  scatter_add: the
+ * gradient rows of the ids this rank owns are added (float atomics; ids may repeat) into its local tables. */
+int igcn_owned_rows_gather_f32(const int64_t *ids, int64_t n, int64_t n_users, int64_t ulo, int64_t uhi,
+                               int64_t ilo, int64_t ihi, const float *tab_u, int64_t ld_u,
+                               const float *tab_i, int64_t ld_i, int32_t d, float *out, int64_t ld_out, void *stream);
+int igcn_owned_rows_scatter_add_f32(const int64_t *ids, int64_t n, int64_t n_users, int64_t ulo, int64_t uhi,
+                                    int64_t ilo, int64_t ihi, const float *g, int64_t ld_g, int32_t d,
+                                    float *gu, int64_t ld_gu, float *gi, int64_t ld_gi, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
