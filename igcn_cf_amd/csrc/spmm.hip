@@ -41,7 +41,7 @@ struct SpmmEpilogue {
     float add_scale;
     const float *row_scale;
     const float *col_scale;
-    const uint8_t *col_mask;   // source rows known to be zero are not gathered
+    const uint32_t *col_mask;  // one bit per source row (26 KB for 206 k rows: stays in L1): rows known to be zero are not gathered
 };
 
 struct SpmmDropout {
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
                 c = col[p];
                 w = val ? val[p] : 1.f;
                 if (ep.col_scale) w *= ep.col_scale[c];
-                if (ep.col_mask && !ep.col_mask[c]) w = 0.f;
+                if (ep.col_mask && !((ep.col_mask[c >> 5] >> (c & 31)) & 1u)) w = 0.f;
                 if (DROPOUT) {
                     const uint64_t e = dr.edge_id ? (uint64_t)(uint32_t)dr.edge_id[p] : (uint64_t)p;
                     w = hash_counter(e, seed0, seed1) < dr.keep_below ? w / dr.keep_prob : 0.f;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
                 c = col[p];
                 w = val ? val[p] : 1.f;
                 if (ep.col_scale) w *= ep.col_scale[c];
-                if (ep.col_mask && !ep.col_mask[c]) w = 0.f;
+                if (ep.col_mask && !((ep.col_mask[c >> 5] >> (c & 31)) & 1u)) w = 0.f;
                 if (DROPOUT) {
                     const uint64_t e = dr.edge_id ? (uint64_t)(uint32_t)dr.edge_id[p] : (uint64_t)p;
                     w = hash_counter(e, seed0, seed1) < dr.keep_below ? w / dr.keep_prob : 0.f;
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_scalar_kernel(
             for (int64_t p = start; p < end; ++p) {
                 float w = val ? val[p] : 1.f;
                 if (ep.col_scale) w *= ep.col_scale[col[p]];
-                if (ep.col_mask && !ep.col_mask[col[p]]) w = 0.f;
+                if (ep.col_mask && !((ep.col_mask[col[p] >> 5] >> (col[p] & 31)) & 1u)) w = 0.f;
                 if (dropout) {
                     const uint64_t e = dr.edge_id ? (uint64_t)(uint32_t)dr.edge_id[p] : (uint64_t)p;
                     w = hash_counter(e, seed0, seed1) < dr.keep_below ? w / dr.keep_prob : 0.f;
@@ -430,6 +430,23 @@ __global__ void mark_rows_kernel(const int64_t *__restrict__ ids, int64_t n, con
     if (lane == 0) { mask1[r] = 1; if (mask2) mask2[r] = 1; }
     if (mask2 && rowptr)
         for (int64_t p = rowptr[r] + lane; p < rowptr[r + 1]; p += kWave) mask2[col[p]] = 1;
+}
+
+// uint8 masks [n_masks][stride] -> one bit per entry, ceil(n / 32) words per mask; a wave packs 64 entries
+__global__ __launch_bounds__(kBlock) void pack_mask_bits_kernel(const uint8_t *__restrict__ masks, int64_t n, int64_t stride,
+                                                                int64_t words, int64_t pairs, int n_masks, uint32_t *__restrict__ bits)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wv = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (wv >= pairs * n_masks) return;
+    const int64_t m = wv / pairs, pair = wv % pairs;
+    const int64_t e = pair * kWave + lane;
+    const bool on = e < n && masks[m * stride + e] != 0;
+    const unsigned long long b = __ballot(on);
+    if (lane == 0) {
+        bits[m * words + 2 * pair] = (uint32_t)b;
+        if (2 * pair + 1 < words) bits[m * words + 2 * pair + 1] = (uint32_t)(b >> 32);
+    }
 }
 
 // Workgroups of this kernel variant that a CU really holds at once (a floor for the grid).  Rows are
@@ -574,7 +591,7 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
                                  float *partial, int32_t long_threshold,
                                  const int32_t *edge_id, uint64_t seed, float keep_prob,
                                  const uint8_t *row_mask, int32_t masked_rows_zero,
-                                 int64_t nnz, const int32_t *row_order, const uint8_t *col_mask,
+                                 int64_t nnz, const int32_t *row_order, const uint32_t *col_mask,
                                  const uint64_t *seed_dev, void *stream)
 {
     if (!rowptr || !x || !y) return IGCN_E_NULL;
@@ -652,6 +669,18 @@ extern "C" int igcn_mark_rows(const int64_t *ids, int64_t n, const int64_t *rowp
     if (n == 0) return IGCN_OK;
     hipLaunchKernelGGL(mark_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
                        ids, n, rowptr, col, mask1, mask2);
+    return launch_status();
+}
+
+extern "C" int igcn_pack_mask_bits(const uint8_t *masks, int64_t n, int64_t stride, int32_t n_masks, uint32_t *bits, void *stream)
+{
+    if (!masks || !bits) return IGCN_E_NULL;
+    if (n < 0 || n_masks < 1 || stride < n) return IGCN_E_SHAPE;
+    if (n == 0) return IGCN_OK;
+    const int64_t words = (n + 31) / 32, pairs = (n + kWave - 1) / kWave;
+    const int64_t waves = pairs * n_masks;
+    hipLaunchKernelGGL(pack_mask_bits_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       masks, n, stride, words, pairs, (int)n_masks, bits);
     return launch_status();
 }
 

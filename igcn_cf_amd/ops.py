@@ -22,7 +22,7 @@ def _require_gpu_f32(t, name):
 def spmm(csr: CsrMatrix, x, out=None, adds=(), out_scale=1.0, add_scale=1.0, row_scale=None, col_scale=None,
          keep_prob=1.0, seed=0, row_mask=None, masked_rows_zero=False, col_mask=None):
     """out = (out_scale * csr @ x + add_scale * sum(adds)) * row_scale  (see igcn_spmm_csr_f32).
-    col_mask uint8 [n_cols]: rows of x with col_mask == 0 are all zero and are not read.
+    col_mask: bit mask over the columns (int32 words, pack_mask_bits): rows of x whose bit is clear are all zero and are not read.
     seed: an int, or a one-element int64 tensor on the GPU (read by the kernel: HIP-graph replays see its current value)."""
     _require_gpu_f32(x, 'x')
     n_rows, n_cols = csr.shape
@@ -44,8 +44,8 @@ def spmm(csr: CsrMatrix, x, out=None, adds=(), out_scale=1.0, add_scale=1.0, row
         raise _lib.IgcnError('row_scale must be float32 [n_rows] on the GPU')
     if row_mask is not None and (row_mask.dtype != torch.uint8 or row_mask.numel() < n_rows or not row_mask.is_cuda):
         raise _lib.IgcnError('row_mask must be uint8 [n_rows] on the GPU')
-    if col_mask is not None and (col_mask.dtype != torch.uint8 or col_mask.numel() < n_cols or not col_mask.is_cuda):
-        raise _lib.IgcnError('col_mask must be uint8 [n_cols] on the GPU')
+    if col_mask is not None and (col_mask.dtype != torch.int32 or col_mask.numel() * 32 < n_cols or not col_mask.is_cuda):
+        raise _lib.IgcnError('col_mask must be a bit mask (int32 words, ops.pack_mask_bits) over the columns, on the GPU')
     if col_scale is not None and (col_scale.dtype != torch.float32 or col_scale.numel() < n_cols or not col_scale.is_cuda):
         raise _lib.IgcnError('col_scale must be float32 [n_cols] on the GPU')
     add_ptrs = (C.c_void_p * max(1, len(adds)))(*[a.data_ptr() for a in adds])
@@ -66,16 +66,29 @@ def spmm(csr: CsrMatrix, x, out=None, adds=(), out_scale=1.0, add_scale=1.0, row
     return out
 
 
+def pack_mask_bits(masks):
+    """uint8 masks [n] or [m, n] (contiguous rows) -> int32 bit words [ceil(n / 32)] or [m, ceil(n / 32)] (igcn_pack_mask_bits)."""
+    if masks.dtype != torch.uint8 or not masks.is_cuda or masks.stride(-1) != 1:
+        raise _lib.IgcnError('masks must be uint8 on the GPU with contiguous rows')
+    two = masks.dim() == 2
+    m, n = (masks.shape if two else (1, masks.shape[0]))
+    bits = torch.empty((m, (n + 31) // 32), dtype=torch.int32, device=masks.device)
+    _lib.check(_lib.lib().igcn_pack_mask_bits(masks.data_ptr(), n, masks.stride(0) if two else n, m, bits.data_ptr(),
+                                              _lib.current_stream()), 'igcn_pack_mask_bits')
+    return bits if two else bits[0]
+
+
 def mark_rows(csr: CsrMatrix, ids, with_neighbours=True):
-    """(mask1, mask2) uint8 [n_rows]: mask1 = the listed rows, mask2 = those rows and their
-    neighbourhood in `csr` (igcn_mark_rows)."""
+    """(mask1, mask2, bits1, bits2): uint8 [n_rows] masks — mask1 = the listed rows, mask2 = those rows and their
+    neighbourhood in `csr` (igcn_mark_rows) — and the same two as bit masks (what spmm's col_mask takes)."""
     _require_i64(ids, 'ids')
     n_rows = csr.shape[0]
     masks = torch.zeros((2, n_rows), dtype=torch.uint8, device=ids.device)
     _lib.check(_lib.lib().igcn_mark_rows(ids.data_ptr(), ids.numel(), csr.rowptr.data_ptr(), csr.col.data_ptr(),
                                          masks[0].data_ptr(), masks[1].data_ptr() if with_neighbours else None, n_rows,
                                          _lib.current_stream()), 'igcn_mark_rows')
-    return masks[0], masks[1]
+    bits = pack_mask_bits(masks)
+    return masks[0], masks[1], bits[0], bits[1]
 
 
 def propagate_mean(csr: CsrMatrix, x0, n_layers, row_scale_last=None, masks=None, zero_masked=True):
@@ -123,10 +136,10 @@ def propagate_mean_backward(csr_t: CsrMatrix, grad, n_layers, row_scale=None, ma
         if cur is None:
             # rows outside masks[1] are zero: written as zeros only when this hop is the result, else never read
             cur = spmm(csr_t, g, adds=[g], out_scale=s, add_scale=s, row_scale=rs,
-                       row_mask=masks[1] if masks else None, masked_rows_zero=last, col_mask=masks[0] if masks else None)
+                       row_mask=masks[1] if masks else None, masked_rows_zero=last, col_mask=masks[2] if masks else None)
         else:
             cur = spmm(csr_t, cur, adds=[g], out_scale=1.0, add_scale=s, row_scale=rs,
-                       col_mask=masks[1] if masks and l == 1 else None)
+                       col_mask=masks[3] if masks and l == 1 else None)
     return cur
 
 

@@ -113,7 +113,8 @@ int igcn_spmm_plan_fill_host(const int64_t *rowptr_host, int64_t n_rows,
  * bipartite matrix the segments of its long rows first, then its rows by descending length, so that heavy work
  * starts first and the rows a wave works on together carry equal work; it changes which wave computes what, not
  * the result;
- * col_mask uint8 [n_cols] or NULL: rows of X the caller knows to be all zero (col_mask[c] == 0) are not read —
+ * col_mask: NULL, or one BIT per column (uint32 words, bit c & 31 of word c >> 5; igcn_pack_mask_bits): rows of X the
+ * caller knows to be all zero (bit clear) are not read —
  * the first backward hops of a training step, whose operand is non-zero on the batch rows / their neighbourhood
  * only.  Edges whose weight comes out zero (masked here, or dropped out) issue no gather at all;
  * seed_dev: NULL, or the dropout seed in device memory (overrides `seed`): a launch captured in a HIP graph reads it
@@ -128,7 +129,7 @@ int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *va
                       float *partial, int32_t long_threshold,
                       const int32_t *edge_id, uint64_t seed, float keep_prob,
                       const uint8_t *row_mask, int32_t masked_rows_zero,
-                      int64_t nnz, const int32_t *row_order, const uint8_t *col_mask,
+                      int64_t nnz, const int32_t *row_order, const uint32_t *col_mask,
                       const uint64_t *seed_dev, void *stream);
 
 /* Row masks for igcn_spmm_csr_f32.  mask1[ids[i] + offsets...] = 1 for every listed row;
@@ -137,6 +138,11 @@ int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *va
  * caller; mask2 may be NULL. */
 int igcn_mark_rows(const int64_t *ids, int64_t n, const int64_t *rowptr, const int32_t *col,
                    uint8_t *mask1, uint8_t *mask2, int64_t n_rows, void *stream);
+
+/* n_masks uint8 masks of n entries each (mask m starts at masks + m * stride) -> one bit per entry, (n + 31) / 32
+ * uint32 words per mask (mask m at bits + m * words): the form igcn_spmm_csr_f32's col_mask takes — 8x smaller, so
+ * the lookups of a launch stay in the CU's L1 instead of going to L2. */
+int igcn_pack_mask_bits(const uint8_t *masks, int64_t n, int64_t stride, int32_t n_masks, uint32_t *bits, void *stream);
 
 /* Device-side index utilities for the graph-swap path (model.py:402-421 is_updating,
  * run/dropui/igcn_dropui.py:26-35): the reference rebuilds its sparse structures on the host

@@ -1,7 +1,6 @@
 """Developer micro-benchmark of the CSR SpMM kernel (not the driver's bench.py)."""
 import json
 import sys
-import time
 
 import numpy as np
 import torch

@@ -2,7 +2,6 @@
 import json
 import sys
 
-import numpy as np
 import torch
 
 sys.path.insert(0, '.')

@@ -1,5 +1,4 @@
 """Randomised sweeps of the two main kernels against the oracle (seeded; ~60 cases each)."""
-import os
 
 import numpy as np
 import pytest

@@ -225,7 +225,7 @@ def test_spmm_row_masks_and_pruned_propagation():
     K-layer pass equals the full one on the needed rows, and so does its backward pass."""
     from igcn_cf_amd.dataset import SyntheticDataset
     from igcn_cf_amd.graph import CsrMatrix, normalized_adjacency_host
-    from igcn_cf_amd.ops import PropagateFn, mark_rows, propagate_mean, spmm
+    from igcn_cf_amd.ops import PropagateFn, mark_rows, pack_mask_bits, propagate_mean, spmm
     ds = SyntheticDataset({'name': 'SyntheticDataset', 'n_users': 3000, 'n_items': 2000, 'n_inter': 120000, 'zipf_q': 0.})
     n = ds.n_users + ds.n_items
     rowptr, col, val = normalized_adjacency_host(ds.train_array, ds.n_users, ds.n_items)
@@ -235,7 +235,10 @@ def test_spmm_row_masks_and_pruned_propagation():
     x = torch.randn(n, 64, device='cuda', generator=g) * 0.1
     ids = torch.randint(0, n, (300,), device='cuda', generator=g)
     ids[0] = int(np.argmax(np.diff(rowptr)))                       # a long row is among the needed rows
-    m1, m2 = mark_rows(csr, ids)
+    m1, m2, b1, b2 = mark_rows(csr, ids)
+    assert torch.equal(b2, pack_mask_bits(m2)) and int(b1.view(torch.uint8).sum()) >= 0
+    unpacked = ((b2.view(-1, 1) >> torch.arange(32, device='cuda').view(1, -1)) & 1).flatten()[:n].to(torch.uint8)
+    assert torch.equal(unpacked, m2)
     deg = np.diff(rowptr)
     want2 = np.zeros(n, dtype=bool)
     for r in ids.cpu().tolist():
@@ -252,8 +255,8 @@ def test_spmm_row_masks_and_pruned_propagation():
     xz = x.clone(); xz[~m2.bool()] = 0.0
     want = spmm(csr, xz)
     xp = x.clone(); xp[~m2.bool()] = float('nan')
-    assert torch.equal(spmm(csr, xp, col_mask=m2), want)
-    assert torch.equal(spmm(csr, xp, col_mask=m2, row_mask=m1, masked_rows_zero=True)[keep], want[keep])
+    assert torch.equal(spmm(csr, xp, col_mask=b2), want)
+    assert torch.equal(spmm(csr, xp, col_mask=b2, row_mask=m1, masked_rows_zero=True)[keep], want[keep])
     for K in (1, 2, 3, 4):
         e_full = x.clone().requires_grad_(True)
         e_prun = x.clone().requires_grad_(True)
