@@ -56,6 +56,36 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kIdxNone = 0x7fffffff;
 
+// ---- candidate sweep on the bf16 matrix cores (MODE 1 of the kernel) --------------------------------------------
+// Every fp32 x is split x = h + l + r, h = bf16(x), l = bf16(x - h), |r| <= 2^-17 |x|.  The sweep forms
+// h_i h_u + h_i l_u + l_i h_u (three bf16 MFMAs per 16 k, fp32 accumulate: 12 instead of 32 fp32 MFMAs per
+// 32 x 32 x 64 tile, each ~38 instead of 64 cycles) — a score off by at most ~2^-16 |u| |i| — and keeps the k + 4
+// best candidates per user; topk_rescore_kernel then recomputes their scores exactly in fp32, orders them, and
+// checks that no item the sweep dropped can reach the k-th exact score (else the user is handed to the fp32 sweep).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kFastExtra = 4;                                    // candidates kept beyond k
+__device__ __forceinline__ unsigned int bf16_rne_bits(float v) {
+    const unsigned int u = __float_as_uint(v);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+// eight consecutive fp32 -> two bf16x8 planes (as float4 bit patterns: two bf16 per dword, low half first)
+__device__ __forceinline__ void split2_x8(const float4 &lo, const float4 &hi, float4 out[2]) {
+    const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    unsigned int w[2][4];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const unsigned int a0 = bf16_rne_bits(v[e]), b0 = bf16_rne_bits(v[e + 1]);
+        const unsigned int a1 = bf16_rne_bits(v[e] - __uint_as_float(a0 << 16));
+        const unsigned int b1 = bf16_rne_bits(v[e + 1] - __uint_as_float(b0 << 16));
+        w[0][e / 2] = a0 | (b0 << 16);
+        w[1][e / 2] = a1 | (b1 << 16);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+        out[p] = make_float4(__uint_as_float(w[p][0]), __uint_as_float(w[p][1]), __uint_as_float(w[p][2]), __uint_as_float(w[p][3]));
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(const float4 &v) { return __builtin_bit_cast(bf16x8, v); }
+
 struct TopkPlan {
     int d_pad;               // 16 / 32 / 64 / 128
     int ng;                  // 32-user groups per wave
@@ -226,12 +256,15 @@ struct TopkArgs {
     int k, cap, n_tiles, p_max, stagger;
     int64_t n_whole, rest_tiles, run;
     int64_t *out_idx; float *out_val; float *ws_val; int32_t *ws_idx;
+    const float4 *packed;     // MODE 1: item planes [tile][plane 0..1][k-step 0..3][lane] x 16 B (topk_pack_items_kernel)
 };
 
-// FULL: d == D, no k-slice of a row is padding.  NG: 32-user groups of a wave.
-template <int D, int NG, bool FULL>
+// FULL: d == D, no k-slice of a row is padding.  NG: 32-user groups of a wave.  MODE 0: fp32 MFMA, the exact fmaf
+// chain.  MODE 1 (D = 64, FULL): the candidate sweep on the bf16 matrix cores described above.
+template <int D, int NG, bool FULL, int MODE = 0>
 __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
 {
+    static_assert(MODE == 0 || (D == 64 && FULL && NG == 2), "the bf16 candidate sweep is built for d = 64");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *const heap_base = reinterpret_cast<unsigned long long *>(smem);       // [k][64 owner lanes]
     unsigned long long *const heap = heap_base + threadIdx.x;                                  // this lane's own heap
@@ -282,7 +315,8 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
 
         // B operands: user (g, j) of this lane.  Lane half h supplies k = 8q + 4h + c (q < D/8, c < 4): the two
         // lanes of a row read adjacent 16-B pieces, so one load instruction touches 32 lines, not 64.
-        float bfrag[NG][D / 2];
+        float bfrag[NG][MODE == 0 ? D / 2 : 1];
+        float4 ub[MODE == 1 ? NG : 1][2][4];                    // MODE 1: [group][plane][k-step], 8 bf16 each: k = 16 s + 8 h .. + 7
         int64_t uid[NG];
         bool user_ok[NG];
 #pragma unroll
@@ -290,12 +324,27 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
             const int64_t b = group * UPW + g * 32 + j;
             user_ok[g] = b < A.batch;
             uid[g] = user_ok[g] ? (A.user_ids ? A.user_ids[b] : b) : 0;
+            if constexpr (MODE == 0) {
 #pragma unroll
-            for (int q = 0; q < D / 8; ++q) {
-                float4 v = f4_zero();
-                const int e = 8 * q + 4 * h;
-                if (user_ok[g] && (FULL || e < A.d)) v = *reinterpret_cast<const float4 *>(A.user_rows + uid[g] * A.ldu + e);
-                bfrag[g][4 * q + 0] = v.x; bfrag[g][4 * q + 1] = v.y; bfrag[g][4 * q + 2] = v.z; bfrag[g][4 * q + 3] = v.w;
+                for (int q = 0; q < D / 8; ++q) {
+                    float4 v = f4_zero();
+                    const int e = 8 * q + 4 * h;
+                    if (user_ok[g] && (FULL || e < A.d)) v = *reinterpret_cast<const float4 *>(A.user_rows + uid[g] * A.ldu + e);
+                    bfrag[g][4 * q + 0] = v.x; bfrag[g][4 * q + 1] = v.y; bfrag[g][4 * q + 2] = v.z; bfrag[g][4 * q + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    float4 lo = f4_zero(), hi = f4_zero();
+                    if (user_ok[g]) {
+                        const float *src = A.user_rows + uid[g] * A.ldu + 16 * st + 8 * h;
+                        lo = *reinterpret_cast<const float4 *>(src);
+                        hi = *reinterpret_cast<const float4 *>(src + 4);
+                    }
+                    float4 planes[2];
+                    split2_x8(lo, hi, planes);
+                    ub[g][0][st] = planes[0]; ub[g][1][st] = planes[1];
+                }
             }
         }
 
@@ -405,12 +454,21 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
             off = t == n_tiles - 1 ? lane_off_last : lane_off;
         };
         auto load_into = [&](float4 (&buf)[D / 8], int t) {
-            const char *tile_ptr; unsigned off;
-            tile_addr(t, tile_ptr, off);
+            if constexpr (MODE == 1) {                             // [plane * 4 + k-step], one coalesced 1 KiB line set each
+                const float4 *pk = A.packed + (int64_t)t * 8 * kWave + lane;
 #pragma unroll
-            for (int q = 0; q < D / 8; ++q)
-                buf[q] = (FULL || 8 * q + 4 * h < A.d) ? *reinterpret_cast<const float4 *>(tile_ptr + off + 32 * q) : f4_zero();
+                for (int i = 0; i < 8; ++i) buf[i] = pk[i * kWave];
+            } else {
+                const char *tile_ptr; unsigned off;
+                tile_addr(t, tile_ptr, off);
+#pragma unroll
+                for (int q = 0; q < D / 8; ++q)
+                    buf[q] = (FULL || 8 * q + 4 * h < A.d) ? *reinterpret_cast<const float4 *>(tile_ptr + off + 32 * q) : f4_zero();
+            }
         };
+        // MODE 1: the three plane products of a k-step, smallest first: (item plane, user plane)
+        constexpr int kTermA[3] = {1, 0, 0};
+        constexpr int kTermB[3] = {0, 1, 0};
         auto load_a = [&](int t) { load_into(a, t); };
         // the chains of one tile, nothing interleaved (prologue of a piece)
         auto chain_plain = [&](f32x16 (&acc)[NG]) {
@@ -418,14 +476,25 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
             for (int g = 0; g < NG; ++g)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+            if constexpr (MODE == 1) {
 #pragma unroll
-            for (int q = 0; q < D / 8; ++q) {
+                for (int tm = 0; tm < 3; ++tm)
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bfrag[g][4 * q + 0], acc[g], 0, 0, 0);
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bfrag[g][4 * q + 1], acc[g], 0, 0, 0);
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bfrag[g][4 * q + 2], acc[g], 0, 0, 0);
-                    acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bfrag[g][4 * q + 3], acc[g], 0, 0, 0);
+                    for (int st = 0; st < 4; ++st)
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[kTermA[tm] * 4 + st]),
+                                                                             as_bf16x8(ub[g][kTermB[tm]][st]), acc[g], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int q = 0; q < D / 8; ++q) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].x, bfrag[g][4 * q + 0], acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].y, bfrag[g][4 * q + 1], acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].z, bfrag[g][4 * q + 2], acc[g], 0, 0, 0);
+                        acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q].w, bfrag[g][4 * q + 3], acc[g], 0, 0, 0);
+                    }
                 }
             }
         };
@@ -564,22 +633,55 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
         auto tile_step = [&](f32x16 (&cur)[NG], f32x16 (&nxt)[NG], float4 (&ause)[D / 8], float4 (&aload)[D / 8], int tile) {
             const int tile_base = tile * 32;
             build_masks(tile, tile_base);
-            constexpr int kSlots = (D / 2) * NG;                  // MFMAs of the block
+            constexpr int kSlots = MODE == 1 ? 12 * NG : (D / 2) * NG;   // MFMAs of the block
             constexpr int kParts = 3 * kQuad * NG;                // selection instructions of the block
             constexpr int kFirst = 4;                             // the first ones wait until the previous block's MFMAs have long retired
             if (tile + 1 < tin1) {
                 const char *tile_ptr = nullptr; unsigned off = 0;
-                tile_addr(tile + 2 < tin1 ? tile + 2 : tin1 - 1, tile_ptr, off);   // (re-reads the last tile at the end)
+                if constexpr (MODE == 0) tile_addr(tile + 2 < tin1 ? tile + 2 : tin1 - 1, tile_ptr, off);   // (re-reads the last tile at the end)
 #pragma unroll
                 for (int g = 0; g < NG; ++g)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) nxt[g][r] = 0.f;
-                if constexpr (kTwoBuffers) {
+                if constexpr (MODE == 1) {
+                    const float4 *pk = A.packed + (int64_t)(tile + 2 < tin1 ? tile + 2 : tin1 - 1) * 8 * kWave + lane;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) aload[i] = pk[i * kWave];
+                } else if constexpr (kTwoBuffers) {
 #pragma unroll
                     for (int q = 0; q < D / 8; ++q)
                         aload[q] = (FULL || 8 * q + 4 * h < A.d) ? *reinterpret_cast<const float4 *>(tile_ptr + off + 32 * q) : f4_zero();
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                auto select_share = [&](int slot) {             // this MFMA's share of tile t's selection instructions
+#ifndef IGCN_X_NOSELECT
+                    if (slot >= kFirst) {
+                        const int p0 = (slot - kFirst) * kParts / (kSlots - kFirst);
+                        const int p1 = (slot - kFirst + 1) * kParts / (kSlots - kFirst);
+#pragma unroll
+                        for (int p = 0; p < kParts; ++p)
+                            if (p >= p0 && p < p1) {
+                                const int pg = p % NG, pp = p / NG;
+                                select_part(cur[pg], pg, pp / 3, pp % 3);
+                            }
+                    }
+#endif
+                };
+                if constexpr (MODE == 1) {
+#pragma unroll
+                    for (int tm = 0; tm < 3; ++tm) {
+#pragma unroll
+                        for (int st = 0; st < 4; ++st) {
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) {
+                                nxt[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ause[kTermA[tm] * 4 + st]),
+                                                                                 as_bf16x8(ub[g][kTermB[tm]][st]), nxt[g], 0, 0, 0);
+                                select_share((tm * 4 + st) * NG + g);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int q = 0; q < D / 8; ++q) {
                     const float4 aq = ause[q];
@@ -589,19 +691,7 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
 #pragma unroll
                         for (int g = 0; g < NG; ++g) {
                             nxt[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bfrag[g][4 * q + c], nxt[g], 0, 0, 0);
-                            const int slot = (4 * q + c) * NG + g;
-#ifndef IGCN_X_NOSELECT
-                            if (slot >= kFirst) {
-                                const int p0 = (slot - kFirst) * kParts / (kSlots - kFirst);
-                                const int p1 = (slot - kFirst + 1) * kParts / (kSlots - kFirst);
-#pragma unroll
-                                for (int p = 0; p < kParts; ++p)
-                                    if (p >= p0 && p < p1) {
-                                        const int pg = p % NG, pp = p / NG;
-                                        select_part(cur[pg], pg, pp / 3, pp % 3);
-                                    }
-                            }
-#endif
+                            select_share((4 * q + c) * NG + g);
 #ifndef IGCN_X_NOLOADA
                             if (!kTwoBuffers && c == 3 && g == NG - 1)
                                 aload[q] = (FULL || 8 * q + 4 * h < A.d) ? *reinterpret_cast<const float4 *>(tile_ptr + off + 32 * q) : f4_zero();
@@ -609,6 +699,7 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
+                }
                 }
             } else {
                 // last tile of the piece: no chain to hide behind; the MFMA results must have landed (the compiler
@@ -801,10 +892,127 @@ __global__ void hit_matrix_kernel(const int64_t *__restrict__ rec, int64_t n_use
     hit[i] = (lo < end && eval_col[lo] == item) ? 1.f : 0.f;
 }
 
-template <int D, int NG, bool FULL>
+// Item table -> MFMA-ready bf16 planes for MODE 1: [tile][plane 0..1][k-step 0..3][lane 0..63] x 16 B, lane (j, kg)
+// holding k = 16 s + 8 kg .. + 7 of item 32 tile + j (rows past the end: zeros).  One thread per (tile, k-step, lane).
+__global__ __launch_bounds__(kBlock) void topk_pack_items_kernel(const float *__restrict__ item_rows, int64_t ldi, int64_t n_items,
+                                                                 int n_tiles, float4 *__restrict__ packed)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_tiles * 4 * kWave) return;
+    const int lane = (int)(i % kWave);
+    const int s = (int)(i / kWave % 4);
+    const int64_t tile = i / (4 * kWave);
+    const int64_t item = tile * 32 + (lane & 31);
+    float4 lo = f4_zero(), hi = f4_zero();
+    if (item < n_items) {
+        const float *src = item_rows + item * ldi + 16 * s + 8 * (lane >> 5);
+        lo = *reinterpret_cast<const float4 *>(src);
+        hi = *reinterpret_cast<const float4 *>(src + 4);
+    }
+    float4 planes[2];
+    split2_x8(lo, hi, planes);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) packed[((tile * 2 + p) * 4 + s) * kWave + lane] = planes[p];
+}
+
+// max over the items of |row|^2 (d = 64: a 16-lane group per item), as the bit pattern of a non-negative float;
+// a fixed small grid walks the table, one atomic per wave at the end
+__global__ __launch_bounds__(kBlock) void topk_item_norm_max_kernel(const float *__restrict__ item_rows, int64_t ldi, int64_t n_items,
+                                                                    unsigned int *__restrict__ max_bits)
+{
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float best = 0.f;
+    for (int64_t t = t0; (t >> 4) < n_items + 3; t += stride) {           // (+3: the four groups of a wave stay together)
+        const int64_t item = t >> 4;
+        float n2 = 0.f;
+        if (item < n_items) {
+            const float4 v = *reinterpret_cast<const float4 *>(item_rows + item * ldi + 4 * (t & 15));
+            n2 = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) n2 += __shfl_xor(n2, o);
+        best = fmaxf(best, n2);
+    }
+#pragma unroll
+    for (int o = 16; o < kWave; o <<= 1) best = fmaxf(best, __shfl_xor(best, o));
+    if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(max_bits, __float_as_uint(best));
+}
+
+// Second stage of the bf16 path, one wave per user, lane c = candidate c of the sweep (kc = k + kFastExtra <= 64 of
+// them, best approximate score first).  The candidate's score is recomputed in fp32 in the order the fp32 sweep adds
+// the products (k = 8q + c, 8q + 4 + c), the candidates are ranked by (exact score, lower id first) and the best k
+// written out.  Then the check that makes the result that of the fp32 sweep: an item the sweep dropped has an
+// approximate score <= a_min (the smallest kept) and an exact one <= a_min + eps, eps = 2^-15 |u| max|i| bounding
+// what the two-plane split and the fp32 accumulation can be off by; if a_min + eps does not stay below the k-th
+// exact score, a dropped item could belong to the list (or tie with its tail) and the user is flagged:
+// flagged[1 + n] = position of the user in the batch, flagged[0] = n.
+__global__ __launch_bounds__(kBlock) void topk_rescore_kernel(const float *__restrict__ user_rows, int64_t ldu,
+                                                              const int64_t *__restrict__ user_ids, int64_t batch,
+                                                              const float *__restrict__ item_rows, int64_t ldi,
+                                                              const int64_t *__restrict__ cand_idx, const float *__restrict__ cand_val,
+                                                              int kc, int k, const unsigned int *__restrict__ max_norm2_bits,
+                                                              int64_t *__restrict__ out_idx, float *__restrict__ out_val,
+                                                              int32_t *__restrict__ flagged)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t b = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (b >= batch) return;
+    const int64_t uid = user_ids ? user_ids[b] : b;
+    const float *u = user_rows + uid * ldu;
+    const bool live = lane < kc;
+    const int64_t item = live ? cand_idx[b * kc + lane] : -1;
+    const float approx = live ? cand_val[b * kc + lane] : -INFINITY;
+    const bool real = item >= 0 && approx > -INFINITY;            // -inf: a masked item filling a short list, or an empty slot
+    float exact = -INFINITY, un2 = 0.f;
+    {
+        const float *it = item_rows + (real ? item : 0) * ldi;
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 ua = *reinterpret_cast<const float4 *>(u + 8 * q), ub = *reinterpret_cast<const float4 *>(u + 8 * q + 4);
+            const float4 ia = *reinterpret_cast<const float4 *>(it + 8 * q), ib = *reinterpret_cast<const float4 *>(it + 8 * q + 4);
+            acc = fmaf(ia.x, ua.x, acc); acc = fmaf(ib.x, ub.x, acc);
+            acc = fmaf(ia.y, ua.y, acc); acc = fmaf(ib.y, ub.y, acc);
+            acc = fmaf(ia.z, ua.z, acc); acc = fmaf(ib.z, ub.z, acc);
+            acc = fmaf(ia.w, ua.w, acc); acc = fmaf(ib.w, ub.w, acc);
+            un2 += ua.x * ua.x + ua.y * ua.y + ua.z * ua.z + ua.w * ua.w + ub.x * ub.x + ub.y * ub.y + ub.z * ub.z + ub.w * ub.w;
+        }
+        if (real) exact = acc;
+    }
+    const int id32 = item >= 0 ? (int)item : kIdxNone;
+    int rank = 0;
+    for (int c = 0; c < kc; ++c) {
+        const float ov = __shfl(exact, c);
+        const int oi = __shfl(id32, c);
+        rank += (ranks_before(ov, oi, exact, id32) || (ov == exact && oi == id32 && c < lane)) ? 1 : 0;
+    }
+    if (live && rank < k) {
+        out_idx[b * k + rank] = item >= 0 ? item : -1;
+        out_val[b * k + rank] = exact;
+    }
+    // the k-th exact score, the smallest kept approximate score, how many candidates are real
+    float e_k = live && rank == k - 1 ? exact : -INFINITY;
+    float a_min = real ? approx : INFINITY;
+    int n_real = real ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        e_k = fmaxf(e_k, __shfl_xor(e_k, o));
+        a_min = fminf(a_min, __shfl_xor(a_min, o));
+        n_real += __shfl_xor(n_real, o);
+    }
+    if (lane == 0) {
+        const float eps = 0x1p-15f * sqrtf(un2 * __uint_as_float(*max_norm2_bits));
+        // fewer real candidates than slots: the sweep dropped nothing real.  eps == 0 (an all-zero user): scores are exact.
+        const bool ok = n_real < kc || eps == 0.f || a_min + eps < e_k;
+        if (!ok) flagged[1 + atomicAdd(flagged, 1)] = (int32_t)b;
+    }
+}
+
+template <int D, int NG, bool FULL, int MODE = 0>
 static int launch_topk(const TopkPlan &p, hipStream_t st, const TopkArgs &args)
 {
-    auto kern = score_topk_kernel<D, NG, FULL>;
+    auto kern = score_topk_kernel<D, NG, FULL, MODE>;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -839,10 +1047,11 @@ extern "C" int64_t igcn_score_topk_workspace_bytes(int64_t batch, int64_t n_item
     return topk_merge_bytes(p, batch, k) + (int64_t)p.n_tiles * 4;       // + the banned items as one word per tile
 }
 
-extern "C" int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
-                                   const float *item_rows, int64_t ldi, int64_t n_items, int32_t d,
-                                   const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned,
-                                   int32_t k, int64_t *out_idx, float *out_val, void *workspace, void *stream)
+// One sweep: MODE 0 the exact fp32 one, MODE 1 the bf16 candidate sweep (d = 64, `packed` = the item planes).
+static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
+                    const float *item_rows, int64_t ldi, int64_t n_items, int32_t d,
+                    const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned,
+                    int32_t k, int64_t *out_idx, float *out_val, void *workspace, const float4 *packed, hipStream_t st)
 {
     if (!user_rows || !item_rows || !out_idx || !out_val) return IGCN_E_NULL;
     if ((excl_rowptr == nullptr) != (excl_col == nullptr)) return IGCN_E_NULL;
@@ -854,7 +1063,6 @@ extern "C" int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const in
     const int64_t rest_users = topk_rest_users(p, batch);
     if ((rest_users > 0 || banned) && !workspace) return IGCN_E_NULL;
     if (workspace && reinterpret_cast<uintptr_t>(workspace) % 8) return IGCN_E_ALIGN;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     float *ws_val = static_cast<float *>(workspace);
     int32_t *ws_idx = reinterpret_cast<int32_t *>(ws_val ? ws_val + rest_users * p.p_max * k : nullptr);
     uint32_t *banned_bits = nullptr;
@@ -875,12 +1083,18 @@ extern "C" int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const in
     a.stagger = stagger < 0 ? 3 : stagger;                        // bit 0: base priority by wave slot, bit 1: boost in the slow path
     a.n_whole = p.n_whole; a.rest_tiles = p.rest_tiles; a.run = p.run;
     a.out_idx = out_idx; a.out_val = out_val; a.ws_val = ws_val; a.ws_idx = ws_idx;
+    a.packed = packed;
 
-    switch (p.d_pad) {
-    case 16: rc = d == 16 ? launch_topk<16, 2, true>(p, st, a) : launch_topk<16, 2, false>(p, st, a); break;
-    case 32: rc = d == 32 ? launch_topk<32, 2, true>(p, st, a) : launch_topk<32, 2, false>(p, st, a); break;
-    case 64: rc = d == 64 ? launch_topk<64, 2, true>(p, st, a) : launch_topk<64, 2, false>(p, st, a); break;
-    default: rc = d == 128 ? launch_topk<128, 1, true>(p, st, a) : launch_topk<128, 1, false>(p, st, a); break;
+    if (mode == 1) {
+        if (d != 64 || !packed) return IGCN_E_SHAPE;
+        rc = launch_topk<64, 2, true, 1>(p, st, a);
+    } else {
+        switch (p.d_pad) {
+        case 16: rc = d == 16 ? launch_topk<16, 2, true>(p, st, a) : launch_topk<16, 2, false>(p, st, a); break;
+        case 32: rc = d == 32 ? launch_topk<32, 2, true>(p, st, a) : launch_topk<32, 2, false>(p, st, a); break;
+        case 64: rc = d == 64 ? launch_topk<64, 2, true>(p, st, a) : launch_topk<64, 2, false>(p, st, a); break;
+        default: rc = d == 128 ? launch_topk<128, 1, true>(p, st, a) : launch_topk<128, 1, false>(p, st, a); break;
+        }
     }
     if (rc != IGCN_OK) return rc;
     if (rest_users > 0) {
@@ -897,6 +1111,81 @@ extern "C" int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const in
         rc = launch_status();
     }
     return rc;
+}
+
+extern "C" int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
+                                   const float *item_rows, int64_t ldi, int64_t n_items, int32_t d,
+                                   const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned,
+                                   int32_t k, int64_t *out_idx, float *out_val, void *workspace, void *stream)
+{
+    return topk_run(0, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, d, excl_rowptr, excl_col, banned, k,
+                    out_idx, out_val, workspace, nullptr, static_cast<hipStream_t>(stream));
+}
+
+// ---- the two-stage evaluation: bf16 candidate sweep + exact fp32 re-scoring (d = 64, k <= 60) --------------------
+// workspace: [sweep workspace for k + 4][item planes][candidate ids][candidate scores][max |item|^2], each 256-aligned
+static inline int64_t align256(int64_t n) { return (n + 255) / 256 * 256; }
+struct FastLayout { int64_t sweep, packed, cand_idx, cand_val, norm, total; int kc; };
+static int topk_fast_layout(int64_t batch, int64_t n_items, int32_t d, int32_t k, FastLayout *L) {
+    if (d != 64 || k < 1 || k + kFastExtra > kWave) return IGCN_E_RANGE;
+    L->kc = k + kFastExtra;
+    TopkPlan p;
+    const int64_t kc = n_items < L->kc ? n_items : L->kc;        // never more candidates than items
+    L->kc = (int)kc;
+    int rc = topk_make_plan(batch, n_items, d, L->kc, &p);
+    if (rc != IGCN_OK) return rc;
+    L->sweep = 0;
+    L->packed = align256(topk_merge_bytes(p, batch, L->kc) + (int64_t)p.n_tiles * 4);
+    L->cand_idx = L->packed + (int64_t)p.n_tiles * 8 * kWave * 16;
+    L->cand_val = L->cand_idx + align256(batch * L->kc * 8);
+    L->norm = L->cand_val + align256(batch * L->kc * 4);
+    L->total = L->norm + 256;
+    return IGCN_OK;
+}
+
+extern "C" int64_t igcn_score_topk_fast_workspace_bytes(int64_t batch, int64_t n_items, int32_t d, int32_t k)
+{
+    FastLayout L;
+    return topk_fast_layout(batch, n_items, d, k, &L) == IGCN_OK ? L.total : -1;
+}
+
+extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
+                                        const float *item_rows, int64_t ldi, int64_t n_items, int32_t d,
+                                        const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned,
+                                        int32_t k, int64_t *out_idx, float *out_val, int32_t *flagged,
+                                        void *workspace, void *stream)
+{
+    if (!workspace || !flagged) return IGCN_E_NULL;
+    if (reinterpret_cast<uintptr_t>(workspace) % 256) return IGCN_E_ALIGN;
+    if (k > n_items) return IGCN_E_RANGE;
+    FastLayout L;
+    int rc = topk_fast_layout(batch, n_items, d, k, &L);
+    if (rc != IGCN_OK) return rc;
+    if (!item_rows || ldi < d || ldi % 4 || reinterpret_cast<uintptr_t>(item_rows) % 16) return IGCN_E_SHAPE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(workspace);
+    float4 *packed = reinterpret_cast<float4 *>(ws + L.packed);
+    int64_t *cand_idx = reinterpret_cast<int64_t *>(ws + L.cand_idx);
+    float *cand_val = reinterpret_cast<float *>(ws + L.cand_val);
+    unsigned int *norm_bits = reinterpret_cast<unsigned int *>(ws + L.norm);
+    hipError_t e = hipMemsetAsync(norm_bits, 0, 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(flagged, 0, 4, st);
+    if (e != hipSuccess) return (int)e;
+    const int n_tiles = (int)((n_items + 31) / 32);
+    const int64_t pack_threads = (int64_t)n_tiles * 4 * kWave;
+    hipLaunchKernelGGL(topk_pack_items_kernel, dim3((unsigned)((pack_threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                       item_rows, ldi, n_items, n_tiles, packed);
+    int64_t norm_blocks = (n_items * 16 + kBlock - 1) / kBlock;
+    if (norm_blocks > 2 * (int64_t)cu_count()) norm_blocks = 2 * (int64_t)cu_count();
+    hipLaunchKernelGGL(topk_item_norm_max_kernel, dim3((unsigned)norm_blocks), dim3(kBlock), 0, st, item_rows, ldi, n_items, norm_bits);
+    rc = launch_status();
+    if (rc != IGCN_OK) return rc;
+    rc = topk_run(1, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, d, excl_rowptr, excl_col, banned, L.kc,
+                  cand_idx, cand_val, ws + L.sweep, packed, st);
+    if (rc != IGCN_OK) return rc;
+    hipLaunchKernelGGL(topk_rescore_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(kBlock), 0, st, user_rows, ldu, user_ids, batch,
+                       item_rows, ldi, cand_idx, cand_val, L.kc, (int)k, norm_bits, out_idx, out_val, flagged);
+    return launch_status();
 }
 
 #ifdef IGCN_TOPK_STATS

@@ -229,6 +229,22 @@ int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const int64_t *user
                         int32_t k, int64_t *out_idx, float *out_val,
                         void *workspace, void *stream);
 
+/* The same evaluation in two stages (d = 64, k <= 60).  Stage 1 sweeps all items on the bf16 matrix cores — every
+ * fp32 value split into two bf16 planes, three plane products per 16 k, fp32 accumulate: scores off by less than
+ * 2^-15 |u| max|i| — and keeps the k + 4 best candidates of every user (masks applied as in igcn_score_topk_f32).
+ * Stage 2 re-computes the candidates' scores in fp32 in the order the fp32 sweep adds the products, orders them
+ * (score, then lower id) and writes the best k: out_idx / out_val as igcn_score_topk_f32 writes them.  A user for
+ * whom an item dropped by stage 1 could still reach the k-th exact score (its bound does not stay below it: near-ties
+ * at the k-th place) is reported instead of trusted: flagged[0] = how many, flagged[1..] = their positions in the
+ * batch (int32 [batch + 1]); the caller runs igcn_score_topk_f32 for those.  No host synchronisation inside.
+ * workspace: igcn_score_topk_fast_workspace_bytes(...) bytes, 256-byte aligned. */
+int64_t igcn_score_topk_fast_workspace_bytes(int64_t batch, int64_t n_items, int32_t d, int32_t k);
+int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
+                             const float *item_rows, int64_t ldi, int64_t n_items, int32_t d,
+                             const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned,
+                             int32_t k, int64_t *out_idx, float *out_val, int32_t *flagged,
+                             void *workspace, void *stream);
+
 /* hit[u, j] = 1 if rec[u, j] is in eval_col[eval_rowptr[u]..eval_rowptr[u+1])
  * (sorted ascending), else 0: the membership loop of trainer.py:111-115.
  * eval_col may be NULL when every list is empty (eval_rowptr all equal): no hit anywhere. */

@@ -56,7 +56,7 @@ def test_score_topk_fuzz():
     for case in range(60):
         n_users = int(rng.integers(1, 400))
         n_items = int(rng.integers(1, 3000))
-        d = int(rng.choice([4, 8, 16, 20, 32, 64, 100, 128]))
+        d = int(rng.choice([4, 8, 16, 20, 32, 64, 64, 64, 100, 128]))
         k = int(rng.integers(1, min(n_items, 64) + 1))
         if case % 3 == 1:
             # few wave slots: every wave sweeps whole groups AND a run of the leftover groups' tiles (+ merge)
@@ -79,7 +79,10 @@ def test_score_topk_fuzz():
             bm = np.zeros(n_items, dtype=np.uint8); bm[ban] = 1
             kw['banned'] = torch.from_numpy(bm).cuda()
         ids = rng.permutation(n_users).astype(np.int64)
-        idx, val = score_topk(torch.from_numpy(U).cuda(), torch.from_numpy(I).cuda(), k, user_ids=torch.from_numpy(ids).cuda(), **kw)
+        # d = 64, k <= 60: every other such case through the two-stage path (bf16 candidate sweep + exact re-scoring)
+        mode = 'fast' if d == 64 and k <= 60 and case % 2 == 0 else 'exact'
+        idx, val = score_topk(torch.from_numpy(U).cuda(), torch.from_numpy(I).cuda(), k, user_ids=torch.from_numpy(ids).cuda(),
+                              mode=mode, **kw)
         s = scores[ids].copy()
         if ex is not None:
             for b, u in enumerate(ids):

@@ -52,7 +52,8 @@ def _check_topk(scores, idx, val, ex_lists, banned, k):
                                                   (32, 33, 9000, 5), (64, 1000, 20000, 50), (16, 5, 64, 64),
                                                   (50, 100, 3000, 20), (6, 40, 200, 7),
                                                   (64, 130, 2000, 100), (32, 70, 1500, 200), (128, 40, 900, 64),
-                                                  (64, 65, 700, 25), (16, 129, 333, 256)])
+                                                  (64, 65, 700, 25), (16, 129, 333, 256), (64, 2500, 9000, 60),
+                                                  (64, 200, 40, 20)])
 def test_score_topk_matches_dense_oracle(d, n_users, n_items, k):
     from igcn_cf_amd.ops import score_topk
     rng = np.random.default_rng(d + n_items)
@@ -77,18 +78,34 @@ def test_score_topk_matches_dense_oracle(d, n_users, n_items, k):
     sub = rng.permutation(n_users)[: max(1, n_users // 2)].astype(np.int64)
     idx, val = score_topk(_dev(U), _dev(I), k, user_ids=_dev(sub))
     _check_topk(scores[sub], idx.cpu().numpy(), val.cpu().numpy(), None, None, k)
+    if d == 64 and k <= 60:
+        # the two-stage path (bf16 candidate sweep + exact fp32 re-scoring): the same lists; integer scores tie in
+        # droves, so many users here take its fall-back through the fp32 sweep
+        idx, val = score_topk(_dev(U), _dev(I), k, user_ids=_dev(users), excl_rowptr=_dev(rowptr), excl_col=_dev(col),
+                              banned=_dev(bmask), mode='fast')
+        _check_topk(scores, idx.cpu().numpy(), val.cpu().numpy(), ex, banned, k)
+        idx, val = score_topk(_dev(U), _dev(I), k, user_ids=_dev(sub), mode='fast')
+        _check_topk(scores[sub], idx.cpu().numpy(), val.cpu().numpy(), None, None, k)
 
 
-def test_score_topk_random_floats_match_sets():
+@pytest.mark.parametrize('mode', ['exact', 'fast'])
+def test_score_topk_random_floats_match_sets(mode):
     """Gaussian fp32 embeddings: same top-k sets as the float64 ranking except where the
-    k-th and (k+1)-th scores are within fp32 rounding of each other."""
+    k-th and (k+1)-th scores are within fp32 rounding of each other — for the fp32 sweep and for the two-stage
+    path, whose lists must moreover be those of the fp32 sweep bit for bit."""
     from igcn_cf_amd.ops import score_topk
     rng = np.random.default_rng(1)
     n_users, n_items, d, k = 512, 30000, 64, 20
     U = (rng.standard_normal((n_users, d)) * 0.1).astype(np.float32)
     I = (rng.standard_normal((n_items, d)) * 0.1).astype(np.float32)
-    idx, val = score_topk(_dev(U), _dev(I), k)
+    I[100] = I[7]; I[20000] = I[7]                       # identical item rows: exact ties, decided by the lower id
+    U[5] = 0.0                                           # an all-zero user: every score ties at 0
+    idx, val = score_topk(_dev(U), _dev(I), k, mode=mode)
+    if mode == 'fast':
+        idx_e, val_e = score_topk(_dev(U), _dev(I), k, mode='exact')
+        assert torch.equal(idx, idx_e) and torch.equal(val, val_e)
     idx, val = idx.cpu().numpy(), val.cpu().numpy()
+    assert list(idx[5]) == list(range(k))
     s64 = U.astype(np.float64) @ I.astype(np.float64).T
     ref = np.argsort(-s64, axis=1, kind='stable')[:, :k + 1]
     np.testing.assert_allclose(val, np.take_along_axis(s64, idx, axis=1), rtol=1e-5, atol=1e-6)
