@@ -12,7 +12,8 @@ sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, 'igcn_cf_amd', '_variants')
 VARIANTS = {'base': [], 'nohits': ['-DIGCN_X_NOHITS'], 'noselect': ['-DIGCN_X_NOSELECT', '-DIGCN_X_NOHITS'],
             'noloada': ['-DIGCN_X_NOLOADA'], 'bare': ['-DIGCN_X_NOSELECT', '-DIGCN_X_NOHITS', '-DIGCN_X_NOLOADA'],
-            'stats': ['-DIGCN_TOPK_STATS'], 'todoonly': ['-DIGCN_X_TODOONLY'], 'noflush': ['-DIGCN_X_NOFLUSH']}
+            'stats': ['-DIGCN_TOPK_STATS'], 'sametile': ['-DIGCN_X_SAMETILE'],
+            'bare_sametile': ['-DIGCN_X_NOSELECT', '-DIGCN_X_NOHITS', '-DIGCN_X_SAMETILE'], 'todoonly': ['-DIGCN_X_TODOONLY'], 'noflush': ['-DIGCN_X_NOFLUSH']}
 
 
 def build(only=None):
@@ -81,7 +82,10 @@ def run():
             for k in (1, 20):
                 for masks in (False, True):
                     kw = dict(excl_rowptr=rp, excl_col=cl) if masks else {}
-                    rec['k%d_masks%d_ms' % (k, masks)] = round(time_ms(lambda: score_topk(U, I, k, user_ids=users, **kw), reps=3, warm=1), 2)
+                    mode = os.environ.get('TOPK_MODE', 'exact')      # 'fast': the two-stage path (ablated builds: garbage lists, timing only)
+                    rec['k%d_masks%d_ms' % (k, masks)] = round(time_ms(lambda: score_topk(U, I, k, user_ids=users, mode=mode, **kw), reps=3, warm=1), 2)
+                    if mode == 'fast':
+                        rec['k%d_masks%d_flagged' % (k, masks)] = score_topk.last_flagged
             for key in tune:
                 _lib.set_tuning(key, None)
             print(json.dumps(rec), flush=True)
