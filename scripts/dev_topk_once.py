@@ -1,4 +1,5 @@
-"""Developer: a few full Amazon-like evaluations (k=20, train+val exclusion), for rocprofv3 passes."""
+"""Developer: a few full Amazon-like evaluations (k=20, train+val exclusion), for rocprofv3 passes.
+TOPK_MODE=exact (default: the fp32 sweep) | fast (the two-stage path)."""
 import os
 import sys
 import torch
@@ -15,5 +16,5 @@ excl = _merge_sorted_csr(ds.csr('train'), ds.csr('val'))
 rp, cl = _csr_to_device(excl[0], excl[1], 'cuda')
 users = torch.arange(ds.n_users, device='cuda')
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
-    score_topk(U, I, 20, user_ids=users, excl_rowptr=rp, excl_col=cl)
+    score_topk(U, I, 20, user_ids=users, excl_rowptr=rp, excl_col=cl, mode=os.environ.get('TOPK_MODE', 'exact'))
 torch.cuda.synchronize()
