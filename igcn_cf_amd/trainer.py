@@ -505,7 +505,7 @@ class BPRTrainer(BasicTrainer):
         """One optimisation step on the node ids of a batch (DeviceSampler.epoch_node_batches).  Full-size batches
         replay ONE captured HIP graph (forward, backward and the fused Adam step: 22 launches become one) unless the
         trainer config says 'hip_graph': False — what a launch-bound step needs (Gowalla-size LightGCN, IMF: -20...-25 %);
-        a GPU-bound step pays ~1 % for the copies into the static buffers (profiles/r02j_*)."""
+        a GPU-bound step pays ~1 % for the copies into the static buffers (profiles/r02n_*)."""
         loss_fn = lambda n: self.model.bpr_loss_nodes(n, self.l2_reg)
         if self._graph_wanted() and nodes.numel() == 3 * self.batch_size:
             loss = self._graph_step((nodes,), loss_fn)
