@@ -37,6 +37,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -213,6 +214,7 @@ def main():
         extras = sharded_side_measurements(ds, device, d, K, rank, world, rowptr, col, val, emb_host, barrier_sync, job_max)
     if not sharded and not args.no_extras:
         extras = side_measurements(ds, device, d, K)
+        extras['propagation_uniform_random_graph'] = uniform_graph_pass(device, args.preset, d, K)
     if not sharded and not args.no_hbm_leg:
         del csr, x0
         torch.cuda.empty_cache()
@@ -283,6 +285,22 @@ def sharded_side_measurements(ds, device, d, K, rank, world, rowptr, col, val, e
                                 'note': 'sharded propagation, one all-gather of the item rows, then every rank scores the users it '
                                         'owns against all items (fused score / mask / top-20, train+val lists masked)'}
     return res
+
+
+def uniform_graph_pass(device, preset, d, K):
+    """The same pass on a graph of the same size whose items are drawn uniformly (zipf_a = 0): no hot item rows for L2
+    to keep, no long rows — the worst-case locality variant SURVEY 8(d) asks for next to the popularity-skewed headline."""
+    from igcn_cf_amd.dataset import SyntheticDataset
+    from igcn_cf_amd.graph import CsrMatrix, normalized_adjacency_host
+    from igcn_cf_amd import ops
+    ds = SyntheticDataset({'name': 'SyntheticDataset', 'preset': preset, 'seed': 2021, 'device': device, 'zipf_a': 0.0})
+    n = ds.n_users + ds.n_items
+    rowptr, col, val = normalized_adjacency_host(ds.train_array, ds.n_users, ds.n_items)
+    csr = CsrMatrix(rowptr, col, val, (n, n), device, order_blocks=[0, ds.n_users, n])
+    x = torch.randn(n, d, device=device) * 0.1
+    ms = time_ms(lambda: ops.propagate_mean(csr, x, K), 50, 5)
+    nnz = int(rowptr[-1])
+    return {'ms_per_pass': ms, 'edges_per_s': K * nnz / (ms / 1e3), 'nnz': nnz, 'max_row_nnz': int(np.diff(rowptr).max())}
 
 
 def time_ms(fn, reps, warm):
