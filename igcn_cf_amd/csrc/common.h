@@ -36,6 +36,7 @@ enum {
     IGCN_TUNE_TOPK_WAVES_PER_CU,        // 8, 4, 2 or 1
     IGCN_TUNE_TOPK_CAP,                 // staging slots per lane and group
     IGCN_TUNE_TOPK_STAGGER,             // 0: no static wave priorities
+    IGCN_TUNE_TOPK_FAST_MODE,           // candidate sweep of the two-stage path: 2 = one fp16 item plane (default), 1 = two bf16 planes
     IGCN_TUNE_COUNT
 };
 extern int g_tuning[IGCN_TUNE_COUNT];   // defined in spmm.hip

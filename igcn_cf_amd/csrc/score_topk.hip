@@ -86,6 +86,32 @@ __device__ __forceinline__ void split2_x8(const float4 &lo, const float4 &hi, fl
 }
 __device__ __forceinline__ bf16x8 as_bf16x8(const float4 &v) { return __builtin_bit_cast(bf16x8, v); }
 
+// ---- MODE 2: the candidate sweep in fp16.  Items as ONE fp16 plane (11 significant bits: half the bytes of the two
+// bf16 planes — the sweep is bound by the L1 throughput of its item-tile loads), users as two (h = fp16(x),
+// l = fp16(x - h)): h_i (h_u + l_u), 8 MFMAs per 32 x 32 x 64 tile, a score off by at most 2^-11 |u| |i|.  Both tables
+// are scaled by a power of two that brings their largest element into [0.5, 1) (fp16 has 5 exponent bits); elements
+// below 2^-14 of the largest lose relative, not absolute, accuracy (<= 2^-25 of the largest each).
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ half8 as_half8(const float4 &v) { return __builtin_bit_cast(half8, v); }
+__device__ __forceinline__ unsigned int f16_bits(_Float16 h) { return (unsigned int)__builtin_bit_cast(unsigned short, h); }
+// power of two s with s * m in [0.5, 1) (m > 0), as its exponent: s = 2^-e
+__device__ __forceinline__ int scale_exp(float m) { int e = 0; if (m > 0.f) (void)frexpf(m, &e); return e; }
+// eight consecutive fp32, scaled by s -> one or two fp16x8 planes (float4 bit patterns, low half first)
+__device__ __forceinline__ void split_f16_x8(const float4 &lo, const float4 &hi, float s, float4 out[2]) {
+    const float v[8] = {lo.x * s, lo.y * s, lo.z * s, lo.w * s, hi.x * s, hi.y * s, hi.z * s, hi.w * s};
+    unsigned int w[2][4];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const _Float16 a0 = (_Float16)v[e], b0 = (_Float16)v[e + 1];
+        const _Float16 a1 = (_Float16)(v[e] - (float)a0), b1 = (_Float16)(v[e + 1] - (float)b0);
+        w[0][e / 2] = f16_bits(a0) | (f16_bits(b0) << 16);
+        w[1][e / 2] = f16_bits(a1) | (f16_bits(b1) << 16);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+        out[p] = make_float4(__uint_as_float(w[p][0]), __uint_as_float(w[p][1]), __uint_as_float(w[p][2]), __uint_as_float(w[p][3]));
+}
+
 struct TopkPlan {
     int d_pad;               // 16 / 32 / 64 / 128
     int ng;                  // 32-user groups per wave
@@ -256,7 +282,8 @@ struct TopkArgs {
     int k, cap, n_tiles, p_max, stagger;
     int64_t n_whole, rest_tiles, run;
     int64_t *out_idx; float *out_val; float *ws_val; int32_t *ws_idx;
-    const float4 *packed;     // MODE 1: item planes [tile][plane 0..1][k-step 0..3][lane] x 16 B (topk_pack_items_kernel)
+    const float4 *packed;     // MODE 1: item planes [tile][plane 0..1][k-step 0..3][lane] x 16 B; MODE 2: [tile][k-step][lane] x 16 B
+    const unsigned int *stats; // MODE 2: bit patterns of max |item row|^2, max |item element|, max |user element|
 };
 
 // FULL: d == D, no k-slice of a row is padding.  NG: 32-user groups of a wave.  MODE 0: fp32 MFMA, the exact fmaf
@@ -264,7 +291,7 @@ struct TopkArgs {
 template <int D, int NG, bool FULL, int MODE = 0>
 __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
 {
-    static_assert(MODE == 0 || (D == 64 && FULL && NG == 2), "the bf16 candidate sweep is built for d = 64");
+    static_assert(MODE == 0 || (D == 64 && FULL && NG == 2), "the candidate sweeps are built for d = 64");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *const heap_base = reinterpret_cast<unsigned long long *>(smem);       // [k][64 owner lanes]
     unsigned long long *const heap = heap_base + threadIdx.x;                                  // this lane's own heap
@@ -316,7 +343,7 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
         // B operands: user (g, j) of this lane.  Lane half h supplies k = 8q + 4h + c (q < D/8, c < 4): the two
         // lanes of a row read adjacent 16-B pieces, so one load instruction touches 32 lines, not 64.
         float bfrag[NG][MODE == 0 ? D / 2 : 1];
-        float4 ub[MODE == 1 ? NG : 1][2][4];                    // MODE 1: [group][plane][k-step], 8 bf16 each: k = 16 s + 8 h .. + 7
+        float4 ub[MODE != 0 ? NG : 1][2][4];                    // MODE 1: [group][plane][k-step], 8 bf16 each: k = 16 s + 8 h .. + 7
         int64_t uid[NG];
         bool user_ok[NG];
 #pragma unroll
@@ -333,6 +360,7 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
                     bfrag[g][4 * q + 0] = v.x; bfrag[g][4 * q + 1] = v.y; bfrag[g][4 * q + 2] = v.z; bfrag[g][4 * q + 3] = v.w;
                 }
             } else {
+                const float su = MODE == 2 ? ldexpf(1.f, -scale_exp(__uint_as_float(A.stats[2]))) : 1.f;
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
                     float4 lo = f4_zero(), hi = f4_zero();
@@ -342,7 +370,7 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
                         hi = *reinterpret_cast<const float4 *>(src + 4);
                     }
                     float4 planes[2];
-                    split2_x8(lo, hi, planes);
+                    if constexpr (MODE == 2) split_f16_x8(lo, hi, su, planes); else split2_x8(lo, hi, planes);
                     ub[g][0][st] = planes[0]; ub[g][1][st] = planes[1];
                 }
             }
@@ -458,6 +486,10 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
                 const float4 *pk = A.packed + (int64_t)t * 8 * kWave + lane;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) buf[i] = pk[i * kWave];
+            } else if constexpr (MODE == 2) {                      // [k-step]
+                const float4 *pk = A.packed + (int64_t)t * 4 * kWave + lane;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) buf[i] = pk[i * kWave];
             } else {
                 const char *tile_ptr; unsigned off;
                 tile_addr(t, tile_ptr, off);
@@ -485,6 +517,14 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
                         for (int g = 0; g < NG; ++g)
                             acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[kTermA[tm] * 4 + st]),
                                                                              as_bf16x8(ub[g][kTermB[tm]][st]), acc[g], 0, 0, 0);
+            } else if constexpr (MODE == 2) {
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)                   // the small term (user plane l) first
+#pragma unroll
+                    for (int st = 0; st < 4; ++st)
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(a[st]), as_half8(ub[g][1 - tm][st]), acc[g], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int q = 0; q < D / 8; ++q) {
@@ -633,7 +673,7 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
         auto tile_step = [&](f32x16 (&cur)[NG], f32x16 (&nxt)[NG], float4 (&ause)[D / 8], float4 (&aload)[D / 8], int tile) {
             const int tile_base = tile * 32;
             build_masks(tile, tile_base);
-            constexpr int kSlots = MODE == 1 ? 12 * NG : (D / 2) * NG;   // MFMAs of the block
+            constexpr int kSlots = MODE == 1 ? 12 * NG : MODE == 2 ? 8 * NG : (D / 2) * NG;   // MFMAs of the block
             constexpr int kParts = 3 * kQuad * NG;                // selection instructions of the block
             constexpr int kFirst = 4;                             // the first ones wait until the previous block's MFMAs have long retired
             if (tile + 1 < tin1) {
@@ -653,6 +693,10 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
 #pragma unroll
                     for (int i = 0; i < 8; ++i) aload[i] = pk[i * kWave];
 #endif
+                } else if constexpr (MODE == 2) {
+                    const float4 *pk = A.packed + (int64_t)(tile + 2 < tin1 ? tile + 2 : tin1 - 1) * 4 * kWave + lane;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) aload[i] = pk[i * kWave];
                 } else if constexpr (kTwoBuffers) {
 #pragma unroll
                     for (int q = 0; q < D / 8; ++q)
@@ -682,6 +726,19 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
                             for (int g = 0; g < NG; ++g) {
                                 nxt[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(ause[kTermA[tm] * 4 + st]),
                                                                                  as_bf16x8(ub[g][kTermB[tm]][st]), nxt[g], 0, 0, 0);
+                                select_share((tm * 4 + st) * NG + g);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+                } else if constexpr (MODE == 2) {
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+                        for (int st = 0; st < 4; ++st) {
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) {
+                                nxt[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(ause[st]), as_half8(ub[g][1 - tm][st]), nxt[g], 0, 0, 0);
                                 select_share((tm * 4 + st) * NG + g);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
@@ -921,43 +978,79 @@ __global__ __launch_bounds__(kBlock) void topk_pack_items_kernel(const float *__
     for (int p = 0; p < 2; ++p) packed[((tile * 2 + p) * 4 + s) * kWave + lane] = planes[p];
 }
 
-// max over the items of |row|^2 (d = 64: a 16-lane group per item), as the bit pattern of a non-negative float;
-// a fixed small grid walks the table, one atomic per wave at the end
-__global__ __launch_bounds__(kBlock) void topk_item_norm_max_kernel(const float *__restrict__ item_rows, int64_t ldi, int64_t n_items,
-                                                                    unsigned int *__restrict__ max_bits)
+// stats[0] = max over the items of |row|^2, stats[1] = max |item element| (d = 64: a 16-lane group per row), as the bit
+// patterns of non-negative floats; a fixed small grid walks the table, one atomic per wave and statistic at the end.
+// With ids: the rows ids[0..n) of the table, and only the element maximum, into stats[2] (the users of a call).
+__global__ __launch_bounds__(kBlock) void topk_row_stats_kernel(const float *__restrict__ rows, int64_t ld, int64_t n,
+                                                                const int64_t *__restrict__ ids, int of_users,
+                                                                unsigned int *__restrict__ stats)
 {
     const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    float best = 0.f;
-    for (int64_t t = t0; (t >> 4) < n_items + 3; t += stride) {           // (+3: the four groups of a wave stay together)
-        const int64_t item = t >> 4;
+    float best_n2 = 0.f, best_el = 0.f;
+    for (int64_t t = t0; (t >> 4) < n + 3; t += stride) {                 // (+3: the four groups of a wave stay together)
+        const int64_t r = t >> 4;
         float n2 = 0.f;
-        if (item < n_items) {
-            const float4 v = *reinterpret_cast<const float4 *>(item_rows + item * ldi + 4 * (t & 15));
+        if (r < n) {
+            const int64_t row = ids ? ids[r] : r;
+            const float4 v = *reinterpret_cast<const float4 *>(rows + row * ld + 4 * (t & 15));
             n2 = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            best_el = fmaxf(best_el, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
         }
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) n2 += __shfl_xor(n2, o);
-        best = fmaxf(best, n2);
+        best_n2 = fmaxf(best_n2, n2);
     }
 #pragma unroll
-    for (int o = 16; o < kWave; o <<= 1) best = fmaxf(best, __shfl_xor(best, o));
-    if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(max_bits, __float_as_uint(best));
+    for (int o = 1; o < kWave; o <<= 1) best_el = fmaxf(best_el, __shfl_xor(best_el, o));
+#pragma unroll
+    for (int o = 16; o < kWave; o <<= 1) best_n2 = fmaxf(best_n2, __shfl_xor(best_n2, o));
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        if (of_users) {
+            atomicMax(stats + 2, __float_as_uint(best_el));
+        } else {
+            atomicMax(stats, __float_as_uint(best_n2));
+            atomicMax(stats + 1, __float_as_uint(best_el));
+        }
+    }
+}
+
+// Item table -> one MFMA-ready fp16 plane for MODE 2: [tile][k-step 0..3][lane 0..63] x 16 B, scaled by the power of
+// two that brings the largest element (stats[1]) into [0.5, 1).  One thread per (tile, k-step, lane).
+__global__ __launch_bounds__(kBlock) void topk_pack_items_f16_kernel(const float *__restrict__ item_rows, int64_t ldi, int64_t n_items,
+                                                                     int n_tiles, const unsigned int *__restrict__ stats,
+                                                                     float4 *__restrict__ packed)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_tiles * 4 * kWave) return;
+    const int lane = (int)(i % kWave);
+    const int s = (int)(i / kWave % 4);
+    const int64_t tile = i / (4 * kWave);
+    const int64_t item = tile * 32 + (lane & 31);
+    float4 lo = f4_zero(), hi = f4_zero();
+    if (item < n_items) {
+        const float *src = item_rows + item * ldi + 16 * s + 8 * (lane >> 5);
+        lo = *reinterpret_cast<const float4 *>(src);
+        hi = *reinterpret_cast<const float4 *>(src + 4);
+    }
+    float4 planes[2];
+    split_f16_x8(lo, hi, ldexpf(1.f, -scale_exp(__uint_as_float(stats[1]))), planes);
+    packed[(tile * 4 + s) * kWave + lane] = planes[0];
 }
 
 // Second stage of the bf16 path, one wave per user, lane c = candidate c of the sweep (kc = k + kFastExtra <= 64 of
 // them, best approximate score first).  The candidate's score is recomputed in fp32 in the order the fp32 sweep adds
 // the products (k = 8q + c, 8q + 4 + c), the candidates are ranked by (exact score, lower id first) and the best k
 // written out.  Then the check that makes the result that of the fp32 sweep: an item the sweep dropped has an
-// approximate score <= a_min (the smallest kept) and an exact one <= a_min + eps, eps = 2^-15 |u| max|i| bounding
-// what the two-plane split and the fp32 accumulation can be off by; if a_min + eps does not stay below the k-th
+// approximate score <= a_min (the smallest kept) and an exact one <= a_min + eps, eps = c |u| max|i| bounding what the
+// reduced-precision operands and the fp32 accumulation can be off by; if a_min + eps does not stay below the k-th
 // exact score, a dropped item could belong to the list (or tie with its tail) and the user is flagged:
 // flagged[1 + n] = position of the user in the batch, flagged[0] = n.
 __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(const float *__restrict__ user_rows, int64_t ldu,
                                                               const int64_t *__restrict__ user_ids, int64_t batch,
                                                               const float *__restrict__ item_rows, int64_t ldi,
                                                               const int64_t *__restrict__ cand_idx, const float *__restrict__ cand_val,
-                                                              int kc, int k, const unsigned int *__restrict__ max_norm2_bits,
+                                                              int kc, int k, const unsigned int *__restrict__ stats, int mode,
                                                               int64_t *__restrict__ out_idx, float *__restrict__ out_val,
                                                               int32_t *__restrict__ flagged)
 {
@@ -1008,7 +1101,11 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(const float *__res
         n_real += __shfl_xor(n_real, o);
     }
     if (lane == 0) {
-        const float eps = 0x1p-15f * sqrtf(un2 * __uint_as_float(*max_norm2_bits));
+        // MODE 1: two bf16 planes each side, three products: 2^-15.  MODE 2: items rounded to fp16 once (2^-11 each), users
+        // exact to 2^-22, fp32 accumulation 2^-18: 2^-11 (1 + 2^-5); its approximate scores carry the two tables' scales.
+        const float coef = mode == 2 ? 0x1.08p-11f : 0x1p-15f;
+        if (mode == 2) a_min = ldexpf(a_min, scale_exp(__uint_as_float(stats[1])) + scale_exp(__uint_as_float(stats[2])));
+        const float eps = coef * sqrtf(un2 * __uint_as_float(stats[0]));
         // fewer real candidates than slots: the sweep dropped nothing real.  eps == 0 (an all-zero user): scores are exact.
         const bool ok = n_real < kc || eps == 0.f || a_min + eps < e_k;
         if (!ok) flagged[1 + atomicAdd(flagged, 1)] = (int32_t)b;
@@ -1057,7 +1154,8 @@ extern "C" int64_t igcn_score_topk_workspace_bytes(int64_t batch, int64_t n_item
 static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
                     const float *item_rows, int64_t ldi, int64_t n_items, int32_t d,
                     const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned,
-                    int32_t k, int64_t *out_idx, float *out_val, void *workspace, const float4 *packed, hipStream_t st)
+                    int32_t k, int64_t *out_idx, float *out_val, void *workspace, const float4 *packed,
+                    const unsigned int *stats, hipStream_t st)
 {
     if (!user_rows || !item_rows || !out_idx || !out_val) return IGCN_E_NULL;
     if ((excl_rowptr == nullptr) != (excl_col == nullptr)) return IGCN_E_NULL;
@@ -1090,10 +1188,11 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
     a.n_whole = p.n_whole; a.rest_tiles = p.rest_tiles; a.run = p.run;
     a.out_idx = out_idx; a.out_val = out_val; a.ws_val = ws_val; a.ws_idx = ws_idx;
     a.packed = packed;
+    a.stats = stats;
 
-    if (mode == 1) {
-        if (d != 64 || !packed) return IGCN_E_SHAPE;
-        rc = launch_topk<64, 2, true, 1>(p, st, a);
+    if (mode != 0) {
+        if (d != 64 || !packed || (mode == 2 && !stats)) return IGCN_E_SHAPE;
+        rc = mode == 2 ? launch_topk<64, 2, true, 2>(p, st, a) : launch_topk<64, 2, true, 1>(p, st, a);
     } else {
         switch (p.d_pad) {
         case 16: rc = d == 16 ? launch_topk<16, 2, true>(p, st, a) : launch_topk<16, 2, false>(p, st, a); break;
@@ -1125,7 +1224,7 @@ extern "C" int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const in
                                    int32_t k, int64_t *out_idx, float *out_val, void *workspace, void *stream)
 {
     return topk_run(0, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, d, excl_rowptr, excl_col, banned, k,
-                    out_idx, out_val, workspace, nullptr, static_cast<hipStream_t>(stream));
+                    out_idx, out_val, workspace, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
 // ---- the two-stage evaluation: bf16 candidate sweep + exact fp32 re-scoring (d = 64, k <= 60) --------------------
@@ -1174,23 +1273,34 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     int64_t *cand_idx = reinterpret_cast<int64_t *>(ws + L.cand_idx);
     float *cand_val = reinterpret_cast<float *>(ws + L.cand_val);
     unsigned int *norm_bits = reinterpret_cast<unsigned int *>(ws + L.norm);
-    hipError_t e = hipMemsetAsync(norm_bits, 0, 4, st);
+    const int mode = tuning_get(IGCN_TUNE_TOPK_FAST_MODE) == 1 ? 1 : 2;    // 2: one fp16 item plane (default), 1: two bf16 planes
+    hipError_t e = hipMemsetAsync(norm_bits, 0, 16, st);
     if (e == hipSuccess) e = hipMemsetAsync(flagged, 0, 4, st);
     if (e != hipSuccess) return (int)e;
     const int n_tiles = (int)((n_items + 31) / 32);
     const int64_t pack_threads = (int64_t)n_tiles * 4 * kWave;
-    hipLaunchKernelGGL(topk_pack_items_kernel, dim3((unsigned)((pack_threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                       item_rows, ldi, n_items, n_tiles, packed);
-    int64_t norm_blocks = (n_items * 16 + kBlock - 1) / kBlock;
-    if (norm_blocks > 2 * (int64_t)cu_count()) norm_blocks = 2 * (int64_t)cu_count();
-    hipLaunchKernelGGL(topk_item_norm_max_kernel, dim3((unsigned)norm_blocks), dim3(kBlock), 0, st, item_rows, ldi, n_items, norm_bits);
+    int64_t stat_blocks = (n_items * 16 + kBlock - 1) / kBlock;
+    if (stat_blocks > 2 * (int64_t)cu_count()) stat_blocks = 2 * (int64_t)cu_count();
+    hipLaunchKernelGGL(topk_row_stats_kernel, dim3((unsigned)stat_blocks), dim3(kBlock), 0, st, item_rows, ldi, n_items,
+                       (const int64_t *)nullptr, 0, norm_bits);
+    if (mode == 2) {
+        if (!user_rows || ldu < d || ldu % 4 || reinterpret_cast<uintptr_t>(user_rows) % 16) return IGCN_E_SHAPE;
+        int64_t ub = (batch * 16 + kBlock - 1) / kBlock;
+        if (ub > 2 * (int64_t)cu_count()) ub = 2 * (int64_t)cu_count();
+        hipLaunchKernelGGL(topk_row_stats_kernel, dim3((unsigned)ub), dim3(kBlock), 0, st, user_rows, ldu, batch, user_ids, 1, norm_bits);
+        hipLaunchKernelGGL(topk_pack_items_f16_kernel, dim3((unsigned)((pack_threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                           item_rows, ldi, n_items, n_tiles, norm_bits, packed);
+    } else {
+        hipLaunchKernelGGL(topk_pack_items_kernel, dim3((unsigned)((pack_threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
+                           item_rows, ldi, n_items, n_tiles, packed);
+    }
     rc = launch_status();
     if (rc != IGCN_OK) return rc;
-    rc = topk_run(1, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, d, excl_rowptr, excl_col, banned, L.kc,
-                  cand_idx, cand_val, ws + L.sweep, packed, st);
+    rc = topk_run(mode, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, d, excl_rowptr, excl_col, banned, L.kc,
+                  cand_idx, cand_val, ws + L.sweep, packed, norm_bits, st);
     if (rc != IGCN_OK) return rc;
     hipLaunchKernelGGL(topk_rescore_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(kBlock), 0, st, user_rows, ldu, user_ids, batch,
-                       item_rows, ldi, cand_idx, cand_val, L.kc, (int)k, norm_bits, out_idx, out_val, flagged);
+                       item_rows, ldi, cand_idx, cand_val, L.kc, (int)k, norm_bits, mode, out_idx, out_val, flagged);
     return launch_status();
 }
 

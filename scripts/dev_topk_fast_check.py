@@ -10,6 +10,9 @@ from igcn_cf_amd.trainer import _csr_to_device, _merge_sorted_csr
 from scripts.dev_spmm_bench import time_ms
 
 g = torch.Generator(device='cuda').manual_seed(0)
+from igcn_cf_amd import _lib
+if os.environ.get('FAST_MODE'):
+    _lib.set_tuning('topk_fast_mode', int(os.environ['FAST_MODE']))      # 1: two bf16 planes, 2 (default): one fp16 item plane
 # 1. small exact-arithmetic case (integers: massive ties -> every user must fall back and still be right)
 U = torch.randint(-3, 4, (300, 64), device='cuda', generator=g).float()
 I = torch.randint(-3, 4, (5000, 64), device='cuda', generator=g).float()

@@ -81,6 +81,7 @@ def test_score_topk_fuzz():
         ids = rng.permutation(n_users).astype(np.int64)
         # d = 64, k <= 60: every other such case through the two-stage path (bf16 candidate sweep + exact re-scoring)
         mode = 'fast' if d == 64 and k <= 60 and case % 2 == 0 else 'exact'
+        _lib.set_tuning('topk_fast_mode', 1 if case % 4 == 0 else None)     # two bf16 planes / one fp16 item plane (default)
         idx, val = score_topk(torch.from_numpy(U).cuda(), torch.from_numpy(I).cuda(), k, user_ids=torch.from_numpy(ids).cuda(),
                               mode=mode, **kw)
         s = scores[ids].copy()
@@ -93,3 +94,5 @@ def test_score_topk_fuzz():
         ref = O.eval_topk(s, None, None, k=k)
         np.testing.assert_array_equal(idx.cpu().numpy(), ref, err_msg=str((case, n_users, n_items, d, k)))
         np.testing.assert_array_equal(val.cpu().numpy(), np.take_along_axis(s, ref, axis=1))
+    _lib.set_tuning('topk_slots', None)
+    _lib.set_tuning('topk_fast_mode', None)

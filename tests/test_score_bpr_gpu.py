@@ -88,7 +88,7 @@ def test_score_topk_matches_dense_oracle(d, n_users, n_items, k):
         _check_topk(scores[sub], idx.cpu().numpy(), val.cpu().numpy(), None, None, k)
 
 
-@pytest.mark.parametrize('mode', ['exact', 'fast'])
+@pytest.mark.parametrize('mode', ['exact', 'fast', 'fast_bf16'])
 def test_score_topk_random_floats_match_sets(mode):
     """Gaussian fp32 embeddings: same top-k sets as the float64 ranking except where the
     k-th and (k+1)-th scores are within fp32 rounding of each other — for the fp32 sweep and for the two-stage
@@ -100,10 +100,22 @@ def test_score_topk_random_floats_match_sets(mode):
     I = (rng.standard_normal((n_items, d)) * 0.1).astype(np.float32)
     I[100] = I[7]; I[20000] = I[7]                       # identical item rows: exact ties, decided by the lower id
     U[5] = 0.0                                           # an all-zero user: every score ties at 0
-    idx, val = score_topk(_dev(U), _dev(I), k, mode=mode)
-    if mode == 'fast':
-        idx_e, val_e = score_topk(_dev(U), _dev(I), k, mode='exact')
-        assert torch.equal(idx, idx_e) and torch.equal(val, val_e)
+    from igcn_cf_amd import _lib
+    if mode == 'fast_bf16':                              # the candidate sweep on two bf16 planes instead of one fp16 item plane
+        _lib.set_tuning('topk_fast_mode', 1)
+        mode = 'fast'
+    try:
+        idx, val = score_topk(_dev(U), _dev(I), k, mode=mode)
+        if mode == 'fast':
+            idx_e, val_e = score_topk(_dev(U), _dev(I), k, mode='exact')
+            assert torch.equal(idx, idx_e) and torch.equal(val, val_e)
+            # badly scaled tables (fp16 has 5 exponent bits: the sweep rescales both tables by a power of two)
+            for su, si in ((1e-6, 3e4), (2e5, 1e-7)):
+                a = score_topk(_dev(U * np.float32(su)), _dev(I * np.float32(si)), k, mode='fast')
+                b = score_topk(_dev(U * np.float32(su)), _dev(I * np.float32(si)), k, mode='exact')
+                assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    finally:
+        _lib.set_tuning('topk_fast_mode', None)
     idx, val = idx.cpu().numpy(), val.cpu().numpy()
     assert list(idx[5]) == list(range(k))
     s64 = U.astype(np.float64) @ I.astype(np.float64).T
