@@ -530,7 +530,7 @@ def side_measurements(ds, device, d, K):
     dt = (time.perf_counter() - t0) / reps
     res['eval_users_per_s'] = ds.n_users / dt
     res['eval_ms'] = dt * 1e3
-    res['eval_path'] = ('two-stage: bf16 candidate sweep (k + 4 per user) + exact fp32 re-scoring and completeness check, users '
+    res['eval_path'] = ('two-stage: fp16 candidate sweep (k + 4 per user) + exact fp32 re-scoring and completeness check, users '
                         'that fail it re-done by the fp32 sweep — the lists of the fp32 sweep, bit for bit (ops.score_topk mode "auto")')
     # the scoring kernels alone on the same representation, HIP events: the fp32 sweep (MFMA roofline) and the two-stage path
     from igcn_cf_amd import ops
@@ -554,10 +554,12 @@ def side_measurements(ds, device, d, K):
                             'peak': 157.3, 'unit': 'TFLOP/s', 'frac': tf / 157.3, 'ms': ms_exact,
                             'note': 'fp32 v_mfma_f32_32x32x2_f32; 2*U*I*d flops per evaluation, no masks in this timing'}
     res['eval_two_stage'] = {'ms': ms_fast, 'speedup_over_fp32_sweep': ms_exact / ms_fast, 'users_flagged_for_the_fp32_sweep': ops.score_topk.last_flagged,
-                             'bf16_mfma_TFLOPs': 3 * flops / (ms_fast / 1e3) / 1e12, 'bf16_mfma_peak_TFLOPs': 2500.0,
-                             'note': 'v_mfma_f32_32x32x16_bf16, three plane products: 3x the flops of the fp32 sweep at 4.4x the rate; '
-                                     'the sweep is bound by the L1 throughput of its per-wave item-tile loads, not by the matrix cores '
-                                     '(profiles/r02k_topk_two_stage_ablation.jsonl)'}
+                             'f16_mfma_TFLOPs': 2 * flops / (ms_fast / 1e3) / 1e12, 'f16_mfma_peak_TFLOPs': 2500.0,
+                             'note': 'candidate sweep: v_mfma_f32_32x32x16_f16, items as one fp16 plane, users as two (2x the flops of '
+                                     'the fp32 sweep at ~13x the matrix rate); the time is no longer matrix time: per wave, staging '
+                                     'candidates 60 %, draining them into the heaps 22 %, mask bits 14 % of its cycles, the item-tile '
+                                     'loads behind them (profiles/r02k_topk_two_stage_ablation.jsonl); includes packing, re-scoring, the '
+                                     'host read of the flagged count and the fp32 sweep of the flagged users'}
     trainer.eval('test')                                   # first call builds the device CSR of the test lists
     model._rep_cache = None
     torch.cuda.synchronize()

@@ -229,9 +229,10 @@ int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const int64_t *user
                         int32_t k, int64_t *out_idx, float *out_val,
                         void *workspace, void *stream);
 
-/* The same evaluation in two stages (d = 64, k <= 60).  Stage 1 sweeps all items on the bf16 matrix cores — every
- * fp32 value split into two bf16 planes, three plane products per 16 k, fp32 accumulate: scores off by less than
- * 2^-15 |u| max|i| — and keeps the k + 4 best candidates of every user (masks applied as in igcn_score_topk_f32).
+/* The same evaluation in two stages (d = 64, k <= 60).  Stage 1 sweeps all items on the 16-bit matrix cores — items as
+ * one fp16 plane, users as two, both tables rescaled by a power of two, fp32 accumulate: scores off by at most
+ * 2^-11 |u| max|i| (igcn_set_tuning("topk_fast_mode", 1): two bf16 planes each side, three products, 2^-15) — and keeps
+ * the k + 4 best candidates of every user (masks applied as in igcn_score_topk_f32).
  * Stage 2 re-computes the candidates' scores in fp32 in the order the fp32 sweep adds the products, orders them
  * (score, then lower id) and writes the best k: out_idx / out_val as igcn_score_topk_f32 writes them.  A user for
  * whom an item dropped by stage 1 could still reach the k-th exact score (its bound does not stay below it: near-ties
