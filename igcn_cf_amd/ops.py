@@ -382,7 +382,7 @@ def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_co
     """Top-k item ids (best first) and scores for each user row; masked items are
     never returned unless fewer than k unmasked items exist.
 
-    mode 'exact': the fp32 sweep (igcn_score_topk_f32).  'fast' (d = 64, k <= 60): the bf16 candidate sweep + exact fp32
+    mode 'exact': the fp32 sweep (igcn_score_topk_f32).  'fast' (d = 64, k <= 60): the fp16 candidate sweep + exact fp32
     re-scoring (igcn_score_topk_fast_f32) — the same ids, exact fp32 scores; users whose candidate set cannot be proven
     complete (near-ties at the k-th place; counted on the device, read back here) go through the fp32 sweep.  'auto':
     'fast' where it applies and the problem is large enough to pay for it."""
