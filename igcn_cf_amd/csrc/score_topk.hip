@@ -485,6 +485,7 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
         // At d = 128 one buffer: each piece is re-loaded as soon as the block has consumed it.
         constexpr bool kTwoBuffers = D <= 64;
         float4 a[D / 8], a2[kTwoBuffers ? D / 8 : 1];
+        float4 a3[MODE == 2 ? D / 8 : 1];                         // MODE 2: a third buffer (its tiles are half the size): loads run two tile steps ahead
         auto tile_addr = [&](int t, const char *&tile_ptr, unsigned &off) {
             tile_ptr = reinterpret_cast<const char *>(A.item_rows + (int64_t)t * 32 * ldi);
             off = t == n_tiles - 1 ? lane_off_last : lane_off;
@@ -702,7 +703,7 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
                     for (int i = 0; i < 8; ++i) aload[i] = pk[i * kWave];
 #endif
                 } else if constexpr (MODE == 2) {
-                    const float4 *pk = A.packed + (int64_t)(tile + 2 < tin1 ? tile + 2 : tin1 - 1) * 4 * kWave + lane;
+                    const float4 *pk = A.packed + (int64_t)(tile + 3 < tin1 ? tile + 3 : tin1 - 1) * 4 * kWave + lane;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) aload[i] = pk[i * kWave];
                 } else if constexpr (kTwoBuffers) {
@@ -789,6 +790,22 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
         f32x16 acc_a[NG], acc_b[NG];
         load_a(tin0);
         chain_plain(acc_a);
+        if constexpr (MODE == 2) {
+            // ring of three item-tile buffers: step t multiplies tile t + 1 and requests tile t + 3 into the buffer step
+            // t - 1 consumed; three steps per turn, the accumulator pair changes roles every step, so the odd turn
+            // ends with a copy (32 moves per three tile steps)
+            load_into(a2, tin0 + 1 < tin1 ? tin0 + 1 : tin1 - 1);
+            load_into(a3, tin0 + 2 < tin1 ? tin0 + 2 : tin1 - 1);
+            for (int tile = tin0; tile < tin1; tile += 3) {
+                tile_step(acc_a, acc_b, a2, a, tile);
+                if (tile + 1 < tin1) tile_step(acc_b, acc_a, a3, a2, tile + 1);
+                if (tile + 2 < tin1) {
+                    tile_step(acc_a, acc_b, a, a3, tile + 2);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) acc_a[g] = acc_b[g];
+                }
+            }
+        } else {
         if (tin0 + 1 < tin1) load_a(tin0 + 1);
         for (int tile = tin0; tile < tin1; tile += 2) {
             if constexpr (kTwoBuffers) {
@@ -798,6 +815,7 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
                 tile_step(acc_a, acc_b, a, a, tile);
                 if (tile + 1 < tin1) tile_step(acc_b, acc_a, a, a, tile + 1);
             }
+        }
         }
         flush();
 
