@@ -468,6 +468,12 @@ def inductive_update_timing(ds, device, d, K):
     small = resize_dataset(ds, 0.8)
     torch.manual_seed(2021)
     model = get_model(m_cfg, small)
+    # a running system has the evaluation kernels loaded: one tiny call of each top-k path before the clock starts
+    from igcn_cf_amd import ops
+    wu, wi = torch.randn(64, d, device=device), torch.randn(4096, d, device=device)
+    ops.score_topk(wu, wi, 20, mode='exact')
+    if d == 64:
+        ops.score_topk(wu, wi, 20, mode='fast')
     torch.cuda.synchronize()
     out = {}
     t0 = time.perf_counter()
