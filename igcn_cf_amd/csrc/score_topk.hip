@@ -1131,7 +1131,11 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(const float *__res
         // exact to 2^-22, fp32 accumulation 2^-18: 2^-11 (1 + 2^-5); its approximate scores carry the two tables' scales.
         const float coef = mode == 2 ? 0x1.08p-11f : 0x1p-15f;
         if (mode == 2) a_min = ldexpf(a_min, scale_exp(__uint_as_float(stats[1])) + scale_exp(__uint_as_float(stats[2])));
-        const float eps = coef * sqrtf(un2 * __uint_as_float(stats[0]));
+        float eps = coef * sqrtf(un2 * __uint_as_float(stats[0]));
+        // MODE 2: scaled elements below 2^-14 are fp16 subnormals (absolute error <= 2^-25 each, both sides): at most
+        // 2^-18 per score in scaled units = 2^-16 max|i_j| max|u_j| — matters only for a user far smaller than the
+        // largest of the batch, whom it then sends to the fp32 sweep
+        if (mode == 2 && eps > 0.f) eps += 0x1p-16f * __uint_as_float(stats[1]) * __uint_as_float(stats[2]);
         // fewer real candidates than slots: the sweep dropped nothing real.  eps == 0 (an all-zero user): scores are exact.
         const bool ok = n_real < kc || eps == 0.f || a_min + eps < e_k;
         if (!ok) flagged[1 + atomicAdd(flagged, 1)] = (int32_t)b;

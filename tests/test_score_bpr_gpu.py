@@ -109,6 +109,11 @@ def test_score_topk_random_floats_match_sets(mode):
         if mode == 'fast':
             idx_e, val_e = score_topk(_dev(U), _dev(I), k, mode='exact')
             assert torch.equal(idx, idx_e) and torch.equal(val, val_e)
+            # users 1e-6 times smaller than the rest of the batch: their scaled elements are fp16 subnormals in the sweep
+            U2 = U.copy(); U2[::7] *= np.float32(1e-6)
+            a = score_topk(_dev(U2), _dev(I), k, mode='fast')
+            b = score_topk(_dev(U2), _dev(I), k, mode='exact')
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
             # badly scaled tables (fp16 has 5 exponent bits: the sweep rescales both tables by a power of two)
             for su, si in ((1e-6, 3e4), (2e5, 1e-7)):
                 a = score_topk(_dev(U * np.float32(su)), _dev(I * np.float32(si)), k, mode='fast')
