@@ -57,9 +57,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kIdxNone = 0x7fffffff;
 
 // ---- candidate sweep on the bf16 matrix cores (MODE 1 of the kernel) --------------------------------------------
-// Every fp32 x is split x = h + l + r, h = bf16(x), l = bf16(x - h), |r| <= 2^-17 |x|.  The sweep forms
+// Every fp32 x is split x = h + l + r, h = bf16(x), l = bf16(x - h), |l| <= 2^-8 |x|, |r| <= 2^-16 |x|.  The sweep forms
 // h_i h_u + h_i l_u + l_i h_u (three bf16 MFMAs per 16 k, fp32 accumulate: 12 instead of 32 fp32 MFMAs per
-// 32 x 32 x 64 tile, each ~38 instead of 64 cycles) — a score off by at most ~2^-16 |u| |i| — and keeps the k + 4
+// 32 x 32 x 64 tile, each ~38 instead of 64 cycles) — a score off by at most 2^-14 |u| |i| — and keeps the k + 4
 // best candidates per user; topk_rescore_kernel then recomputes their scores exactly in fp32, orders them, and
 // checks that no item the sweep dropped can reach the k-th exact score (else the user is handed to the fp32 sweep).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -1127,9 +1127,11 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(const float *__res
         n_real += __shfl_xor(n_real, o);
     }
     if (lane == 0) {
-        // MODE 1: two bf16 planes each side, three products: 2^-15.  MODE 2: items rounded to fp16 once (2^-11 each), users
+        // MODE 1: two bf16 planes each side (8 significant bits each: x = h + l + r, |l| <= 2^-8 |x|, |r| <= 2^-16 |x|), three
+        // products kept, l_i l_u and the r terms dropped: 3 * 2^-16 per product, 2^-14 with the accumulation.  MODE 2: items
+        // rounded to fp16 once (11 bits: 2^-11 each), users
         // exact to 2^-22, fp32 accumulation 2^-18: 2^-11 (1 + 2^-5); its approximate scores carry the two tables' scales.
-        const float coef = mode == 2 ? 0x1.08p-11f : 0x1p-15f;
+        const float coef = mode == 2 ? 0x1.08p-11f : 0x1p-14f;
         if (mode == 2) a_min = ldexpf(a_min, scale_exp(__uint_as_float(stats[1])) + scale_exp(__uint_as_float(stats[2])));
         float eps = coef * sqrtf(un2 * __uint_as_float(stats[0]));
         // MODE 2: scaled elements below 2^-14 are fp16 subnormals (absolute error <= 2^-25 each, both sides): at most
