@@ -39,8 +39,8 @@ enum {
     IGCN_TUNE_TOPK_FAST_MODE,           // candidate sweep of the two-stage path: 2 = one fp16 item plane (default), 1 = two bf16 planes
     IGCN_TUNE_COUNT
 };
-extern int g_tuning[IGCN_TUNE_COUNT];   // defined in spmm.hip
-inline int tuning_get(int key) { return g_tuning[key]; }
+extern int g_tuning[IGCN_TUNE_COUNT];   // defined in spmm.hip; holds value + 1, 0 = unset
+inline int tuning_get(int key) { return g_tuning[key] - 1; }
 
 // 32-bit finaliser (lowbias32-style); used as a counter-based RNG: the value
 // depends only on (seed, counter), so a matrix and its transposed view agree.

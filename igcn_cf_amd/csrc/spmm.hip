@@ -407,7 +407,7 @@ __global__ void csr_row_pow_kernel(const int64_t *__restrict__ rowptr, const flo
     }
 }
 
-int g_tuning[IGCN_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1};
+int g_tuning[IGCN_TUNE_COUNT];          // value + 1; 0 (the static initialiser) = library default
 
 // Developer tuning knobs (igcn_set_tuning): spmm_blocks_per_cu, spmm_multirow.
 struct SpmmTuning { int blocks_per_cu; int multirow; };
@@ -715,7 +715,7 @@ extern "C" int igcn_set_tuning(const char *name, int32_t value)
                                                        "topk_waves_per_cu", "topk_cap", "topk_stagger", "topk_fast_mode"};
     if (!name) return IGCN_E_NULL;
     for (int i = 0; i < IGCN_TUNE_COUNT; ++i)
-        if (strcmp(name, names[i]) == 0) { g_tuning[i] = value < 0 ? -1 : value; return IGCN_OK; }
+        if (strcmp(name, names[i]) == 0) { g_tuning[i] = value < 0 ? 0 : value + 1; return IGCN_OK; }
     return IGCN_E_RANGE;
 }
 

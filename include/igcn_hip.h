@@ -39,7 +39,8 @@ int         igcn_abi_version(void);
 const char *igcn_error_string(int code);
 
 /* Developer / test knobs of the launch heuristics (no reference counterpart).  name: "spmm_blocks_per_cu",
- * "spmm_multirow", "topk_slots", "topk_waves_per_cu", "topk_cap", "topk_stagger"; value < 0 restores the library
+ * "spmm_multirow", "topk_slots", "topk_waves_per_cu", "topk_cap", "topk_stagger", "topk_fast_mode" (candidate sweep of
+ * igcn_score_topk_fast_f32: 2 = one fp16 item plane, 1 = two bf16 planes); value < 0 restores the library
  * default.  Results never depend on them (tests/test_spmm_gpu.py::test_launch_shape_does_not_change_results).
  * Not thread-safe against concurrent launches.  Returns IGCN_E_RANGE for an unknown name. */
 int igcn_set_tuning(const char *name, int32_t value);
