@@ -703,9 +703,15 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
                     for (int i = 0; i < 8; ++i) aload[i] = pk[i * kWave];
 #endif
                 } else if constexpr (MODE == 2) {
+#ifndef IGCN_X_NOLOADA
+#ifdef IGCN_X_SAMETILE
+                    const float4 *pk = A.packed + lane;           // developer build: every load hits the same lines
+#else
                     const float4 *pk = A.packed + (int64_t)(tile + 3 < tin1 ? tile + 3 : tin1 - 1) * 4 * kWave + lane;
+#endif
 #pragma unroll
                     for (int i = 0; i < 4; ++i) aload[i] = pk[i * kWave];
+#endif
                 } else if constexpr (kTwoBuffers) {
 #pragma unroll
                     for (int q = 0; q < D / 8; ++q)
