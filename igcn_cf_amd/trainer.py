@@ -184,11 +184,11 @@ class BasicTrainer:
         m = self.model                       # a swapped graph / feature matrix / optimizer means new pointers: capture again
         return (id(getattr(m, 'norm_adj', None)), id(getattr(m, 'feat_mat', None)), id(self.opt), self.batch_size)
 
-    def _graph_step(self, inputs, loss_fn):
+    def _graph_step(self, inputs, loss_fn, kind='nodes'):
         """Replays the captured step on `inputs` (tensors copied into the static buffers the graph reads); captures
         it first when there is none for the current model state.  Returns the loss tensor, or None when capture is not
         possible here (the caller then runs the step eagerly — same kernels, launched one by one)."""
-        key = self._graph_key()
+        key = self._graph_key() + (kind,)
         if getattr(self, '_graph', None) is None or self._graph_for != key:
             try:
                 self._capture_step(inputs, loss_fn)
@@ -488,12 +488,19 @@ class BPRTrainer(BasicTrainer):
         return DeviceSampler(self.dataset, self.device, self.config.get('seed', 2021))
 
     def bpr_step(self, inputs):
-        """One optimisation step on an int64 [B, 3] batch; returns the loss tensor."""
-        users, pos_items, neg_items = inputs.t().contiguous().unbind(0)          # one transpose, three row views
-        return self._optimise(self.model.bpr_loss_terms(users, pos_items, neg_items))
+        """One optimisation step on an int64 [B, 3] batch; returns the loss tensor.  Full-size batches replay one
+        captured HIP graph like node_step (MF has no node-id path), unless the loss needs a collective (a
+        column-sharded model) or the config says 'hip_graph': False."""
+        if self._graph_wanted() and inputs.shape[0] == self.batch_size and getattr(self.model, 'slice_reduce_fn', None) is None:
+            loss = self._graph_step((inputs,), self._triplet_loss, kind='triplets')
+            if loss is not None:
+                return loss
+        return self._optimise_loss(self._triplet_loss(inputs))
 
-    def _optimise(self, terms):
-        return self._optimise_loss(terms[0] + self.l2_reg * terms[1])
+    def _triplet_loss(self, inputs):
+        users, pos_items, neg_items = inputs.t().contiguous().unbind(0)          # one transpose, three row views
+        terms = self.model.bpr_loss_terms(users, pos_items, neg_items)
+        return terms[0] + self.l2_reg * terms[1]
 
     def _optimise_loss(self, loss):
         self.opt.zero_grad()
