@@ -2,11 +2,19 @@
 
 Runs ONLY in the build container (needs /root/reference).  It imports the
 reference modules that import unmodified on CPU — ``utils``, ``dataset``,
-``trainer`` — and records their outputs on small seeded inputs.  ``model.py``
-is NOT imported: it needs DGL, which the image lacks, and no stand-in for it is
-written (see oracle/oracle.py header).  Where a reference trainer needs a model
-object, a small hand-written one defined in this file is passed in; it is an
-*input* to the reference code and is recorded with the outputs.
+``trainer`` — and records their outputs on small seeded inputs.  Where a reference
+trainer needs a model object, a small hand-written one defined in this file is
+passed in; it is an *input* to the reference code and is recorded with the outputs.
+
+``model.py`` (round 3): its one missing import is DGL (``model.py:11``), which the image
+lacks.  NO stand-in for DGL exists here: ``model_fixtures`` registers an INERT module
+object under the name ``dgl`` — it has no attributes; touching any raises and is logged —
+so that the ``import dgl`` statement passes, runs only the functions of ``model.py`` that
+never call DGL (graph / feature construction, anneal, dropout of a sparse matrix,
+bpr_forward / predict with ``get_rep`` replaced by a recorded tensor, save / load), and
+asserts at the end that the placeholder was never touched.  Every recorded number is
+therefore computed by the reference's own scipy / torch code.  ``get_rep`` and
+``inductive_rep_layer`` (the two gspmm callers) cannot be run and stay definitional.
 
 Outputs are data only (inputs + expected outputs): .npz arrays and toy datasets
 in the reference's own text format.  Usage:  python oracle/gen_golden.py
@@ -175,6 +183,189 @@ def train_protocol_fixture(ref_trainer, ds):
         events, ret, left = run_train_script(ref_trainer.BasicTrainer, ds, TRAIN_SCRIPTS[0], False, tmp)
     g['train_nontrainable_events'], g['train_nontrainable_return'] = np.array(events), np.float64(ret)
     return g
+
+
+class _InertPlaceholder(type(sys)):
+    """What ``import dgl`` resolves to in model_fixtures(): a module object with NOTHING in it.  Any attribute the
+    reference asks of it raises (and is logged), so no number in a fixture can come from here."""
+    touched = []
+
+    def __getattr__(self, name):
+        if not (name.startswith('__') and name.endswith('__')):        # introspection by importlib / inspect is not use
+            _InertPlaceholder.touched.append(name)
+        raise AttributeError('inert placeholder: dgl.%s does not exist (DGL is not installed)' % name)
+
+
+def _coo(t):
+    t = t.coalesce()
+    return t.indices().numpy().copy(), t.values().detach().numpy().copy()
+
+
+def _map_arrays(m):
+    k = np.array([int(x) for x in m.keys()], dtype=np.int64)
+    v = np.array([int(x) for x in m.values()], dtype=np.int64)
+    return k, v
+
+
+def model_fixtures():
+    """tests/golden/<toy>_model.npz: outputs of the DGL-free functions of the reference's model.py
+    (model.py:52-72, :85-94, :108-123, :263-275, :293-299, :355-421, :448-466)."""
+    sys.path.insert(0, REF)
+    assert 'dgl' not in sys.modules
+    sys.modules['dgl'] = _InertPlaceholder('dgl')
+    quiet = contextlib.redirect_stdout(io.StringIO())
+    import warnings
+    warnings.filterwarnings('ignore')
+    # model.py:460 calls torch.load(path) on a checkpoint holding dicts with numpy keys: torch >= 2.6 refuses that by
+    # default (weights_only); the documented environment switch restores the behaviour the reference was written for
+    os.environ['TORCH_FORCE_NO_WEIGHTS_ONLY_LOAD'] = '1'
+    with quiet:
+        import dataset as ref_dataset      # noqa: E402  (reference, unmodified)
+        import model as ref_model          # noqa: E402  (reference, unmodified)
+    d = 8
+
+    def dataset_at(path):
+        with quiet:
+            return ref_dataset.get_dataset({'name': 'ProcessedDataset', 'path': path, 'device': 'cpu'})
+
+    def build(name, ds, **kw):
+        cfg = {'name': name, 'embedding_size': d, 'n_layers': 2, 'device': 'cpu'}
+        cfg.update(kw)
+        with quiet:
+            return ref_model.get_model(cfg, ds)
+
+    for toy in ('toy_a', 'toy_b'):
+        g = {}
+        ds = dataset_at(os.path.join(OUT, toy))
+        n = ds.n_users + ds.n_items
+        gen = torch.Generator().manual_seed(31)
+        users = torch.randint(0, ds.n_users, (40,), generator=gen)
+        pos = torch.randint(0, ds.n_items, (40,), generator=gen)
+        neg = torch.randint(0, ds.n_items, (40,), generator=gen)
+        users[1] = users[0]; pos[3] = neg[3]                         # duplicate user, positive == negative
+        rep = torch.randn(n, d, generator=gen) * 0.4
+        pred_users = torch.arange(0, ds.n_users, 3)
+        g['users'], g['pos'], g['neg'], g['rep'], g['pred_users'] = (t.numpy() for t in (users, pos, neg, rep, pred_users))
+
+        # ---- MF (model.py:52-72)
+        torch.manual_seed(41)
+        mf = build('MF', ds)
+        g['mf_user_emb'], g['mf_item_emb'] = mf.user_embedding.weight.detach().numpy().copy(), mf.item_embedding.weight.detach().numpy().copy()
+        out = mf.bpr_forward(users, pos, neg)
+        for tag, t in zip(('u', 'p', 'n', 'l2'), out):
+            g['mf_bpr_' + tag] = t.detach().numpy().copy()
+        g['mf_predict'] = mf.predict(pred_users).detach().numpy().copy()
+        g['mf_state_keys'] = np.array(list(mf.state_dict().keys()))
+
+        # ---- LightGCN (model.py:75-123)
+        torch.manual_seed(42)
+        lg = build('LightGCN', ds)
+        g['lgcn_adj_indices'], g['lgcn_adj_values'] = _coo(lg.norm_adj)
+        g['lgcn_adj_shape'] = np.array(lg.norm_adj.shape)
+        g['lgcn_emb'] = lg.embedding.weight.detach().numpy().copy()
+        lg.get_rep = lambda: rep                                     # get_rep needs DGL: replaced by a recorded tensor (an input)
+        out = lg.bpr_forward(users, pos, neg)
+        for tag, t in zip(('u', 'p', 'n', 'l2'), out):
+            g['lgcn_bpr_' + tag] = t.detach().numpy().copy()
+        g['lgcn_predict'] = lg.predict(pred_users).detach().numpy().copy()
+        g['lgcn_state_keys'] = np.array(list(lg.state_dict().keys()))
+
+        # ---- IGCN (model.py:355-466) at several template ratios / rankings
+        for tag, ratio, metric in (('r100', 1.0, 'sort'), ('r50d', 0.5, 'degree'), ('r50s', 0.5, 'sort'), ('r30s', 0.3, 'sort')):
+            torch.manual_seed(43)
+            ig = build('IGCN', ds, dropout=0.3, feature_ratio=ratio, ranking_metric=metric)
+            k = 'igcn_%s_' % tag
+            g[k + 'adj_indices'], g[k + 'adj_values'] = _coo(ig.norm_adj)
+            g[k + 'feat_indices'], g[k + 'feat_values_a0'] = _coo(ig.feat_mat)          # after update_feat_mat at alpha = 1
+            g[k + 'feat_shape'] = np.array(ig.feat_mat.shape)
+            g[k + 'row_sum'] = ig.row_sum.numpy().copy()
+            g[k + 'user_map_k'], g[k + 'user_map_v'] = _map_arrays(ig.user_map)
+            g[k + 'item_map_k'], g[k + 'item_map_v'] = _map_arrays(ig.item_map)
+            g[k + 'emb_shape'] = np.array(ig.embedding.weight.shape)
+            g[k + 'w'] = ig.w.detach().numpy().copy()
+            g[k + 'state_keys'] = np.array(list(ig.state_dict().keys()))
+            # dropout_sp_mat (model.py:263-275): identity in eval mode; in train mode keep iff floor(1 - p + U) == 1
+            ig.eval()
+            g[k + 'dropout_eval_is_identity'] = np.bool_(ref_model.NGCF.dropout_sp_mat(ig, ig.feat_mat) is ig.feat_mat)
+            ig.train()
+            torch.manual_seed(51)
+            dropped = ref_model.NGCF.dropout_sp_mat(ig, ig.feat_mat)
+            torch.manual_seed(51)
+            g[k + 'dropout_rand'] = torch.rand(ig.feat_mat._nnz()).numpy().copy()      # the draw of model.py:267, same seed
+            g[k + 'dropout_p'] = np.float64(ig.dropout)
+            g[k + 'dropout_indices'], g[k + 'dropout_values'] = _coo(dropped)
+            # bpr_forward / predict with get_rep replaced (model.py:293-299 via :448-449; :118-123 via :451-452)
+            ig.get_rep = lambda: rep
+            out = ig.bpr_forward(users, pos, neg)
+            for t_tag, t in zip(('u', 'p', 'n', 'l2'), out):
+                g[k + 'bpr_' + t_tag] = t.detach().numpy().copy()
+            g[k + 'predict'] = ig.predict(pred_users).detach().numpy().copy()
+            # anneal (model.py:374-381)
+            for _ in range(3):
+                ig.feat_mat_anneal()
+            g[k + 'alpha_a3'] = np.float64(ig.alpha)
+            idx3, g[k + 'feat_values_a3'] = _coo(ig.feat_mat)
+            assert np.array_equal(idx3, g[k + 'feat_indices'])
+            # save / load (model.py:454-466): keys of the checkpoint, and the state a fresh model has after load()
+            import tempfile
+            with tempfile.TemporaryDirectory() as tmp:
+                path = os.path.join(tmp, 'igcn.pth')
+                ig.save(path)
+                params = torch.load(path, map_location='cpu', weights_only=False)
+                g[k + 'ckpt_keys'] = np.array(list(params.keys()))
+                g[k + 'ckpt_state_keys'] = np.array(list(params['sate_dict'].keys()))
+                torch.manual_seed(44)
+                fresh = build('IGCN', ds, dropout=0.3, feature_ratio=ratio, ranking_metric='degree' if metric == 'sort' else 'sort')
+                fresh.load(path)
+            g[k + 'loaded_alpha'] = np.float64(fresh.alpha)
+            g[k + 'loaded_feat_indices'], g[k + 'loaded_feat_values'] = _coo(fresh.feat_mat)
+            g[k + 'loaded_row_sum'] = fresh.row_sum.numpy().copy()
+            g[k + 'loaded_emb_equal'] = np.bool_(torch.equal(fresh.embedding.weight, ig.embedding.weight))
+
+        # ---- the live-model update of the inductive scripts (run/dropui/igcn_dropui.py:26-32, run/dropit/igcn_dropit.py:
+        #      26-35): a model built on the reduced split gets the full graph, generate_feat(is_updating=True)
+        for split in ('dropui', 'dropit', 'dropui_half'):
+            small = dataset_at(os.path.join(OUT, toy + '_' + split))
+            for tag, ratio in (('r100', 1.0), ('r50', 0.5)):
+                torch.manual_seed(45)
+                ig = build('IGCN', small, dropout=0.3, feature_ratio=ratio, ranking_metric='sort')
+                for _ in range(2):
+                    ig.feat_mat_anneal()
+                k = 'upd_%s_%s_' % (split, tag)
+                g[k + 'small_n'] = np.array([small.n_users, small.n_items])
+                g[k + 'small_feat_indices'], g[k + 'small_feat_values'] = _coo(ig.feat_mat)
+                g[k + 'user_map_k'], g[k + 'user_map_v'] = _map_arrays(ig.user_map)
+                g[k + 'item_map_k'], g[k + 'item_map_v'] = _map_arrays(ig.item_map)
+                ig.config['dataset'] = ds
+                ig.n_users, ig.n_items = ds.n_users, ds.n_items
+                ig.norm_adj = ig.generate_graph(ds)
+                ig.feat_mat, _, _, ig.row_sum = ig.generate_feat(ds, is_updating=True)
+                ig.update_feat_mat()
+                g[k + 'alpha'] = np.float64(ig.alpha)
+                g[k + 'adj_indices'], g[k + 'adj_values'] = _coo(ig.norm_adj)
+                g[k + 'feat_indices'], g[k + 'feat_values'] = _coo(ig.feat_mat)
+                g[k + 'feat_shape'] = np.array(ig.feat_mat.shape)
+                g[k + 'row_sum'] = ig.row_sum.numpy().copy()
+
+        # ---- IMF (model.py:536-543) shares every DGL-free function with IGCN; record that it builds the same state
+        torch.manual_seed(43)
+        imf = build('IMF', ds, dropout=0.3, feature_ratio=0.5, ranking_metric='sort')
+        fi, fv = _coo(imf.feat_mat)
+        assert np.array_equal(fi, g['igcn_r50s_feat_indices']) and np.array_equal(fv, g['igcn_r50s_feat_values_a0'])
+        g['imf_state_keys'] = np.array(list(imf.state_dict().keys()))
+
+        np.savez_compressed(os.path.join(OUT, toy + '_model.npz'), **g)
+        print('wrote', toy + '_model.npz', len(g), 'arrays')
+
+    # the two gspmm callers really are out of reach, and nothing above went through the placeholder
+    assert _InertPlaceholder.touched == [], _InertPlaceholder.touched
+    try:
+        lg2 = build('LightGCN', ds)
+        lg2.get_rep()
+        raise SystemExit('get_rep ran without DGL?')
+    except AttributeError:
+        assert _InertPlaceholder.touched == ['graph']
+    print('dgl placeholder untouched by every recorded function; LightGCN.get_rep -> AttributeError(dgl.graph) as expected')
 
 
 def main():
@@ -365,4 +556,8 @@ def main():
 
 
 if __name__ == '__main__':
-    main()
+    if '--model' in sys.argv[1:]:          # only the model.py fixtures (the others are left byte-identical)
+        model_fixtures()
+    else:
+        main()
+        model_fixtures()
