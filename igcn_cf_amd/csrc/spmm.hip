@@ -378,7 +378,9 @@ __global__ __launch_bounds__(kBlock) void spmm_csr_scalar_kernel(
                     const uint64_t e = dr.edge_id ? (uint64_t)(uint32_t)dr.edge_id[p] : (uint64_t)p;
                     w = hash_counter(e, seed0, seed1) < dr.keep_below ? w / dr.keep_prob : 0.f;
                 }
-                if (j < d) acc = fmaf(w, x[(int64_t)col[p] * ldx + j], acc);
+                // as in the vector kernels: a zero-weight edge (masked source row, dropped edge) is not read —
+                // a masked source row may hold uninitialised memory (0 * NaN would poison the sum)
+                if (j < d && w != 0.f) acc = fmaf(w, x[(int64_t)col[p] * ldx + j], acc);
             }
             if (j < d) {
                 float rr = acc * ep.out_scale;

@@ -37,13 +37,41 @@ def csr_to_lists(rowptr, col):
     return [col[rowptr[u]:rowptr[u + 1]] for u in range(len(rowptr) - 1)]
 
 
+def _notifying(name):
+    def method(self, *args, **kw):
+        out = getattr(list, name)(self, *args, **kw)
+        self._changed()
+        return out
+    method.__name__ = name
+    return method
+
+
+class _SplitLists(list):
+    """The list-of-lists of one split.  Mutating the OUTER list — dataset.test_data[user] = [...], the reference's
+    own idiom (trainer.py:183-216, run/dropui/dataset_dropui.py:13-21) — invalidates the split's cached CSR / device
+    views by itself.  Editing an inner list in place (dataset.test_data[user].append(i)) is not seen: call
+    dataset.invalidate(split)."""
+
+    def __init__(self, items, changed):
+        super().__init__(items)
+        self._changed = changed
+
+    for _n in ('__setitem__', '__delitem__', '__iadd__', '__imul__', 'append', 'extend', 'insert', 'pop', 'remove',
+               'clear', 'sort', 'reverse'):
+        locals()[_n] = _notifying(_n)
+    del _n
+
+    def __reduce__(self):                      # pickles / copies as a plain list
+        return (list, (list(self),))
+
+
 class BasicDataset:
     """Attribute contract of the reference's BasicDataset (dataset.py:47-64).
 
     train_data / val_data / test_data are properties: assigning a new list-of-lists bumps the split's
-    version (what the trainers key their device copies on) and drops its cached CSR views.  Code that
-    edits a list IN PLACE (dataset.test_data[user] = [], as trainer.py:183-184 does) must call
-    invalidate(which) afterwards."""
+    version (what the trainers key their device copies on) and drops its cached CSR views, and so does
+    assigning to / deleting from / appending to the list of a split (dataset.test_data[user] = [], as
+    trainer.py:183-184 does).  Only code that edits one user's INNER list in place must call invalidate(which)."""
 
     SPLITS = ('train', 'val', 'test')
 
@@ -63,8 +91,11 @@ class BasicDataset:
     def _get_list(self, name):
         return self._lists.get(name)
 
+    def _track(self, name, value):
+        return _SplitLists(value, lambda: self.invalidate(name))
+
     def _set_list(self, name, value):
-        self._lists[name] = value
+        self._lists[name] = self._track(name, value)
         self._drop_csr(name)
         self._version[name] += 1
 
@@ -242,7 +273,7 @@ class CsrBackedDataset(BasicDataset):
 
     def _get_list(self, name):
         if name not in self._lists:
-            self._lists[name] = csr_to_lists(*self._csr[(name, False)])
+            self._lists[name] = self._track(name, csr_to_lists(*self._csr[(name, False)]))
         return self._lists[name]
 
     def csr(self, which, sort=True):

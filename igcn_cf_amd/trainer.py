@@ -178,34 +178,65 @@ class BasicTrainer:
 
     # ---- one optimisation step as ONE captured HIP graph (config key 'hip_graph', default True) -----------------
     def _graph_wanted(self):
-        return bool(self.config.get('hip_graph', True)) and not getattr(self, '_graph_failed', False)
+        """Steps are captured unless the config says 'hip_graph': False or the optimizer cannot sit in a graph: torch's
+        Adam reads its step count on the host unless built capturable (initialize_optimizer does that); SGD has no host
+        state.  Decided up front — nothing raised during a capture is ever swallowed."""
+        if not self.config.get('hip_graph', True) or self.opt is None:
+            return False
+        if isinstance(self.opt, Adam):
+            return all(g.get('capturable', False) for g in self.opt.param_groups)
+        return isinstance(self.opt, SGD)
+
+    _tokens = iter(range(1, 1 << 62))
+
+    @classmethod
+    def _token(cls, obj):
+        """A number that identifies `obj` for good (id() can come back after the object is freed)."""
+        if obj is None:
+            return 0
+        tok = getattr(obj, '_igcn_token', None)
+        if tok is None:
+            tok = next(cls._tokens)
+            obj._igcn_token = tok
+        return tok
 
     def _graph_key(self):
-        m = self.model                       # a swapped graph / feature matrix / optimizer means new pointers: capture again
-        return (id(getattr(m, 'norm_adj', None)), id(getattr(m, 'feat_mat', None)), id(self.opt), self.batch_size)
+        """Everything a captured step bakes in as pointers or launch constants: a swapped graph / feature matrix /
+        optimizer, or a changed dropout rate, regulariser weight or learning rate, captures again."""
+        m = self.model
+        return (self._token(getattr(m, 'norm_adj', None)), self._token(getattr(m, 'feat_mat', None)), self._token(self.opt),
+                self.batch_size, getattr(m, 'dropout', None), bool(m.training), getattr(self, 'l2_reg', None),
+                getattr(self, 'aux_reg', None), tuple(float(g['lr']) for g in self.opt.param_groups))
 
     def _graph_step(self, inputs, loss_fn, kind='nodes'):
         """Replays the captured step on `inputs` (tensors copied into the static buffers the graph reads); captures
-        it first when there is none for the current model state.  Returns the loss tensor, or None when capture is not
-        possible here (the caller then runs the step eagerly — same kernels, launched one by one)."""
+        it first when there is none for the current model / trainer state.  Returns the loss tensor.  An error raised
+        while capturing is the caller's: the parameters, the optimizer state and the seeds are put back first."""
         key = self._graph_key() + (kind,)
         if getattr(self, '_graph', None) is None or self._graph_for != key:
-            try:
-                self._capture_step(inputs, loss_fn)
-                self._graph_for = key
-            except Exception as e:           # e.g. an optimizer that cannot be captured
-                self._graph, self._graph_failed = None, True
-                print('hip_graph: capture failed (%r); steps are launched eagerly' % (e,), file=sys.stderr)
-                return None
+            self._graph = None
+            self._capture_step(inputs, loss_fn)
+            self._graph_for = key
         for st, t in zip(self._static_inputs, inputs):
             st.copy_(t)
         self._graph.replay()
         return self._static_loss.clone()
 
+    def _seed_for_step(self, graph):
+        """Dropout seeds of a model that drops edges (IGCN / IMF): a captured step must read its seed from device
+        memory — a host seed would be baked into the graph and every replay would drop the same edges — so the seed
+        moves there and is advanced before EVERY step, captured or not, from the same CPU-generator sequence the
+        eager path draws (model.py:263-267 draws per get_rep call)."""
+        m = self.model
+        if hasattr(m, 'advance_dropout_seed'):
+            if graph:
+                m.use_device_seed()
+            m.advance_dropout_seed()
+
     def _capture_step(self, inputs, loss_fn):
         """Warm-up steps (lazy initialisation, workspaces) on a side stream, then the capture.  The warm-up is made
         invisible: parameters, optimizer state, the CPU generator the dropout seeds come from and the device seed are
-        put back, so a run with hip_graph follows the run without it."""
+        put back — also when the warm-up or the capture raises — so a run with hip_graph follows the run without it."""
         self._static_inputs = [t.clone() for t in inputs]
         params = [p for g in self.opt.param_groups for p in g['params']]
         saved_p = [p.detach().clone() for p in params]
@@ -214,36 +245,48 @@ class BasicTrainer:
         rng = torch.get_rng_state()
         seed_dev = getattr(self.model, '_seed_dev', None)
         saved_seed = seed_dev.clone() if seed_dev is not None else None
+
+        def put_back():
+            with torch.no_grad():
+                for p, sp in zip(params, saved_p):
+                    p.copy_(sp)
+                for p in params:
+                    for k, v in self.opt.state.get(p, {}).items():
+                        if torch.is_tensor(v):
+                            old = saved_s.get(id(p), {}).get(k)
+                            v.copy_(old) if old is not None else v.zero_()
+                if saved_seed is not None:
+                    seed_dev.copy_(saved_seed)
+            torch.set_rng_state(rng)
+            self.opt.zero_grad(set_to_none=True)
+
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                if hasattr(self.model, 'advance_dropout_seed'):
-                    self.model.advance_dropout_seed()
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    if hasattr(self.model, 'advance_dropout_seed'):
+                        self.model.advance_dropout_seed()
+                    loss = loss_fn(*self._static_inputs)
+                    self.opt.zero_grad()
+                    loss.backward()
+                    self.opt.step()
+                    del loss                  # no autograd graph of the warm-up (its AccumulateGrad nodes) outlives it
+        finally:
+            torch.cuda.current_stream().wait_stream(side)
+            put_back()
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph):
                 loss = loss_fn(*self._static_inputs)
-                self.opt.zero_grad()
                 loss.backward()
                 self.opt.step()
-                del loss                      # no autograd graph of the warm-up (its AccumulateGrad nodes) outlives it
-        torch.cuda.current_stream().wait_stream(side)
-        with torch.no_grad():
-            for p, sp in zip(params, saved_p):
-                p.copy_(sp)
-            for p in params:
-                for k, v in self.opt.state[p].items():
-                    if torch.is_tensor(v):
-                        old = saved_s.get(id(p), {}).get(k)
-                        v.copy_(old) if old is not None else v.zero_()
-            if saved_seed is not None:
-                seed_dev.copy_(saved_seed)
-        torch.set_rng_state(rng)
-        self.opt.zero_grad(set_to_none=True)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            loss = loss_fn(*self._static_inputs)
-            loss.backward()
-            self.opt.step()
-            self._static_loss = loss.detach()
+                self._static_loss = loss.detach()
+        except BaseException:
+            torch.cuda.synchronize()
+            put_back()
+            raise
+        self._graph = graph
 
     def train_one_epoch(self):
         raise NotImplementedError
@@ -369,7 +412,8 @@ class BasicTrainer:
 
     def _eval_lists_device(self, val_or_test):
         """Device CSR of the evaluated lists (rowptr, sorted items, lengths); rebuilt only when the
-        split's version changed.  In-place edits of the lists need dataset.invalidate(split)."""
+        split's version changed (assignment to the split or to one of its users' entries bumps it by itself;
+        only an edit INSIDE one user's list needs dataset.invalidate(split))."""
         key = ('eval', val_or_test) + self._split_version(val_or_test)
         if self._excl_cache.get('eval_key') != key or None in key:
             rp, cl = _sorted_csr_device([self.dataset.csr(val_or_test, sort=False)], self.dataset.n_items, self.device)
@@ -491,10 +535,10 @@ class BPRTrainer(BasicTrainer):
         """One optimisation step on an int64 [B, 3] batch; returns the loss tensor.  Full-size batches replay one
         captured HIP graph like node_step (MF has no node-id path), unless the loss needs a collective (a
         column-sharded model) or the config says 'hip_graph': False."""
-        if self._graph_wanted() and inputs.shape[0] == self.batch_size and getattr(self.model, 'slice_reduce_fn', None) is None:
-            loss = self._graph_step((inputs,), self._triplet_loss, kind='triplets')
-            if loss is not None:
-                return loss
+        graph = self._graph_wanted() and getattr(self.model, 'slice_reduce_fn', None) is None
+        self._seed_for_step(graph)
+        if graph and inputs.shape[0] == self.batch_size:
+            return self._graph_step((inputs,), self._triplet_loss, kind='triplets')
         return self._optimise_loss(self._triplet_loss(inputs))
 
     def _triplet_loss(self, inputs):
@@ -514,10 +558,10 @@ class BPRTrainer(BasicTrainer):
         trainer config says 'hip_graph': False — what a launch-bound step needs (Gowalla-size LightGCN, IMF: -20...-25 %);
         a GPU-bound step pays ~1 % for the copies into the static buffers (profiles/r02n_*)."""
         loss_fn = lambda n: self.model.bpr_loss_nodes(n, self.l2_reg)
-        if self._graph_wanted() and nodes.numel() == 3 * self.batch_size:
-            loss = self._graph_step((nodes,), loss_fn)
-            if loss is not None:
-                return loss
+        graph = self._graph_wanted()
+        self._seed_for_step(graph)
+        if graph and nodes.numel() == 3 * self.batch_size:
+            return self._graph_step((nodes,), loss_fn)
         return self._optimise_loss(loss_fn(nodes))
 
     def train_one_epoch(self):
@@ -570,13 +614,9 @@ class IGCNTrainer(BasicTrainer):
         (IGCN.use_device_seed) and is advanced before every step, captured or not — the same sequence of seeds as
         the eager path draws."""
         graph = self._graph_wanted()
-        if graph:
-            self.model.use_device_seed()
-        self.model.advance_dropout_seed()
+        self._seed_for_step(graph)
         if graph and nodes.numel() == 3 * self.batch_size and aux_inputs.shape[0] == self.batch_size:
-            loss = self._graph_step((nodes, aux_inputs), self._igcn_loss)
-            if loss is not None:
-                return loss
+            return self._graph_step((nodes, aux_inputs), self._igcn_loss)
         return self._igcn_optimise(None, aux_inputs, self.model.bpr_loss_nodes(nodes, self.l2_reg))
 
     def _igcn_loss(self, nodes, aux_inputs):

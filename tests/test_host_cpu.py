@@ -254,10 +254,12 @@ def test_split_versions_track_list_changes(golden):
         assert ds.version('test') == v['test'] + 1 and ds.version('train') == v['train']
         rp1, _ = ds.csr('test', sort=True)
         assert rp1[1] == 0 and rp1[-1] == rp0[-1] - (rp0[1] - rp0[0])
-        ds.test_data[1] = []                                             # in place: needs invalidate()
-        ds.invalidate('test')
+        ds.test_data[1] = []                                             # entry assignment: seen by itself
         assert ds.version('test') == v['test'] + 2 and ds.version('val') == v['val']
         assert ds.csr('test', sort=True)[0][2] == 0
+        ds.test_data[2].clear()                                          # inside one user's list: needs invalidate()
+        ds.invalidate('test')
+        assert ds.version('test') == v['test'] + 3 and ds.csr('test', sort=True)[0][3] == 0
 
 
 def test_batch_seeds_are_mixed():
@@ -381,3 +383,48 @@ def test_trainer_constructor_states_the_scorer_limits():
     m = Model(); m.embedding_size = 192
     with pytest.raises(ValueError, match='embedding_size'):
         BasicTrainer(dict(cfg, model=m))
+
+
+def test_utils_entry_points(golden, tmp_path):
+    """The reference's utils.py entry points run scripts call (utils.py:12-29, :41-49, :138-151)."""
+    import random
+    import sys
+    from igcn_cf_amd import utils
+    utils.set_seed(5)
+    a = (random.random(), np.random.rand(), float(torch.rand(1)))
+    utils.set_seed(5)
+    assert a == (random.random(), np.random.rand(), float(torch.rand(1))) and os.environ['PYTHONHASHSEED'] == '5'
+
+    class DS:
+        n_users, n_items, train_array = int(golden['n_users']), int(golden['n_items']), golden['train_array']
+    rowptr, col, val = utils.generate_daj_mat(DS())
+    np.testing.assert_array_equal(rowptr, golden['adj_indptr'])
+    np.testing.assert_array_equal(col, golden['adj_indices'])
+    np.testing.assert_array_equal(val, golden['adj_data'])
+    out, err = sys.stdout, sys.stderr
+    try:
+        utils.init_run(str(tmp_path / 'log'), 7)
+        print('hello log')
+    finally:
+        f = sys.stdout
+        sys.stdout, sys.stderr = out, err
+        f.close()
+    assert open(tmp_path / 'log' / 'log.txt').read() == 'hello log\n'
+
+
+def test_split_lists_invalidate_themselves(golden):
+    from igcn_cf_amd.dataset import get_dataset
+    ds = get_dataset({'name': 'ProcessedDataset', 'path': golden['path'], 'device': 'cpu'})
+    v0 = ds.version('test')
+    rp0, col0 = ds.csr('test')
+    u = int(np.flatnonzero(np.diff(rp0) > 0)[0])
+    ds.test_data[u] = []                                       # the reference's idiom (trainer.py:183-184)
+    assert ds.version('test') == v0 + 1 and ds.version('train') == ds.version('train')
+    rp1, _ = ds.csr('test')
+    assert rp1[u + 1] == rp1[u] and rp1[-1] == rp0[-1] - (rp0[u + 1] - rp0[u])
+    ds.test_data.append([1, 2])
+    assert ds.version('test') == v0 + 2
+    ds.test_data.pop()
+    assert isinstance(ds.test_data[:3], list) and ds.test_data[:3] == [list(x) for x in ds.test_data[:3]]
+    import copy
+    assert type(copy.deepcopy(ds.test_data)) is list

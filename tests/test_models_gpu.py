@@ -614,3 +614,108 @@ def test_captured_step_is_recaptured_when_the_graph_is_swapped(golden):
     assert np.allclose(runs[0][0], runs[1][0], atol=2e-5)
     diff = np.abs(runs[0][1] - runs[1][1])
     assert diff.max() < 5e-3 and np.mean(diff > 1e-5) < 2e-2
+
+
+@pytest.mark.parametrize('name', ['IGCN', 'IMF'])
+def test_bpr_trainer_with_a_dropout_model_draws_a_new_mask_every_replay(golden, name):
+    """BPRTrainer (not IGCNTrainer) on IGCN / IMF with dropout > 0: the captured step reads the dropout seed from
+    device memory and the trainer advances it before every step — two replays on the SAME batch drop different edges
+    (different losses), and the captured run follows the eager one, which draws the same seed sequence."""
+    from igcn_cf_amd.model import get_model
+    from igcn_cf_amd.trainer import get_trainer
+    ds = _dataset(golden)
+    mcfg = {'name': name, 'embedding_size': 64, 'n_layers': 2, 'device': 'cuda', 'dropout': 0.4, 'feature_ratio': 1.}
+    tcfg = {'name': 'BPRTrainer', 'optimizer': 'Adam', 'lr': 0., 'l2_reg': 1e-3, 'device': 'cuda', 'n_epochs': 1,
+            'batch_size': 32, 'dataloader_num_workers': 0, 'test_batch_size': 64, 'topks': [5], 'seed': 9}
+    runs = []
+    for hip_graph in (True, False):
+        torch.manual_seed(3)
+        model = get_model(dict(mcfg), ds)
+        trainer = get_trainer(dict(tcfg, hip_graph=hip_graph), ds, model)
+        model.train()
+        batch = next(iter(trainer.sampler.epoch_node_batches(32, ds.n_users)))
+        torch.manual_seed(11)
+        losses = [float(trainer.node_step(batch)) for _ in range(4)]          # lr = 0: only the mask differs between steps
+        assert (trainer._graph is not None) == hip_graph
+        assert len({round(x, 7) for x in losses}) == 4, losses
+        runs.append(losses)
+    assert np.allclose(runs[0], runs[1], atol=2e-6), runs
+    # the triplet-batch entry point (bpr_step) as well
+    torch.manual_seed(3)
+    model = get_model(dict(mcfg), ds)
+    trainer = get_trainer(dict(tcfg), ds, model)
+    model.train()
+    inputs = next(iter(trainer.sampler.epoch_batches(32)))
+    losses = [float(trainer.bpr_step(inputs)) for _ in range(3)]
+    assert trainer._graph is not None and len({round(x, 7) for x in losses}) == 3
+
+
+def test_captured_step_follows_changed_hyperparameters_and_capture_errors_surface(golden):
+    """What a captured step bakes in as launch constants is part of its key: a changed l2_reg / dropout / lr captures
+    again.  An optimizer that cannot sit in a graph is launched eagerly (decided up front); an error raised while
+    capturing is NOT swallowed, and the parameters are where they were before the attempt."""
+    from igcn_cf_amd.model import get_model
+    from igcn_cf_amd.trainer import get_trainer
+    ds = _dataset(golden)
+    tcfg = {'name': 'BPRTrainer', 'optimizer': 'Adam', 'lr': 1e-2, 'l2_reg': 1e-3, 'device': 'cuda', 'n_epochs': 1,
+            'batch_size': 32, 'dataloader_num_workers': 0, 'test_batch_size': 64, 'topks': [5], 'seed': 9}
+    torch.manual_seed(3)
+    model = get_model({'name': 'LightGCN', 'embedding_size': 32, 'n_layers': 2, 'device': 'cuda'}, ds)
+    trainer = get_trainer(dict(tcfg), ds, model)
+    model.train()
+    batch = next(iter(trainer.sampler.epoch_node_batches(32, ds.n_users)))
+    l_a = float(trainer.node_step(batch)); g_a = trainer._graph
+    trainer.l2_reg = 10.
+    l_b = float(trainer.node_step(batch))
+    assert trainer._graph is not g_a and l_b > l_a + 0.01                      # the new weight is in the loss
+    g_b = trainer._graph
+    for grp in trainer.opt.param_groups:
+        grp['lr'] = 0.
+    before = model.embedding.weight.detach().clone()
+    trainer.node_step(batch)
+    assert trainer._graph is not g_b and torch.equal(before, model.embedding.weight.detach())   # lr = 0 took effect
+    # an Adam that is not capturable: eager, no attempt
+    model2 = get_model({'name': 'LightGCN', 'embedding_size': 32, 'n_layers': 2, 'device': 'cuda'}, ds)
+    t2 = get_trainer(dict(tcfg, fused_optimizer=False), ds, model2)
+    model2.train()
+    t2.node_step(batch)
+    assert t2._graph is None and not t2._graph_wanted()
+    # an error inside the captured region surfaces, parameters and optimizer state restored
+    model3 = get_model({'name': 'LightGCN', 'embedding_size': 32, 'n_layers': 2, 'device': 'cuda'}, ds)
+    t3 = get_trainer(dict(tcfg), ds, model3)
+    model3.train()
+    p0 = model3.embedding.weight.detach().clone()
+    calls = {'n': 0}
+    real = model3.bpr_loss_nodes
+
+    def flaky(nodes, l2_reg):
+        calls['n'] += 1
+        if calls['n'] == 4:                                  # 3 warm-up calls, then the one inside the capture
+            raise RuntimeError('boom inside capture')
+        return real(nodes, l2_reg)
+    model3.bpr_loss_nodes = flaky
+    with pytest.raises(RuntimeError, match='boom inside capture'):
+        t3.node_step(batch)
+    assert t3._graph is None and torch.equal(p0, model3.embedding.weight.detach())
+    model3.bpr_loss_nodes = real
+    assert np.isfinite(float(t3.node_step(batch))) and t3._graph is not None    # and the trainer still works
+
+
+def test_assignment_to_a_split_entry_reaches_the_next_evaluation(golden):
+    """dataset.test_data[user] = [...] — the reference's own idiom (trainer.py:183-216) — is seen by the next eval
+    without an invalidate() call."""
+    from igcn_cf_amd.model import get_model
+    from igcn_cf_amd.trainer import get_trainer
+    ds = _dataset(golden)
+    torch.manual_seed(0)
+    model = get_model({'name': 'MF', 'embedding_size': 16, 'device': 'cuda'}, ds)
+    trainer = get_trainer({'name': 'BasicTrainer', 'device': 'cuda', 'n_epochs': 0, 'topks': [5], 'test_batch_size': 64,
+                           'host_metrics': True}, ds, model)
+    _, m0 = trainer.eval('test')
+    rec = trainer.last_rec_items.cpu().numpy()
+    for u in range(ds.n_users):
+        ds.test_data[u] = [int(rec[u, 0])]                   # every user's test list = the first recommendation
+    _, m1 = trainer.eval('test')
+    assert m1['Recall'][5] == 1.0 and m0['Recall'][5] < 1.0
+    ref = O.calculate_metrics(ds.test_data, rec, [5])
+    assert m1['NDCG'][5] == ref['NDCG'][5]

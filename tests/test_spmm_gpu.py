@@ -429,3 +429,25 @@ def test_dropout_seed_from_device_memory_matches_the_launch_argument():
     assert not torch.equal(outs[0], outs[1])
     with pytest.raises(_lib.IgcnError):
         spmm(csr, x, keep_prob=0.6, seed=torch.zeros(1, dtype=torch.int32, device='cuda'))
+
+
+@pytest.mark.parametrize('d', [64, 6])
+def test_col_mask_never_reads_masked_source_rows(d):
+    """col_mask: a source row whose bit is clear is NOT read — it may hold uninitialised memory (the first backward
+    hop of a training step leaves rows outside the batch's neighbourhood unwritten).  NaNs in the masked rows must
+    not reach the result, on the vector path (d = 64) and on the scalar path for odd shapes (d = 6)."""
+    from igcn_cf_amd.graph import CsrMatrix
+    from igcn_cf_amd.ops import pack_mask_bits, spmm
+    rng = np.random.default_rng(3)
+    n_rows, n_cols = 200, 150
+    rowptr, col, val = _random_csr(rng, n_rows, n_cols, rng.integers(0, 30, size=n_rows))
+    x = rng.standard_normal((n_cols, d)).astype(np.float32)
+    keep = rng.random(n_cols) < 0.5
+    x_clean = x * keep[:, None]
+    x_dirty = x.copy()
+    x_dirty[~keep] = np.nan
+    csr = CsrMatrix(rowptr, col, val, (n_rows, n_cols), 'cuda')
+    bits = pack_mask_bits(torch.from_numpy(keep.astype(np.uint8)).cuda())
+    y = spmm(csr, torch.from_numpy(x_dirty).cuda(), col_mask=bits).cpu().numpy()
+    assert np.isfinite(y).all()
+    assert _rel_err(y, _oracle(rowptr, col, val, x_clean, n_rows)) < TOL
