@@ -92,7 +92,7 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     from igcn_cf_amd.dataset import SyntheticDataset
-    from igcn_cf_amd.graph import CsrMatrix, normalized_adjacency_host
+    from igcn_cf_amd.graph import XCD_PLAN, CsrMatrix, normalized_adjacency_host
     from igcn_cf_amd import ops
 
     ds = SyntheticDataset({'name': 'SyntheticDataset', 'preset': args.preset, 'seed': 2021, 'device': device})
@@ -116,7 +116,7 @@ def main():
         return float(t.item())
 
     if not sharded:
-        csr = CsrMatrix(rowptr, col, val, (n, n), device, order_blocks=[0, ds.n_users, n])
+        csr = CsrMatrix(rowptr, col, val, (n, n), device, order_blocks=[0, ds.n_users, n], xcd_plan=XCD_PLAN)   # what LightGCN.generate_graph builds
         x0 = emb_host.to(device)
         step = lambda: ops.propagate_mean(csr, x0, K)
         local_nnz, local_rows, launches_per_step = nnz, n, K
@@ -291,12 +291,12 @@ def uniform_graph_pass(device, preset, d, K):
     """The same pass on a graph of the same size whose items are drawn uniformly (zipf_a = 0): no hot item rows for L2
     to keep, no long rows — the worst-case locality variant SURVEY 8(d) asks for next to the popularity-skewed headline."""
     from igcn_cf_amd.dataset import SyntheticDataset
-    from igcn_cf_amd.graph import CsrMatrix, normalized_adjacency_host
+    from igcn_cf_amd.graph import XCD_PLAN, CsrMatrix, normalized_adjacency_host
     from igcn_cf_amd import ops
     ds = SyntheticDataset({'name': 'SyntheticDataset', 'preset': preset, 'seed': 2021, 'device': device, 'zipf_a': 0.0})
     n = ds.n_users + ds.n_items
     rowptr, col, val = normalized_adjacency_host(ds.train_array, ds.n_users, ds.n_items)
-    csr = CsrMatrix(rowptr, col, val, (n, n), device, order_blocks=[0, ds.n_users, n])
+    csr = CsrMatrix(rowptr, col, val, (n, n), device, order_blocks=[0, ds.n_users, n], xcd_plan=XCD_PLAN)
     x = torch.randn(n, d, device=device) * 0.1
     ms = time_ms(lambda: ops.propagate_mean(csr, x, K), 50, 5)
     nnz = int(rowptr[-1])

@@ -30,7 +30,7 @@ SIGNATURES = {
     'igcn_spmm_csr_f32': (C.c_int, [vp, vp, vp, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                     C.c_float, C.POINTER(vp), C.c_int32, C.c_float, vp, vp,
                                     vp, C.c_int64, vp, C.c_int64, vp, C.c_int32,
-                                    vp, C.c_uint64, C.c_float, vp, C.c_int32, C.c_int64, vp, vp, vp, vp]),
+                                    vp, C.c_uint64, C.c_float, vp, C.c_int32, C.c_int64, vp, vp, vp, vp, vp]),
     'igcn_mark_rows': (C.c_int, [vp, C.c_int64, vp, vp, vp, vp, C.c_int64, vp]),
     'igcn_pack_mask_bits': (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int32, vp, vp]),
     'igcn_csr_from_sorted_coo': (C.c_int, [vp, C.c_int64, C.c_int64, vp, vp]),

@@ -55,13 +55,40 @@ struct SpmmDropout {
 
 #ifdef IGCN_SPMM_TRACE
 // Developer build only (scripts/dev_spmm_trace.py): [begin, end] of every wave in s_memrealtime ticks (100 MHz)
-__device__ unsigned long long g_spmm_wave_times[6 * 16384];   // begin, end, HW_ID, rows, nonzeros, 64-entry chunks
+__device__ unsigned long long g_spmm_wave_times[6 * 131072];   // begin, end, HW_ID, rows, nonzeros, 64-entry chunks
 __device__ __forceinline__ unsigned long long spmm_realtime() {
     unsigned long long t;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");
     return t;
 }
 #endif
+
+// The part of the dealing order a wave walks: entries first, first + stride, ... < end, `per_wave` consecutive entries
+// at a time.  Without xcd_off: the whole order, waves of the grid interleaved.  With xcd_off (int64 [9], device): the
+// order is 8 lists back to back, list x = [xcd_off[x], xcd_off[x + 1]), and a workgroup walks list blockIdx.x % 8 only,
+// interleaved with the other workgroups of that residue.  Workgroups b and b + 8 share an XCD under the hardware's
+// round-robin placement, so the work of one list goes through ONE 4 MiB L2: the host puts into a list the rows and row
+// segments that gather from the same slice of the operand (graph.py: xcd plan).  Placement is a speed assumption only —
+// every entry is computed exactly once wherever its workgroup runs.
+struct DealRange { int64_t first, end, stride; };
+__device__ __forceinline__ DealRange deal_range(const int64_t *__restrict__ xcd_off, int64_t n_virtual, int per_wave)
+{
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    DealRange r;
+    if (xcd_off) {
+        const int x = blockIdx.x & 7;
+        const int64_t blocks_x = ((int64_t)gridDim.x - x + 7) >> 3;          // workgroups with this residue
+        const int64_t wave_x = (int64_t)(blockIdx.x >> 3) * (kBlock / kWave) + wave_in_block;
+        r.first = xcd_off[x] + wave_x * per_wave;
+        r.end = xcd_off[x + 1];
+        r.stride = blocks_x * (kBlock / kWave) * per_wave;
+    } else {
+        r.first = ((int64_t)blockIdx.x * (kBlock / kWave) + wave_in_block) * per_wave;
+        r.end = n_virtual;
+        r.stride = (int64_t)gridDim.x * (kBlock / kWave) * per_wave;
+    }
+    return r;
+}
 
 // 80 scalar registers at most: a wave is charged its SGPRs + 16 (rounded up to 16) out of 800 per SIMD, so 80 is
 // the most that still lets 8 waves share a SIMD; without the cap the d = 32 variant took 100 and ran 6 (-15 %).
@@ -72,16 +99,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
     int64_t n_rows, int d, SpmmEpilogue ep, SpmmDropout dr,
     const igcn_row_segment *__restrict__ segments, int64_t n_segments,
     float *__restrict__ partial, int long_threshold,
-    const uint8_t *__restrict__ row_mask, int masked_rows_zero, const int32_t *__restrict__ row_order)
+    const uint8_t *__restrict__ row_mask, int masked_rows_zero, const int32_t *__restrict__ row_order,
+    const int64_t *__restrict__ xcd_off)
 {
     constexpr int G = kWave / LPR;           // source rows per gather instruction
     const int lane = threadIdx.x & (kWave - 1);
     const int g = lane / LPR;
     const int t = lane % LPR;
     const bool lane_on = (4 * t) < d;
-    const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)));
-    const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
     const int64_t n_virtual = n_rows + n_segments;
+    const DealRange deal = deal_range(xcd_off, n_virtual, 1);
     const uint32_t seed0 = DROPOUT && dr.seed_words ? dr.seed_words[0] : dr.s0;
     const uint32_t seed1 = DROPOUT && dr.seed_words ? dr.seed_words[1] : dr.s1;
 #ifdef IGCN_SPMM_TRACE
@@ -89,7 +116,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
     unsigned long long tr_rows = 0, tr_nnz = 0, tr_chunks = 0;
 #endif
 
-    for (int64_t vv = wave0; vv < n_virtual; vv += n_waves) {
+    for (int64_t vv = deal.first; vv < deal.end; vv += deal.stride) {
         int64_t start, end, dst;
         bool to_partial;
         const int64_t v = row_order ? (int64_t)row_order[vv] : vv;
@@ -181,7 +208,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
         }
     }
 #ifdef IGCN_SPMM_TRACE
-    if (lane == 0 && wave0 < 16384) {
+    const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)));
+    if (lane == 0 && wave0 < 131072) {
         g_spmm_wave_times[6 * wave0] = tr_begin;
         g_spmm_wave_times[6 * wave0 + 1] = spmm_realtime();
         g_spmm_wave_times[6 * wave0 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
@@ -203,7 +231,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
     int64_t n_rows, int d, SpmmEpilogue ep, SpmmDropout dr,
     const igcn_row_segment *__restrict__ segments, int64_t n_segments,
     float *__restrict__ partial, int long_threshold,
-    const uint8_t *__restrict__ row_mask, int masked_rows_zero, const int32_t *__restrict__ row_order)
+    const uint8_t *__restrict__ row_mask, int masked_rows_zero, const int32_t *__restrict__ row_order,
+    const int64_t *__restrict__ xcd_off)
 {
     constexpr int S = kWave / R;             // lanes of a sub-wave
     constexpr int G = S / LPR;               // source rows per gather instruction and sub-wave
@@ -214,15 +243,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
     const int g = sl / LPR;
     const int t = sl % LPR;
     const bool lane_on = (4 * t) < d;
-    const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)));
-    const int64_t n_waves = (int64_t)gridDim.x * (kBlock / kWave);
     const int64_t n_virtual = n_rows + n_segments;
+    const DealRange deal = deal_range(xcd_off, n_virtual, R);
     const uint32_t seed0 = DROPOUT && dr.seed_words ? dr.seed_words[0] : dr.s0;
     const uint32_t seed1 = DROPOUT && dr.seed_words ? dr.seed_words[1] : dr.s1;
+#ifdef IGCN_SPMM_TRACE
+    const unsigned long long tr_begin = spmm_realtime();
+    unsigned long long tr_rows = 0, tr_nnz = 0;
+#endif
 
-    for (int64_t vb = wave0 * R; vb < n_virtual; vb += n_waves * R) {
+    for (int64_t vb = deal.first; vb < deal.end; vb += deal.stride) {
         const int64_t vv = vb + lane / S;                         // this sub-wave's entry of the dealing order
-        const int64_t v = (row_order && vv < n_virtual) ? (int64_t)row_order[vv] : vv;
+        const int64_t v = vv >= deal.end ? n_virtual : row_order ? (int64_t)row_order[vv] : vv;
         // kind: 0 nothing, 1 ordinary row -> y, 2 row segment -> partial, 3 masked row that must read as zero
         int64_t start = 0, dst = 0;
         int len = 0, kind = 0;
@@ -239,6 +271,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
             kind = masked ? 0 : 2;
         }
         if (kind != 1 && kind != 2) len = 0;
+#ifdef IGCN_SPMM_TRACE
+        if (sl == 0) { tr_rows += kind != 0; tr_nnz += len; }
+#endif
 
         float4 acc = f4_zero();
         for (int off = 0; __any(off < len); off += S) {
@@ -301,6 +336,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
             }
         }
     }
+#ifdef IGCN_SPMM_TRACE
+    {
+        const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)));
+        unsigned long long rows_w = tr_rows, nnz_w = tr_nnz;
+        for (int o = S; o < kWave; o <<= 1) { rows_w += __shfl_xor(rows_w, o); nnz_w += __shfl_xor(nnz_w, o); }
+        if (lane == 0 && wave0 < 131072) {
+            g_spmm_wave_times[6 * wave0] = tr_begin;
+            g_spmm_wave_times[6 * wave0 + 1] = spmm_realtime();
+            g_spmm_wave_times[6 * wave0 + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) |
+                                               ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32);
+            g_spmm_wave_times[6 * wave0 + 3] = rows_w; g_spmm_wave_times[6 * wave0 + 4] = nnz_w; g_spmm_wave_times[6 * wave0 + 5] = 0;
+        }
+    }
+#endif
 }
 
 // Adds the partial sums of each long row and applies the epilogue.  One wave per
@@ -474,7 +523,7 @@ static int launch_rows(bool dropout, int64_t blocks, hipStream_t st,
                        float *y, int64_t ldy, int64_t n_rows, int d, const SpmmEpilogue &ep, const SpmmDropout &dr,
                        const igcn_row_segment *segments, int64_t n_segments, float *partial, int long_threshold,
                        const igcn_long_row *long_rows, int64_t n_long, const uint8_t *row_mask, int masked_rows_zero,
-                       int64_t nnz, const int32_t *row_order)
+                       int64_t nnz, const int32_t *row_order, const int64_t *xcd_off)
 {
     // Grid: `blocks` on entry = one wave per row.  Fewer, longer-lived waves amortise the per-wave set-up;
     // many short ones let the hardware dispatcher even out the load (a power-law graph deals very
@@ -500,6 +549,7 @@ static int launch_rows(bool dropout, int64_t blocks, hipStream_t st,
         if (want < fill) want = fill;
     }
     if (blocks > want) blocks = want;
+    if (xcd_off) blocks = (blocks + 7) / 8 * 8;                       // the same number of workgroups for every list
     const dim3 grid((unsigned)blocks);
     // rows a wave works on at once: 2 at d = 64 and 32 (-7 % / -23 %), 4 below (-17...-22 %; 8 was measured too: no
     // different — at d <= 16 the kernel then moves ~8 TB/s of 128-byte lines, the gather granularity, and is bound
@@ -510,17 +560,17 @@ static int launch_rows(bool dropout, int64_t blocks, hipStream_t st,
         if constexpr (R > 1) {
             if (dropout)
                 hipLaunchKernelGGL((spmm_csr_multirow_kernel<LPR, R, true>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y,
-                                   ldy, n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order);
+                                   ldy, n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order, xcd_off);
             else
                 hipLaunchKernelGGL((spmm_csr_multirow_kernel<LPR, R, false>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y,
-                                   ldy, n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order);
+                                   ldy, n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order, xcd_off);
         }
     } else if (dropout)
         hipLaunchKernelGGL((spmm_csr_rows_kernel<LPR, true>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
-                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order);
+                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order, xcd_off);
     else
         hipLaunchKernelGGL((spmm_csr_rows_kernel<LPR, false>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
-                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order);
+                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order, xcd_off);
     int rc = launch_status();
     if (rc != IGCN_OK) return rc;
     if (n_long > 0) {
@@ -594,7 +644,7 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
                                  const int32_t *edge_id, uint64_t seed, float keep_prob,
                                  const uint8_t *row_mask, int32_t masked_rows_zero,
                                  int64_t nnz, const int32_t *row_order, const uint32_t *col_mask,
-                                 const uint64_t *seed_dev, void *stream)
+                                 const uint64_t *seed_dev, const int64_t *xcd_off, void *stream)
 {
     if (!rowptr || !x || !y) return IGCN_E_NULL;
     if (n_rows < 0 || n_cols < 0 || d < 1 || d > 256 || ldx < d || ldy < d) return IGCN_E_SHAPE;
@@ -604,6 +654,7 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
     if ((n_long_rows > 0 || n_segments > 0) && (!long_rows || !segments || !partial || n_long_rows < 1 || n_segments < 1))
         return IGCN_E_NULL;
     if (n_segments > 0 && long_threshold < 1) return IGCN_E_RANGE;
+    if (xcd_off && !row_order) return IGCN_E_NULL;
     if (x == y) return IGCN_E_RANGE;     // in-place propagation would read rows being written
     if (n_rows == 0) return IGCN_OK;
     // col may be NULL only for a matrix without stored entries (rowptr all zero): it is never read then
@@ -642,7 +693,7 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
     for (int i = 0; i < n_adds && vec; ++i) vec = reinterpret_cast<uintptr_t>(ep.add[i]) % 16 == 0;
     if (n_segments > 0 && (reinterpret_cast<uintptr_t>(partial) % 16 != 0)) return IGCN_E_ALIGN;
     if (!vec) {
-        if (n_segments > 0 || row_mask || row_order) return IGCN_E_ALIGN;   // plan / row masks / row order need the vector path
+        if (n_segments > 0 || row_mask || row_order || xcd_off) return IGCN_E_ALIGN;   // plan / row masks / row order need the vector path
         hipLaunchKernelGGL(spmm_csr_scalar_kernel, scalar_grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
                            n_rows, (int)d, ep, dr, dropout);
         return launch_status();
@@ -650,7 +701,7 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
 #define IGCN_SPMM_CASE(L)                                                                                         \
     return launch_rows<L>(dropout, blocks, st, rowptr, col, val, x, ldx, y, ldy, n_rows, (int)d, ep, dr, segments,  \
                           n_segments, partial, (int)long_threshold, long_rows, n_long_rows, row_mask, (int)masked_rows_zero, \
-                          nnz, row_order)
+                          nnz, row_order, xcd_off)
     const int q = d / 4;
     if (q <= 1) IGCN_SPMM_CASE(1);
     if (q <= 2) IGCN_SPMM_CASE(2);

@@ -134,7 +134,7 @@ def _csr_from_keys_device(key, n_rows, n_cols):
     return rowptr, row, col, counts.to(torch.float32)
 
 
-def normalized_adjacency_device(train_array, n_users, n_items, device):
+def normalized_adjacency_device(train_array, n_users, n_items, device, xcd_plan='default'):
     """normalized_adjacency_host built in HBM (the graph-swap path of the inductive update, run/dropui/igcn_dropui.py:
     26-35, rebuilds the graph on a live model): one sort of the 2 T keys on the GPU instead of host argsorts.  Values
     are BIT-IDENTICAL to the host builder / model.py:85-94: degrees are small integers, so D^-1/2 comes from a table of
@@ -149,7 +149,8 @@ def normalized_adjacency_device(train_array, n_users, n_items, device):
     table = np.power(np.maximum(np.arange(max_deg + 1, dtype=np.float32), np.float32(1.)), np.float32(-0.5)).astype(np.float32)
     d_inv = torch.from_numpy(table).to(device)[degree.to(torch.int64)]
     val = (d_inv[row] * val) * d_inv[col.to(torch.int64)]
-    return CsrMatrix.from_device(rowptr, col, val, (n, n), order_blocks=[0, n_users, n])
+    return CsrMatrix.from_device(rowptr, col, val, (n, n), order_blocks=[0, n_users, n],
+                                 xcd_plan=XCD_PLAN if xcd_plan == 'default' else xcd_plan)
 
 
 def feature_matrix_device(train_array, n_users, n_items, user_map, item_map, device):
@@ -206,6 +207,147 @@ def graph_rank_nodes(dataset, ranking_metric):
     return np.argsort(metric[:n_users])[::-1].copy(), np.argsort(metric[n_users:])[::-1].copy()
 
 
+# Default plan of the propagation matrices (A_hat): rows above 112 nonzeros are cut at the slice boundaries.  Measured on
+# MI355X, same-process A/Bs against the round-2 dealing order (profiles/r03b_*, r03d_*): Amazon-like d = 64 -11 %, d = 128
+# -11 %, Yelp-like -16 %, Gowalla-like -26 %, d = 32 +-1 %; thresholds 96...160 within 2 % of each other, 64 and below lose
+# (8 partial rows per cut row).  None = the plain long-row plan.
+XCD_PLAN = {'threshold': 112}
+N_XCD = 8                  # lists of the XCD plan = XCDs of an MI355X (igcn_spmm_csr_f32: xcd_off has N_XCD + 1 entries)
+
+
+def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assign='affinity'):
+    """The XCD plan of a CSR matrix: the work of one SpMM launch cut into N_XCD lists, one per XCD, such that a list
+    gathers as much as possible from ONE slice of the operand — a slice (1/8 of the operand's rows) fits an XCD's 4 MiB
+    L2 where the whole operand does not, and the eight L2s are private (igcn_hip.h: xcd_off).
+
+    Per block of rows (for A_hat: the user rows, which gather item rows, then the item rows, which gather user rows):
+      * the block's column range is cut into N_XCD contiguous slices with equal numbers of gathers;
+      * a row with more than `slice_threshold` nonzeros is cut at the slice boundaries (columns are ascending inside
+        a row, so a slice is a contiguous run of its nonzeros) and each piece into segments of <= segment_len
+        nonzeros; a segment goes to the list of its slice.  Segments write partial sums that the long-row reduce
+        kernel adds up in slot order, exactly as for the plain long-row plan — up to 8 partial rows per cut row, which
+        only pays for rows of a hundred nonzeros or so (measured: profiles/r03b_*, r03d_*);
+      * a shorter row is computed whole by the list that holds most of its columns (assign='affinity'; 'spread' deals
+        them without looking), as long as that list's share of the block's work (nonzeros + row_cost per row) is not
+        exceeded; the overflow fills the lists that are short.
+    Inside a list: per block the segments first, then the rows by descending length (igcn_hip.h: row_order).
+
+    rowptr int64 [n_rows + 1], col int32/int64 [nnz]: torch tensors on ANY device — the plan is built where the matrix
+    lives (in HBM for the device builders: the inductive update rebuilds the graph on a live model).
+    Returns (long_rows int32 [n_long, 4], segments int32 [n_seg, 6] — the byte layouts of igcn_long_row /
+    igcn_row_segment —, row_order int32, xcd_off int64 [N_XCD + 1], load float64 [N_XCD]) on that device."""
+    dev = rowptr.device
+    i64 = dict(dtype=torch.int64, device=dev)
+    n_rows = rowptr.shape[0] - 1
+    lens = rowptr[1:] - rowptr[:-1]
+    cut = lens > slice_threshold
+    rp = rowptr.cpu().tolist() if len(blocks) <= 8 else None
+    seg_parts, per_block = [], []
+    empty = torch.zeros(0, **i64)
+    for lo, hi in zip(blocks[:-1], blocks[1:]):
+        e0, e1 = (rp[lo], rp[hi]) if rp is not None else (int(rowptr[lo]), int(rowptr[hi]))
+        rows = torch.arange(lo, hi, **i64)
+        whole = rows[~cut[lo:hi]]
+        if e1 == e0:
+            per_block.append((whole, torch.zeros_like(whole), torch.zeros(whole.shape[0], dtype=torch.float64, device=dev)))
+            continue
+        c = col[e0:e1].to(torch.int64)
+        cmin = int(c.min())
+        cum = torch.cumsum(torch.bincount(c - cmin), 0)
+        targets = (torch.arange(1, N_XCD, **i64).to(torch.float64) * (float(cum[-1]) / N_XCD))
+        bounds = cmin + 1 + torch.searchsorted(cum.to(torch.float64), targets)
+        sl = torch.searchsorted(bounds, c, right=True)                 # slice of every nonzero of the block, 0..N_XCD-1
+        row_e = torch.repeat_interleave(rows, lens[lo:hi])
+        in_cut = cut[row_e]
+        pos = e0 + torch.nonzero(in_cut).flatten()                     # nonzeros of the cut rows, in storage order
+        if pos.numel():
+            key = row_e[in_cut] * N_XCD + sl[in_cut]
+            first = torch.ones_like(key, dtype=torch.bool)
+            first[1:] = (key[1:] != key[:-1]) | (pos[1:] != pos[:-1] + 1)
+            fidx = torch.nonzero(first).flatten()
+            p_start, p_key = pos[fidx], key[fidx]
+            p_len = torch.diff(torch.cat([fidx, torch.tensor([key.shape[0]], **i64)]))
+            n_chunks = (p_len + segment_len - 1) // segment_len
+            rep = torch.repeat_interleave(torch.arange(p_start.shape[0], **i64), n_chunks)
+            within = torch.arange(rep.shape[0], **i64) - torch.repeat_interleave(torch.cumsum(n_chunks, 0) - n_chunks, n_chunks)
+            s_start = p_start[rep] + within * segment_len
+            s_len = torch.clamp(p_len[rep] - within * segment_len, max=segment_len)
+            seg_parts.append((s_start, s_len, p_key[rep] // N_XCD, p_key[rep] % N_XCD))
+        # rows that stay whole: nonzeros per slice -> the list they would like and how much of the row it holds
+        w_e = ~in_cut
+        cnt = torch.bincount((row_e[w_e] - lo) * N_XCD + sl[w_e], minlength=(hi - lo) * N_XCD).reshape(hi - lo, N_XCD)
+        cnt = cnt[~cut[lo:hi]]
+        best, pref = cnt.max(dim=1)
+        per_block.append((whole, pref, best.to(torch.float64) / torch.clamp(lens[whole], min=1).to(torch.float64)))
+    if seg_parts:
+        seg_start, seg_len, seg_row, seg_xcd = (torch.cat([p[j] for p in seg_parts]) for j in range(4))
+    else:
+        seg_start = seg_len = seg_row = seg_xcd = empty
+    n_seg = seg_start.shape[0]
+    segments = torch.zeros((n_seg, 6), dtype=torch.int32, device=dev)
+    if n_seg:
+        segments[:, 0:2] = seg_start.contiguous().view(torch.int32).reshape(n_seg, 2)      # int64 start, little endian
+        segments[:, 2], segments[:, 3], segments[:, 4] = seg_len.int(), torch.arange(n_seg, device=dev).int(), seg_row.int()
+    long_ids = torch.nonzero(cut).flatten()
+    long_rows = torch.zeros((long_ids.shape[0], 4), dtype=torch.int32, device=dev)
+    if long_ids.shape[0]:
+        # segments were generated block by block in storage order: those of one row are consecutive
+        is_first = torch.ones(n_seg, dtype=torch.bool, device=dev)
+        is_first[1:] = seg_row[1:] != seg_row[:-1]
+        firsts = torch.nonzero(is_first).flatten()
+        if firsts.shape[0] != long_ids.shape[0] or not torch.equal(seg_row[firsts], long_ids):
+            raise ValueError('every cut row needs its own run of segments (rows sorted, nonzeros stored row by row)')
+        long_rows[:, 0], long_rows[:, 1] = long_ids.int(), firsts.int()
+        long_rows[:, 2] = torch.diff(torch.cat([firsts, torch.tensor([n_seg], **i64)])).int()
+
+    # deal the blocks, one after the other, keeping the lists' total work level
+    load = torch.zeros(N_XCD, dtype=torch.float64, device=dev)
+    lists = [[] for _ in range(N_XCD)]
+    inner = torch.tensor(list(blocks[1:-1]), **i64)
+    seg_block = torch.searchsorted(inner, seg_row, right=True) if n_seg else seg_row
+    for b, (whole, pref, aff) in enumerate(per_block):
+        sb = torch.nonzero(seg_block == b).flatten() if n_seg else empty
+        seg_cost = torch.bincount(seg_xcd[sb], weights=(seg_len[sb] + row_cost).to(torch.float64), minlength=N_XCD) \
+            if sb.numel() else torch.zeros(N_XCD, dtype=torch.float64, device=dev)
+        cost = (lens[whole] + row_cost).to(torch.float64)
+        level = (load.sum() + seg_cost.sum() + cost.sum()) / N_XCD
+        quota = torch.clamp(level - load - seg_cost, min=0.)
+        if float(quota.sum()) > 0:
+            quota = quota * (cost.sum() / quota.sum())
+        owner = torch.full((whole.shape[0],), -1, **i64)
+        if assign == 'affinity' and whole.numel():
+            order = torch.sort(-aff, stable=True).indices
+            order = order[torch.sort(pref[order], stable=True).indices]      # by list, strongest affinity first
+            po = pref[order]
+            run = torch.cumsum(cost[order], 0)
+            before = torch.bincount(po, weights=cost[order], minlength=N_XCD).cumsum(0) - \
+                torch.bincount(po, weights=cost[order], minlength=N_XCD)           # work of the lists before po
+            fits = (run - before[po]) <= quota[po]
+            owner[order[fits]] = po[fits]
+        rest = torch.nonzero(owner < 0).flatten()
+        if rest.numel():
+            rest = rest[torch.sort(-lens[whole[rest]], stable=True).indices]
+            got = owner >= 0
+            used = torch.bincount(owner[got], weights=cost[got], minlength=N_XCD) if bool(got.any()) else torch.zeros_like(quota)
+            room = torch.clamp(quota - used, min=0.)
+            edges = torch.cumsum(room * (cost[rest].sum() / torch.clamp(room.sum(), min=1e-30)), 0)
+            mid = torch.cumsum(cost[rest], 0) - cost[rest] / 2
+            owner[rest] = torch.clamp(torch.searchsorted(edges, mid), max=N_XCD - 1)
+        for x in range(N_XCD):
+            sx = sb[seg_xcd[sb] == x]
+            lists[x].append(n_rows + sx[torch.sort(-seg_len[sx], stable=True).indices])
+            rx = whole[owner == x]
+            lists[x].append(rx[torch.sort(-lens[rx], stable=True).indices])
+        load = load + seg_cost + (torch.bincount(owner, weights=cost, minlength=N_XCD) if whole.numel() else 0.)
+    per_list = [torch.cat(l) if l else empty for l in lists]
+    xcd_off = torch.zeros(N_XCD + 1, **i64)
+    xcd_off[1:] = torch.cumsum(torch.tensor([a.shape[0] for a in per_list], **i64), 0)
+    row_order = torch.cat(per_list).to(torch.int32)
+    if row_order.shape[0] != n_rows - long_ids.shape[0] + n_seg:
+        raise AssertionError('XCD plan lost or duplicated work items')
+    return long_rows, segments, row_order, xcd_off, load
+
+
 class CsrMatrix:
     """A CSR matrix resident in HBM with the SpMM long-row schedule.
 
@@ -213,7 +355,7 @@ class CsrMatrix:
     ones), edge_id int32 [nnz] or None."""
 
     def __init__(self, rowptr, col, val, shape, device, edge_id=None,
-                 long_threshold=LONG_THRESHOLD, segment_len=SEGMENT_LEN, keep_host=False, order_blocks=None):
+                 long_threshold=LONG_THRESHOLD, segment_len=SEGMENT_LEN, keep_host=False, order_blocks=None, xcd_plan=None):
         rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
         col = np.ascontiguousarray(col, dtype=np.int32)
         self.shape = (int(shape[0]), int(shape[1]))
@@ -232,6 +374,7 @@ class CsrMatrix:
         self.long_threshold = int(long_threshold)
         self.segment_len = int(segment_len)
         self.order_blocks = order_blocks
+        self.xcd_plan = xcd_plan
         self._build_plan()
         self._partial = {}
         self._col_host = col if keep_host else None
@@ -239,7 +382,7 @@ class CsrMatrix:
 
     @classmethod
     def from_device(cls, rowptr, col, val, shape, edge_id=None, long_threshold=LONG_THRESHOLD, segment_len=SEGMENT_LEN,
-                    order_blocks=None):
+                    order_blocks=None, xcd_plan=None):
         """Wrap CSR arrays that already live in HBM (int64 rowptr, int32 col, float32 val or None);
         only rowptr is copied to the host, for the long-row schedule."""
         self = cls.__new__(cls)
@@ -252,6 +395,7 @@ class CsrMatrix:
             raise ValueError('inconsistent CSR arrays')
         self.long_threshold, self.segment_len = int(long_threshold), int(segment_len)
         self.order_blocks = order_blocks
+        self.xcd_plan = xcd_plan
         self._build_plan()
         self._partial = {}
         self._col_host = None
@@ -285,6 +429,20 @@ class CsrMatrix:
         return self._transposed
 
     def _build_plan(self):
+        """xcd_plan: None, or {'threshold': T[, 'row_cost': c, 'assign': 'affinity' | 'spread']} — the XCD plan
+        (xcd_plan_host) instead of the plain long-row plan + dealing order; needs order_blocks."""
+        self.xcd_off = None
+        if self.xcd_plan is not None and self.order_blocks is not None and self.nnz > 0:
+            cfg = dict(self.xcd_plan)
+            self.long_threshold = int(cfg['threshold'])
+            self.segment_len = min(self.segment_len, self.long_threshold)
+            lr, sg, order, xcd_off, load = xcd_plan(self.rowptr, self.col, list(self.order_blocks), self.long_threshold,
+                                                    self.segment_len, cfg.get('row_cost', 4), cfg.get('assign', 'affinity'))
+            self.n_long, self.n_segments = int(lr.shape[0]), int(sg.shape[0])
+            self.long_rows = lr.contiguous().view(torch.uint8).reshape(-1) if self.n_long else None
+            self.segments = sg.contiguous().view(torch.uint8).reshape(-1) if self.n_long else None
+            self.row_order, self.xcd_off, self.xcd_load = order, xcd_off, load
+            return
         L = _lib.lib()
         n_long, n_seg = C.c_int64(0), C.c_int64(0)
         _lib.check(L.igcn_spmm_plan_count_host(self.rowptr_host.ctypes.data, self.shape[0], self.long_threshold,

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IGCN_ABI_VERSION 4
+#define IGCN_ABI_VERSION 5
 
 #define IGCN_OK            0
 #define IGCN_E_NULL       -1   /* a required pointer is NULL               */
@@ -119,7 +119,13 @@ int igcn_spmm_plan_fill_host(const int64_t *rowptr_host, int64_t n_rows,
  * the first backward hops of a training step, whose operand is non-zero on the batch rows / their neighbourhood
  * only.  Edges whose weight comes out zero (masked here, or dropped out) issue no gather at all;
  * seed_dev: NULL, or the dropout seed in device memory (overrides `seed`): a launch captured in a HIP graph reads it
- * at every replay, so the caller changes the dropped edges by writing 8 bytes, not by re-capturing. */
+ * at every replay, so the caller changes the dropped edges by writing 8 bytes, not by re-capturing;
+ * xcd_off (ABI v5): NULL, or int64 [9] in device memory: row_order then holds EIGHT lists back to back, list x =
+ * row_order[xcd_off[x] .. xcd_off[x + 1]), xcd_off[0] = 0, and workgroup b walks list b % 8 only (workgroups b and b + 8
+ * share an XCD and its 4 MiB L2 under the hardware's round-robin placement).  Every row that is not cut into segments
+ * and every row segment appears in exactly one list (rows that are cut may be left out).  The caller groups into one
+ * list the rows / segments that gather from the same slice of X, so that the slice stays in that XCD's L2 — there is
+ * no counterpart in the reference (DGL's CPU gspmm walks rows in order); results do not depend on it. */
 int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val,
                       const float *x, int64_t ldx, float *y, int64_t ldy,
                       int64_t n_rows, int64_t n_cols, int32_t d,
@@ -131,7 +137,7 @@ int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *va
                       const int32_t *edge_id, uint64_t seed, float keep_prob,
                       const uint8_t *row_mask, int32_t masked_rows_zero,
                       int64_t nnz, const int32_t *row_order, const uint32_t *col_mask,
-                      const uint64_t *seed_dev, void *stream);
+                      const uint64_t *seed_dev, const int64_t *xcd_off, void *stream);
 
 /* Row masks for igcn_spmm_csr_f32.  mask1[ids[i] + offsets...] = 1 for every listed row;
  * when rowptr/col are given, mask2[r] = 1 for every listed row r and every column

@@ -42,7 +42,7 @@ def main():
     for _ in range(3):
         y = ops.spmm(csr, x)
     torch.cuda.synchronize()
-    nw = 16384
+    nw = 131072
     buf = (C.c_uint64 * (6 * nw))()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert getattr(_lib.lib(), name) is not None
-    assert _lib.lib().igcn_abi_version() == 4
+    assert _lib.lib().igcn_abi_version() == 5
     assert _lib.lib().igcn_error_string(-1).decode().startswith('a required pointer')
 
 
@@ -428,3 +428,51 @@ def test_split_lists_invalidate_themselves(golden):
     assert isinstance(ds.test_data[:3], list) and ds.test_data[:3] == [list(x) for x in ds.test_data[:3]]
     import copy
     assert type(copy.deepcopy(ds.test_data)) is list
+
+
+@pytest.mark.parametrize('threshold', [3, 8, 1000])
+def test_xcd_plan_covers_every_nonzero_once(golden, threshold):
+    """graph.xcd_plan (what igcn_spmm_csr_f32's xcd_off / row_order take): every row that is not cut and every segment
+    appears in exactly one of the eight lists, the segments of a cut row tile it in storage order with consecutive
+    slots, a segment never crosses a slice boundary's list, and the lists' work is level."""
+    from igcn_cf_amd import _lib
+    from igcn_cf_amd.graph import N_XCD, normalized_adjacency_host, xcd_plan
+    nu, ni = int(golden['n_users']), int(golden['n_items'])
+    n = nu + ni
+    rowptr, col, _ = normalized_adjacency_host(golden['train_array'], nu, ni)
+    lr, sg, order, off, load = xcd_plan(torch.from_numpy(rowptr), torch.from_numpy(col), [0, nu, n], threshold, 4)
+    sg = sg.numpy().view(np.uint8).reshape(-1).view(_lib.ROW_SEGMENT_DTYPE)
+    lr = lr.numpy().view(np.uint8).reshape(-1).view(_lib.LONG_ROW_DTYPE)
+    order, off = order.numpy(), off.numpy()
+    lens = np.diff(rowptr)
+    cut = lens > threshold
+    assert off[0] == 0 and off[-1] == order.shape[0] and off.shape[0] == N_XCD + 1 and (np.diff(off) >= 0).all()
+    rows, segs = order[order < n], order[order >= n] - n
+    assert sorted(rows.tolist()) == np.flatnonzero(~cut).tolist() and sorted(segs.tolist()) == list(range(len(sg)))
+    assert lr['row'].tolist() == np.flatnonzero(cut).tolist()
+    covered = np.zeros(int(rowptr[-1]), dtype=np.int64)
+    for r, f, k in zip(lr['row'], lr['first_slot'], lr['n_slots']):
+        s = sg[f:f + k]
+        assert (s['row'] == r).all() and (s['slot'] == np.arange(f, f + k)).all() and (s['len'] >= 1).all() and (s['len'] <= 4).all()
+        assert s['start'][0] == rowptr[r] and s['start'][-1] + s['len'][-1] == rowptr[r + 1]
+        assert (s['start'][1:] == s['start'][:-1] + s['len'][:-1]).all()
+        for a, l in zip(s['start'], s['len']):
+            covered[a:a + l] += 1
+    for r in rows:
+        covered[rowptr[r]:rowptr[r + 1]] += 1
+    assert (covered == 1).all()
+    # a segment's list = the slice of its columns; all its columns lie in that one slice
+    list_of = np.repeat(np.arange(N_XCD), np.diff(off))
+    seg_list = np.empty(len(sg), dtype=np.int64)
+    seg_list[order[order >= n] - n] = list_of[order >= n]
+    for blk_lo, blk_hi in ((0, nu), (nu, n)):
+        in_blk = (sg['row'] >= blk_lo) & (sg['row'] < blk_hi)
+        lo_col = np.array([col[a] for a in sg['start'][in_blk]]); hi_col = np.array([col[a + l - 1] for a, l in zip(sg['start'][in_blk], sg['len'][in_blk])])
+        for x in range(N_XCD - 1):                                # slices are ordered: list x's columns lie below list x + 1's
+            a, b = hi_col[seg_list[in_blk] == x], lo_col[seg_list[in_blk] == x + 1]
+            if len(a) and len(b):
+                assert a.max() < b.min()
+    if threshold < 1000:
+        assert cut.any() and float(load.max() / load.mean()) < 1.25
+    else:
+        assert not cut.any() and len(sg) == 0

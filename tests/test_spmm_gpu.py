@@ -197,7 +197,7 @@ def test_c_abi_error_codes_without_launch():
 
     def call(rowptr_p, x_p, y_p, d=64, ldx=64, n_adds=0, keep=1.0, n_rows=8):
         return L.igcn_spmm_csr_f32(rowptr_p, col.data_ptr(), None, x_p, ldx, y_p, 64, n_rows, 8, d, 1.0, nul, n_adds, 1.0,
-                                   None, None, None, 0, None, 0, None, 256, None, 0, keep, None, 0, 0, None, None, None, None)
+                                   None, None, None, 0, None, 0, None, 256, None, 0, keep, None, 0, 0, None, None, None, None, None)
     assert call(None, x.data_ptr(), y.data_ptr()) == -1                       # IGCN_E_NULL
     assert call(rowptr.data_ptr(), x.data_ptr(), y.data_ptr(), d=0) == -2     # IGCN_E_SHAPE
     assert call(rowptr.data_ptr(), x.data_ptr(), y.data_ptr(), d=300) == -2
@@ -332,7 +332,7 @@ def test_launch_shape_does_not_change_results():
         rc = _lib.lib().igcn_spmm_csr_f32(csr.rowptr.data_ptr(), csr.col.data_ptr(), csr.val.data_ptr(), x.data_ptr(), d,
                                           y.data_ptr(), d, n_rows, n_cols, d, 1.0, nul, 0, 0.0, None, None,
                                           _lib.ptr(csr.long_rows), csr.n_long, _lib.ptr(csr.segments), csr.n_segments,
-                                          _lib.ptr(csr.partial(d)), csr.long_threshold, None, 0, 1.0, None, 0, nnz_hint, None, None, None,
+                                          _lib.ptr(csr.partial(d)), csr.long_threshold, None, 0, 1.0, None, 0, nnz_hint, None, None, None, None,
                                           torch.cuda.current_stream().cuda_stream)
         assert rc == 0 and torch.equal(y, ref)
     # a row order (rows dealt to the waves by descending length inside two blocks) changes who computes a row, not the result
@@ -451,3 +451,75 @@ def test_col_mask_never_reads_masked_source_rows(d):
     y = spmm(csr, torch.from_numpy(x_dirty).cuda(), col_mask=bits).cpu().numpy()
     assert np.isfinite(y).all()
     assert _rel_err(y, _oracle(rowptr, col, val, x_clean, n_rows)) < TOL
+
+
+@pytest.mark.parametrize('d', [64, 128, 32, 8])
+def test_xcd_plan_changes_who_computes_what_not_the_result(d):
+    """igcn_spmm_csr_f32 with xcd_off (ABI v5): eight per-XCD lists, rows above the threshold cut at operand-slice
+    boundaries.  Against the float64 oracle <= 1e-4; against the plain plan <= 1e-5 (a cut row is summed piecewise);
+    bit-identical from launch to launch and for every grid size; row masks / zero-filled masked rows / col masks / the
+    fused epilogue behave as without the plan; a matrix without entries and one without rows to cut are fine."""
+    from igcn_cf_amd import _lib
+    from igcn_cf_amd.graph import CsrMatrix
+    from igcn_cf_amd.ops import pack_mask_bits, spmm
+    rng = np.random.default_rng(5)
+    nu, ni = 9000, 4000
+    n = nu + ni
+    deg_u = np.minimum((rng.pareto(1.3, nu) * 6).astype(np.int64) + 1, 600)
+    users = np.repeat(np.arange(nu), deg_u)
+    pop = 1. / (np.arange(ni) + 20.)
+    items = rng.choice(ni, size=users.shape[0], p=pop / pop.sum())
+    from igcn_cf_amd.graph import normalized_adjacency_host
+    rowptr, col, val = normalized_adjacency_host(np.stack([users, items], 1), nu, ni)
+    x = (rng.standard_normal((n, d)) * 0.1).astype(np.float32)
+    xt = torch.from_numpy(x).cuda()
+    plain = CsrMatrix(rowptr, col, val, (n, n), 'cuda', order_blocks=[0, nu, n])
+    ref64 = _oracle(rowptr, col, val, x, n)
+    y_plain = spmm(plain, xt)
+    for T in (16, 112):
+        plan = CsrMatrix(rowptr, col, val, (n, n), 'cuda', order_blocks=[0, nu, n], xcd_plan={'threshold': T})
+        assert plan.xcd_off is not None and plan.n_long > 0 and plan.long_threshold == T
+        y = spmm(plan, xt)
+        assert _rel_err(y.cpu().numpy(), ref64) < TOL
+        assert _rel_err(y.cpu().numpy(), y_plain.cpu().numpy()) < 1e-5
+        assert torch.equal(spmm(plan, xt), y)
+        for bpc in (1, 3, 64):
+            _lib.set_tuning('spmm_blocks_per_cu', bpc)
+            assert torch.equal(spmm(plan, xt), y)
+        _lib.set_tuning('spmm_blocks_per_cu', None)
+        # epilogue + row mask (+ zero fill) + col mask
+        mask = torch.from_numpy((rng.random(n) < 0.3).astype(np.uint8)).cuda()
+        keep = torch.from_numpy((rng.random(n) < 0.6).astype(np.uint8)).cuda()
+        add = torch.randn(n, d, device='cuda')
+        rs = torch.rand(n, device='cuda') + 0.5
+        kw = dict(adds=[add, xt], out_scale=0.25, add_scale=0.5, row_scale=rs, row_mask=mask, masked_rows_zero=True,
+                  col_mask=pack_mask_bits(keep))
+        a, b = spmm(plan, xt, **kw), spmm(plain, xt, **kw)
+        assert _rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+        assert float(a[mask == 0].abs().max()) == 0.0
+        out = torch.full((n, d), 7., device='cuda')
+        spmm(plan, xt, out=out, row_mask=mask, masked_rows_zero=False)
+        assert bool((out[mask == 0] == 7.).all()) and _rel_err(out[mask == 1].cpu().numpy(), y[mask == 1].cpu().numpy()) == 0.0
+    none_cut = CsrMatrix(rowptr, col, val, (n, n), 'cuda', order_blocks=[0, nu, n], xcd_plan={'threshold': 100000})
+    assert none_cut.n_long == 0 and none_cut.xcd_off is not None
+    assert _rel_err(spmm(none_cut, xt).cpu().numpy(), ref64) < TOL
+    empty = CsrMatrix(np.zeros(n + 1, dtype=np.int64), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.float32), (n, n), 'cuda',
+                      order_blocks=[0, nu, n], xcd_plan={'threshold': 16})
+    assert float(spmm(empty, xt).abs().max()) == 0.0
+
+
+def test_default_graph_builder_uses_the_xcd_plan_and_matches_the_plain_one(golden):
+    """LightGCN.generate_graph builds A_hat with graph.XCD_PLAN (built in HBM by the same torch code as on the host);
+    the propagation through it equals the one through the plain plan and the oracle's."""
+    from igcn_cf_amd.graph import XCD_PLAN, normalized_adjacency_device
+    from igcn_cf_amd.ops import propagate_mean
+    nu, ni = int(golden['n_users']), int(golden['n_items'])
+    a = normalized_adjacency_device(golden['train_array'], nu, ni, 'cuda')
+    b = normalized_adjacency_device(golden['train_array'], nu, ni, 'cuda', xcd_plan=None)
+    assert a.xcd_off is not None and a.long_threshold == XCD_PLAN['threshold'] and b.xcd_off is None
+    assert torch.equal(a.col, b.col) and torch.equal(a.val, b.val)
+    x = torch.randn(nu + ni, 64, device='cuda')
+    ya, yb = propagate_mean(a, x, 3), propagate_mean(b, x, 3)
+    assert _rel_err(ya.cpu().numpy(), yb.cpu().numpy()) < 1e-5
+    adj = O.lightgcn_norm_adj(golden['train_array'], nu, ni)
+    assert _rel_err(ya.cpu().numpy(), O.lightgcn_get_rep(adj, x.cpu().numpy(), 3)) < TOL
