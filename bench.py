@@ -44,6 +44,42 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X spec (MI355X_MICROARCH.md: 8 TB/s peak, ~6.3 TB/s achievable)
+MALL_GATHER_PEAK_GBPS = 8600.0  # MI355X_MICROARCH.md "Indexed rows": 38 MB table, uniformly random rows (Infinity Cache): 8.6 TB/s chip-wide
+INFINITY_CACHE_BYTES = 256 << 20
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def lift_flat(out, extras):
+    """Driver-visible copies of what `extras` holds: top-level scalars (the driver's parser keeps those, drops nested
+    objects) — the second half of BASELINE's metric (eval users/s) with its MFMA fraction, the HBM-bound leg, the steps."""
+    def get(*path):
+        cur = extras
+        for k in path:
+            if not isinstance(cur, dict) or k not in cur:
+                return None
+            cur = cur[k]
+        return cur
+    flat = {
+        'eval_users_per_s': get('eval_users_per_s'), 'eval_ms': get('eval_ms'),
+        'eval_users_per_s_fp32_sweep': get('eval_users_per_s_fp32_sweep'),
+        'eval_mfma_TFLOPs_fp32_sweep': get('eval_roofline', 'achieved'), 'eval_mfma_frac': get('eval_roofline', 'frac'),
+        'eval_scoring_ms_fp32_sweep': get('eval_roofline', 'ms'), 'eval_scoring_ms_two_stage': get('eval_two_stage', 'ms'),
+        'eval_with_metrics_ms': get('eval_with_metrics_ms'),
+        'hbm_bound_kernel': get('roofline_hbm_bound', 'kernel'), 'hbm_bound_GBps': get('roofline_hbm_bound', 'achieved'),
+        'hbm_bound_frac': get('roofline_hbm_bound', 'frac'), 'hbm_bound_ms': get('roofline_hbm_bound', 'avg_launch_ms'),
+        'hbm_bound_workload': get('roofline_hbm_bound', 'workload_short'),
+        'hbm_bound_rank_ms_min': get('roofline_hbm_bound', 'rank_ms_min'), 'hbm_bound_rank_ms_max': get('roofline_hbm_bound', 'rank_ms_max'),
+        'train_step_ms': get('train_step_ms'), 'train_step_ms_gowalla_hip_graph': get('launch_bound_config', 'train_step_ms_hip_graph'),
+        'igcn_train_step_ms_yelp': get('igcn_step', 'train_step_ms'),
+        'inductive_update_plus_eval_s': get('inductive_update', 'update_plus_eval_s'),
+        'propagation_uniform_graph_edges_per_s': get('propagation_uniform_random_graph', 'edges_per_s'),
+    }
+    out.update({k: v for k, v in flat.items() if v is not None})
+    r = out.get('roofline')
+    if isinstance(r, dict):
+        for k in ('eval_mfma_frac', 'hbm_bound_frac', 'hbm_bound_GBps', 'hbm_bound_kernel'):
+            if flat.get(k) is not None:
+                r[k] = flat[k]
 
 
 def parse():
@@ -188,27 +224,36 @@ def main():
         g = gather_roof(device, local_csr.col, local_csr.val, rep[0], y.shape[0], d)
     ach = b_alg / ms_launch / 1e6
     x_mb = n * d * 4 / 1e6
-    peak = b_alg / g['best_ms'] / 1e6       # same units as `achieved`: the algorithmic rate this SpMM would have at the bare-gather speed
-    roof = {'bound': 'hbm', 'kernel': kernel_name, 'achieved': ach, 'peak': peak, 'unit': 'GB/s', 'frac': ach / peak,
+    gathered = local_nnz * 4 * d / ms_launch / 1e6                  # GB/s of gathered operand rows alone
+    probe_peak = b_alg / g['best_ms'] / 1e6    # the algorithmic rate this SpMM would have at the bare-gather speed of this box
+    cache_resident = x_mb * 1e6 <= INFINITY_CACHE_BYTES
+    # Flat scalars and short strings only: the driver's parser drops nested objects and cuts strings at 120 characters.
+    roof = {'bound': 'mall-gather' if cache_resident else 'hbm', 'kernel': kernel_name, 'achieved': ach, 'peak': HBM_PEAK_GBPS,
+            'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBPS,
+            'frac_note': ('operand %.0f MB is Infinity-Cache resident: frac vs the 8 TB/s HBM spec can exceed 1, not a bound here' % x_mb)
+            if cache_resident else 'operand beyond the Infinity Cache: HBM-bound',
             'algorithmic_bytes_per_launch': b_alg, 'compulsory_bytes_per_launch': b_min, 'avg_launch_ms': ms_launch,
-            'avg_launch_note': launch_note, 'frac_of_hbm_spec': ach / HBM_PEAK_GBPS, 'hbm_spec_GBps': HBM_PEAK_GBPS,
-            'frac_of_compulsory': b_min / b_alg,
-            'peak_source': 'measured in this run: row-structure-free gather+FMA+store kernel over the SAME col/val stream and '
-                           'operand (roof_probe.hip), best of %d grids' % len(g['same_stream_ms']),
-            'gather_roof': g,
-            'note': ('rank 0 of %d; ' % world if sharded else '') +
-                    'X (%.1f MB) fits the 256 MiB Infinity Cache: the HBM roof (8 TB/s) does not bind this workload '
-                    '(frac_of_hbm_spec may exceed 1); peak/frac use the measured cache-resident gather roof; the HBM-bound leg '
-                    'is extras.roofline_hbm_bound (N = 1 runs)' % x_mb}
+            'avg_launch_note': launch_note,
+            'gathered_row_GBps': gathered, 'mall_gather_peak_GBps': MALL_GATHER_PEAK_GBPS,
+            'frac_of_mall_gather': gathered / MALL_GATHER_PEAK_GBPS,
+            'mall_gather_note': 'guide: 8.6 TB/s of uniformly random rows of a 38 MB Infinity-Cache table; L2 hits lift a skewed gather above it',
+            'probe_peak_GBps': probe_peak, 'frac_of_probe': ach / probe_peak,
+            'probe_note': 'in-run rowless gather+FMA+store over the same col/val stream (roof_probe.hip): a sibling kernel, not a hardware roof',
+            'probe_gathered_row_GBps_same_stream': g['gathered_row_GBps_same_stream'],
+            'probe_gathered_row_GBps_uniform_random': g['gathered_row_GBps_uniform_random'],
+            'frac_of_compulsory': b_min / b_alg, 'rank': rank, 'world': world}
     if not sharded:
         roof['hbm_copy_measured_GBps'] = measured_copy_GBps(device)
         t = stored_traffic(kernel_name, args.preset, nnz, d)
         roof['traffic'] = t['bytes'] if t else None
         roof['traffic_source'] = t['source'] if t else 'no PMC pass on file for this kernel/workload'
+        if t:
+            roof['traffic_over_compulsory'] = t['bytes'] / b_min
+            roof['traffic_over_algorithmic'] = t['bytes'] / b_alg
+            roof['l2_hit_rate'] = t.get('l2_hit_rate')
     else:
         roof['traffic'] = None
     out['roofline'] = roof
-
     extras = {}
     if sharded and not args.no_extras:
         extras = sharded_side_measurements(ds, device, d, K, rank, world, rowptr, col, val, emb_host, barrier_sync, job_max)
@@ -219,7 +264,9 @@ def main():
         del csr, x0
         torch.cuda.empty_cache()
         extras['roofline_hbm_bound'] = hbm_bound_leg(device)
+    extras['gather_roof'] = g
     out['extras'] = extras
+    lift_flat(out, extras)
 
     if not sharded and rank == 0 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(rowptr, col, val, emb_host.numpy(), K, nnz, ds.n_users)
@@ -381,46 +428,58 @@ def stored_traffic(kernel_name, preset, nnz, d):
     stored_kernel = t.get('kernel', '').replace('void ', '').replace(' ', '')
     if stored_kernel != kernel_name.replace(' ', '') or t.get('preset') != preset or t.get('nnz') != nnz or t.get('d') != d:
         return None
-    return {'bytes': t.get('spmm_hbm_bytes_per_launch'),
+    return {'bytes': t.get('spmm_hbm_bytes_per_launch'), 'l2_hit_rate': t.get('l2_hit_rate'),
             'source': 'profiles/pmc_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2 x FETCH + WRITE '
                       '(gfx950 correction); L2-miss traffic incl. Infinity-Cache hits; NOT measured in this run' % t.get('tag', '?')}
 
 
-def hbm_bound_leg(device, reps=5):
-    """The HBM-bound leg: ONE GPU's share of BASELINE config 5 under row sharding — 1/8 of the rows of A_hat
-    (1.5 M rows, 125 M nonzeros) against the full replicated operand X (12 M x 128 fp32 = 6.1 GB, far beyond the
-    Infinity Cache), generated on the device.  One launch of igcn_spmm_csr_f32 (spmm_csr_rows_kernel<32,false>)."""
-    from igcn_cf_amd.graph import CsrMatrix
+def hbm_bound_leg(device, reps=5, ranks=(0,)):
+    """The HBM-bound leg: BASELINE config 5 as written — the bipartite 10 M x 2 M x ~500 M-edge graph generated in HBM
+    (igcn_cf_amd/synth.py, SURVEY 8(d) generator rules), cut with ShardLayout.balanced(world = 8); rank 0's share (its
+    user block gathering item rows + its item block gathering user rows, ~125 M nonzeros) against the full replicated
+    operand X (12 M x 128 fp32 = 6.1 GB, far beyond the Infinity Cache).  One launch of igcn_spmm_csr_f32
+    (spmm_csr_rows_kernel<32,false>) per share; `ranks` = the shares to run (scripts/dev_config5_shares.py runs all 8)."""
+    from igcn_cf_amd.dist import ShardLayout
+    from igcn_cf_amd.synth import BipartiteGraphDevice, check_rows_f64
     from igcn_cf_amd import ops
-    d, n_cols, n_rows, nnz_target = 128, 12_000_000, 1_500_000, 125_000_000
-    g = torch.Generator(device=device).manual_seed(1)
-    w = torch.exp(torch.randn(n_rows, device=device, generator=g))              # log-normal row lengths
-    deg = torch.clamp((w / w.sum() * nnz_target).round().long(), min=1)
-    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=device)
-    torch.cumsum(deg, 0, out=rowptr[1:])
-    nnz = int(rowptr[-1].item())
-    col = torch.randint(0, n_cols, (nnz,), device=device, generator=g, dtype=torch.int32)
-    val = torch.rand(nnz, device=device, generator=g) * 0.1
-    csr = CsrMatrix.from_device(rowptr, col, val, (n_rows, n_cols), order_blocks=[0, n_rows])
-    x = torch.randn(n_cols, d, device=device, generator=g) * 0.1
-    y = torch.empty(n_rows, d, device=device)
-    ms = min(time_ms(lambda: ops.spmm(csr, x, out=y), reps, 2) for _ in range(2))
-    b_alg = nnz * (8 + 4 * d) + n_rows * (4 * d + 4)
-    # f64 check of a row sample (the leg is timed on the product kernel: it must also be right)
-    rows = torch.randint(0, n_rows, (64,), device=device, generator=g)
-    err = 0.0
-    for r in rows.tolist():
-        s, e = int(rowptr[r]), int(rowptr[r + 1])
-        ref = (x[col[s:e].long()].double() * val[s:e].double()[:, None]).sum(0)
-        err = max(err, float((y[r].double() - ref).abs().max() / (ref.abs().max() + 1e-30)))
-    gr = gather_roof(device, col, val, x, n_rows, d, reps=3)
+    d, world = 128, 8
+    t0 = time.perf_counter()
+    g = BipartiteGraphDevice(10_000_000, 2_000_000, 500_000_000, device, seed=2021)
+    layout = ShardLayout.balanced(g.rowptr_host(), g.n_users, g.n_items, world)
+    torch.cuda.synchronize()
+    gen_s = time.perf_counter() - t0
+    gen = torch.Generator(device=device).manual_seed(1)
+    x = torch.randn(g.n, d, device=device, generator=gen) * 0.1
+    per_rank = []
+    for r in ranks:
+        csr, _ = g.rank_share(layout, r)
+        y = torch.empty(csr.shape[0], d, device=device)
+        ms = min(time_ms(lambda: ops.spmm(csr, x, out=y), reps, 2) for _ in range(2))
+        rows = torch.randint(0, csr.shape[0], (64,), device=device, generator=gen).tolist()
+        err = check_rows_f64(csr, x, y, rows)
+        (ulo, uhi), (ilo, ihi) = layout.user_rows(r), layout.item_rows(r)
+        b_alg = csr.nnz * (8 + 4 * d) + csr.shape[0] * (4 * d + 4)
+        per_rank.append({'rank': r, 'user_rows': uhi - ulo, 'item_rows': ihi - ilo, 'nnz': csr.nnz, 'ms': ms,
+                         'algorithmic_GBps': b_alg / ms / 1e6, 'sample_rel_err_vs_f64': err, 'n_long_rows': csr.n_long})
+        if r == ranks[0]:
+            first = (csr, y, b_alg, ms, err)
+        else:
+            del csr, y
+    csr, y, b_alg, ms, err = first
+    gr = gather_roof(device, csr.col, csr.val, x, csr.shape[0], d, reps=3)
     ach = b_alg / ms / 1e6
-    return {'bound': 'hbm', 'kernel': 'spmm_csr_rows_kernel<32,false>', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-            'frac': ach / HBM_PEAK_GBPS, 'avg_launch_ms': ms, 'algorithmic_bytes_per_launch': b_alg,
-            'workload': 'BASELINE config 5 (10M x 2M x 500M edges, d=128), one rank of 8 under row sharding: '
-                        '%d rows, %d nonzeros, operand %d x %d fp32 = %.1f GB' % (n_rows, nnz, n_cols, d, n_cols * d * 4 / 1e9),
-            'gedges_per_s': nnz / ms / 1e6, 'sample_rel_err_vs_f64': err,
-            'frac_of_measured_gather_roof': gr['best_ms'] / ms, 'gather_roof_ms': gr['best_ms']}
+    out = {'bound': 'hbm', 'kernel': 'spmm_csr_rows_kernel<32,false>', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
+           'frac': ach / HBM_PEAK_GBPS, 'avg_launch_ms': ms, 'algorithmic_bytes_per_launch': b_alg,
+           'workload': 'BASELINE config 5: bipartite %d users x %d items x %d edges (synthetic, Zipf-Mandelbrot items, log-normal '
+                       'user degrees >= 7), d=128, rank %d of 8 under nnz-balanced row sharding: %d user rows + %d item rows, %d '
+                       'nonzeros, operand %d x %d fp32 = %.1f GB' % (g.n_users, g.n_items, g.n_edges, ranks[0], per_rank[0]['user_rows'],
+                                                                    per_rank[0]['item_rows'], csr.nnz, g.n, d, g.n * d * 4 / 1e9),
+           'workload_short': 'config 5 bipartite 10M x 2M x %.0fM edges d=128: rank %d of 8, %dM nnz vs 6.1 GB operand'
+                             % (g.n_edges / 1e6, ranks[0], csr.nnz // 1000000),
+           'gedges_per_s': csr.nnz / ms / 1e6, 'sample_rel_err_vs_f64': err, 'graph_generation_s': gen_s,
+           'frac_of_measured_gather_roof': gr['best_ms'] / ms, 'gather_roof_ms': gr['best_ms'], 'per_rank': per_rank,
+           'rank_ms_min': min(p['ms'] for p in per_rank), 'rank_ms_max': max(p['ms'] for p in per_rank)}
+    return out
 
 
 def train_step_ms(trainer, steps, warm):
@@ -451,6 +510,41 @@ def small_graph_steps(device, d, K):
         model = get_model(dict(m_cfg, embedding_size=d, n_layers=K), ds)
         trainer = get_trainer(dict(t_cfg, hip_graph=hip_graph), ds, model)
         out[key] = train_step_ms(trainer, 100, 10)
+    return out
+
+
+def igcn_step_yelp(device, d, K):
+    """BASELINE config 3: IGCN (INMO + LightGCN) on the Yelp-like split, dropout 0.3, auxiliary loss; the trainer's step
+    (one captured HIP graph) and a full evaluation."""
+    from igcn_cf_amd import config as cfg
+    from igcn_cf_amd.dataset import get_dataset
+    from igcn_cf_amd.model import get_model
+    from igcn_cf_amd.trainer import get_trainer
+    ds_cfg, m_cfg, t_cfg = cfg.get_synthetic_config(device, 'yelp')[2]
+    ds = get_dataset(ds_cfg)
+    torch.manual_seed(2021)
+    model = get_model(dict(m_cfg, embedding_size=d, n_layers=K), ds)
+    trainer = get_trainer(t_cfg, ds, model)
+    model.train()
+    it = zip(trainer.sampler.epoch_node_batches(trainer.batch_size, model.n_users), trainer.aux_sampler.epoch_batches(trainer.batch_size))
+    for _ in range(8):
+        trainer.igcn_node_step(*next(it))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        trainer.igcn_node_step(*next(it))
+    torch.cuda.synchronize()
+    out = {'workload': 'IGCN %d-layer d=%d, Yelp-like (users=%d items=%d), dropout %.1f, B=%d' % (K, d, ds.n_users, ds.n_items, model.dropout, trainer.batch_size),
+           'train_step_ms': (time.perf_counter() - t0) * 1e3 / 50}
+    model.eval()
+    trainer.recommend_all('test')
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        model._rep_cache = None
+        trainer.recommend_all('test')
+    torch.cuda.synchronize()
+    out['eval_users_per_s'] = ds.n_users / ((time.perf_counter() - t0) / 3)
     return out
 
 
@@ -522,6 +616,7 @@ def side_measurements(ds, device, d, K):
     res['train_step_ms'] = train_step_ms(trainer, 30, 5)
     res['train_step_edges_per_s_fwd_bwd'] = 2 * K * model.norm_adj.nnz / (res['train_step_ms'] / 1e3)
     res['launch_bound_config'] = small_graph_steps(device, d, K)
+    res['igcn_step'] = igcn_step_yelp(device, d, K)
     res['inductive_update'] = inductive_update_timing(ds, device, d, K)
     # evaluation: propagate once + fused score/mask/top-20 for every user (device part of trainer.eval)
     model.eval()
@@ -536,6 +631,15 @@ def side_measurements(ds, device, d, K):
     dt = (time.perf_counter() - t0) / reps
     res['eval_users_per_s'] = ds.n_users / dt
     res['eval_ms'] = dt * 1e3
+    trainer.recommend_all('test', mode='exact')
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        model._rep_cache = None
+        rec_exact = trainer.recommend_all('test', mode='exact')
+    torch.cuda.synchronize()
+    res['eval_users_per_s_fp32_sweep'] = ds.n_users / ((time.perf_counter() - t0) / reps)
+    res['eval_lists_equal_both_paths'] = bool(torch.equal(rec, rec_exact))
     res['eval_path'] = ('two-stage: fp16 candidate sweep (k + 4 per user) + exact fp32 re-scoring and completeness check, users '
                         'that fail it re-done by the fp32 sweep — the lists of the fp32 sweep, bit for bit (ops.score_topk mode "auto")')
     # the scoring kernels alone on the same representation, HIP events: the fp32 sweep (MFMA roofline) and the two-stage path
@@ -577,57 +681,76 @@ def side_measurements(ds, device, d, K):
 
 
 def cpu_baseline(rowptr, col, val, x, K, nnz, n_users):
-    """The C restatement (oracle/oracle_c.c) on the host cores, same graph, bounded sample."""
+    """The host side, same graph, bounded to ~30 s: `value` is the BEST host path for the propagation — the C
+    restatement (oracle/oracle_c.c: nnz-balanced contiguous chunk per thread, local accumulators) at its best thread
+    count, or torch's sparse CSR / COO matmul on all threads (what a user of the reference has on a host without DGL),
+    or scipy on one thread — each timed warm.  The evaluation side likewise: the C restatement and torch mm + topk in
+    512-user batches (trainer.py:140-164), best of 3 warm repetitions."""
+    import warnings
+    import scipy.sparse as sp
     from oracle import c_oracle as CO
-    threads = CO.num_threads()
-    CO.propagate_mean(rowptr, col, val, x, 1)                    # warm
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        CO.propagate_mean(rowptr, col, val, x, K)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt > 12.0 or reps >= 2000:
-            break
-    v = reps * K * nnz / dt
-    # eval side: users/s of the C restatement on a bounded user sample
-    n_sample = 256
-    U = x[:n_sample]
-    items = x[n_users:]
-    t0 = time.perf_counter()
-    CO.score_topk(U, items, 20)
-    ev = n_sample / (time.perf_counter() - t0)
-    out = {'value': v, 'unit': 'edges/s', 'cores': threads, 'kind': 'port',
-           'sample': '%d full %d-layer passes of the same graph (%.1f s) with the OpenMP C restatement on %d threads; '
-                     'eval side: %d users x all items -> %.0f users/s' % (reps, K, dt, threads, n_sample, ev),
-           'eval_users_per_s': ev}
-    # what a user of the reference would run on this host without DGL (SURVEY 8d): torch CSR / COO sparse
-    # matmul on all threads, scipy CSR on one; a few seconds each
+    all_threads = CO.num_threads()
+
+    def rate(fn, budget, units):
+        fn()                                                          # warm
+        t0, reps = time.perf_counter(), 0
+        while True:
+            fn()
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget:
+                return reps * units / dt, reps, dt
+    cands = sorted({t for t in (8, 16, 32, 64, all_threads) if t <= all_threads})
+    sweep = {t: rate(lambda: CO.propagate_mean(rowptr, col, val, x, K, threads=t), 1.5, K * nnz)[0] for t in cands}
+    best_t = max(sweep, key=sweep.get)
+    port, reps, dt = rate(lambda: CO.propagate_mean(rowptr, col, val, x, K, threads=best_t), 8.0, K * nnz)
+    paths = {'c_port_%d_threads' % best_t: port}
     try:
-        import warnings
-        import numpy as np
-        import scipy.sparse as sp
         warnings.filterwarnings('ignore', message='Sparse CSR tensor support is in beta state')
         xt = torch.from_numpy(x)
-        crow, ccol, cval = torch.from_numpy(rowptr), torch.from_numpy(col.astype(np.int64)), torch.from_numpy(val)
         n = rowptr.shape[0] - 1
-        a_csr = torch.sparse_csr_tensor(crow, ccol, cval, size=(n, n))
+        a_csr = torch.sparse_csr_tensor(torch.from_numpy(rowptr), torch.from_numpy(col.astype(np.int64)), torch.from_numpy(val), size=(n, n))
         a_coo = a_csr.to_sparse_coo().coalesce()
         a_sp = sp.csr_matrix((val, col, rowptr), shape=(n, n))
-
-        def rate(fn, budget):
-            fn()
-            t0, reps = time.perf_counter(), 0
-            while time.perf_counter() - t0 < budget:
-                fn()
-                reps += 1
-            return reps * nnz / (time.perf_counter() - t0)
-        out['other_host_paths_edges_per_s'] = {
-            'torch_sparse_csr_matmul_%d_threads' % torch.get_num_threads(): rate(lambda: a_csr @ xt, 3.0),
-            'torch_sparse_coo_mm_%d_threads' % torch.get_num_threads(): rate(lambda: torch.sparse.mm(a_coo, xt), 3.0),
-            'scipy_csr_1_thread': rate(lambda: a_sp @ x, 3.0)}
+        nt = torch.get_num_threads()
+        paths['torch_sparse_csr_matmul_%d_threads' % nt] = rate(lambda: a_csr @ xt, 2.5, nnz)[0]
+        paths['torch_sparse_coo_mm_%d_threads' % nt] = rate(lambda: torch.sparse.mm(a_coo, xt), 2.5, nnz)[0]
+        paths['scipy_csr_1_thread'] = rate(lambda: a_sp @ x, 2.5, nnz)[0]
     except Exception as e:                                           # reported, never fatal for the bench line
-        out['other_host_paths_edges_per_s'] = {'error': repr(e)}
+        paths['error'] = repr(e)[:100]
+    numeric = {k: v for k, v in paths.items() if isinstance(v, float)}
+    best_path = max(numeric, key=numeric.get)
+    # evaluation: users/s, best of 3 warm repetitions each
+    n_sample = 1024
+    U, items = np.ascontiguousarray(x[:n_sample]), np.ascontiguousarray(x[n_users:])
+    CO.score_topk(U[:64], items, 20)
+
+    def best_of(fn, reps=3):
+        best = 1e30
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            best = min(best, time.perf_counter() - t0)
+        return best
+    ev_port = n_sample / best_of(lambda: CO.score_topk(U, items, 20))
+    ut, it = torch.from_numpy(U), torch.from_numpy(items)
+
+    def torch_eval():
+        for b in range(0, n_sample, 512):
+            torch.topk(torch.mm(ut[b:b + 512], it.t()), k=20, dim=1)
+    torch_eval()
+    ev_torch = n_sample / best_of(torch_eval)
+    cores = best_t if best_path.startswith('c_port') else (1 if best_path.startswith('scipy') else torch.get_num_threads())
+    out = {'value': numeric[best_path], 'unit': 'edges/s', 'cores': cores, 'kind': 'port', 'best_path': best_path,
+           'sample': '%d full %d-layer passes of the same graph in %.1f s (C port, %d of %d threads); other host paths 2.5 s each'
+                     % (reps, K, dt, best_t, all_threads),
+           'host_threads': all_threads, 'c_port_edges_per_s': port, 'c_port_threads': best_t,
+           'eval_users_per_s': max(ev_port, ev_torch), 'eval_best_path': 'c_port' if ev_port >= ev_torch else 'torch_mm_topk',
+           'eval_c_port_users_per_s': ev_port, 'eval_torch_mm_topk_users_per_s': ev_torch,
+           'eval_sample': '%d users x all items, k=20, best of 3 warm repetitions' % n_sample}
+    for k, v in numeric.items():
+        out['edges_per_s_' + k] = v
+    out['c_port_thread_sweep'] = {str(t): v for t, v in sweep.items()}
     return out
 
 

@@ -85,12 +85,13 @@ class BasicModel(nn.Module):
         rep = self.get_rep()
         return rep, rep[self.n_users:]
 
-    def recommend(self, users, k, excl_rowptr=None, excl_col=None, banned=None):
+    def recommend(self, users, k, excl_rowptr=None, excl_col=None, banned=None, mode='auto'):
         """Top-k item ids per user (best first), masked by the exclusion CSR and the
-        banned mask: predict -> mask -> topk of trainer.py:147-163, fused."""
+        banned mask: predict -> mask -> topk of trainer.py:147-163, fused.  mode: ops.score_topk's ('exact' = the
+        fp32 sweep alone; the lists are the same either way)."""
         user_rows, item_rows = self.score_tables()
         idx, _ = ops.score_topk(user_rows, item_rows, k, user_ids=users.contiguous(), excl_rowptr=excl_rowptr,
-                                excl_col=excl_col, banned=banned)
+                                excl_col=excl_col, banned=banned, mode=mode)
         return idx
 
     def _cached_rep(self, key, compute):

@@ -447,7 +447,7 @@ class BasicTrainer:
             self._excl_cache['excl_val_' + val_or_test] = _sorted_csr_device(lists, self.dataset.n_items, self.device)
         return self._excl_cache['excl_val_' + val_or_test]
 
-    def recommend_all(self, val_or_test, banned_items=None):
+    def recommend_all(self, val_or_test, banned_items=None, mode='auto'):
         """[n_users, max(topks)] recommended item ids on the device."""
         k = max(self.topks)
         excl_rowptr, excl_col = self._exclusion(val_or_test)
@@ -460,7 +460,7 @@ class BasicTrainer:
             for start in range(0, self.dataset.n_users, self.eval_chunk):
                 users = torch.arange(start, min(start + self.eval_chunk, self.dataset.n_users), dtype=torch.int64,
                                      device=self.device)
-                out.append(self.model.recommend(users, k, excl_rowptr, excl_col, banned))
+                out.append(self.model.recommend(users, k, excl_rowptr, excl_col, banned, **({} if mode == 'auto' else {'mode': mode})))
         return torch.cat(out, dim=0) if len(out) > 1 else out[0]
 
     def eval(self, val_or_test, banned_items=None, _eval_lists=None):

@@ -476,3 +476,57 @@ def test_xcd_plan_covers_every_nonzero_once(golden, threshold):
         assert cut.any() and float(load.max() / load.mean()) < 1.25
     else:
         assert not cut.any() and len(sg) == 0
+
+
+def test_c_oracle_score_topk_masks_and_ragged_batches(golden):
+    """The C restatement's evaluation loop (8 users at a time, sorted k-list) against the numpy one: exclusion lists,
+    banned items, user ids, a batch that is not a multiple of 8, k larger than the unmasked items."""
+    from oracle import c_oracle as CO
+    nu, ni = int(golden['n_users']), int(golden['n_items'])
+    rng = np.random.default_rng(1)
+    x = rng.integers(-3, 4, size=(nu + ni, 16)).astype(np.float32)        # exact arithmetic, many ties
+    train, _ = O.read_data(os.path.join(golden['path'], 'train.txt'))
+    users = rng.permutation(nu)[:min(nu, 29)].astype(np.int64)
+    rp = np.zeros(nu + 1, dtype=np.int64)
+    np.cumsum([len(t) for t in train], out=rp[1:])
+    ec = np.array([i for t in train for i in sorted(t)], dtype=np.int32)
+    banned = (rng.random(ni) < 0.3).astype(np.uint8)
+    k = 7
+    idx, val = CO.score_topk(x[:nu], x[nu:], k, user_ids=users, excl_rowptr=rp, excl_col=ec, banned=banned)
+    scores = x[users] @ x[nu:].T
+    ref = O.eval_topk(scores, [train[u] for u in users], np.flatnonzero(banned), k=k)
+    np.testing.assert_array_equal(idx, ref)
+    k_all = ni                                                             # every item, masked ones last as -inf
+    idx, val = CO.score_topk(x[:nu], x[nu:], k_all, user_ids=users[:3], banned=banned)
+    assert np.isneginf(val[:, int((banned == 0).sum()):]).all() and np.isfinite(val[:, :int((banned == 0).sum())]).all()
+
+
+def test_generated_bipartite_graph_rank_shares_match_the_host_builder():
+    """synth.BipartiteGraphDevice (the config-5 generator, here small and on the CPU): generator rules (>= min_inter per
+    user, no duplicate pair, popularity skew), and every rank's share under ShardLayout.balanced — rows, global column
+    ids and A_hat values — equals the same rows of graph.normalized_adjacency_host on the pair list, bit for bit."""
+    from igcn_cf_amd.dist import ShardLayout
+    from igcn_cf_amd.graph import normalized_adjacency_host
+    from igcn_cf_amd.synth import BipartiteGraphDevice
+    g = BipartiteGraphDevice(3000, 700, 60000, 'cpu', seed=5, min_inter=7, zipf_q=40.)
+    users, items = g.users.numpy(), g.items.numpy()
+    assert abs(g.n_edges - 60000) < 6000 and np.bincount(users, minlength=3000).min() >= 5       # 7 draws, rarely duplicates
+    assert len(np.unique(users * 700 + items)) == g.n_edges
+    deg_i = np.sort(np.bincount(items, minlength=700))[::-1]
+    assert deg_i[:7].sum() > 8 * deg_i[-350:].mean() * 7                                        # a head and a tail
+    rowptr, col, val = normalized_adjacency_host(np.stack([users, items], 1), 3000, 700)
+    np.testing.assert_array_equal(rowptr, g.rowptr_host())
+    world = 3
+    layout = ShardLayout.balanced(rowptr, 3000, 700, world)
+    total = 0
+    for r in range(world):
+        csr, grow = g.rank_share(layout, r)
+        grow = grow.numpy()
+        lp = csr.rowptr.numpy()
+        total += csr.nnz
+        for j in list(range(0, len(grow), 97)) + [len(grow) - 1]:
+            gr = grow[j]
+            np.testing.assert_array_equal(csr.col.numpy()[lp[j]:lp[j + 1]], col[rowptr[gr]:rowptr[gr + 1]])
+            np.testing.assert_array_equal(csr.val.numpy()[lp[j]:lp[j + 1]], val[rowptr[gr]:rowptr[gr + 1]])
+        assert abs(csr.nnz / (rowptr[-1] / world) - 1) < 0.05                                    # nnz-balanced
+    assert total == rowptr[-1] == g.nnz

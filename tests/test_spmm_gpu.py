@@ -341,37 +341,42 @@ def test_launch_shape_does_not_change_results():
     assert torch.equal(spmm(ordered, x), ref)
 
 
-def test_config5_rank_shard_hbm_bound_variant():
-    """BASELINE config 5 (10 M users x 2 M items x 500 M edges, d = 128, 8 GPUs): ONE rank's share under row
-    sharding — 1.5 M rows, 125 M nonzeros against the full replicated 12 M x 128 operand (6.1 GB, far beyond the
-    Infinity Cache) — through igcn_spmm_csr_f32 (kernel spmm_csr_rows_kernel<32,false>, the HBM-bound variant):
-    256 sampled rows against float64, and <Y, A X> = <A^T Y, X> with the device-built transposed view."""
+def test_config5_bipartite_graph_all_eight_rank_shares():
+    """BASELINE config 5 AS WRITTEN: a bipartite 10 M users x 2 M items x ~500 M edges graph generated in HBM with the
+    SURVEY 8(d) rules (log-normal user degrees >= 7, Zipf-Mandelbrot items over a random permutation, de-duplicated),
+    cut with ShardLayout.balanced(world = 8), every rank's share — its user block (gathering from the 2 M item rows)
+    and its item block (gathering from the 10 M user rows) — run one after the other on this one GPU against the full
+    replicated 12 M x 128 operand (6.1 GB; the 'halves' exchange of dist.py is a device copy here, SURVEY 8(e) caveat):
+    256 sampled rows per rank against float64 <= 1e-4, sum of the local nonzeros == nnz(A_hat), shares nnz-balanced,
+    and the adjoint identity on one share's transposed view."""
+    from igcn_cf_amd.dist import ShardLayout
     from igcn_cf_amd.graph import CsrMatrix
     from igcn_cf_amd.ops import spmm
-    d, n_cols, n_rows, nnz_target = 128, 12_000_000, 1_500_000, 125_000_000
-    g = torch.Generator(device='cuda').manual_seed(5)
-    w = torch.exp(torch.randn(n_rows, device='cuda', generator=g))
-    deg = torch.clamp((w / w.sum() * nnz_target).round().long(), min=1)
-    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device='cuda')
-    torch.cumsum(deg, 0, out=rowptr[1:])
-    nnz = int(rowptr[-1].item())
-    col = torch.randint(0, n_cols, (nnz,), device='cuda', generator=g, dtype=torch.int32)
-    val = torch.rand(nnz, device='cuda', generator=g) * 0.1
-    csr = CsrMatrix.from_device(rowptr, col, val, (n_rows, n_cols))
-    assert csr.n_long > 0                                               # log-normal rows: the long-row pass is exercised too
-    x = torch.randn(n_cols, d, device='cuda', generator=g) * 0.1
-    y = spmm(csr, x)
-    rows = torch.randint(0, n_rows, (256,), device='cuda', generator=g).tolist()
-    for r in rows:
-        s, e = int(rowptr[r]), int(rowptr[r + 1])
-        ref = (x[col[s:e].long()].double() * val[s:e].double()[:, None]).sum(0)
-        assert float((y[r].double() - ref).abs().max() / (ref.abs().max() + 1e-30)) < 1e-4, r
-    # adjoint identity on the transposed view (values = ones there: fold A's values into the test through val = None)
-    ones = CsrMatrix.from_device(rowptr, col, None, (n_rows, n_cols))
-    yt = torch.randn(n_rows, d, device='cuda', generator=g)
-    lhs = (spmm(ones, x).double() * yt.double()).sum().item()
-    rhs = (spmm(ones.transposed_view(), yt).double() * x.double()).sum().item()
-    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+    from igcn_cf_amd.synth import BipartiteGraphDevice, check_rows_f64
+    d, world = 128, 8
+    g = BipartiteGraphDevice(10_000_000, 2_000_000, 500_000_000, 'cuda', seed=2021)
+    assert abs(g.n_edges / 5e8 - 1) < 0.03 and int(g.deg_u.min()) >= 5
+    layout = ShardLayout.balanced(g.rowptr_host(), g.n_users, g.n_items, world)
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.randn(g.n, d, device='cuda', generator=gen) * 0.1
+    total = 0
+    for r in range(world):
+        csr, grow = g.rank_share(layout, r)
+        total += csr.nnz
+        assert abs(csr.nnz / (g.nnz / world) - 1) < 0.02, (r, csr.nnz)                      # balanced by nonzeros
+        assert csr.n_long > 0                                                               # popular items: the long-row pass too
+        y = spmm(csr, x)
+        rows = torch.randint(0, csr.shape[0], (256,), device='cuda', generator=gen).tolist()
+        assert check_rows_f64(csr, x, y, rows) < 1e-4, r
+        if r == 3:                                                                           # <Y, A X> = <A^T Y, X>
+            ones = CsrMatrix.from_device(csr.rowptr, csr.col, None, csr.shape)
+            yt = torch.randn(csr.shape[0], d, device='cuda', generator=gen)
+            lhs = (spmm(ones, x).double() * yt.double()).sum().item()
+            rhs = (spmm(ones.transposed_view(), yt).double() * x.double()).sum().item()
+            assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0), (lhs, rhs)
+            del ones, yt
+        del csr, grow, y
+    assert total == g.nnz
 
 
 def test_device_graph_builders_are_bit_identical_to_the_host_ones(golden):
