@@ -134,8 +134,12 @@ class RowShardedPropagator:
             from . import ops
             spmm_fn = ops.spmm
         if csr_factory is None:
-            from .graph import CsrMatrix
-            csr_factory = lambda rp, c, v, shape, blocks=None: CsrMatrix(rp, c, v, shape, self.device, order_blocks=blocks)
+            from .graph import XCD_PLAN, CsrMatrix
+            # 'fused' (operand of tens of MB, slices of it fit an XCD's L2): the XCD plan, as on one GPU; 'halves'
+            # (operand of GBs): the plain long-row plan — cutting rows buys nothing when a slice is 100x an L2
+            plan = XCD_PLAN if exchange == 'fused' else None
+            csr_factory = lambda rp, c, v, shape, blocks=None: CsrMatrix(rp, c, v, shape, self.device, order_blocks=blocks,
+                                                                         xcd_plan=plan)
         self.spmm = spmm_fn
         (urp, ucol, uval), (irp, icol, ival) = local_blocks_host(rowptr, col, val, self.layout, rank)
         L = self.layout

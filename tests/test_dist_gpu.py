@@ -109,3 +109,101 @@ def test_row_sharded_product_path_ranks_share_one_gpu(golden, world, exchange, d
             np.testing.assert_allclose(scores[u, rec[j]], want, rtol=1e-4, atol=1e-6)
         users_seen += uhi - ulo
     assert users_seen == nu
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE config 4 at its real size: LightGCN 3-layer d = 64 on the Amazon-book-like split, rows sharded over 2 and 4
+# ranks (here sharing the one GPU, exchange over gloo), against the UNSHARDED HIP path on the same weights.
+# ------------------------------------------------------------------------------------------------------------------
+def _amazon_worker(rank, world, port, seed, batch, k, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from igcn_cf_amd.dataset import SyntheticDataset
+        from igcn_cf_amd.dist import ShardedLightGCN
+        from igcn_cf_amd.trainer import _merge_sorted_csr
+        dev = torch.device('cuda', 0)
+        ds = SyntheticDataset({'name': 'SyntheticDataset', 'preset': 'amazon', 'seed': 2021, 'device': dev})
+        model = ShardedLightGCN(ds, 64, 3, rank, world, dev, seed=seed)           # the same N(0, 0.1^2) table on every rank
+        L = model.prop.layout
+        (ulo, uhi), (ilo, ihi) = L.user_rows(rank), L.item_rows(rank)
+        excl = _merge_sorted_csr(ds.csr('train', sort=True), ds.csr('val', sort=True))
+        with torch.no_grad():
+            ru, ri = model.get_rep_local()
+            rep_u, rep_i = ru[:uhi - ulo:53].cpu().numpy().copy(), ri[:ihi - ilo:53].cpu().numpy().copy()
+            rec = model.recommend_local(k, excl=excl)[::29].cpu().numpy().copy()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        b = torch.from_numpy(batch).to(dev)
+        losses = []
+        for _ in range(2):
+            terms = model.bpr_loss_terms(b[:, 0].contiguous(), b[:, 1].contiguous(), b[:, 2].contiguous())
+            loss = terms[0] + 1e-2 * terms[1]
+            opt.zero_grad(); loss.backward(); opt.step()
+            losses.append(float(loss.detach()))
+        emb_u = model.emb_users.detach()[:uhi - ulo:53].cpu().numpy().copy()
+        emb_i = model.emb_items.detach()[:ihi - ilo:53].cpu().numpy().copy()
+        ret[rank] = dict(bounds=(ulo, uhi, ilo, ihi), rep_u=rep_u, rep_i=rep_i, rec=rec, losses=losses, emb_u=emb_u, emb_i=emb_i,
+                         exchange=model.prop.exchange, local_nnz=model.prop.local_nnz)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_config4_amazon_size_row_sharded_against_the_unsharded_hip_path(world):
+    from igcn_cf_amd import ops
+    from igcn_cf_amd.dataset import SyntheticDataset
+    from igcn_cf_amd.model import get_model
+    from igcn_cf_amd.trainer import _merge_sorted_csr, _csr_to_device
+    k, seed = 20, 77
+    ds = SyntheticDataset({'name': 'SyntheticDataset', 'preset': 'amazon', 'seed': 2021, 'device': 'cuda'})
+    nu, ni = ds.n_users, ds.n_items
+    rng = np.random.default_rng(3)
+    B = 2048
+    batch = np.stack([rng.integers(0, nu, B), rng.integers(0, ni, B), rng.integers(0, ni, B)], axis=1).astype(np.int64)
+    batch[5] = batch[4]
+    # the unsharded product path on the same table
+    model = get_model({'name': 'LightGCN', 'embedding_size': 64, 'n_layers': 3, 'device': 'cuda'}, ds)
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    with torch.no_grad():
+        model.embedding.weight.copy_((torch.randn(nu + ni, 64, generator=g) * 0.1).cuda())
+    model.eval()
+    with torch.no_grad():
+        rep = model.get_rep().clone()
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    b = torch.from_numpy(batch).cuda()
+    ref_losses = []
+    for _ in range(2):
+        terms = model.bpr_loss_terms(b[:, 0].contiguous(), b[:, 1].contiguous(), b[:, 2].contiguous())
+        loss = terms[0] + 1e-2 * terms[1]
+        opt.zero_grad(); loss.backward(); opt.step()
+        ref_losses.append(float(loss.detach()))
+    emb2 = model.embedding.weight.detach()
+    excl = _merge_sorted_csr(ds.csr('train', sort=True), ds.csr('val', sort=True))
+    erp, ecl = _csr_to_device(excl[0], excl[1], 'cuda')
+
+    ret = mp.Manager().dict()
+    mp.spawn(_amazon_worker, args=(world, _free_port(), seed, batch, k, ret), nprocs=world, join=True)
+    users_seen = nnz_seen = 0
+    for r in range(world):
+        out = ret[r]
+        ulo, uhi, ilo, ihi = out['bounds']
+        assert out['exchange'] == 'fused'                                         # 52.8 MB operand: one all-gather per layer
+        scale = float(rep.abs().max())
+        assert np.abs(out['rep_u'] - rep[ulo:uhi:53].cpu().numpy()).max() <= 1e-5 * scale
+        assert np.abs(out['rep_i'] - rep[nu + ilo:nu + ihi:53].cpu().numpy()).max() <= 1e-5 * scale
+        np.testing.assert_allclose(out['losses'], ref_losses, rtol=2e-6)
+        # two Adam steps (lr 1e-2): an update is lr * m / sqrt(v); rounding-level gradient differences show at 1e-5
+        np.testing.assert_allclose(out['emb_u'], emb2[ulo:uhi:53].cpu().numpy(), rtol=1e-4, atol=3e-5)
+        np.testing.assert_allclose(out['emb_i'], emb2[nu + ilo:nu + ihi:53].cpu().numpy(), rtol=1e-4, atol=3e-5)
+        # user-sharded top-20 (train + val lists masked): the same score multiset as the unsharded fused scorer's
+        users = torch.arange(ulo, uhi, 29, device='cuda')
+        idx, val = ops.score_topk(rep, rep[nu:], k, user_ids=users, excl_rowptr=erp, excl_col=ecl, mode='exact')
+        got = (rep[users][:, None, :] * rep[nu:][torch.from_numpy(out['rec']).cuda()]).sum(-1)
+        assert float((got - val).abs().max()) <= 1e-5 * float(val.abs().max())
+        assert float((torch.from_numpy(out['rec']).cuda() == idx).float().mean()) > 0.999      # ids: equal up to near-ties
+        users_seen += uhi - ulo
+        nnz_seen += out['local_nnz']
+    assert users_seen == nu and nnz_seen == model.norm_adj.nnz
+    nnzs = [ret[r]['local_nnz'] for r in range(world)]
+    assert max(nnzs) / (sum(nnzs) / world) < 1.02                                 # nnz-balanced blocks
