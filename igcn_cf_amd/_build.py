@@ -9,7 +9,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(PKG, 'libigcn_hip.so')
 ROOF_LIB = os.path.join(PKG, 'libigcn_roof.so')
-SOURCES = [f for f in ('spmm.hip', 'bpr.hip', 'score_topk.hip', 'sampler.hip', 'csr_util.hip')
+SOURCES = [f for f in ('spmm.hip', 'bpr.hip', 'score_topk.hip', 'topk_order.hip', 'sampler.hip', 'csr_util.hip')
            if os.path.exists(os.path.join(CSRC, f))]
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-Wall', '-Wno-unused-function',
          '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]

@@ -48,9 +48,11 @@ SIGNATURES = {
     'igcn_score_topk_workspace_bytes': (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
     'igcn_score_topk_f32': (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32,
                                       vp, vp, vp, C.c_int32, vp, vp, vp, vp]),
-    'igcn_score_topk_fast_workspace_bytes': (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32]),
+    'igcn_score_topk_bounded_f32': (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32,
+                                              vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp]),
+    'igcn_score_topk_fast_workspace_bytes': (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64]),
     'igcn_score_topk_fast_f32': (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32,
-                                           vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp]),
+                                           vp, vp, C.c_int64, C.c_int64, vp, C.c_int32, vp, vp, vp, vp, vp, vp]),
     'igcn_hit_matrix': (C.c_int, [vp, C.c_int64, C.c_int32, vp, vp, vp, vp]),
     'igcn_bpr_sample': (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, vp, vp]),
     'igcn_bpr_sample_nodes': (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, vp, vp]),

@@ -49,6 +49,7 @@
 #include <math.h>
 #include <type_traits>
 #include "common.h"
+#include "topk_order.h"
 
 namespace igcn {
 
@@ -292,6 +293,7 @@ struct TopkArgs {
     int64_t *out_idx; float *out_val; float *ws_val; int32_t *ws_idx;
     const float4 *packed;     // MODE 1: item planes [tile][plane 0..1][k-step 0..3][lane] x 16 B; MODE 2: [tile][k-step][lane] x 16 B
     const unsigned int *stats; // MODE 2: bit patterns of max |item row|^2, max |item element|, max |user element|
+    const float *init_thr;     // NULL, or per batch position a LOWER BOUND of the user's k-th best score: only items that reach it are looked at
 };
 
 // FULL: d == D, no k-slice of a row is padding.  NG: 32-user groups of a wave.  MODE 0: fp32 MFMA, the exact fmaf
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
         for (int g = 0; g < NG; ++g) {
             // a lane without a user (past the end of the batch) never has a candidate: its zero embedding would
             // otherwise tie every score with its threshold and flood the staging lists
-            thr[g] = user_ok[g] ? -INFINITY : INFINITY;
+            thr[g] = user_ok[g] ? (A.init_thr ? A.init_thr[group * UPW + g * 32 + j] : -INFINITY) : INFINITY;
             cnt[g] = 0;
             stage_addr[g] = (unsigned)(uintptr_t)(stage_all + (g * cap) * kWave + lane);
         }
@@ -463,6 +465,8 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
                 cnt[g] = 0;
                 const unsigned long long r = heap_base[g * 32 + j];     // root of user (g, j), kept by lane g * 32 + j
                 thr[g] = !user_ok[g] ? INFINITY : r ? key_score(r) : -INFINITY;   // list not full yet: everything may enter
+                // ... that reaches the caller's lower bound (the list fills from the items above it: there are >= k)
+                if (A.init_thr && user_ok[g]) thr[g] = fmaxf(thr[g], A.init_thr[group * UPW + g * 32 + j]);
             }
 #ifdef IGCN_TOPK_STATS
             asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(thr[0]) : "memory");
@@ -956,12 +960,12 @@ __global__ __launch_bounds__(kBlock) void topk_merge_lanes_kernel(const float *_
 
 // banned uint8 [n_items] -> one bit per item, one 32-bit word per 32-item tile
 __global__ __launch_bounds__(kBlock) void topk_pack_banned_kernel(const uint8_t *__restrict__ banned, int64_t n_items, int n_tiles,
-                                                                  uint32_t *__restrict__ bits)
+                                                                  const int32_t *__restrict__ perm, uint32_t *__restrict__ bits)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t pair = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);     // a wave packs two tiles
-    const int64_t item = pair * kWave + lane;
-    const bool b = item < n_items && banned[item] != 0;
+    const int64_t item = pair * kWave + lane;                                              // sweep position
+    const bool b = item < n_items && banned[perm ? perm[item] : item] != 0;
     const unsigned long long m = __ballot(b);
     if (lane == 0) {
         if (2 * pair < n_tiles) bits[2 * pair] = (uint32_t)m;
@@ -990,17 +994,17 @@ __global__ void hit_matrix_kernel(const int64_t *__restrict__ rec, int64_t n_use
 // Item table -> MFMA-ready bf16 planes for MODE 1: [tile][plane 0..1][k-step 0..3][lane 0..63] x 16 B, lane (j, kg)
 // holding k = 16 s + 8 kg .. + 7 of item 32 tile + j (rows past the end: zeros).  One thread per (tile, k-step, lane).
 __global__ __launch_bounds__(kBlock) void topk_pack_items_kernel(const float *__restrict__ item_rows, int64_t ldi, int64_t n_items,
-                                                                 int n_tiles, float4 *__restrict__ packed)
+                                                                 int n_tiles, const int32_t *__restrict__ perm, float4 *__restrict__ packed)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n_tiles * 4 * kWave) return;
     const int lane = (int)(i % kWave);
     const int s = (int)(i / kWave % 4);
     const int64_t tile = i / (4 * kWave);
-    const int64_t item = tile * 32 + (lane & 31);
+    const int64_t item = tile * 32 + (lane & 31);                 // sweep position
     float4 lo = f4_zero(), hi = f4_zero();
     if (item < n_items) {
-        const float *src = item_rows + item * ldi + 16 * s + 8 * (lane >> 5);
+        const float *src = item_rows + (int64_t)(perm ? perm[item] : item) * ldi + 16 * s + 8 * (lane >> 5);
         lo = *reinterpret_cast<const float4 *>(src);
         hi = *reinterpret_cast<const float4 *>(src + 4);
     }
@@ -1011,12 +1015,15 @@ __global__ __launch_bounds__(kBlock) void topk_pack_items_kernel(const float *__
 }
 
 // stats[0] = max over the items of |row|^2, stats[1] = max |item element| (d = 64: a 16-lane group per row), as the bit
-// patterns of non-negative floats; a fixed small grid walks the table, one atomic per wave and statistic at the end.
+// patterns of non-negative floats; norm2_out (optional): |row|^2 of every row (what the sweep order sorts by).  A small
+// fixed grid walks the table; the maxima are reduced inside the workgroup and ONE lane per workgroup issues the atomics
+// (one atomic per wave from 2 048 waves on the same two words took 43 us).
 // With ids: the rows ids[0..n) of the table, and only the element maximum, into stats[2] (the users of a call).
 __global__ __launch_bounds__(kBlock) void topk_row_stats_kernel(const float *__restrict__ rows, int64_t ld, int64_t n,
                                                                 const int64_t *__restrict__ ids, int of_users,
-                                                                unsigned int *__restrict__ stats)
+                                                                unsigned int *__restrict__ stats, float *__restrict__ norm2_out)
 {
+    __shared__ float sh[2][kBlock / kWave];
     const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     float best_n2 = 0.f, best_el = 0.f;
@@ -1031,13 +1038,18 @@ __global__ __launch_bounds__(kBlock) void topk_row_stats_kernel(const float *__r
         }
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) n2 += __shfl_xor(n2, o);
+        if (norm2_out && r < n && (t & 15) == 0) norm2_out[r] = n2;
         best_n2 = fmaxf(best_n2, n2);
     }
 #pragma unroll
     for (int o = 1; o < kWave; o <<= 1) best_el = fmaxf(best_el, __shfl_xor(best_el, o));
 #pragma unroll
     for (int o = 16; o < kWave; o <<= 1) best_n2 = fmaxf(best_n2, __shfl_xor(best_n2, o));
-    if ((threadIdx.x & (kWave - 1)) == 0) {
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & (kWave - 1)) == 0) { sh[0][w] = best_n2; sh[1][w] = best_el; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < kBlock / kWave; ++i) { best_n2 = fmaxf(best_n2, sh[0][i]); best_el = fmaxf(best_el, sh[1][i]); }
         if (of_users) {
             atomicMax(stats + 2, __float_as_uint(best_el));
         } else {
@@ -1051,17 +1063,17 @@ __global__ __launch_bounds__(kBlock) void topk_row_stats_kernel(const float *__r
 // two that brings the largest element (stats[1]) into [0.5, 1).  One thread per (tile, k-step, lane).
 __global__ __launch_bounds__(kBlock) void topk_pack_items_f16_kernel(const float *__restrict__ item_rows, int64_t ldi, int64_t n_items,
                                                                      int n_tiles, const unsigned int *__restrict__ stats,
-                                                                     float4 *__restrict__ packed)
+                                                                     const int32_t *__restrict__ perm, float4 *__restrict__ packed)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n_tiles * 4 * kWave) return;
     const int lane = (int)(i % kWave);
     const int s = (int)(i / kWave % 4);
     const int64_t tile = i / (4 * kWave);
-    const int64_t item = tile * 32 + (lane & 31);
+    const int64_t item = tile * 32 + (lane & 31);                 // sweep position
     float4 lo = f4_zero(), hi = f4_zero();
     if (item < n_items) {
-        const float *src = item_rows + item * ldi + 16 * s + 8 * (lane >> 5);
+        const float *src = item_rows + (int64_t)(perm ? perm[item] : item) * ldi + 16 * s + 8 * (lane >> 5);
         lo = *reinterpret_cast<const float4 *>(src);
         hi = *reinterpret_cast<const float4 *>(src + 4);
     }
@@ -1078,21 +1090,26 @@ __global__ __launch_bounds__(kBlock) void topk_pack_items_f16_kernel(const float
 // reduced-precision operands and the fp32 accumulation can be off by; if a_min + eps does not stay below the k-th
 // exact score, a dropped item could belong to the list (or tie with its tail) and the user is flagged:
 // flagged[1 + n] = position of the user in the batch, flagged[0] = n.
+template <int LANES>                      // lanes of a user: 64, or 32 (two users per wave) when kc <= 32
 __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(const float *__restrict__ user_rows, int64_t ldu,
                                                               const int64_t *__restrict__ user_ids, int64_t batch,
                                                               const float *__restrict__ item_rows, int64_t ldi,
                                                               const int64_t *__restrict__ cand_idx, const float *__restrict__ cand_val,
                                                               int kc, int k, const unsigned int *__restrict__ stats, int mode,
+                                                              const int32_t *__restrict__ perm,
                                                               int64_t *__restrict__ out_idx, float *__restrict__ out_val,
-                                                              int32_t *__restrict__ flagged)
+                                                              int32_t *__restrict__ flagged, float *__restrict__ flagged_thr)
 {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int64_t b = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-    if (b >= batch) return;
+    constexpr int UPW = kWave / LANES;                            // users per wave
+    const int lane = threadIdx.x & (LANES - 1);
+    const int base = (threadIdx.x & (kWave - 1)) - lane;          // first lane of this user's lane group
+    const int64_t b = ((int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * UPW + (base ? 1 : 0);
+    if (b >= batch) return;                                       // (a whole lane group leaves: the shuffles below stay inside a group)
     const int64_t uid = user_ids ? user_ids[b] : b;
     const float *u = user_rows + uid * ldu;
     const bool live = lane < kc;
-    const int64_t item = live ? cand_idx[b * kc + lane] : -1;
+    int64_t item = live ? cand_idx[b * kc + lane] : -1;           // a sweep position
+    if (perm && item >= 0) item = perm[item];
     const float approx = live ? cand_val[b * kc + lane] : -INFINITY;
     const bool real = item >= 0 && approx > -INFINITY;            // -inf: a masked item filling a short list, or an empty slot
     float exact = -INFINITY, un2 = 0.f;
@@ -1114,8 +1131,8 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(const float *__res
     const int id32 = item >= 0 ? (int)item : kIdxNone;
     int rank = 0;
     for (int c = 0; c < kc; ++c) {
-        const float ov = __shfl(exact, c);
-        const int oi = __shfl(id32, c);
+        const float ov = __shfl(exact, base + c);
+        const int oi = __shfl(id32, base + c);
         rank += (ranks_before(ov, oi, exact, id32) || (ov == exact && oi == id32 && c < lane)) ? 1 : 0;
     }
     if (live && rank < k) {
@@ -1127,7 +1144,7 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(const float *__res
     float a_min = real ? approx : INFINITY;
     int n_real = real ? 1 : 0;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = LANES / 2; o > 0; o >>= 1) {
         e_k = fmaxf(e_k, __shfl_xor(e_k, o));
         a_min = fminf(a_min, __shfl_xor(a_min, o));
         n_real += __shfl_xor(n_real, o);
@@ -1144,9 +1161,19 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(const float *__res
         // 2^-18 per score in scaled units = 2^-16 max|i_j| max|u_j| — matters only for a user far smaller than the
         // largest of the batch, whom it then sends to the fp32 sweep
         if (mode == 2 && eps > 0.f) eps += 0x1p-16f * __uint_as_float(stats[1]) * __uint_as_float(stats[2]);
-        // fewer real candidates than slots: the sweep dropped nothing real.  eps == 0 (an all-zero user): scores are exact.
-        const bool ok = n_real < kc || eps == 0.f || a_min + eps < e_k;
-        if (!ok) flagged[1 + atomicAdd(flagged, 1)] = (int32_t)b;
+        // fewer real candidates than slots: the sweep dropped nothing real.  eps == 0 (an all-zero user): scores are exact —
+        // enough in an id-order sweep (ties are kept by lower id there too); in a permuted sweep the ties at the end of
+        // the candidate list were kept by POSITION, so the user goes to the fp32 sweep (a_min + 0 < e_k fails on a tie).
+        // Fewer than k real candidates: the list ends with masked fill-ins, which the fp32 sweep picks by lower id and a
+        // permuted sweep by lower position: that user goes to the fp32 sweep too.
+        const bool ok = (n_real < kc && (!perm || n_real >= k)) || (eps == 0.f && !perm) || a_min + eps < e_k;
+        if (!ok) {
+            // e_k, the k-th exact score among real (unmasked) candidates, is a lower bound of the user's k-th best:
+            // the fp32 sweep that re-does this user starts from it instead of from an empty list
+            const int slot = atomicAdd(flagged, 1);
+            flagged[1 + slot] = (int32_t)b;
+            if (flagged_thr) flagged_thr[slot] = e_k;
+        }
     }
 }
 
@@ -1193,7 +1220,7 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
                     const float *item_rows, int64_t ldi, int64_t n_items, int32_t d,
                     const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned,
                     int32_t k, int64_t *out_idx, float *out_val, void *workspace, const float4 *packed,
-                    const unsigned int *stats, hipStream_t st)
+                    const unsigned int *stats, hipStream_t st, const int32_t *perm = nullptr, const float *init_thr = nullptr)
 {
     if (!user_rows || !item_rows || !out_idx || !out_val) return IGCN_E_NULL;
     if ((excl_rowptr == nullptr) != (excl_col == nullptr)) return IGCN_E_NULL;
@@ -1212,7 +1239,7 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
         banned_bits = reinterpret_cast<uint32_t *>(static_cast<char *>(workspace) + topk_merge_bytes(p, batch, k));
         const int64_t pairs = ((int64_t)p.n_tiles + 1) / 2;
         hipLaunchKernelGGL(topk_pack_banned_kernel, dim3((unsigned)((pairs + 3) / 4)), dim3(kBlock), 0, st, banned, n_items,
-                           p.n_tiles, banned_bits);
+                           p.n_tiles, perm, banned_bits);
         rc = launch_status();
         if (rc != IGCN_OK) return rc;
     }
@@ -1227,6 +1254,7 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
     a.out_idx = out_idx; a.out_val = out_val; a.ws_val = ws_val; a.ws_idx = ws_idx;
     a.packed = packed;
     a.stats = stats;
+    a.init_thr = init_thr;
 
     if (mode != 0) {
         if (d != 64 || !packed || (mode == 2 && !stats)) return IGCN_E_SHAPE;
@@ -1265,11 +1293,22 @@ extern "C" int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const in
                     out_idx, out_val, workspace, nullptr, nullptr, static_cast<hipStream_t>(stream));
 }
 
+extern "C" int igcn_score_topk_bounded_f32(const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
+                                           const float *item_rows, int64_t ldi, int64_t n_items, int32_t d,
+                                           const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned,
+                                           int32_t k, const float *lower_bound, int64_t *out_idx, float *out_val,
+                                           void *workspace, void *stream)
+{
+    if (!lower_bound) return IGCN_E_NULL;
+    return topk_run(0, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, d, excl_rowptr, excl_col, banned, k,
+                    out_idx, out_val, workspace, nullptr, nullptr, static_cast<hipStream_t>(stream), nullptr, lower_bound);
+}
+
 // ---- the two-stage evaluation: bf16 candidate sweep + exact fp32 re-scoring (d = 64, k <= 60) --------------------
 // workspace: [sweep workspace for k + 4][item planes][candidate ids][candidate scores][max |item|^2], each 256-aligned
 static inline int64_t align256(int64_t n) { return (n + 255) / 256 * 256; }
-struct FastLayout { int64_t sweep, packed, cand_idx, cand_val, norm, total; int kc; };
-static int topk_fast_layout(int64_t batch, int64_t n_items, int32_t d, int32_t k, FastLayout *L) {
+struct FastLayout { int64_t sweep, packed, cand_idx, cand_val, norm, order, total; int kc; TopkOrderLayout ord; };
+static int topk_fast_layout(int64_t batch, int64_t n_items, int32_t d, int32_t k, int64_t excl_rows, int64_t excl_nnz, FastLayout *L) {
     if (d != 64 || k < 1 || k + kFastExtra > kWave) return IGCN_E_RANGE;
     L->kc = k + kFastExtra;
     TopkPlan p;
@@ -1277,32 +1316,39 @@ static int topk_fast_layout(int64_t batch, int64_t n_items, int32_t d, int32_t k
     L->kc = (int)kc;
     int rc = topk_make_plan(batch, n_items, d, L->kc, &p, true);
     if (rc != IGCN_OK) return rc;
+    rc = topk_order_layout(n_items, excl_rows, excl_nnz, &L->ord);
+    if (rc != IGCN_OK) return rc;
     L->sweep = 0;
     L->packed = align256(topk_merge_bytes(p, batch, L->kc) + (int64_t)p.n_tiles * 4);
     L->cand_idx = L->packed + (int64_t)p.n_tiles * 8 * kWave * 16;
     L->cand_val = L->cand_idx + align256(batch * L->kc * 8);
     L->norm = L->cand_val + align256(batch * L->kc * 4);
-    L->total = L->norm + 256;
+    L->order = L->norm + 256;
+    L->total = L->order + L->ord.total;
     return IGCN_OK;
 }
 
-extern "C" int64_t igcn_score_topk_fast_workspace_bytes(int64_t batch, int64_t n_items, int32_t d, int32_t k)
+extern "C" int64_t igcn_score_topk_fast_workspace_bytes(int64_t batch, int64_t n_items, int32_t d, int32_t k,
+                                                        int64_t excl_rows, int64_t excl_nnz)
 {
     FastLayout L;
-    return topk_fast_layout(batch, n_items, d, k, &L) == IGCN_OK ? L.total : -1;
+    return topk_fast_layout(batch, n_items, d, k, excl_rows, excl_nnz, &L) == IGCN_OK ? L.total : -1;
 }
 
 extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
                                         const float *item_rows, int64_t ldi, int64_t n_items, int32_t d,
-                                        const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned,
-                                        int32_t k, int64_t *out_idx, float *out_val, int32_t *flagged,
-                                        void *workspace, void *stream)
+                                        const int64_t *excl_rowptr, const int32_t *excl_col, int64_t excl_rows, int64_t excl_nnz,
+                                        const uint8_t *banned, int32_t k, int64_t *out_idx, float *out_val,
+                                        int32_t *flagged, float *flagged_lower_bound, void *workspace, void *stream)
 {
     if (!workspace || !flagged) return IGCN_E_NULL;
     if (reinterpret_cast<uintptr_t>(workspace) % 256) return IGCN_E_ALIGN;
     if (k > n_items) return IGCN_E_RANGE;
+    if ((excl_rowptr == nullptr) != (excl_col == nullptr)) return IGCN_E_NULL;
+    if (!excl_rowptr) excl_rows = excl_nnz = 0;
+    if (excl_rowptr && (excl_rows < 1 || excl_nnz < 1)) return IGCN_E_SHAPE;
     FastLayout L;
-    int rc = topk_fast_layout(batch, n_items, d, k, &L);
+    int rc = topk_fast_layout(batch, n_items, d, k, excl_rows, excl_nnz, &L);
     if (rc != IGCN_OK) return rc;
     if (!item_rows || ldi < d || ldi % 4 || reinterpret_cast<uintptr_t>(item_rows) % 16) return IGCN_E_SHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1311,34 +1357,50 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     int64_t *cand_idx = reinterpret_cast<int64_t *>(ws + L.cand_idx);
     float *cand_val = reinterpret_cast<float *>(ws + L.cand_val);
     unsigned int *norm_bits = reinterpret_cast<unsigned int *>(ws + L.norm);
+    char *ows = ws + L.order;
     const int mode = tuning_get(IGCN_TUNE_TOPK_FAST_MODE) == 1 ? 1 : 2;    // 2: one fp16 item plane (default), 1: two bf16 planes
+    const bool by_norm = tuning_get(IGCN_TUNE_TOPK_FAST_ORDER) != 0;       // developer knob: 0 = sweep in id order
     hipError_t e = hipMemsetAsync(norm_bits, 0, 16, st);
     if (e == hipSuccess) e = hipMemsetAsync(flagged, 0, 4, st);
     if (e != hipSuccess) return (int)e;
     const int n_tiles = (int)((n_items + 31) / 32);
     const int64_t pack_threads = (int64_t)n_tiles * 4 * kWave;
     int64_t stat_blocks = (n_items * 16 + kBlock - 1) / kBlock;
-    if (stat_blocks > 2 * (int64_t)cu_count()) stat_blocks = 2 * (int64_t)cu_count();
+    if (stat_blocks > (int64_t)cu_count()) stat_blocks = (int64_t)cu_count();
     hipLaunchKernelGGL(topk_row_stats_kernel, dim3((unsigned)stat_blocks), dim3(kBlock), 0, st, item_rows, ldi, n_items,
-                       (const int64_t *)nullptr, 0, norm_bits);
+                       (const int64_t *)nullptr, 0, norm_bits, by_norm ? reinterpret_cast<float *>(ows + L.ord.norm2) : (float *)nullptr);
+    const int32_t *perm = nullptr, *excl_pos = nullptr;
+    if (by_norm) {
+        rc = topk_order_build(L.ord, ows, n_items, excl_rowptr, excl_col, excl_rows, excl_nnz, st, &perm, &excl_pos);
+        if (rc != IGCN_OK) return rc;
+    }
     if (mode == 2) {
         if (!user_rows || ldu < d || ldu % 4 || reinterpret_cast<uintptr_t>(user_rows) % 16) return IGCN_E_SHAPE;
         int64_t ub = (batch * 16 + kBlock - 1) / kBlock;
-        if (ub > 2 * (int64_t)cu_count()) ub = 2 * (int64_t)cu_count();
-        hipLaunchKernelGGL(topk_row_stats_kernel, dim3((unsigned)ub), dim3(kBlock), 0, st, user_rows, ldu, batch, user_ids, 1, norm_bits);
+        if (ub > (int64_t)cu_count()) ub = (int64_t)cu_count();
+        hipLaunchKernelGGL(topk_row_stats_kernel, dim3((unsigned)ub), dim3(kBlock), 0, st, user_rows, ldu, batch, user_ids, 1, norm_bits,
+                           (float *)nullptr);
         hipLaunchKernelGGL(topk_pack_items_f16_kernel, dim3((unsigned)((pack_threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                           item_rows, ldi, n_items, n_tiles, norm_bits, packed);
+                           item_rows, ldi, n_items, n_tiles, norm_bits, perm, packed);
     } else {
         hipLaunchKernelGGL(topk_pack_items_kernel, dim3((unsigned)((pack_threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                           item_rows, ldi, n_items, n_tiles, packed);
+                           item_rows, ldi, n_items, n_tiles, perm, packed);
     }
     rc = launch_status();
     if (rc != IGCN_OK) return rc;
-    rc = topk_run(mode, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, d, excl_rowptr, excl_col, banned, L.kc,
-                  cand_idx, cand_val, ws + L.sweep, packed, norm_bits, st);
+    // the sweep runs in position space: its exclusion lists and banned bits are those of the positions, and the
+    // candidate ids it returns are positions (mapped back by the re-scoring kernel)
+    rc = topk_run(mode, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, d, excl_rowptr, by_norm && excl_rowptr ? excl_pos : excl_col,
+                  banned, L.kc, cand_idx, cand_val, ws + L.sweep, packed, norm_bits, st, perm);
     if (rc != IGCN_OK) return rc;
-    hipLaunchKernelGGL(topk_rescore_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(kBlock), 0, st, user_rows, ldu, user_ids, batch,
-                       item_rows, ldi, cand_idx, cand_val, L.kc, (int)k, norm_bits, mode, out_idx, out_val, flagged);
+    if (L.kc <= 32)
+        hipLaunchKernelGGL(topk_rescore_kernel<32>, dim3((unsigned)((batch + 7) / 8)), dim3(kBlock), 0, st, user_rows, ldu, user_ids, batch,
+                           item_rows, ldi, cand_idx, cand_val, L.kc, (int)k, norm_bits, mode, perm, out_idx, out_val, flagged,
+                           flagged_lower_bound);
+    else
+        hipLaunchKernelGGL(topk_rescore_kernel<64>, dim3((unsigned)((batch + 3) / 4)), dim3(kBlock), 0, st, user_rows, ldu, user_ids, batch,
+                           item_rows, ldi, cand_idx, cand_val, L.kc, (int)k, norm_bits, mode, perm, out_idx, out_val, flagged,
+                           flagged_lower_bound);
     return launch_status();
 }
 

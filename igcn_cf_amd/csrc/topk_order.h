@@ -1,0 +1,20 @@
+// Internal interface between score_topk.hip and topk_order.hip (the sweep order of the two-stage evaluation).
+#pragma once
+#include "common.h"
+
+namespace igcn {
+
+// byte offsets into the order workspace (each 256-aligned); norm2 is filled by topk_row_stats_kernel
+struct TopkOrderLayout {
+    int64_t norm2, keys, keys_sorted, iota, perm, inv, ekeys, ekeys_sorted, excl_pos, tmp, total;
+    size_t tmp_bytes;
+};
+
+int topk_order_layout(int64_t n_items, int64_t excl_rows, int64_t excl_nnz, TopkOrderLayout *L);
+
+// perm (position -> item id, descending |row|^2, ties by ascending id), its inverse, and — when an exclusion CSR is given
+// — that CSR's entries as sweep positions, ascending inside every row.  Everything lives in `ws`.
+int topk_order_build(const TopkOrderLayout &L, char *ws, int64_t n_items, const int64_t *excl_rowptr, const int32_t *excl_col,
+                     int64_t excl_rows, int64_t excl_nnz, hipStream_t st, const int32_t **perm_out, const int32_t **excl_pos_out);
+
+}  // namespace igcn

@@ -378,14 +378,17 @@ def bpr_loss_terms(u_tab, p_tab, l2u_tab, l2p_tab, w, users, pos, neg, item_offs
 FAST_TOPK_MIN_WORK = 1 << 26      # users x items from which the two-stage path pays for its packing pass and its host check
 
 
-def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_col=None, banned=None, batch=None, mode='auto'):
+def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_col=None, banned=None, batch=None, mode='auto',
+               lower_bound=None):
     """Top-k item ids (best first) and scores for each user row; masked items are
     never returned unless fewer than k unmasked items exist.
 
     mode 'exact': the fp32 sweep (igcn_score_topk_f32).  'fast' (d = 64, k <= 60): the fp16 candidate sweep + exact fp32
     re-scoring (igcn_score_topk_fast_f32) — the same ids, exact fp32 scores; users whose candidate set cannot be proven
     complete (near-ties at the k-th place; counted on the device, read back here) go through the fp32 sweep.  'auto':
-    'fast' where it applies and the problem is large enough to pay for it."""
+    'fast' where it applies and the problem is large enough to pay for it.
+    lower_bound (mode 'exact' only): float32 [B] on the GPU, per user a VALID lower bound of its k-th best score
+    (igcn_score_topk_bounded_f32): only items that reach it are looked at."""
     if mode not in ('auto', 'exact', 'fast'):
         raise ValueError("mode must be 'auto', 'exact' or 'fast'")
     _require_gpu_f32(user_rows, 'user_rows')
@@ -414,6 +417,8 @@ def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_co
         raise _lib.IgcnError('banned must be uint8 [n_items] on the GPU')
     L = _lib.lib()
     fast_ok = d == 64 and k + 4 <= 64 and k <= n_items and B > 0
+    if lower_bound is not None and mode != 'exact':
+        raise _lib.IgcnError("lower_bound goes with mode='exact'")
     if mode == 'fast' and not fast_ok:
         raise _lib.IgcnError('the two-stage top-k path needs d == 64 and k <= 60 (got d=%d k=%d)' % (d, k))
     if mode == 'fast' or (mode == 'auto' and fast_ok and B * n_items >= FAST_TOPK_MIN_WORK):
@@ -425,6 +430,15 @@ def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_co
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=item_rows.device)
     out_idx = torch.empty((B, k), dtype=torch.int64, device=item_rows.device)
     out_val = torch.empty((B, k), dtype=torch.float32, device=item_rows.device)
+    if lower_bound is not None:
+        if lower_bound.dtype != torch.float32 or lower_bound.numel() != B or not lower_bound.is_cuda or not lower_bound.is_contiguous():
+            raise _lib.IgcnError('lower_bound must be a contiguous float32 [batch] tensor on the GPU')
+        _lib.check(L.igcn_score_topk_bounded_f32(
+            user_rows.data_ptr(), user_rows.stride(0), _lib.ptr(user_ids), B,
+            item_rows.data_ptr(), item_rows.stride(0), n_items, d,
+            _lib.ptr(excl_rowptr), _lib.ptr(excl_col), _lib.ptr(banned), k, lower_bound.data_ptr(),
+            out_idx.data_ptr(), out_val.data_ptr(), ws.data_ptr(), _lib.current_stream()), 'igcn_score_topk_bounded_f32')
+        return out_idx, out_val
     _lib.check(L.igcn_score_topk_f32(
         user_rows.data_ptr(), user_rows.stride(0), _lib.ptr(user_ids), B,
         item_rows.data_ptr(), item_rows.stride(0), n_items, d,
@@ -435,7 +449,9 @@ def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_co
 
 def _score_topk_fast(L, user_rows, item_rows, k, user_ids, excl_rowptr, excl_col, banned, B, n_items, d):
     dev = item_rows.device
-    ws_bytes = L.igcn_score_topk_fast_workspace_bytes(B, n_items, d, k)
+    excl_rows = excl_rowptr.numel() - 1 if excl_rowptr is not None else 0
+    excl_nnz = excl_col.numel() if excl_rowptr is not None else 0
+    ws_bytes = L.igcn_score_topk_fast_workspace_bytes(B, n_items, d, k, excl_rows, excl_nnz)
     if ws_bytes < 0:
         raise _lib.IgcnError('unsupported two-stage top-k shape: batch=%d n_items=%d d=%d k=%d' % (B, n_items, d, k))
     ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
@@ -443,17 +459,21 @@ def _score_topk_fast(L, user_rows, item_rows, k, user_ids, excl_rowptr, excl_col
     out_idx = torch.empty((B, k), dtype=torch.int64, device=dev)
     out_val = torch.empty((B, k), dtype=torch.float32, device=dev)
     flagged = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    bounds = torch.empty(B, dtype=torch.float32, device=dev)
     _lib.check(L.igcn_score_topk_fast_f32(
         user_rows.data_ptr(), user_rows.stride(0), _lib.ptr(user_ids), B,
         item_rows.data_ptr(), item_rows.stride(0), n_items, d,
-        _lib.ptr(excl_rowptr), _lib.ptr(excl_col), _lib.ptr(banned), k,
-        out_idx.data_ptr(), out_val.data_ptr(), flagged.data_ptr(), ws_ptr, _lib.current_stream()), 'igcn_score_topk_fast_f32')
+        _lib.ptr(excl_rowptr), _lib.ptr(excl_col), excl_rows, excl_nnz, _lib.ptr(banned), k,
+        out_idx.data_ptr(), out_val.data_ptr(), flagged.data_ptr(), bounds.data_ptr(), ws_ptr, _lib.current_stream()),
+        'igcn_score_topk_fast_f32')
     n_flagged = int(flagged[0].item())                      # the one host read of the path
     if n_flagged:
+        # the users whose candidate set could not be proven complete: the fp32 sweep, started from the k-th exact score
+        # of their candidates (a valid lower bound) instead of from an empty list
         pos = flagged[1:1 + n_flagged].long()
         ids = user_ids[pos] if user_ids is not None else pos
         idx_f, val_f = score_topk(user_rows, item_rows, k, user_ids=ids.contiguous(), excl_rowptr=excl_rowptr, excl_col=excl_col,
-                                  banned=banned, mode='exact')
+                                  banned=banned, mode='exact', lower_bound=bounds[:n_flagged].contiguous())
         out_idx[pos] = idx_f
         out_val[pos] = val_f
     score_topk.last_flagged = n_flagged                     # developer statistic

@@ -39,7 +39,7 @@ int         igcn_abi_version(void);
 const char *igcn_error_string(int code);
 
 /* Developer / test knobs of the launch heuristics (no reference counterpart).  name: "spmm_blocks_per_cu",
- * "spmm_multirow", "topk_slots", "topk_waves_per_cu", "topk_cap", "topk_stagger", "topk_fast_mode" (candidate sweep of
+ * "spmm_multirow", "topk_slots", "topk_waves_per_cu", "topk_cap", "topk_stagger", "topk_fast_order", "topk_fast_mode" (candidate sweep of
  * igcn_score_topk_fast_f32: 2 = one fp16 item plane, 1 = two bf16 planes); value < 0 restores the library
  * default.  Results never depend on them (tests/test_spmm_gpu.py::test_launch_shape_does_not_change_results).
  * Not thread-safe against concurrent launches.  Returns IGCN_E_RANGE for an unknown name. */
@@ -236,6 +236,18 @@ int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const int64_t *user
                         int32_t k, int64_t *out_idx, float *out_val,
                         void *workspace, void *stream);
 
+/* igcn_score_topk_f32 for users whose k-th best score the caller can bound from below (ABI v5): lower_bound float
+ * [batch] (device) — only items whose score reaches lower_bound[b] are looked at, which removes the list warm-up of a
+ * sweep (k ln(n / k) heap updates per user, half of them in the first 2 % of the items).  The bound must be valid (at
+ * least k unmasked items score >= it), else the list comes back short (id -1).  Same lists as igcn_score_topk_f32
+ * otherwise.  Used by the two-stage evaluation for the users it hands back (their re-scored candidates give the bound).
+ * No reference counterpart: trainer.py:163 is a dense torch.topk. */
+int igcn_score_topk_bounded_f32(const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
+                                const float *item_rows, int64_t ldi, int64_t n_items, int32_t d,
+                                const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned,
+                                int32_t k, const float *lower_bound, int64_t *out_idx, float *out_val,
+                                void *workspace, void *stream);
+
 /* The same evaluation in two stages (d = 64, k <= 60).  Stage 1 sweeps all items on the 16-bit matrix cores — items as
  * one fp16 plane, users as two, both tables rescaled by a power of two, fp32 accumulate: scores off by at most
  * 2^-11 |u| max|i| (igcn_set_tuning("topk_fast_mode", 1): two bf16 planes each side, three products, 2^-14) — and keeps
@@ -244,14 +256,23 @@ int igcn_score_topk_f32(const float *user_rows, int64_t ldu, const int64_t *user
  * (score, then lower id) and writes the best k: out_idx / out_val as igcn_score_topk_f32 writes them.  A user for
  * whom an item dropped by stage 1 could still reach the k-th exact score (its bound does not stay below it: near-ties
  * at the k-th place) is reported instead of trusted: flagged[0] = how many, flagged[1..] = their positions in the
- * batch (int32 [batch + 1]); the caller runs igcn_score_topk_f32 for those.  No host synchronisation inside.
+ * batch (int32 [batch + 1]), flagged_lower_bound[0..] (float [batch] or NULL) = for each of them, in the same order,
+ * the k-th exact score among its candidates — a valid lower bound for igcn_score_topk_bounded_f32, which the caller
+ * runs for those users.  No host synchronisation inside.
+ * ABI v5: stage 1 meets the items by DESCENDING squared norm (likely winners first: the running thresholds are near
+ * their final values early and most later items fail the cheap selection test; -16 % on the Amazon-like evaluation),
+ * not by id: a permutation, its inverse and the exclusion lists in sweep positions are built per call in the
+ * workspace (rocPRIM radix sorts), which is why the exclusion CSR's size is passed: excl_rows = rows of excl_rowptr
+ * (every user id of the batch < excl_rows), excl_nnz = its entries; both 0 when excl_rowptr is NULL.  The lists
+ * returned do not depend on the order.  igcn_set_tuning("topk_fast_order", 0) sweeps in id order.
  * workspace: igcn_score_topk_fast_workspace_bytes(...) bytes, 256-byte aligned. */
-int64_t igcn_score_topk_fast_workspace_bytes(int64_t batch, int64_t n_items, int32_t d, int32_t k);
+int64_t igcn_score_topk_fast_workspace_bytes(int64_t batch, int64_t n_items, int32_t d, int32_t k,
+                                             int64_t excl_rows, int64_t excl_nnz);
 int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
                              const float *item_rows, int64_t ldi, int64_t n_items, int32_t d,
-                             const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned,
-                             int32_t k, int64_t *out_idx, float *out_val, int32_t *flagged,
-                             void *workspace, void *stream);
+                             const int64_t *excl_rowptr, const int32_t *excl_col, int64_t excl_rows, int64_t excl_nnz,
+                             const uint8_t *banned, int32_t k, int64_t *out_idx, float *out_val,
+                             int32_t *flagged, float *flagged_lower_bound, void *workspace, void *stream);
 
 /* hit[u, j] = 1 if rec[u, j] is in eval_col[eval_rowptr[u]..eval_rowptr[u+1])
  * (sorted ascending), else 0: the membership loop of trainer.py:111-115.

@@ -11,7 +11,7 @@ import csv, glob
 f = glob.glob('$OUT/kt/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in csv.DictReader(open(f))))
 # last 40 steps: find bpr_sample_kernel launches as step markers
-marks = [i for i, r in enumerate(rows) if 'bpr_fwd_kernel' in r[2]]
+marks = [i for i, r in enumerate(rows) if 'bpr_sample_kernel' in r[2]]
 a, b = marks[-41], marks[-1]
 seg = rows[a:b]
 wall = seg[-1][1] - seg[0][0]
