@@ -298,10 +298,13 @@ struct TopkArgs {
 
 // FULL: d == D, no k-slice of a row is padding.  NG: 32-user groups of a wave.  MODE 0: fp32 MFMA, the exact fmaf
 // chain.  MODE 1 (D = 64, FULL): the candidate sweep on the bf16 matrix cores described above.
-template <int D, int NG, bool FULL, int MODE = 0>
+// BOUNDED: A.init_thr holds a lower bound of every user's k-th best score (igcn_score_topk_bounded_f32); a variant of
+// its own so that the plain sweeps carry nothing of it (two more live values cost the fp32 sweep 4 %).
+template <int D, int NG, bool FULL, int MODE = 0, bool BOUNDED = false>
 __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
 {
     static_assert(MODE == 0 || (D == 64 && FULL && NG == 2), "the candidate sweeps are built for d = 64");
+    static_assert(!BOUNDED || MODE == 0, "a lower bound goes with the exact sweep");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *const heap_base = reinterpret_cast<unsigned long long *>(smem);       // [k][64 owner lanes]
     unsigned long long *const heap = heap_base + threadIdx.x;                                  // this lane's own heap
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
         for (int g = 0; g < NG; ++g) {
             // a lane without a user (past the end of the batch) never has a candidate: its zero embedding would
             // otherwise tie every score with its threshold and flood the staging lists
-            thr[g] = user_ok[g] ? (A.init_thr ? A.init_thr[group * UPW + g * 32 + j] : -INFINITY) : INFINITY;
+            thr[g] = user_ok[g] ? (BOUNDED ? A.init_thr[group * UPW + g * 32 + j] : -INFINITY) : INFINITY;
             cnt[g] = 0;
             stage_addr[g] = (unsigned)(uintptr_t)(stage_all + (g * cap) * kWave + lane);
         }
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
                 const unsigned long long r = heap_base[g * 32 + j];     // root of user (g, j), kept by lane g * 32 + j
                 thr[g] = !user_ok[g] ? INFINITY : r ? key_score(r) : -INFINITY;   // list not full yet: everything may enter
                 // ... that reaches the caller's lower bound (the list fills from the items above it: there are >= k)
-                if (A.init_thr && user_ok[g]) thr[g] = fmaxf(thr[g], A.init_thr[group * UPW + g * 32 + j]);
+                if constexpr (BOUNDED) { if (user_ok[g]) thr[g] = fmaxf(thr[g], A.init_thr[group * UPW + g * 32 + j]); }
             }
 #ifdef IGCN_TOPK_STATS
             asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(thr[0]) : "memory");
@@ -1177,10 +1180,10 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(const float *__res
     }
 }
 
-template <int D, int NG, bool FULL, int MODE = 0>
+template <int D, int NG, bool FULL, int MODE = 0, bool BOUNDED = false>
 static int launch_topk(const TopkPlan &p, hipStream_t st, const TopkArgs &args)
 {
-    auto kern = score_topk_kernel<D, NG, FULL, MODE>;
+    auto kern = score_topk_kernel<D, NG, FULL, MODE, BOUNDED>;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1263,7 +1266,11 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
         switch (p.d_pad) {
         case 16: rc = d == 16 ? launch_topk<16, 2, true>(p, st, a) : launch_topk<16, 2, false>(p, st, a); break;
         case 32: rc = d == 32 ? launch_topk<32, 2, true>(p, st, a) : launch_topk<32, 2, false>(p, st, a); break;
-        case 64: rc = d == 64 ? launch_topk<64, 2, true>(p, st, a) : launch_topk<64, 2, false>(p, st, a); break;
+        case 64:
+            // the bound is an optimisation: the variants without it (other widths) simply do not use it
+            if (d == 64 && init_thr) rc = launch_topk<64, 2, true, 0, true>(p, st, a);
+            else rc = d == 64 ? launch_topk<64, 2, true>(p, st, a) : launch_topk<64, 2, false>(p, st, a);
+            break;
         default: rc = d == 128 ? launch_topk<128, 1, true>(p, st, a) : launch_topk<128, 1, false>(p, st, a); break;
         }
     }

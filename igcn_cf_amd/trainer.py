@@ -276,10 +276,11 @@ class BasicTrainer:
             torch.cuda.current_stream().wait_stream(side)
             put_back()
         graph = torch.cuda.CUDAGraph()
+        one = self._graph_one = torch.ones((), dtype=torch.float32, device=self.device)   # the root gradient: autograd would fill a new one per replay
         try:
             with torch.cuda.graph(graph):
                 loss = loss_fn(*self._static_inputs)
-                loss.backward()
+                loss.backward(one)
                 self.opt.step()
                 self._static_loss = loss.detach()
         except BaseException:
