@@ -180,7 +180,7 @@ def feature_matrix_device(train_array, n_users, n_items, user_map, item_map, dev
     n_rows = n_users + n_items
     rowptr, row, col, val = _csr_from_keys_device(key, n_rows, n_cols)
     row_sum = torch.zeros(n_rows, dtype=torch.float32, device=device).index_add_(0, row, val)
-    f = CsrMatrix.from_device(rowptr, col, None, (n_rows, n_cols), order_blocks=[0, n_users, n_rows])
+    f = CsrMatrix.from_device(rowptr, col, None, (n_rows, n_cols), order_blocks=[0, n_users, n_rows], xcd_plan=XCD_PLAN_FEATURES)
     f.transposed_order_blocks = [0, user_dim, user_dim + item_dim, n_cols]
     return f, row_sum
 
@@ -212,6 +212,7 @@ def graph_rank_nodes(dataset, ranking_metric):
 # -11 %, Yelp-like -16 %, Gowalla-like -26 %, d = 32 +-1 %; thresholds 96...160 within 2 % of each other, 64 and below lose
 # (8 partial rows per cut row).  None = the plain long-row plan.
 XCD_PLAN = {'threshold': 112}
+XCD_PLAN_FEATURES = XCD_PLAN   # INMO's template-feature matrix F and its transposed view: -1...-3 % (profiles/r03m_*); None = plain plan
 N_XCD = 8                  # lists of the XCD plan = XCDs of an MI355X (igcn_spmm_csr_f32: xcd_off has N_XCD + 1 entries)
 
 
@@ -419,8 +420,10 @@ class CsrMatrix:
                                                 t_rowptr.data_ptr(), _lib.ptr(t_col), _lib.ptr(edge_id), ws.data_ptr(),
                                                 _lib.current_stream()), 'igcn_csr_transpose')
                 self._transposed = CsrMatrix.from_device(t_rowptr, t_col, None, (self.shape[1], self.shape[0]), edge_id=edge_id,
-                                                         long_threshold=self.long_threshold, segment_len=self.segment_len,
-                                                         order_blocks=getattr(self, 'transposed_order_blocks', None))
+                                                         long_threshold=LONG_THRESHOLD if self.xcd_plan else self.long_threshold,
+                                                         segment_len=SEGMENT_LEN if self.xcd_plan else self.segment_len,
+                                                         order_blocks=getattr(self, 'transposed_order_blocks', None),
+                                                         xcd_plan=self.xcd_plan if getattr(self, 'transposed_order_blocks', None) else None)
             else:
                 col = self._col_host if self._col_host is not None else self.col.cpu().numpy()
                 self._transposed = CsrMatrix.transposed(self.rowptr_host, col, self.shape, self.device,
