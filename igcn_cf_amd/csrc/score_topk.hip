@@ -294,6 +294,10 @@ struct TopkArgs {
     const float4 *packed;     // MODE 1: item planes [tile][plane 0..1][k-step 0..3][lane] x 16 B; MODE 2: [tile][k-step][lane] x 16 B
     const unsigned int *stats; // MODE 2: bit patterns of max |item row|^2, max |item element|, max |user element|
     const float *init_thr;     // NULL, or per batch position a LOWER BOUND of the user's k-th best score: only items that reach it are looked at
+    // MODE 2, descending-norm order: tile_bound[t] >= s_i |i| (1 + margin) for every item of tile t AND of every later
+    // tile; unorm2[b] = |u_b|^2.  |approximate score| <= s_u |u| tile_bound: once no user of the wave can be reached, the
+    // rest of the sweep is skipped.  NULL: no early exit.
+    const float *tile_bound; const float *unorm2;
 };
 
 // FULL: d == D, no k-slice of a row is padding.  NG: 32-user groups of a wave.  MODE 0: fp32 MFMA, the exact fmaf
@@ -810,6 +814,17 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
             load_into(a2, tin0 + 1 < tin1 ? tin0 + 1 : tin1 - 1);
             load_into(a3, tin0 + 2 < tin1 ? tin0 + 2 : tin1 - 1);
             for (int tile = tin0; tile < tin1; tile += 3) {
+                if (A.tile_bound && tile > tin0 && (tile - tin0) % 24 == 0) {
+                    // Cauchy-Schwarz exit (every 24 tiles): the items come by descending norm, so if no user of this wave
+                    // can still be reached by a row as long as this tile's longest, none of the remaining tiles matters
+                    // (a user whose list is not full yet has thr = -inf and keeps the sweep alive)
+                    const float reach = A.tile_bound[tile] * ldexpf(1.f, -scale_exp(__uint_as_float(A.stats[2])));
+                    bool alive = false;
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        if (user_ok[g]) alive |= sqrtf(A.unorm2[group * UPW + g * 32 + j]) * reach >= thr[g];
+                    if (!__any(alive)) break;
+                }
                 tile_step(acc_a, acc_b, a2, a, tile);
                 if (tile + 1 < tin1) tile_step(acc_b, acc_a, a3, a2, tile + 1);
                 if (tile + 2 < tin1) {
@@ -1066,7 +1081,8 @@ __global__ __launch_bounds__(kBlock) void topk_row_stats_kernel(const float *__r
 // two that brings the largest element (stats[1]) into [0.5, 1).  One thread per (tile, k-step, lane).
 __global__ __launch_bounds__(kBlock) void topk_pack_items_f16_kernel(const float *__restrict__ item_rows, int64_t ldi, int64_t n_items,
                                                                      int n_tiles, const unsigned int *__restrict__ stats,
-                                                                     const int32_t *__restrict__ perm, float4 *__restrict__ packed)
+                                                                     const int32_t *__restrict__ perm, float4 *__restrict__ packed,
+                                                                     const float *__restrict__ norm2, float *__restrict__ tile_bound)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n_tiles * 4 * kWave) return;
@@ -1074,6 +1090,10 @@ __global__ __launch_bounds__(kBlock) void topk_pack_items_f16_kernel(const float
     const int s = (int)(i / kWave % 4);
     const int64_t tile = i / (4 * kWave);
     const int64_t item = tile * 32 + (lane & 31);                 // sweep position
+    if (tile_bound && lane == 0 && s == 0)
+        // the tile's first row is its longest up to the sort's granularity (norms ordered on 18 bits: < 2^-10 apart
+        // in |row|^2 inside a bucket); 1 % covers that, the fp16 rounding of the plane and the fp32 accumulation
+        tile_bound[tile] = 1.01f * sqrtf(norm2[perm[item]]) * ldexpf(1.f, -scale_exp(__uint_as_float(stats[1])));
     float4 lo = f4_zero(), hi = f4_zero();
     if (item < n_items) {
         const float *src = item_rows + (int64_t)(perm ? perm[item] : item) * ldi + 16 * s + 8 * (lane >> 5);
@@ -1223,7 +1243,8 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
                     const float *item_rows, int64_t ldi, int64_t n_items, int32_t d,
                     const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned,
                     int32_t k, int64_t *out_idx, float *out_val, void *workspace, const float4 *packed,
-                    const unsigned int *stats, hipStream_t st, const int32_t *perm = nullptr, const float *init_thr = nullptr)
+                    const unsigned int *stats, hipStream_t st, const int32_t *perm = nullptr, const float *init_thr = nullptr,
+                    const float *tile_bound = nullptr, const float *unorm2 = nullptr)
 {
     if (!user_rows || !item_rows || !out_idx || !out_val) return IGCN_E_NULL;
     if ((excl_rowptr == nullptr) != (excl_col == nullptr)) return IGCN_E_NULL;
@@ -1258,6 +1279,7 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
     a.packed = packed;
     a.stats = stats;
     a.init_thr = init_thr;
+    a.tile_bound = tile_bound; a.unorm2 = unorm2;
 
     if (mode != 0) {
         if (d != 64 || !packed || (mode == 2 && !stats)) return IGCN_E_SHAPE;
@@ -1314,7 +1336,7 @@ extern "C" int igcn_score_topk_bounded_f32(const float *user_rows, int64_t ldu, 
 // ---- the two-stage evaluation: bf16 candidate sweep + exact fp32 re-scoring (d = 64, k <= 60) --------------------
 // workspace: [sweep workspace for k + 4][item planes][candidate ids][candidate scores][max |item|^2], each 256-aligned
 static inline int64_t align256(int64_t n) { return (n + 255) / 256 * 256; }
-struct FastLayout { int64_t sweep, packed, cand_idx, cand_val, norm, order, total; int kc; TopkOrderLayout ord; };
+struct FastLayout { int64_t sweep, packed, cand_idx, cand_val, norm, tile_bound, unorm2, order, total; int kc; TopkOrderLayout ord; };
 static int topk_fast_layout(int64_t batch, int64_t n_items, int32_t d, int32_t k, int64_t excl_rows, int64_t excl_nnz, FastLayout *L) {
     if (d != 64 || k < 1 || k + kFastExtra > kWave) return IGCN_E_RANGE;
     L->kc = k + kFastExtra;
@@ -1330,7 +1352,9 @@ static int topk_fast_layout(int64_t batch, int64_t n_items, int32_t d, int32_t k
     L->cand_idx = L->packed + (int64_t)p.n_tiles * 8 * kWave * 16;
     L->cand_val = L->cand_idx + align256(batch * L->kc * 8);
     L->norm = L->cand_val + align256(batch * L->kc * 4);
-    L->order = L->norm + 256;
+    L->tile_bound = L->norm + 256;
+    L->unorm2 = L->tile_bound + align256((int64_t)p.n_tiles * 4);
+    L->order = L->unorm2 + align256(batch * 4);
     L->total = L->order + L->ord.total;
     return IGCN_OK;
 }
@@ -1377,6 +1401,8 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     hipLaunchKernelGGL(topk_row_stats_kernel, dim3((unsigned)stat_blocks), dim3(kBlock), 0, st, item_rows, ldi, n_items,
                        (const int64_t *)nullptr, 0, norm_bits, by_norm ? reinterpret_cast<float *>(ows + L.ord.norm2) : (float *)nullptr);
     const int32_t *perm = nullptr, *excl_pos = nullptr;
+    float *tile_bound = reinterpret_cast<float *>(ws + L.tile_bound), *unorm2 = reinterpret_cast<float *>(ws + L.unorm2);
+    bool early_exit = false;
     if (by_norm) {
         rc = topk_order_build(L.ord, ows, n_items, excl_rowptr, excl_col, excl_rows, excl_nnz, st, &perm, &excl_pos);
         if (rc != IGCN_OK) return rc;
@@ -1385,10 +1411,13 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
         if (!user_rows || ldu < d || ldu % 4 || reinterpret_cast<uintptr_t>(user_rows) % 16) return IGCN_E_SHAPE;
         int64_t ub = (batch * 16 + kBlock - 1) / kBlock;
         if (ub > (int64_t)cu_count()) ub = (int64_t)cu_count();
+        early_exit = by_norm && tuning_get(IGCN_TUNE_TOPK_FAST_EXIT) != 0;     // developer knob: 0 = always sweep to the end
         hipLaunchKernelGGL(topk_row_stats_kernel, dim3((unsigned)ub), dim3(kBlock), 0, st, user_rows, ldu, batch, user_ids, 1, norm_bits,
-                           (float *)nullptr);
+                           early_exit ? unorm2 : (float *)nullptr);
         hipLaunchKernelGGL(topk_pack_items_f16_kernel, dim3((unsigned)((pack_threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                           item_rows, ldi, n_items, n_tiles, norm_bits, perm, packed);
+                           item_rows, ldi, n_items, n_tiles, norm_bits, perm, packed,
+                           early_exit ? reinterpret_cast<const float *>(ows + L.ord.norm2) : (const float *)nullptr,
+                           early_exit ? tile_bound : (float *)nullptr);
     } else {
         hipLaunchKernelGGL(topk_pack_items_kernel, dim3((unsigned)((pack_threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                            item_rows, ldi, n_items, n_tiles, perm, packed);
@@ -1398,7 +1427,8 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     // the sweep runs in position space: its exclusion lists and banned bits are those of the positions, and the
     // candidate ids it returns are positions (mapped back by the re-scoring kernel)
     rc = topk_run(mode, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, d, excl_rowptr, by_norm && excl_rowptr ? excl_pos : excl_col,
-                  banned, L.kc, cand_idx, cand_val, ws + L.sweep, packed, norm_bits, st, perm);
+                  banned, L.kc, cand_idx, cand_val, ws + L.sweep, packed, norm_bits, st, perm, nullptr,
+                  early_exit ? tile_bound : nullptr, early_exit ? unorm2 : nullptr);
     if (rc != IGCN_OK) return rc;
     if (L.kc <= 32)
         hipLaunchKernelGGL(topk_rescore_kernel<32>, dim3((unsigned)((batch + 7) / 8)), dim3(kBlock), 0, st, user_rows, ldu, user_ids, batch,

@@ -29,10 +29,15 @@ def timed(I, mode):
     return round(e0.elapsed_time(e1) / 3, 3)
 
 
-for tag, I in (('random_init', I0), ('trained_like_row_scales_lognormal_0.5', I0 * torch.exp(0.5 * torch.randn(ni, 1, device='cuda', generator=g)))):
+from igcn_cf_amd import _lib
+for tag, I in (('random_init', I0), ('trained_like_row_scales_lognormal_0.5', I0 * torch.exp(0.5 * torch.randn(ni, 1, device='cuda', generator=g))),
+               ('row_scales_lognormal_1.0', I0 * torch.exp(1.0 * torch.randn(ni, 1, device='cuda', generator=g)))):
     n2 = (I * I).sum(1)
     out = {'table': tag}
     for name, order in (('given', None), ('norm_descending', torch.argsort(n2, descending=True)), ('norm_ascending', torch.argsort(n2))):
         T = I if order is None else I[order].contiguous()
         out[name] = {'two_stage_ms': timed(T, 'fast'), 'flagged': score_topk.last_flagged, 'fp32_sweep_ms': timed(T, 'exact')}
+    _lib.set_tuning('topk_fast_exit', 0)
+    out['given_without_early_exit'] = {'two_stage_ms': timed(I, 'fast')}
+    _lib.set_tuning('topk_fast_exit', None)
     print(json.dumps(out), flush=True)

@@ -434,3 +434,43 @@ def test_bpr_column_slices_sum_to_the_full_loss():
             (terms[0] + 0.1 * terms[1]).backward()
             np.testing.assert_allclose(Rs.grad.cpu().numpy(), R.grad.cpu().numpy()[:, r * dl:(r + 1) * dl], rtol=1e-4, atol=1e-8)
             np.testing.assert_allclose(Es.grad.cpu().numpy(), E.grad.cpu().numpy()[:, r * dl:(r + 1) * dl], rtol=1e-4, atol=1e-8)
+
+
+def test_two_stage_sweep_order_and_early_exit_do_not_change_the_lists():
+    """Round 3: the candidate sweep meets the items by descending norm and stops once no user of a wave can be reached
+    by the rows still to come (|score| <= |u| |i|).  On tables whose row norms spread over orders of magnitude — where
+    the exit skips most of the sweep — with exclusion lists, banned items, duplicated rows, a zero user, users of very
+    different scale and a ragged item count: the lists are those of the fp32 sweep, bit for bit, with the order and
+    the exit switched on and off."""
+    from igcn_cf_amd import _lib
+    from igcn_cf_amd.ops import score_topk
+    rng = np.random.default_rng(11)
+    n_users, n_items, d, k = 700, 41003, 64, 20
+    U = (rng.standard_normal((n_users, d)) * 0.1 * np.exp(rng.standard_normal((n_users, 1)))).astype(np.float32)
+    I = (rng.standard_normal((n_items, d)) * 0.1 * np.exp(1.2 * rng.standard_normal((n_items, 1)))).astype(np.float32)
+    I[300] = I[17]; I[40000] = I[17]
+    I[5000:5040] = 0.0                                   # zero rows: tie at score 0 for every user
+    U[9] = 0.0
+    ex = [sorted(rng.choice(n_items, size=int(rng.integers(0, 60)), replace=False).tolist()) for _ in range(n_users)]
+    top_norm = np.argsort(-(I * I).sum(1))[:200]
+    for u in range(0, n_users, 3):                       # exclude some of the longest rows: the would-be winners
+        ex[u] = sorted(set(ex[u]) | set(rng.choice(top_norm, size=30, replace=False).tolist()))
+    rowptr = np.zeros(n_users + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in ex], out=rowptr[1:])
+    col = np.array([i for x in ex for i in x], dtype=np.int32)
+    bmask = np.zeros(n_items, dtype=np.uint8); bmask[rng.choice(n_items, size=n_items // 9, replace=False)] = 1
+    users = rng.permutation(n_users).astype(np.int64)
+    kw = dict(user_ids=_dev(users), excl_rowptr=_dev(rowptr), excl_col=_dev(col), banned=_dev(bmask))
+    ref = score_topk(_dev(U), _dev(I), k, mode='exact', **kw)
+    try:
+        for order, ex_it in ((None, None), (None, 0), (0, None)):
+            _lib.set_tuning('topk_fast_order', order)
+            _lib.set_tuning('topk_fast_exit', ex_it)
+            got = score_topk(_dev(U), _dev(I), k, mode='fast', **kw)
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (order, ex_it)
+            got = score_topk(_dev(U), _dev(I), k, mode='fast')          # no masks
+            ref0 = score_topk(_dev(U), _dev(I), k, mode='exact')
+            assert torch.equal(got[0], ref0[0]) and torch.equal(got[1], ref0[1]), (order, ex_it)
+    finally:
+        _lib.set_tuning('topk_fast_order', None)
+        _lib.set_tuning('topk_fast_exit', None)
