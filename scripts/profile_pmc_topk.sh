@@ -17,11 +17,13 @@ for P in "$P1" "$P2" "$P3"; do
 done
 python3 - <<PY | tee $OUT/summary.txt
 import csv, glob, collections
-agg = collections.defaultdict(lambda: [0.0, 0])
+agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob('$OUT/p*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         if 'score_topk_kernel' in r['Kernel_Name']:
-            a = agg[r['Counter_Name']]; a[0] += float(r['Counter_Value']); a[1] += 1
-for k in sorted(agg):
-    print('   %-32s %16.0f   (avg per dispatch, n=%d)' % (k, agg[k][0] / agg[k][1], agg[k][1]))
+            a = agg[r['Kernel_Name'].split('(')[0]][r['Counter_Name']]; a[0] += float(r['Counter_Value']); a[1] += 1
+for kern in sorted(agg):
+    print(kern)
+    for k in sorted(agg[kern]):
+        print('   %-32s %16.0f   (avg per dispatch, n=%d)' % (k, agg[kern][k][0] / agg[kern][k][1], agg[kern][k][1]))
 PY
