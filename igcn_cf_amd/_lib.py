@@ -66,6 +66,9 @@ SIGNATURES = {
     'igcn_bpr_loss_bwd_f32': (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, vp, C.c_int64, vp, vp, vp,
                                         C.c_int64, C.c_int32, vp, vp, vp, C.c_float,
                                         vp, vp, vp, vp, vp, vp, vp, vp]),
+    'igcn_bpr_loss_bwd_scaled_f32': (C.c_int, [vp, vp, vp, C.c_int64, vp, vp, vp, C.c_int64, vp, vp, vp,
+                                               C.c_int64, C.c_int32, vp, vp, vp, C.c_float, C.c_float,
+                                               vp, vp, vp, vp, vp, vp, vp, vp]),
 }
 
 _handle = None

@@ -347,6 +347,19 @@ extern "C" int igcn_bpr_loss_bwd_f32(const float *u_tab, const float *p_tab, con
                           gu_tab, gp_tab, gn_tab, gl2_u_tab, gl2_p_tab, gl2_n_tab, gw_out, 1, 1.f, l2_weight, stream);
 }
 
+extern "C" int igcn_bpr_loss_bwd_scaled_f32(const float *u_tab, const float *p_tab, const float *n_tab, int64_t ld,
+                                            const float *l2_u_tab, const float *l2_p_tab, const float *l2_n_tab, int64_t ld_l2,
+                                            const int64_t *users, const int64_t *pos, const int64_t *neg,
+                                            int64_t batch, int32_t d, const float *w, const float *work, const float *g_loss,
+                                            float bpr_weight, float l2_weight,
+                                            float *gu_tab, float *gp_tab, float *gn_tab,
+                                            float *gl2_u_tab, float *gl2_p_tab, float *gl2_n_tab,
+                                            float *gw_out, void *stream)
+{
+    return bpr_bwd_launch(u_tab, p_tab, n_tab, ld, l2_u_tab, l2_p_tab, l2_n_tab, ld_l2, users, pos, neg, batch, d, w, work, g_loss,
+                          gu_tab, gp_tab, gn_tab, gl2_u_tab, gl2_p_tab, gl2_n_tab, gw_out, 1, bpr_weight, l2_weight, stream);
+}
+
 extern "C" int igcn_owned_rows_gather_f32(const int64_t *ids, int64_t n, int64_t n_users, int64_t ulo, int64_t uhi,
                                           int64_t ilo, int64_t ihi, const float *tab_u, int64_t ld_u,
                                           const float *tab_i, int64_t ld_i, int32_t d, float *out, int64_t ld_out, void *stream)

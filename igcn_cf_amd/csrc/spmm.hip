@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
         if (v < n_rows) {
             start = rowptr[v];
             end = rowptr[v + 1];
-            if (n_segments > 0 && end - start > long_threshold) continue;   // handled as segments
+            if (!xcd_off && n_segments > 0 && end - start > long_threshold) continue;   // handled as segments (a plan's lists hold no cut row)
             dst = v;
             to_partial = false;
             if (row_mask && !row_mask[v]) {                                   // output not needed
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
         int len = 0, kind = 0;
         if (v < n_rows) {
             const int64_t s0 = rowptr[v], e0 = rowptr[v + 1];
-            const bool is_long = n_segments > 0 && e0 - s0 > long_threshold;
+            const bool is_long = !xcd_off && n_segments > 0 && e0 - s0 > long_threshold;    // (a plan's lists hold no cut row)
             const bool masked = row_mask && !row_mask[v];
             start = s0; len = (int)(e0 - s0); dst = v;
             kind = is_long ? 0 : masked ? (masked_rows_zero ? 3 : 0) : 1;

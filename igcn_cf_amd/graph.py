@@ -216,7 +216,7 @@ XCD_PLAN_FEATURES = XCD_PLAN   # INMO's template-feature matrix F and its transp
 N_XCD = 8                  # lists of the XCD plan = XCDs of an MI355X (igcn_spmm_csr_f32: xcd_off has N_XCD + 1 entries)
 
 
-def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assign='affinity'):
+def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assign='affinity', list_order='segments_first'):
     """The XCD plan of a CSR matrix: the work of one SpMM launch cut into N_XCD lists, one per XCD, such that a list
     gathers as much as possible from ONE slice of the operand — a slice (1/8 of the operand's rows) fits an XCD's 4 MiB
     L2 where the whole operand does not, and the eight L2s are private (igcn_hip.h: xcd_off).
@@ -241,7 +241,13 @@ def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assi
     i64 = dict(dtype=torch.int64, device=dev)
     n_rows = rowptr.shape[0] - 1
     lens = rowptr[1:] - rowptr[:-1]
-    cut = lens > slice_threshold
+    if isinstance(slice_threshold, (list, tuple)):                 # one threshold per block of rows (developer A/Bs)
+        thr_row = torch.empty(n_rows, **i64)
+        for (lo, hi), t in zip(zip(blocks[:-1], blocks[1:]), slice_threshold):
+            thr_row[lo:hi] = int(t)
+        cut = lens > thr_row
+    else:
+        cut = lens > slice_threshold
     rp = rowptr.cpu().tolist() if len(blocks) <= 8 else None
     seg_parts, per_block = [], []
     empty = torch.zeros(0, **i64)
@@ -336,9 +342,19 @@ def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assi
             owner[rest] = torch.clamp(torch.searchsorted(edges, mid), max=N_XCD - 1)
         for x in range(N_XCD):
             sx = sb[seg_xcd[sb] == x]
-            lists[x].append(n_rows + sx[torch.sort(-seg_len[sx], stable=True).indices])
+            sx = n_rows + sx[torch.sort(-seg_len[sx], stable=True).indices]
             rx = whole[owner == x]
-            lists[x].append(rx[torch.sort(-lens[rx], stable=True).indices])
+            rx = rx[torch.sort(-lens[rx], stable=True).indices]
+            if list_order == 'rows_first':
+                lists[x] += [rx, sx]
+            elif list_order == 'interleaved' and sx.numel() and rx.numel():
+                # spread the segments evenly among the rows (both keep their own order)
+                pos_s = (torch.arange(sx.numel(), **i64).to(torch.float64) + 0.5) * ((sx.numel() + rx.numel()) / sx.numel())
+                pos_r = (torch.arange(rx.numel(), **i64).to(torch.float64) + 0.5) * ((sx.numel() + rx.numel()) / rx.numel())
+                both = torch.cat([sx, rx])[torch.sort(torch.cat([pos_s, pos_r]), stable=True).indices]
+                lists[x].append(both)
+            else:
+                lists[x] += [sx, rx]
         load = load + seg_cost + (torch.bincount(owner, weights=cost, minlength=N_XCD) if whole.numel() else 0.)
     per_list = [torch.cat(l) if l else empty for l in lists]
     xcd_off = torch.zeros(N_XCD + 1, **i64)
@@ -437,10 +453,12 @@ class CsrMatrix:
         self.xcd_off = None
         if self.xcd_plan is not None and self.order_blocks is not None and self.nnz > 0:
             cfg = dict(self.xcd_plan)
-            self.long_threshold = int(cfg['threshold'])
-            self.segment_len = min(self.segment_len, self.long_threshold)
-            lr, sg, order, xcd_off, load = xcd_plan(self.rowptr, self.col, list(self.order_blocks), self.long_threshold,
-                                                    self.segment_len, cfg.get('row_cost', 4), cfg.get('assign', 'affinity'))
+            thr = cfg['threshold']
+            self.long_threshold = int(min(thr)) if isinstance(thr, (list, tuple)) else int(thr)
+            self.segment_len = min(self.segment_len, int(cfg.get('segment_len', self.long_threshold)))
+            lr, sg, order, xcd_off, load = xcd_plan(self.rowptr, self.col, list(self.order_blocks), thr,
+                                                    self.segment_len, cfg.get('row_cost', 4), cfg.get('assign', 'affinity'),
+                                                    cfg.get('list_order', 'segments_first'))
             self.n_long, self.n_segments = int(lr.shape[0]), int(sg.shape[0])
             self.long_rows = lr.contiguous().view(torch.uint8).reshape(-1) if self.n_long else None
             self.segments = sg.contiguous().view(torch.uint8).reshape(-1) if self.n_long else None

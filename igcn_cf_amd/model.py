@@ -345,6 +345,17 @@ class IGCN(BasicModel):
         return ops.graph_bpr_terms(x0, self.norm_adj, self.norm_adj, self._prop_layers(), nodes, 'rep', self._batch_grads,
                                    self.config.get('prune_propagation', True), l2_reg)
 
+    def step_loss_nodes(self, nodes, aux_inputs, l2_reg, aux_reg):
+        """The whole training loss of IGCNTrainer (trainer.py:300-312: bpr + l2_reg * mean l2_norm_sq + aux_reg * auxiliary
+        loss) as ONE differentiable scalar and one autograd node (ops.InmoStepFn).  nodes: int64 [3 B] node ids of the
+        batch; aux_inputs: int64 [Ba, 3] triplets of the auxiliary dataset (template space)."""
+        if self._feat_scale is None:
+            self.update_feat_mat()
+        keep_prob, seed = self._dropout_args()
+        return ops.inmo_step_loss(self.embedding.weight, self.w, self.feat_mat, self.feat_mat.transposed_view(), self._feat_scale,
+                                  keep_prob, seed, self.norm_adj, self._prop_layers(), nodes, aux_inputs, len(self.user_map),
+                                  self._batch_grads, self.config.get('prune_propagation', True), l2_reg, aux_reg)
+
     def _prop_layers(self):
         return self.n_layers
 

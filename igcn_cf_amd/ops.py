@@ -256,6 +256,88 @@ def graph_bpr_terms(x0, csr, csr_t, n_layers, nodes, l2_on, table, prune=True, l
     return GraphBprFn.apply(x0, csr, csr_t, n_layers, nodes, l2_on, table, prune, l2_reg)
 
 
+class InmoStepFn(torch.autograd.Function):
+    """The differentiable part of one INMO training step (IGCN / IMF under IGCNTrainer, trainer.py:294-320) as ONE autograd
+    node: template layer X0 = dropout(F) T (model.py:423-435), K-layer propagation pruned to the batch, the BPR loss with
+    its L2 term on the propagated rows (model.py:293-299, trainer.py:300-303), AND the self-enhanced auxiliary loss on the
+    raw template rows weighted by w (trainer.py:304-312):
+
+        loss = bpr + l2_reg * mean l2_norm_sq + aux_reg * aux_bpr.
+
+    Backward: batch-row gradients -> the persistent zero table, K SpMMs (Horner), the transposed template layer — which
+    yields the DENSE gradient of the template table — and then the auxiliary loss adds its row gradients straight into
+    that result (float atomics) and produces d / d w.  As separate autograd nodes the auxiliary loss cost a zero-filled
+    30 MB table, a dense add of two table gradients and four elementwise launches per step.
+
+    forward(templ [Tn, d], w [d], feat, feat_t, feat_scale, keep_prob, seed, csr, n_layers, nodes [3 B], aux [Ba, 3]
+            (template-space users | positives | negatives), item_offset (= len(user_map): template rows of the items start
+            there), table: BatchGradTable, prune, l2_reg, aux_reg) -> scalar loss"""
+
+    @staticmethod
+    def forward(ctx, templ, w, feat, feat_t, feat_scale, keep_prob, seed, csr, n_layers, nodes, aux, item_offset, table, prune,
+                l2_reg, aux_reg):
+        _require_gpu_f32(templ, 'templ')
+        _require_i64(nodes, 'nodes')
+        if nodes.numel() % 3 or not templ.is_contiguous() or aux.dim() != 2 or aux.shape[1] != 3 or aux.dtype != torch.int64:
+            raise _lib.IgcnError('nodes must hold 3 * B ids, aux must be int64 [Ba, 3], templ contiguous')
+        L = _lib.lib()
+        td, wd = templ.detach(), w.detach().contiguous()
+        B, d = nodes.numel() // 3, td.shape[1]
+        x0 = spmm(feat, td, row_scale=feat_scale, keep_prob=keep_prob, seed=seed)
+        masks = mark_rows(csr, nodes) if prune and n_layers > 0 else None
+        rep = propagate_mean(csr, x0, n_layers, masks=masks, zero_masked=False) if n_layers > 0 else x0
+        users, pos, neg = nodes[:B], nodes[B:2 * B], nodes[2 * B:]
+        out = torch.empty(3, dtype=torch.float32, device=td.device)
+        work = torch.empty(3 * B, dtype=torch.float32, device=td.device)
+        rp, ld = rep.data_ptr(), rep.stride(0)
+        _lib.check(L.igcn_bpr_loss_f32(rp, rp, rp, ld, rp, rp, rp, ld, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B, d, None,
+                                       float(l2_reg), out.data_ptr(), work.data_ptr(), _lib.current_stream()), 'igcn_bpr_loss_f32')
+        a3 = aux.t().contiguous()                                  # [3, Ba]: users | positives | negatives
+        Ba = a3.shape[1]
+        out_a = torch.empty(3, dtype=torch.float32, device=td.device)
+        work_a = torch.empty(3 * Ba, dtype=torch.float32, device=td.device)
+        tp, tpi = td.data_ptr(), _row_view(td, item_offset)
+        _lib.check(L.igcn_bpr_loss_f32(tp, tpi, tpi, td.stride(0), None, None, None, td.stride(0), a3[0].data_ptr(), a3[1].data_ptr(),
+                                       a3[2].data_ptr(), Ba, d, wd.data_ptr(), 0.0, out_a.data_ptr(), work_a.data_ptr(),
+                                       _lib.current_stream()), 'igcn_bpr_loss_f32')
+        ctx.state = (td, wd, x0, rep, feat_t, feat_scale, keep_prob, seed, csr, n_layers, nodes, a3, item_offset, table, masks, work,
+                     work_a, float(l2_reg), float(aux_reg))
+        return torch.add(out[2], out_a[0], alpha=float(aux_reg))
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (td, wd, x0, rep, feat_t, feat_scale, keep_prob, seed, csr, n_layers, nodes, a3, item_offset, table, masks, work, work_a,
+         l2_reg, aux_reg) = ctx.state
+        L = _lib.lib()
+        B, d = nodes.numel() // 3, rep.shape[1]
+        users, pos, neg = nodes[:B], nodes[B:2 * B], nodes[2 * B:]
+        g = g_out.contiguous().float().reshape(1)
+        gt = table.get(rep)
+        rp, gp, ld = rep.data_ptr(), gt.data_ptr(), rep.stride(0)
+        _lib.check(L.igcn_bpr_loss_bwd_f32(rp, rp, rp, ld, rp, rp, rp, ld, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B, d, None,
+                                           work.data_ptr(), g.data_ptr(), l2_reg, gp, gp, gp, gp, gp, gp, None,
+                                           _lib.current_stream()), 'igcn_bpr_loss_bwd_f32')
+        grad_x0 = propagate_mean_backward(csr, gt, n_layers, masks=masks)          # A_hat is symmetric; n_layers == 0: a copy
+        _lib.check(L.igcn_rows_finish_f32(None, grad_x0.stride(0), None, grad_x0.stride(0), gp, gt.stride(0), nodes.data_ptr(), 3 * B, d,
+                                          None, 0.0, _lib.current_stream()), 'igcn_rows_finish_f32')
+        g_templ = spmm(feat_t, grad_x0, col_scale=feat_scale, keep_prob=keep_prob, seed=seed)     # dense [Tn, d]
+        g_w = torch.zeros_like(wd)
+        Ba = a3.shape[1]
+        tp, tpi = td.data_ptr(), _row_view(td, item_offset)
+        gtp, gtpi = g_templ.data_ptr(), _row_view(g_templ, item_offset)
+        _lib.check(L.igcn_bpr_loss_bwd_scaled_f32(tp, tpi, tpi, td.stride(0), None, None, None, td.stride(0), a3[0].data_ptr(),
+                                                  a3[1].data_ptr(), a3[2].data_ptr(), Ba, d, wd.data_ptr(), work_a.data_ptr(),
+                                                  g.data_ptr(), aux_reg, 0.0, gtp, gtpi, gtpi, None, None, None, g_w.data_ptr(),
+                                                  _lib.current_stream()), 'igcn_bpr_loss_bwd_scaled_f32')
+        return (g_templ, g_w) + (None,) * 14
+
+
+def inmo_step_loss(templ, w, feat, feat_t, feat_scale, keep_prob, seed, csr, n_layers, nodes, aux, item_offset, table, prune,
+                   l2_reg, aux_reg):
+    return InmoStepFn.apply(templ, w, feat, feat_t, feat_scale, keep_prob, seed, csr, n_layers, nodes, aux, item_offset, table, prune,
+                            l2_reg, aux_reg)
+
+
 def bpr_sample_nodes(train_rowptr, train_col, nonempty_users, n_items, batch, seed, item_offset):
     """int64 [3 * batch] node ids of the draws of bpr_sample(seed): users | item_offset + positives | item_offset +
     negatives (igcn_bpr_sample_nodes)."""

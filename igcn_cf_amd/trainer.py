@@ -618,9 +618,15 @@ class IGCNTrainer(BasicTrainer):
         self._seed_for_step(graph)
         if graph and nodes.numel() == 3 * self.batch_size and aux_inputs.shape[0] == self.batch_size:
             return self._graph_step((nodes, aux_inputs), self._igcn_loss)
-        return self._igcn_optimise(None, aux_inputs, self.model.bpr_loss_nodes(nodes, self.l2_reg))
+        loss = self._igcn_loss(nodes, aux_inputs)
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        return loss.detach()
 
     def _igcn_loss(self, nodes, aux_inputs):
+        if self.config.get('fused_inmo_step', True) and hasattr(self.model, 'step_loss_nodes'):
+            return self.model.step_loss_nodes(nodes, aux_inputs, self.l2_reg, self.aux_reg)       # one autograd node
         a_users, a_pos, a_neg = aux_inputs.t().contiguous().unbind(0)
         return self.model.bpr_loss_nodes(nodes, self.l2_reg) + self.aux_reg * self.model.aux_loss(a_users, a_pos, a_neg)
 

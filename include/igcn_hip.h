@@ -314,6 +314,19 @@ int igcn_bpr_loss_bwd_f32(const float *u_tab, const float *p_tab, const float *n
                           float *gl2_u_tab, float *gl2_p_tab, float *gl2_n_tab,
                           float *gw_out, void *stream);
 
+/* igcn_bpr_loss_bwd_f32 for a loss that enters the total with a weight: d total / d (bpr_weight * bpr + l2_weight * l2)
+ * given g_loss = d total / d that sum (DEVICE pointer to one float).  The INMO step's auxiliary loss
+ * (trainer.py:304-312: aux_reg * mean softplus over raw template rows weighted by w) adds its row gradients straight
+ * into the dense gradient of the template table with it — no zero-filled table and no dense add of its own. */
+int igcn_bpr_loss_bwd_scaled_f32(const float *u_tab, const float *p_tab, const float *n_tab, int64_t ld,
+                                 const float *l2_u_tab, const float *l2_p_tab, const float *l2_n_tab, int64_t ld_l2,
+                                 const int64_t *users, const int64_t *pos, const int64_t *neg,
+                                 int64_t batch, int32_t d, const float *w, const float *work, const float *g_loss,
+                                 float bpr_weight, float l2_weight,
+                                 float *gu_tab, float *gp_tab, float *gn_tab,
+                                 float *gl2_u_tab, float *gl2_p_tab, float *gl2_n_tab,
+                                 float *gw_out, void *stream);
+
 /* The row-sparse tail of a training step's backward pass (trainer.py:244-246: loss.backward()), one launch:
  *  dst != NULL: dst[ids[i]] += scale_host * (scale_dev ? *scale_dev : 1) * src[ids[i]] for i < n, float atomics (an id may
  *  repeat) — the gradient of the L2 term on the raw embedding rows (model.py:110-113) added to the dense gradient the

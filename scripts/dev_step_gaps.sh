@@ -2,7 +2,7 @@
 # Developer: GPU-busy time vs wall time of a LightGCN training step (how much is launch gaps?)
 set -o pipefail
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$REPO/gpurun_out/step_gaps
+OUT=$REPO/gpurun_out/step_gaps_${PRESET:-amazon}_${INDEX:-1}; rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt -- python3 $REPO/scripts/dev_step_profile.py ${PRESET:-amazon} ${INDEX:-1} > $OUT/kt.log 2>&1 || { tail -5 $OUT/kt.log; exit 1; }

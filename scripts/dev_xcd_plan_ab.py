@@ -35,6 +35,19 @@ for T in [int(t) for t in os.environ.get('THRESHOLDS', '32,64,96,128,256').split
             continue
         variants['xcd_T%d_%s' % (T, assign)] = CsrMatrix(rowptr, col, val, (n, n), 'cuda', order_blocks=blocks,
                                                          xcd_plan={'threshold': T, 'assign': assign})
+if os.environ.get('EXTRA') == '1':
+    for tu, ti in ((64, 112), (256, 112), (10 ** 9, 112), (112, 96), (112, 160), (256, 128)):
+        variants['xcd_Tuser%d_Titem%d' % (min(tu, 99999), ti)] = CsrMatrix(rowptr, col, val, (n, n), 'cuda', order_blocks=blocks,
+                                                                       xcd_plan={'threshold': [tu, ti], 'segment_len': 112})
+    for lo in ('rows_first', 'interleaved'):
+        variants['xcd_T112_' + lo] = CsrMatrix(rowptr, col, val, (n, n), 'cuda', order_blocks=blocks,
+                                               xcd_plan={'threshold': 112, 'list_order': lo})
+    for sl in (56, 224):
+        variants['xcd_T112_seglen%d' % sl] = CsrMatrix(rowptr, col, val, (n, n), 'cuda', order_blocks=blocks,
+                                                       xcd_plan={'threshold': 112, 'segment_len': sl})
+    for rc in (0, 2, 8):
+        variants['xcd_T112_rowcost%d' % rc] = CsrMatrix(rowptr, col, val, (n, n), 'cuda', order_blocks=blocks,
+                                                        xcd_plan={'threshold': 112, 'row_cost': rc})
 # upper bound of any locality scheme: the same structure gathering from an 8192-row (2 MB) table: every gather hits L2
 variants['legacy_all_gathers_hit_L2'] = CsrMatrix(rowptr, (col % 8192).astype(np.int32), val, (n, n), 'cuda', order_blocks=blocks)
 # one phase at a time (the other block's rows emptied): where the time and the misses are

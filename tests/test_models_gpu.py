@@ -719,3 +719,44 @@ def test_assignment_to_a_split_entry_reaches_the_next_evaluation(golden):
     assert m1['Recall'][5] == 1.0 and m0['Recall'][5] < 1.0
     ref = O.calculate_metrics(ds.test_data, rec, [5])
     assert m1['NDCG'][5] == ref['NDCG'][5]
+
+
+@pytest.mark.parametrize('name,ratio,dropout', [('IGCN', 1.0, 0.0), ('IGCN', 0.5, 0.3), ('IMF', 1.0, 0.3)])
+def test_fused_inmo_step_equals_the_separate_losses(golden, name, ratio, dropout):
+    """ops.InmoStepFn (the whole IGCNTrainer loss as one autograd node, trainer.py:300-312) against the same loss
+    composed from bpr_loss_nodes + aux_reg * aux_loss: value, d / d embedding, d / d w — with dropout (same device seed
+    on both sides), template ratios below 1, batch ids that repeat, and auxiliary batches of another size."""
+    from igcn_cf_amd.dataset import AuxiliaryDataset
+    from igcn_cf_amd.model import get_model
+    ds = _dataset(golden)
+    torch.manual_seed(4)
+    model = get_model({'name': name, 'embedding_size': 64, 'n_layers': 2, 'device': 'cuda', 'dropout': dropout,
+                       'feature_ratio': ratio, 'ranking_metric': 'degree'}, ds)
+    with torch.no_grad():
+        model.w.copy_(torch.rand(64, device='cuda') + 0.5)
+    model.train()
+    model.use_device_seed()
+    model.advance_dropout_seed()
+    nu, ni = ds.n_users, ds.n_items
+    rng = np.random.default_rng(2)
+    B, Ba = 96, 70
+    nodes = np.concatenate([rng.integers(0, nu, B), nu + rng.integers(0, ni, B), nu + rng.integers(0, ni, B)])
+    nodes[1] = nodes[0]
+    tu, ti = len(model.user_map), len(model.item_map)
+    aux = np.stack([rng.integers(0, tu, Ba), rng.integers(0, ti, Ba), rng.integers(0, ti, Ba)], axis=1)
+    nodes_t, aux_t = torch.from_numpy(nodes).cuda(), torch.from_numpy(aux).cuda()
+    l2_reg, aux_reg = 1e-2, 0.3
+    a_u, a_p, a_n = aux_t.t().contiguous().unbind(0)
+    ref = model.bpr_loss_nodes(nodes_t, l2_reg) + aux_reg * model.aux_loss(a_u, a_p, a_n)
+    ref.backward()
+    g_e, g_w = model.embedding.weight.grad.clone(), model.w.grad.clone()
+    model.embedding.weight.grad = None; model.w.grad = None
+    got = model.step_loss_nodes(nodes_t, aux_t, l2_reg, aux_reg)
+    got.backward()
+    assert abs(float(got) - float(ref)) < 2e-6 * max(1., abs(float(ref)))
+    scale = float(g_e.abs().max())
+    assert float((model.embedding.weight.grad - g_e).abs().max()) <= 2e-5 * scale         # float atomics: another order
+    assert float((model.w.grad - g_w).abs().max()) <= 2e-5 * float(g_w.abs().max())
+    # the persistent batch-gradient table is all zeros again
+    tab = model._batch_grads._t
+    assert tab is None or float(tab.abs().max()) == 0.0
