@@ -338,11 +338,14 @@ def inmo_step_loss(templ, w, feat, feat_t, feat_scale, keep_prob, seed, csr, n_l
                             l2_reg, aux_reg)
 
 
-def bpr_sample_nodes(train_rowptr, train_col, nonempty_users, n_items, batch, seed, item_offset):
+def bpr_sample_nodes(train_rowptr, train_col, nonempty_users, n_items, batch, seed, item_offset, out=None):
     """int64 [3 * batch] node ids of the draws of bpr_sample(seed): users | item_offset + positives | item_offset +
-    negatives (igcn_bpr_sample_nodes)."""
+    negatives (igcn_bpr_sample_nodes).  out: write there (e.g. the input buffer of a captured step) instead of a new tensor."""
     _require_i64(train_rowptr, 'train_rowptr')
-    out = torch.empty(3 * batch, dtype=torch.int64, device=train_rowptr.device)
+    if out is None:
+        out = torch.empty(3 * batch, dtype=torch.int64, device=train_rowptr.device)
+    elif out.dtype != torch.int64 or out.numel() != 3 * batch or not out.is_contiguous() or out.device != train_rowptr.device:
+        raise _lib.IgcnError('out must be a contiguous int64 [3 * batch] tensor on the sampler\'s device')
     _lib.check(_lib.lib().igcn_bpr_sample_nodes(train_rowptr.data_ptr(), train_col.data_ptr(), nonempty_users.data_ptr(),
                                                 nonempty_users.numel(), n_items, batch, int(seed) & 0xFFFFFFFFFFFFFFFF,
                                                 int(item_offset), out.data_ptr(), _lib.current_stream()), 'igcn_bpr_sample_nodes')
@@ -574,10 +577,13 @@ def hit_matrix(rec, eval_rowptr, eval_col):
     return hit
 
 
-def bpr_sample(train_rowptr, train_col, nonempty_users, n_items, batch, seed):
-    """int64 [batch, 3] (user, pos, neg) drawn on the device (igcn_bpr_sample)."""
+def bpr_sample(train_rowptr, train_col, nonempty_users, n_items, batch, seed, out=None):
+    """int64 [batch, 3] (user, pos, neg) drawn on the device (igcn_bpr_sample).  out: as bpr_sample_nodes."""
     _require_i64(train_rowptr, 'train_rowptr')
-    out = torch.empty((batch, 3), dtype=torch.int64, device=train_rowptr.device)
+    if out is None:
+        out = torch.empty((batch, 3), dtype=torch.int64, device=train_rowptr.device)
+    elif out.dtype != torch.int64 or tuple(out.shape) != (batch, 3) or not out.is_contiguous() or out.device != train_rowptr.device:
+        raise _lib.IgcnError('out must be a contiguous int64 [batch, 3] tensor on the sampler\'s device')
     _lib.check(_lib.lib().igcn_bpr_sample(train_rowptr.data_ptr(), train_col.data_ptr(), nonempty_users.data_ptr(),
                                           nonempty_users.numel(), n_items, batch, int(seed) & 0xFFFFFFFFFFFFFFFF,
                                           out.data_ptr(), _lib.current_stream()), 'igcn_bpr_sample')

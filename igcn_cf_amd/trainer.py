@@ -118,17 +118,20 @@ class DeviceSampler:
         self.seed = int(seed)
         self.calls = 0
 
-    def epoch_batches(self, batch_size):
+    def epoch_batches(self, batch_size, into=None):
         """ceil(len / batch_size) batches, the last one short, as a DataLoader over
-        a dataset of len(train_array) draws (dataset.py:116-117)."""
+        a dataset of len(train_array) draws (dataset.py:116-117).  into: callable(b) -> tensor to draw batch b into, or
+        None (a captured step's input buffer: the draw then needs no copy; the yielded tensor is only valid until the
+        next draw)."""
         left = self.length
         while left > 0:
             b = min(batch_size, left)
             left -= b
             self.calls += 1
-            yield ops.bpr_sample(self.rowptr, self.col, self.nonempty, self.n_items, b, batch_seed(self.seed, self.calls))
+            yield ops.bpr_sample(self.rowptr, self.col, self.nonempty, self.n_items, b, batch_seed(self.seed, self.calls),
+                                 out=into(b) if into else None)
 
-    def epoch_node_batches(self, batch_size, item_offset):
+    def epoch_node_batches(self, batch_size, item_offset, into=None):
         """The same draws as epoch_batches (same seeds), each as int64 [3 * b] NODE ids: users | item_offset +
         positives | item_offset + negatives — what a graph model's bpr_loss_terms_nodes takes, with no transpose,
         offset add or concatenation per step."""
@@ -138,7 +141,7 @@ class DeviceSampler:
             left -= b
             self.calls += 1
             yield ops.bpr_sample_nodes(self.rowptr, self.col, self.nonempty, self.n_items, b,
-                                       batch_seed(self.seed, self.calls), item_offset)
+                                       batch_seed(self.seed, self.calls), item_offset, out=into(b) if into else None)
 
 
 class BasicTrainer:
@@ -218,9 +221,20 @@ class BasicTrainer:
             self._capture_step(inputs, loss_fn)
             self._graph_for = key
         for st, t in zip(self._static_inputs, inputs):
-            st.copy_(t)
+            if st.data_ptr() != t.data_ptr():                # (a sampler that drew straight into the buffer: nothing to copy)
+                st.copy_(t)
         self._graph.replay()
         return self._static_loss.clone()
+
+    def _draw_into(self, index, shape):
+        """For the samplers: the captured step's input buffer `index` if a full-size batch of `shape` fits it, else None."""
+        def pick(b):
+            st = getattr(self, '_static_inputs', None)
+            if getattr(self, '_graph', None) is None or st is None or index >= len(st) or not self._graph_wanted():
+                return None
+            want = tuple(shape(b))
+            return st[index] if tuple(st[index].shape) == want else None
+        return pick
 
     def _seed_for_step(self, graph):
         """Dropout seeds of a model that drops edges (IGCN / IMF): a captured step must read its seed from device
@@ -569,7 +583,7 @@ class BPRTrainer(BasicTrainer):
         losses = AverageMeter()
         pending = []
         if hasattr(self.model, 'bpr_loss_terms_nodes') and self.model.slice_reduce_fn is None:
-            for nodes in self.sampler.epoch_node_batches(self.batch_size, self.model.n_users):
+            for nodes in self.sampler.epoch_node_batches(self.batch_size, self.model.n_users, into=self._draw_into(0, lambda b: (3 * b,))):
                 pending.append((self.node_step(nodes), nodes.shape[0] // 3))
         else:
             for inputs in self.sampler.epoch_batches(self.batch_size):
@@ -645,8 +659,9 @@ class IGCNTrainer(BasicTrainer):
         losses = AverageMeter()
         pending = []
         if self.model.slice_reduce_fn is None:
-            for nodes, aux_inputs in zip(self.sampler.epoch_node_batches(self.batch_size, self.model.n_users),
-                                         self.aux_sampler.epoch_batches(self.batch_size)):
+            for nodes, aux_inputs in zip(self.sampler.epoch_node_batches(self.batch_size, self.model.n_users,
+                                                                         into=self._draw_into(0, lambda b: (3 * b,))),
+                                         self.aux_sampler.epoch_batches(self.batch_size, into=self._draw_into(1, lambda b: (b, 3)))):
                 pending.append((self.igcn_node_step(nodes, aux_inputs), nodes.shape[0] // 3))
         else:
             for inputs, aux_inputs in zip(self.sampler.epoch_batches(self.batch_size),
