@@ -197,8 +197,8 @@ def main():
         'value': value, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': wall * 1e3 / args.steps, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'LightGCN %d-layer d=%d propagation on synthetic %s-like (users=%d items=%d nnz(A_hat)=%d), the same '
-                               'graph at every N' % (K, d, args.preset, ds.n_users, ds.n_items, nnz),
+        'config': {'workload': 'LightGCN %d-layer d=%d propagation, synthetic %s-like (users=%d items=%d nnz=%d), same graph at every N'
+                               % (K, d, args.preset, ds.n_users, ds.n_items, nnz),
                    'preset': args.preset, 'nnz': nnz, 'd': d, 'n_layers': K, 'parallelism': parallelism},
     }
 
@@ -209,8 +209,7 @@ def main():
         else 'spmm_csr_rows_kernel<%d,false>' % (d // 4)
     if not sharded:
         ms_launch = dev_ms / (args.steps * launches_per_step)
-        launch_note = ('HIP events over the timed region / launches: one igcn_spmm_csr_f32 call = the main kernel + the '
-                       'long-row reduce kernel (~5 us) + the launch gap')
+        launch_note = 'HIP events over the timed region / launches; one call = main kernel + long-row reduce (~5 us) + gap'   # < 120 chars
         g = gather_roof(device, csr.col, csr.val, x0, n, d)
     else:
         # the timed region holds collectives: the local product is timed on its own, same operands, same stream
@@ -220,7 +219,7 @@ def main():
         ms_launch = time_ms(lambda: ops.spmm(local_csr, rep[0], out=y), 50, 5)
         if prop.exchange != 'fused':
             b_alg = local_csr.nnz * (8 + 4 * d) + L.bu * (4 * d + 4)
-        launch_note = 'HIP events around 50 back-to-back launches of the rank-local product (the timed region also holds the collectives)'
+        launch_note = 'HIP events around 50 back-to-back launches of the rank-local product (timed region also holds collectives)'
         g = gather_roof(device, local_csr.col, local_csr.val, rep[0], y.shape[0], d)
     ach = b_alg / ms_launch / 1e6
     x_mb = n * d * 4 / 1e6
@@ -236,9 +235,9 @@ def main():
             'avg_launch_note': launch_note,
             'gathered_row_GBps': gathered, 'mall_gather_peak_GBps': MALL_GATHER_PEAK_GBPS,
             'frac_of_mall_gather': gathered / MALL_GATHER_PEAK_GBPS,
-            'mall_gather_note': 'guide: 8.6 TB/s of uniformly random rows of a 38 MB Infinity-Cache table; L2 hits lift a skewed gather above it',
+            'mall_gather_note': 'guide: 8.6 TB/s for uniform random rows of a 38 MB Infinity-Cache table; L2 hits lift a skewed gather',
             'probe_peak_GBps': probe_peak, 'frac_of_probe': ach / probe_peak,
-            'probe_note': 'in-run rowless gather+FMA+store over the same col/val stream (roof_probe.hip): a sibling kernel, not a hardware roof',
+            'probe_note': 'in-run rowless gather+FMA+store on the same col/val stream (roof_probe.hip): sibling kernel, not a roof',
             'probe_gathered_row_GBps_same_stream': g['gathered_row_GBps_same_stream'],
             'probe_gathered_row_GBps_uniform_random': g['gathered_row_GBps_uniform_random'],
             'frac_of_compulsory': b_min / b_alg, 'rank': rank, 'world': world}
@@ -429,8 +428,8 @@ def stored_traffic(kernel_name, preset, nnz, d):
     if stored_kernel != kernel_name.replace(' ', '') or t.get('preset') != preset or t.get('nnz') != nnz or t.get('d') != d:
         return None
     return {'bytes': t.get('spmm_hbm_bytes_per_launch'), 'l2_hit_rate': t.get('l2_hit_rate'),
-            'source': 'profiles/pmc_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, 2 x FETCH + WRITE '
-                      '(gfx950 correction); L2-miss traffic incl. Infinity-Cache hits; NOT measured in this run' % t.get('tag', '?')}
+            'source': 'profiles/pmc_traffic.json (%s): rocprofv3 --pmc passes of this command, 2*FETCH+WRITE; not measured in this run'
+                      % t.get('tag', '?')}
 
 
 def hbm_bound_leg(device, reps=5, ranks=(0,)):

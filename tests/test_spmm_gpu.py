@@ -213,9 +213,33 @@ def test_c_abi_error_codes_without_launch():
     assert L.igcn_score_topk_workspace_bytes(10, 100, 66, 5) == -1
     assert L.igcn_score_topk_workspace_bytes(10, 100, 256, 5) == -1
     assert L.igcn_score_topk_workspace_bytes(10, 100, 64, 101) == -1
+    # ABI v5: xcd_off needs a dealing order; the bounded sweep needs its bounds; the two-stage path its exclusion sizes
+    xo = torch.zeros(9, dtype=torch.int64, device='cuda')
+    assert L.igcn_spmm_csr_f32(rowptr.data_ptr(), col.data_ptr(), None, x.data_ptr(), 64, y.data_ptr(), 64, 8, 8, 64, 1.0, nul, 0, 1.0,
+                               None, None, None, 0, None, 0, None, 256, None, 0, 1.0, None, 0, 0, None, None, None, xo.data_ptr(),
+                               None) == -1
+    items = torch.randn(100, 64, device='cuda')
+    oi = torch.empty(8, 5, dtype=torch.int64, device='cuda'); ov = torch.empty(8, 5, device='cuda')
+    ws = torch.empty(1 << 22, dtype=torch.uint8, device='cuda')
+    assert L.igcn_score_topk_bounded_f32(x.data_ptr(), 64, None, 8, items.data_ptr(), 64, 100, 64, None, None, None, 5, None,
+                                         oi.data_ptr(), ov.data_ptr(), ws.data_ptr(), None) == -1
+    fl = torch.zeros(9, dtype=torch.int32, device='cuda')
+    wsp = (ws.data_ptr() + 255) // 256 * 256
+    assert L.igcn_score_topk_fast_workspace_bytes(8, 100, 64, 5, 0, 0) > 0
+    assert L.igcn_score_topk_fast_workspace_bytes(8, 100, 32, 5, 0, 0) == -1                  # d = 64 only
+    assert L.igcn_score_topk_fast_workspace_bytes(8, 100, 64, 61, 0, 0) == -1                 # k + 4 <= 64
+    assert L.igcn_score_topk_fast_f32(x.data_ptr(), 64, None, 8, items.data_ptr(), 64, 100, 64, rowptr.data_ptr(), None, 8, 3, None, 5,
+                                      oi.data_ptr(), ov.data_ptr(), fl.data_ptr(), None, wsp, None) == -1   # rowptr without col
+    assert L.igcn_score_topk_fast_f32(x.data_ptr(), 64, None, 8, items.data_ptr(), 64, 100, 64, rowptr.data_ptr(), col.data_ptr(), 0, 0,
+                                      None, 5, oi.data_ptr(), ov.data_ptr(), fl.data_ptr(), None, wsp, None) == -2  # sizes missing
+    assert L.igcn_score_topk_fast_f32(x.data_ptr(), 64, None, 8, items.data_ptr(), 64, 100, 64, None, None, 0, 0, None, 5,
+                                      oi.data_ptr(), ov.data_ptr(), None, None, wsp, None) == -1            # no flagged list
+    torch.cuda.synchronize()
     from igcn_cf_amd.ops import score_topk
     with pytest.raises(_lib.IgcnError):
         score_topk(x, y, 9)                                                   # k > n_items
+    with pytest.raises(_lib.IgcnError):
+        score_topk(x, items, 5, mode='fast', lower_bound=torch.zeros(8, device='cuda'))   # a bound goes with the exact sweep
     with pytest.raises(_lib.IgcnError):
         score_topk(x.cpu(), y, 2)                                             # CPU tensor
 
