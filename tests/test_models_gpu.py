@@ -760,3 +760,168 @@ def test_fused_inmo_step_equals_the_separate_losses(golden, name, ratio, dropout
     # the persistent batch-gradient table is all zeros again
     tab = model._batch_grads._t
     assert tab is None or float(tab.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('preset,epochs', [('gowalla', 2), ('amazon', 1)])
+def test_full_size_training_recall_parity_with_a_float64_restatement(preset, epochs):
+    """BASELINE configs 2 and 4's workload (the headline's "Amazon-book dim=64; Recall@20 parity") at full size, TRAINED:
+    two epochs (688 steps) of LightGCN 3-layer d = 64 on the Gowalla-like split / one epoch (1 065 steps) on the Amazon-like
+    through the product path (device sampler, captured HIP-graph steps, fused Adam) against the reference algorithm
+    restated in float64 torch on the SAME batches — model.py:96-116 (propagation as torch.sparse.mm on the module's own
+    A_hat, layer mean, L2 on the raw rows), trainer.py:238-245 (softplus BPR + l2_reg * mean, torch Adam) — and then the
+    north-star's gate: Recall@20 and NDCG@20 of the trained models within +-0.001 of each other (float64 scores, train +
+    val items masked, metrics by the oracle's calculate_metrics), parameters close, loss curves equal."""
+    from igcn_cf_amd import config as cfg
+    from igcn_cf_amd.dataset import get_dataset
+    from igcn_cf_amd.model import get_model
+    from igcn_cf_amd.trainer import DeviceSampler, get_trainer
+    dev = torch.device('cuda')
+    ds_cfg, m_cfg, t_cfg = cfg.get_synthetic_config(dev, preset)[1]
+    ds = get_dataset(ds_cfg)
+    nu, ni = ds.n_users, ds.n_items
+    torch.manual_seed(2021)
+    model = get_model(m_cfg, ds)
+    trainer = get_trainer(t_cfg, ds, model)
+    K, lr, l2_reg, B = m_cfg['n_layers'], t_cfg['lr'], t_cfg['l2_reg'], t_cfg['batch_size']
+    a64 = model.norm_adj.to_torch_coo().double()
+    e64 = torch.nn.Parameter(model.embedding.weight.detach().double().clone())
+    opt64 = torch.optim.Adam([e64], lr=lr)
+
+    def rep64(e):
+        x, acc = e, e
+        for _ in range(K):
+            x = torch.sparse.mm(a64, x)
+            acc = acc + x
+        return acc / (K + 1)
+    model.train()
+    sampler = DeviceSampler(ds, dev, seed=99)
+    n_steps, loss_a, loss_b = 0, [], []
+    for epoch in range(epochs):
+        for nodes in sampler.epoch_node_batches(B, nu):
+            loss_a.append(trainer.node_step(nodes))                          # product: one captured graph per full batch
+            b = nodes.numel() // 3
+            u, p, n = nodes[:b], nodes[b:2 * b], nodes[2 * b:]
+            rep = rep64(e64)
+            x = (rep[u] * rep[n]).sum(1) - (rep[u] * rep[p]).sum(1)
+            l2 = (e64[u] ** 2).sum(1) + (e64[p] ** 2).sum(1) + (e64[n] ** 2).sum(1)
+            loss = torch.nn.functional.softplus(x).mean() + l2_reg * l2.mean()
+            opt64.zero_grad(); loss.backward(); opt64.step()
+            loss_b.append(loss.detach())
+            n_steps += 1
+    assert n_steps == epochs * ((len(ds) + B - 1) // B) and trainer._graph is not None
+    loss_a = torch.stack([x.double() for x in loss_a]).cpu().numpy(); loss_b = torch.stack(loss_b).cpu().numpy()
+    assert np.abs(loss_a - loss_b).max() < 2e-5, np.abs(loss_a - loss_b).max()
+    assert loss_b[-20:].mean() < loss_b[:20].mean() - 0.01                   # it trained
+    diff = (model.embedding.weight.detach().double() - e64.detach()).abs()
+    assert float(diff.max()) < 1e-4, float(diff.max())                        # measured: 1.3e-6
+    # the gate: metrics of the two trained models
+    _, m_prod = trainer.eval('test')
+    with torch.no_grad():
+        r = rep64(e64.detach())
+        rp_t, c_t = ds.csr('train'); rp_v, c_v = ds.csr('val')
+        rows_t = torch.from_numpy(np.repeat(np.arange(nu), np.diff(rp_t))).cuda(); cols_t = torch.from_numpy(c_t).cuda()
+        rows_v = torch.from_numpy(np.repeat(np.arange(nu), np.diff(rp_v))).cuda(); cols_v = torch.from_numpy(c_v).cuda()
+        recs = []
+        for lo in range(0, nu, 4096):
+            hi = min(nu, lo + 4096)
+            s = r[lo:hi] @ r[nu:].T
+            for rows, cols in ((rows_t, cols_t), (rows_v, cols_v)):
+                m = (rows >= lo) & (rows < hi)
+                s[rows[m] - lo, cols[m]] = -float('inf')
+            recs.append(torch.topk(s, 20, dim=1).indices)
+        rec64 = torch.cat(recs).cpu().numpy()
+    m_ref = O.calculate_metrics(ds.test_data, rec64, [20])
+    for name in ('Recall', 'NDCG', 'Precision'):
+        assert abs(float(m_prod[name][20]) - float(m_ref[name][20])) < 1e-3, (name, m_prod[name][20], m_ref[name][20])
+    assert float(m_ref['Recall'][20]) > 0.01                                 # a trained model, not noise
+    print('recall parity (%s, %d steps): product %r float64 %r; max |d param| %.2e, loss curve max diff %.1e'
+          % (preset, n_steps, {k: round(float(v[20]), 5) for k, v in m_prod.items()}, {k: round(float(v[20]), 5) for k, v in m_ref.items()},
+             float(diff.max()), float(np.abs(loss_a - loss_b).max())))
+
+
+def test_yelp_size_inmo_training_recall_parity_with_a_float64_restatement():
+    """BASELINE config 3 at full size, TRAINED (dropout switched off — the product's dropout is a device hash, not the
+    reference's torch.rand stream, so a mask cannot be shared): one epoch (660 steps) of IGCN 3-layer d = 64 on the Yelp-like
+    split through the product path — ONE autograd node and one captured HIP graph per step, the template layer, the
+    auxiliary loss with w, the anneal at the epoch's end — against the reference algorithm restated in float64 torch on
+    the same batches: model.py:374-377, :423-446 (F's values row_sum^((alpha-1)/2 - 1/2), X0 = F T, propagation, mean),
+    :293-299 (L2 on the propagated rows), trainer.py:300-318 (BPR + l2_reg * mean + aux_reg * auxiliary BPR weighted by w
+    on raw template rows, items offset by len(user_map); Adam over T and w; feat_mat_anneal).  Gate: Recall@20 / NDCG@20 /
+    Precision@20 of the two trained models within 0.001, parameters and loss curves close."""
+    from igcn_cf_amd import config as cfg
+    from igcn_cf_amd.dataset import get_dataset
+    from igcn_cf_amd.model import get_model
+    from igcn_cf_amd.trainer import DeviceSampler, get_trainer
+    dev = torch.device('cuda')
+    ds_cfg, m_cfg, t_cfg = cfg.get_synthetic_config(dev, 'yelp')[2]
+    m_cfg = dict(m_cfg, dropout=0.)
+    ds = get_dataset(ds_cfg)
+    nu, ni = ds.n_users, ds.n_items
+    torch.manual_seed(2021)
+    model = get_model(m_cfg, ds)
+    trainer = get_trainer(t_cfg, ds, model)
+    K, lr, l2_reg, aux_reg, B = m_cfg['n_layers'], t_cfg['lr'], t_cfg['l2_reg'], t_cfg['aux_reg'], t_cfg['batch_size']
+    a64 = model.norm_adj.to_torch_coo().double()
+    f = model.feat_mat
+    f_row = torch.repeat_interleave(torch.arange(f.shape[0], device=dev), f.rowptr[1:] - f.rowptr[:-1])
+    f_idx = torch.stack([f_row, f.col.long()])
+    row_sum64 = model.row_sum.double()
+    t64 = torch.nn.Parameter(model.embedding.weight.detach().double().clone())
+    w64 = torch.nn.Parameter(model.w.detach().double().clone())
+    opt64 = torch.optim.Adam([w64, t64], lr=lr)
+    off = len(model.user_map)
+    alpha = 1.0
+
+    def rep64(t, alpha):
+        vals = torch.pow(row_sum64[f_row], (alpha - 1.) / 2. - 0.5)
+        fm = torch.sparse_coo_tensor(f_idx, vals, f.shape).coalesce()
+        x = torch.sparse.mm(fm, t)
+        acc = x
+        for _ in range(K):
+            x = torch.sparse.mm(a64, x)
+            acc = acc + x
+        return acc / (K + 1)
+    model.train()
+    sampler, aux_sampler = DeviceSampler(ds, dev, seed=5), DeviceSampler(trainer.aux_dataset, dev, seed=6)
+    loss_a, loss_b = [], []
+    for nodes, aux in zip(sampler.epoch_node_batches(B, nu), aux_sampler.epoch_batches(B)):
+        loss_a.append(trainer.igcn_node_step(nodes, aux))
+        b = nodes.numel() // 3
+        u, p, n = nodes[:b], nodes[b:2 * b], nodes[2 * b:]
+        rep = rep64(t64, alpha)
+        ur, pr, nr = rep[u], rep[p], rep[n]
+        l2 = (ur ** 2).sum(1) + (pr ** 2).sum(1) + (nr ** 2).sum(1)
+        main = torch.nn.functional.softplus((ur * nr).sum(1) - (ur * pr).sum(1)).mean() + l2_reg * l2.mean()
+        au, ap, an = t64[aux[:, 0]], t64[off + aux[:, 1]], t64[off + aux[:, 2]]
+        aux_loss = torch.nn.functional.softplus((au * an * w64).sum(1) - (au * ap * w64).sum(1)).mean()
+        loss = main + aux_reg * aux_loss
+        opt64.zero_grad(); loss.backward(); opt64.step()
+        loss_b.append(loss.detach())
+    model.feat_mat_anneal(); alpha *= model.delta                            # trainer.py:318
+    assert len(loss_b) == (len(ds) + B - 1) // B and trainer._graph is not None and abs(model.alpha - alpha) < 1e-15
+    loss_a = torch.stack([x.double() for x in loss_a]).cpu().numpy(); loss_b = torch.stack(loss_b).cpu().numpy()
+    assert np.abs(loss_a - loss_b).max() < 2e-5, np.abs(loss_a - loss_b).max()
+    d_t = float((model.embedding.weight.detach().double() - t64.detach()).abs().max())
+    d_w = float((model.w.detach().double() - w64.detach()).abs().max())
+    assert d_t < 1e-4 and d_w < 1e-4, (d_t, d_w)
+    _, m_prod = trainer.eval('test')                                         # at the annealed alpha, eval mode
+    with torch.no_grad():
+        r = rep64(t64.detach(), alpha)
+        rp_t, c_t = ds.csr('train'); rp_v, c_v = ds.csr('val')
+        rows_t = torch.from_numpy(np.repeat(np.arange(nu), np.diff(rp_t))).cuda(); cols_t = torch.from_numpy(c_t).cuda()
+        rows_v = torch.from_numpy(np.repeat(np.arange(nu), np.diff(rp_v))).cuda(); cols_v = torch.from_numpy(c_v).cuda()
+        recs = []
+        for lo in range(0, nu, 4096):
+            hi = min(nu, lo + 4096)
+            s_ = r[lo:hi] @ r[nu:].T
+            for rows, cols in ((rows_t, cols_t), (rows_v, cols_v)):
+                m = (rows >= lo) & (rows < hi)
+                s_[rows[m] - lo, cols[m]] = -float('inf')
+            recs.append(torch.topk(s_, 20, dim=1).indices)
+        rec64 = torch.cat(recs).cpu().numpy()
+    m_ref = O.calculate_metrics(ds.test_data, rec64, [20])
+    for name in ('Recall', 'NDCG', 'Precision'):
+        assert abs(float(m_prod[name][20]) - float(m_ref[name][20])) < 1e-3, (name, m_prod[name][20], m_ref[name][20])
+    print('INMO recall parity (%d steps): product %r float64 %r; max |d T| %.2e, |d w| %.2e, loss curve max diff %.1e'
+          % (len(loss_b), {k: round(float(v[20]), 5) for k, v in m_prod.items()}, {k: round(float(v[20]), 5) for k, v in m_ref.items()},
+             d_t, d_w, float(np.abs(loss_a - loss_b).max())))
