@@ -839,9 +839,28 @@ def test_full_size_training_recall_parity_with_a_float64_restatement(preset, epo
              float(diff.max()), float(np.abs(loss_a - loss_b).max())))
 
 
-def test_yelp_size_inmo_training_recall_parity_with_a_float64_restatement():
-    """BASELINE config 3 at full size, TRAINED (dropout switched off — the product's dropout is a device hash, not the
-    reference's torch.rand stream, so a mask cannot be shared): one epoch (660 steps) of IGCN 3-layer d = 64 on the Yelp-like
+def _dropout_keep_mask(nnz, seed, keep_prob, device):
+    """The product's edge-dropout decision restated with torch integer ops (csrc/common.h hash_counter, spmm.hip: keep edge
+    p iff hash(p, seed) < keep_prob * 2^32): which edges a launch with this seed keeps."""
+    M = 0xFFFFFFFF
+
+    def mix32(x):
+        x = x ^ (x >> 16); x = (x * 0x21f0aaad) & M
+        x = x ^ (x >> 15); x = (x * 0x735a2d97) & M
+        return x ^ (x >> 15)
+    p = torch.arange(nnz, dtype=torch.int64, device=device)
+    s0, s1 = seed & M, (seed >> 32) & M
+    h = mix32((p & M) ^ s0)
+    h = mix32((h + (((p >> 32) ^ s1) * 0x9e3779b9 & M) + 0x85ebca6b) & M)
+    keep_below = min(int(float(np.float32(keep_prob)) * 4294967296.0), 4294967295)
+    return h < keep_below
+
+
+@pytest.mark.parametrize('dropout', [0., 0.3])
+def test_yelp_size_inmo_training_recall_parity_with_a_float64_restatement(dropout):
+    """BASELINE config 3 at full size, TRAINED — with the config's edge dropout 0.3 (the float64 side applies the SAME mask:
+    the product's keep decision is a hash of (seed, edge position), restated above with torch integer ops; semantics of
+    NGCF.dropout_sp_mat, model.py:263-275: kept values / (1 - p)) and without: one epoch (646 steps) of IGCN 3-layer d = 64 on the Yelp-like
     split through the product path — ONE autograd node and one captured HIP graph per step, the template layer, the
     auxiliary loss with w, the anneal at the epoch's end — against the reference algorithm restated in float64 torch on
     the same batches: model.py:374-377, :423-446 (F's values row_sum^((alpha-1)/2 - 1/2), X0 = F T, propagation, mean),
@@ -854,7 +873,7 @@ def test_yelp_size_inmo_training_recall_parity_with_a_float64_restatement():
     from igcn_cf_amd.trainer import DeviceSampler, get_trainer
     dev = torch.device('cuda')
     ds_cfg, m_cfg, t_cfg = cfg.get_synthetic_config(dev, 'yelp')[2]
-    m_cfg = dict(m_cfg, dropout=0.)
+    m_cfg = dict(m_cfg, dropout=dropout)
     ds = get_dataset(ds_cfg)
     nu, ni = ds.n_users, ds.n_items
     torch.manual_seed(2021)
@@ -872,8 +891,11 @@ def test_yelp_size_inmo_training_recall_parity_with_a_float64_restatement():
     off = len(model.user_map)
     alpha = 1.0
 
-    def rep64(t, alpha):
+    def rep64(t, alpha, seed=None):
         vals = torch.pow(row_sum64[f_row], (alpha - 1.) / 2. - 0.5)
+        if seed is not None:                                                 # train mode: same edges dropped as the product
+            keep = _dropout_keep_mask(f.nnz, seed, 1. - dropout, dev)
+            vals = torch.where(keep, vals / float(np.float32(1. - dropout)), torch.zeros_like(vals))
         fm = torch.sparse_coo_tensor(f_idx, vals, f.shape).coalesce()
         x = torch.sparse.mm(fm, t)
         acc = x
@@ -888,7 +910,7 @@ def test_yelp_size_inmo_training_recall_parity_with_a_float64_restatement():
         loss_a.append(trainer.igcn_node_step(nodes, aux))
         b = nodes.numel() // 3
         u, p, n = nodes[:b], nodes[b:2 * b], nodes[2 * b:]
-        rep = rep64(t64, alpha)
+        rep = rep64(t64, alpha, int(model._seed_dev.item()) if dropout > 0 else None)
         ur, pr, nr = rep[u], rep[p], rep[n]
         l2 = (ur ** 2).sum(1) + (pr ** 2).sum(1) + (nr ** 2).sum(1)
         main = torch.nn.functional.softplus((ur * nr).sum(1) - (ur * pr).sum(1)).mean() + l2_reg * l2.mean()
@@ -922,8 +944,8 @@ def test_yelp_size_inmo_training_recall_parity_with_a_float64_restatement():
     m_ref = O.calculate_metrics(ds.test_data, rec64, [20])
     for name in ('Recall', 'NDCG', 'Precision'):
         assert abs(float(m_prod[name][20]) - float(m_ref[name][20])) < 1e-3, (name, m_prod[name][20], m_ref[name][20])
-    print('INMO recall parity (%d steps): product %r float64 %r; max |d T| %.2e, |d w| %.2e, loss curve max diff %.1e'
-          % (len(loss_b), {k: round(float(v[20]), 5) for k, v in m_prod.items()}, {k: round(float(v[20]), 5) for k, v in m_ref.items()},
+    print('INMO recall parity (dropout %.1f, %d steps): product %r float64 %r; max |d T| %.2e, |d w| %.2e, loss curve max diff %.1e'
+          % (dropout, len(loss_b), {k: round(float(v[20]), 5) for k, v in m_prod.items()}, {k: round(float(v[20]), 5) for k, v in m_ref.items()},
              d_t, d_w, float(np.abs(loss_a - loss_b).max())))
 
 
