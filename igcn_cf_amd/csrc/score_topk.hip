@@ -54,6 +54,10 @@
 namespace igcn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// A pointer into the CONSTANT address space: a wave-uniform load through it is a scalar load (s_load).  Through a plain
+// global pointer the compiler emits a vector load + s_waitcnt vmcnt(0) + readfirstlane, and that wait also drains every
+// item tile in flight.  Only for memory no kernel of the same launch writes (the banned items packed by a pre-kernel).
+typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
 
 constexpr int kIdxNone = 0x7fffffff;
 
@@ -581,7 +585,7 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
                 mflag = true;
             }
             if (A.banned_bits) {
-                const unsigned bm = A.banned_bits[tile];          // wave-uniform: one scalar load per tile
+                const unsigned bm = ((const_u32_ptr)(uintptr_t)A.banned_bits)[tile];   // wave-uniform: one SCALAR load per tile
                 if (bm) {
 #pragma unroll
                     for (int g = 0; g < NG; ++g) exm[g] |= bm >> (4 * h);
