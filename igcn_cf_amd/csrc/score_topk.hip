@@ -118,7 +118,7 @@ __device__ __forceinline__ void split_f16_x8(const float4 &lo, const float4 &hi,
 }
 
 struct TopkPlan {
-    int d_pad;               // 16 / 32 / 64 / 128
+    int d_pad;               // 16 / 32 / 64 / 128 / 256
     int ng;                  // 32-user groups per wave
     int64_t groups;          // wave-groups (32 * ng users each)
     int n_tiles;             // 32-item tiles of one sweep
@@ -137,9 +137,9 @@ static inline int topk_groups_per_wave(int d_pad) { return d_pad <= 64 ? 2 : 1; 
 
 static inline int topk_make_plan(int64_t batch, int64_t n_items, int32_t d, int32_t k, TopkPlan *p, bool candidate_sweep = false) {
     if (batch < 1 || n_items < 1) return IGCN_E_SHAPE;
-    if (d < 4 || d > 128 || d % 4 != 0) return IGCN_E_SHAPE;
+    if (d < 4 || d > 256 || d % 4 != 0) return IGCN_E_SHAPE;
     if (k < 1 || k > IGCN_MAX_TOPK || k > n_items) return IGCN_E_RANGE;
-    p->d_pad = d <= 16 ? 16 : d <= 32 ? 32 : d <= 64 ? 64 : 128;
+    p->d_pad = d <= 16 ? 16 : d <= 32 ? 32 : d <= 64 ? 64 : d <= 128 ? 128 : 256;
     p->ng = topk_groups_per_wave(p->d_pad);
     const int upw = 32 * p->ng;
     p->groups = (batch + upw - 1) / upw;
@@ -1297,7 +1297,8 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
             if (d == 64 && init_thr) rc = launch_topk<64, 2, true, 0, true>(p, st, a);
             else rc = d == 64 ? launch_topk<64, 2, true>(p, st, a) : launch_topk<64, 2, false>(p, st, a);
             break;
-        default: rc = d == 128 ? launch_topk<128, 1, true>(p, st, a) : launch_topk<128, 1, false>(p, st, a); break;
+        case 128: rc = d == 128 ? launch_topk<128, 1, true>(p, st, a) : launch_topk<128, 1, false>(p, st, a); break;
+        default: rc = d == 256 ? launch_topk<256, 1, true>(p, st, a) : launch_topk<256, 1, false>(p, st, a); break;
         }
     }
     if (rc != IGCN_OK) return rc;

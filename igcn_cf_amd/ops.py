@@ -510,7 +510,7 @@ def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_co
         return _score_topk_fast(L, user_rows, item_rows, k, user_ids, excl_rowptr, excl_col, banned, B, n_items, d)
     ws_bytes = L.igcn_score_topk_workspace_bytes(B, n_items, d, k)
     if ws_bytes < 0:
-        raise _lib.IgcnError('unsupported top-k shape: batch=%d n_items=%d d=%d k=%d (need d%%4==0, d<=128, '
+        raise _lib.IgcnError('unsupported top-k shape: batch=%d n_items=%d d=%d k=%d (need d%%4==0, d<=256, '
                              'k<=%d, k<=n_items)' % (B, n_items, d, k, _lib.MAX_TOPK))
     ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=item_rows.device)
     out_idx = torch.empty((B, k), dtype=torch.int64, device=item_rows.device)

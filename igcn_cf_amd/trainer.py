@@ -153,8 +153,8 @@ class BasicTrainer:
         self.topks = trainer_config['topks']
         # limits of the fused scorer (csrc/score_topk.hip), checked here rather than at the first eval
         d = getattr(self.model, 'embedding_size', None)
-        if max(self.topks) > MAX_TOPK or (d is not None and (d % 4 or d > 128)):
-            raise ValueError('fused score/top-k kernel: needs max(topks) <= %d and embedding_size %% 4 == 0, <= 128 '
+        if max(self.topks) > MAX_TOPK or (d is not None and (d % 4 or d > 256)):
+            raise ValueError('fused score/top-k kernel: needs max(topks) <= %d and embedding_size %% 4 == 0, <= 256 '
                              '(got topks=%s, embedding_size=%s)' % (MAX_TOPK, self.topks, d))
         self.device = torch.device(trainer_config['device'])
         self.n_epochs = trainer_config['n_epochs']

@@ -225,7 +225,8 @@ int igcn_bpr_bwd_f32(const float *u_tab, const float *p_tab, const float *n_tab,
  *   out_val[b, 0..k) = their scores (-inf for masked fill-ins).
  * user_ids int64 [B] or NULL (then row b of user_rows is user b);
  * excl_rowptr int64 / excl_col int32 may be NULL; banned uint8 [n_items] or NULL.
- * d <= 128, d % 4 == 0; k <= IGCN_MAX_TOPK and k <= n_items (k <= 24 runs 8 waves per CU; the heaps of a
+ * d <= 256, d % 4 == 0 (built for d <= 128: 64 users per wave up to 64, 32 at 128; 129..256 runs the same kernel with a
+ * whole item row and user row in registers, which spills — correct, about a third slower per flop); k <= IGCN_MAX_TOPK and k <= n_items (k <= 24 runs 8 waves per CU; the heaps of a
  * larger k take more of the CU's LDS and fewer waves are resident: 4 up to 56, 2 up to 120, 1 above).
  * workspace (8-byte aligned): igcn_score_topk_workspace_bytes(B, n_items, d, k) bytes (partial lists of the
  * item-range splits that fill the chip when B is small + the banned items packed one bit each). */

@@ -53,7 +53,7 @@ def _check_topk(scores, idx, val, ex_lists, banned, k):
                                                   (50, 100, 3000, 20), (6, 40, 200, 7),
                                                   (64, 130, 2000, 100), (32, 70, 1500, 200), (128, 40, 900, 64),
                                                   (64, 65, 700, 25), (16, 129, 333, 256), (64, 2500, 9000, 60),
-                                                  (64, 200, 40, 20)])
+                                                  (64, 200, 40, 20), (256, 70, 1500, 20), (192, 33, 800, 30)])
 def test_score_topk_matches_dense_oracle(d, n_users, n_items, k):
     from igcn_cf_amd.ops import score_topk
     rng = np.random.default_rng(d + n_items)

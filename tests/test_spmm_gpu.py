@@ -211,7 +211,7 @@ def test_c_abi_error_codes_without_launch():
     # top-k: unsupported shapes are reported by the workspace query and the call
     assert L.igcn_score_topk_workspace_bytes(10, 100, 64, 0) == -1
     assert L.igcn_score_topk_workspace_bytes(10, 100, 66, 5) == -1
-    assert L.igcn_score_topk_workspace_bytes(10, 100, 256, 5) == -1
+    assert L.igcn_score_topk_workspace_bytes(10, 100, 260, 5) == -1                          # d <= 256
     assert L.igcn_score_topk_workspace_bytes(10, 100, 64, 101) == -1
     # ABI v5: xcd_off needs a dealing order; the bounded sweep needs its bounds; the two-stage path its exclusion sizes
     xo = torch.zeros(9, dtype=torch.int64, device='cuda')
