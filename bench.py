@@ -70,6 +70,7 @@ def lift_flat(out, extras):
         'hbm_bound_workload': get('roofline_hbm_bound', 'workload_short'),
         'hbm_bound_rank_ms_min': get('roofline_hbm_bound', 'rank_ms_min'), 'hbm_bound_rank_ms_max': get('roofline_hbm_bound', 'rank_ms_max'),
         'train_step_ms': get('train_step_ms'), 'train_step_ms_gowalla_hip_graph': get('launch_bound_config', 'train_step_ms_hip_graph'),
+        'mf_train_step_ms_gowalla': get('launch_bound_config', 'mf_train_step_ms_hip_graph'),
         'igcn_train_step_ms_yelp': get('igcn_step', 'train_step_ms'),
         'inductive_update_plus_eval_s': get('inductive_update', 'update_plus_eval_s'),
         'propagation_uniform_graph_edges_per_s': get('propagation_uniform_random_graph', 'edges_per_s'),
@@ -510,6 +511,21 @@ def small_graph_steps(device, d, K):
         model = get_model(dict(m_cfg, embedding_size=d, n_layers=K), ds)
         trainer = get_trainer(dict(t_cfg, hip_graph=hip_graph), ds, model)
         out[key] = train_step_ms(trainer, 100, 10)
+    # BASELINE config 1's model (MF) on the same split: a launch-bound step (a dozen kernels), one captured graph
+    ds_cfg, m_cfg, t_cfg = cfg.get_synthetic_config(device, 'gowalla')[0]
+    torch.manual_seed(2021)
+    model = get_model(dict(m_cfg, embedding_size=d), ds)
+    trainer = get_trainer(t_cfg, ds, model)
+    model.train()
+    it = trainer.sampler.epoch_node_batches(trainer.batch_size, 0, into=trainer._draw_into(0, lambda b: (3 * b,)))
+    for _ in range(10):
+        trainer.flat_step(next(it))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        trainer.flat_step(next(it))
+    torch.cuda.synchronize()
+    out['mf_train_step_ms_hip_graph'] = (time.perf_counter() - t0) * 1e3 / 200
     return out
 
 

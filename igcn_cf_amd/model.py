@@ -123,6 +123,13 @@ class MF(BasicModel):
         u, i = self.user_embedding.weight, self.item_embedding.weight
         return ops.bpr_loss_terms(u, i, u, i, None, users, pos_items, neg_items, reduce_fn=self.slice_reduce_fn)
 
+    def bpr_loss(self, users, pos_items, neg_items, l2_reg):
+        """The scalar training loss of trainer.py:242 as one autograd node (column-sharded slices keep the two-term path)."""
+        if self.slice_reduce_fn is not None:
+            terms = self.bpr_loss_terms(users, pos_items, neg_items)
+            return terms[0] + l2_reg * terms[1]
+        return ops.bpr_scalar_loss(self.user_embedding.weight, self.item_embedding.weight, users, pos_items, neg_items, l2_reg)
+
     def score_tables(self):
         return self.user_embedding.weight.detach(), self.item_embedding.weight.detach()
 

@@ -456,6 +456,51 @@ class BprLossFn(torch.autograd.Function):
         return once(gu), once(gp), once(g2u), once(g2p), gw, None, None, None, None, None, None
 
 
+class BprScalarLossFn(torch.autograd.Function):
+    """trainer.py:238-243 for a model without propagation (MF, model.py:62-67) as ONE autograd node: the scalar
+    bpr + l2_reg * mean l2_norm_sq straight from the reduce kernel (igcn_bpr_loss_f32) and its gradient back in as one float
+    (igcn_bpr_loss_bwd_f32) — composed from the two-term vector with torch ops, the scaling, the add and their backward
+    cost eight launch-bound elementwise launches per step.
+
+    forward(u_tab [U, d], i_tab [I, d], users, pos, neg [B] int64, l2_reg) -> scalar; the L2 term reads the same rows."""
+
+    @staticmethod
+    def forward(ctx, u_tab, i_tab, users, pos, neg, l2_reg):
+        for t in (u_tab, i_tab):
+            _require_gpu_f32(t, 'table')
+            if not t.is_contiguous():
+                raise _lib.IgcnError('BPR tables must be contiguous')
+        for t, n in ((users, 'users'), (pos, 'pos_items'), (neg, 'neg_items')):
+            _require_i64(t, n)
+        d, B = u_tab.shape[1], users.numel()
+        if i_tab.shape[1] != d:
+            raise _lib.IgcnError('BPR tables differ in width')
+        ud, idt = u_tab.detach(), i_tab.detach()
+        out = torch.empty(3, dtype=torch.float32, device=ud.device)
+        work = torch.empty(3 * B, dtype=torch.float32, device=ud.device)
+        up, ip = ud.data_ptr(), idt.data_ptr()
+        _lib.check(_lib.lib().igcn_bpr_loss_f32(up, ip, ip, d, up, ip, ip, d, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B, d, None,
+                                                float(l2_reg), out.data_ptr(), work.data_ptr(), _lib.current_stream()), 'igcn_bpr_loss_f32')
+        ctx.state = (ud, idt, users, pos, neg, work, float(l2_reg))
+        return out[2]
+
+    @staticmethod
+    def backward(ctx, g_out):
+        ud, idt, users, pos, neg, work, l2_reg = ctx.state
+        d, B = ud.shape[1], users.numel()
+        g = g_out.contiguous().float().reshape(1)
+        gu, gi = torch.zeros_like(ud), torch.zeros_like(idt)
+        up, ip, gup, gip = ud.data_ptr(), idt.data_ptr(), gu.data_ptr(), gi.data_ptr()
+        _lib.check(_lib.lib().igcn_bpr_loss_bwd_f32(up, ip, ip, d, up, ip, ip, d, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), B, d,
+                                                    None, work.data_ptr(), g.data_ptr(), l2_reg, gup, gip, gip, gup, gip, gip, None,
+                                                    _lib.current_stream()), 'igcn_bpr_loss_bwd_f32')
+        return gu, gi, None, None, None, None
+
+
+def bpr_scalar_loss(u_tab, i_tab, users, pos, neg, l2_reg):
+    return BprScalarLossFn.apply(u_tab, i_tab, users, pos, neg, l2_reg)
+
+
 def bpr_loss_terms(u_tab, p_tab, l2u_tab, l2p_tab, w, users, pos, neg, item_offset=0, l2_item_offset=0, reduce_fn=None):
     return BprLossFn.apply(u_tab, p_tab, l2u_tab, l2p_tab, w, users, pos, neg, item_offset, l2_item_offset, reduce_fn)
 

@@ -558,6 +558,8 @@ class BPRTrainer(BasicTrainer):
 
     def _triplet_loss(self, inputs):
         users, pos_items, neg_items = inputs.t().contiguous().unbind(0)          # one transpose, three row views
+        if hasattr(self.model, 'bpr_loss'):                                      # MF: the scalar loss as one autograd node
+            return self.model.bpr_loss(users, pos_items, neg_items, self.l2_reg)
         terms = self.model.bpr_loss_terms(users, pos_items, neg_items)
         return terms[0] + self.l2_reg * terms[1]
 
@@ -579,14 +581,31 @@ class BPRTrainer(BasicTrainer):
             return self._graph_step((nodes,), loss_fn)
         return self._optimise_loss(loss_fn(nodes))
 
+    def flat_step(self, flat):
+        """One optimisation step of a model without propagation (MF) on a batch as int64 [3 B] = users | positives |
+        negatives (DeviceSampler.epoch_node_batches with item_offset 0): the three id vectors are views — no transpose
+        kernel — and full-size batches replay one captured HIP graph."""
+        def loss_fn(f):
+            b = f.numel() // 3
+            return self.model.bpr_loss(f[:b], f[b:2 * b], f[2 * b:], self.l2_reg)
+        graph = self._graph_wanted()
+        self._seed_for_step(graph)
+        if graph and flat.numel() == 3 * self.batch_size:
+            return self._graph_step((flat,), loss_fn, kind='flat')
+        return self._optimise_loss(loss_fn(flat))
+
     def train_one_epoch(self):
         losses = AverageMeter()
         pending = []
-        if hasattr(self.model, 'bpr_loss_terms_nodes') and self.model.slice_reduce_fn is None:
+        if hasattr(self.model, 'bpr_loss') and getattr(self.model, 'slice_reduce_fn', None) is None \
+                and not hasattr(self.model, 'bpr_loss_terms_nodes'):
+            for flat in self.sampler.epoch_node_batches(self.batch_size, 0, into=self._draw_into(0, lambda b: (3 * b,))):
+                pending.append((self.flat_step(flat), flat.shape[0] // 3))
+        elif hasattr(self.model, 'bpr_loss_terms_nodes') and self.model.slice_reduce_fn is None:
             for nodes in self.sampler.epoch_node_batches(self.batch_size, self.model.n_users, into=self._draw_into(0, lambda b: (3 * b,))):
                 pending.append((self.node_step(nodes), nodes.shape[0] // 3))
         else:
-            for inputs in self.sampler.epoch_batches(self.batch_size):
+            for inputs in self.sampler.epoch_batches(self.batch_size, into=self._draw_into(0, lambda b: (b, 3))):
                 pending.append((self.bpr_step(inputs), inputs.shape[0]))
         for loss, n in pending:               # one host sync per epoch, not per step (trainer.py:247)
             losses.update(loss.item(), n)

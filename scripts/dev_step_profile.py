@@ -15,8 +15,13 @@ torch.manual_seed(2021)
 model = get_model(m_cfg, ds)
 trainer = get_trainer(t_cfg, ds, model)
 model.train()
-its = trainer.sampler.epoch_node_batches(2048, model.n_users)
-aux = trainer.aux_sampler.epoch_batches(2048) if hasattr(trainer, 'aux_sampler') else None
-for i in range(60):                               # the loop of train_one_epoch
-    trainer.igcn_node_step(next(its), next(aux)) if aux else trainer.node_step(next(its))
+if not hasattr(model, 'bpr_loss_terms_nodes'):     # MF: triplet batches
+    its = trainer.sampler.epoch_batches(2048, into=trainer._draw_into(0, lambda b: (b, 3)))
+    for i in range(60):
+        trainer.bpr_step(next(its))
+else:
+    its = trainer.sampler.epoch_node_batches(2048, model.n_users, into=trainer._draw_into(0, lambda b: (3 * b,)))
+    aux = trainer.aux_sampler.epoch_batches(2048, into=trainer._draw_into(1, lambda b: (b, 3))) if hasattr(trainer, 'aux_sampler') else None
+    for i in range(60):                               # the loop of train_one_epoch
+        trainer.igcn_node_step(next(its), next(aux)) if aux else trainer.node_step(next(its))
 torch.cuda.synchronize()

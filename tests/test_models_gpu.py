@@ -1006,3 +1006,27 @@ def test_gowalla_size_mf_training_recall_parity_with_a_float64_restatement():
         assert abs(float(m_prod[name][20]) - float(m_ref[name][20])) < 1e-3, (name, m_prod[name][20], m_ref[name][20])
     print('MF recall parity (%d steps): product %r float64 %r; max |d U| %.2e |d I| %.2e'
           % (len(loss_b), {k: round(float(v[20]), 5) for k, v in m_prod.items()}, {k: round(float(v[20]), 5) for k, v in m_ref.items()}, d_u, d_i))
+
+
+def test_mf_scalar_loss_node_equals_the_two_term_composition(golden):
+    """MF.bpr_loss (trainer.py:242 as one autograd node) against bpr_loss_terms composed with torch ops: value and both
+    table gradients, with repeated ids in the batch."""
+    from igcn_cf_amd.model import get_model
+    ds = _dataset(golden)
+    torch.manual_seed(6)
+    model = get_model({'name': 'MF', 'embedding_size': 64, 'device': 'cuda'}, ds)
+    rng = np.random.default_rng(4)
+    B = 130
+    u = torch.from_numpy(rng.integers(0, ds.n_users, B)).cuda(); p = torch.from_numpy(rng.integers(0, ds.n_items, B)).cuda()
+    n = torch.from_numpy(rng.integers(0, ds.n_items, B)).cuda()
+    u[1] = u[0]; p[2] = n[2]
+    terms = model.bpr_loss_terms(u, p, n)
+    ref = terms[0] + 0.05 * terms[1]
+    ref.backward()
+    gu, gi = model.user_embedding.weight.grad.clone(), model.item_embedding.weight.grad.clone()
+    model.user_embedding.weight.grad = None; model.item_embedding.weight.grad = None
+    got = model.bpr_loss(u, p, n, 0.05)
+    got.backward()
+    assert abs(float(got) - float(ref)) < 1e-6 * max(1., abs(float(ref)))
+    assert float((model.user_embedding.weight.grad - gu).abs().max()) <= 1e-6 * float(gu.abs().max())
+    assert float((model.item_embedding.weight.grad - gi).abs().max()) <= 1e-6 * float(gi.abs().max())
