@@ -347,6 +347,56 @@ def model_fixtures():
                 g[k + 'feat_shape'] = np.array(ig.feat_mat.shape)
                 g[k + 'row_sum'] = ig.row_sum.numpy().copy()
 
+        # ---- BASELINE config 1 END TO END with the reference's own classes (MF needs no DGL at all): get_model ->
+        #      get_trainer -> BPRTrainer.train_one_epoch x 3 (DataLoader over BasicDataset.__getitem__, Adam) ->
+        #      BasicTrainer.eval('test').  Recorded: initial tables, every batch the DataLoader produced, the epoch
+        #      losses, the tables after training, the recommended ids and the metrics.
+        import random as _random
+        with quiet:
+            ref_trainer = __import__('trainer')
+        torch.manual_seed(61); _random.seed(61); np.random.seed(61)
+        with quiet:
+            mf2 = ref_model.get_model({'name': 'MF', 'embedding_size': 16, 'device': 'cpu'}, ds)
+        tcfg = {'name': 'BPRTrainer', 'optimizer': 'Adam', 'lr': 1.e-2, 'l2_reg': 1.e-3, 'device': 'cpu', 'n_epochs': 3,
+                'batch_size': 64, 'dataloader_num_workers': 0, 'test_batch_size': 7, 'topks': [5, 20] if ds.n_items > 20 else [5, 10]}
+        with quiet:
+            tr = ref_trainer.get_trainer(tcfg, ds, mf2)
+        g['e2e_mf_user_emb0'] = mf2.user_embedding.weight.detach().numpy().copy()
+        g['e2e_mf_item_emb0'] = mf2.item_embedding.weight.detach().numpy().copy()
+        seen, loader = [], tr.dataloader
+
+        class Tap:
+            def __iter__(self_inner):
+                for bd in loader:
+                    seen.append(bd[:, 0, :].numpy().copy())
+                    yield bd
+        tr.dataloader = Tap()
+        epoch_losses, per_epoch = [], []
+        for _ in range(3):
+            n0 = len(seen)
+            epoch_losses.append(tr.train_one_epoch())
+            per_epoch.append(len(seen) - n0)
+        g['e2e_mf_batches'] = np.concatenate(seen, axis=0)
+        g['e2e_mf_batch_sizes'] = np.array([b.shape[0] for b in seen], dtype=np.int64)
+        g['e2e_mf_batches_per_epoch'] = np.array(per_epoch, dtype=np.int64)
+        g['e2e_mf_epoch_losses'] = np.array(epoch_losses, dtype=np.float64)
+        g['e2e_mf_lr'], g['e2e_mf_l2_reg'], g['e2e_mf_topks'] = tcfg['lr'], tcfg['l2_reg'], np.array(tcfg['topks'])
+        g['e2e_mf_user_emb1'] = mf2.user_embedding.weight.detach().numpy().copy()
+        g['e2e_mf_item_emb1'] = mf2.item_embedding.weight.detach().numpy().copy()
+        got = {}
+        orig_cm = tr.calculate_metrics
+
+        def spy_cm(eval_data, rec_items, _got=got):
+            _got['rec'] = rec_items.copy()
+            return orig_cm(eval_data, rec_items)
+        tr.calculate_metrics = spy_cm
+        for stage in ('val', 'test'):
+            _, metrics = tr.eval(stage)
+            g['e2e_mf_%s_rec' % stage] = got['rec']
+            for m in metrics:
+                for kk in metrics[m]:
+                    g['e2e_mf_%s_%s_%d' % (stage, m, kk)] = np.float64(metrics[m][kk])
+
         # ---- IMF (model.py:536-543) shares every DGL-free function with IGCN; record that it builds the same state
         torch.manual_seed(43)
         imf = build('IMF', ds, dropout=0.3, feature_ratio=0.5, ranking_metric='sort')

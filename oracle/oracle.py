@@ -32,6 +32,9 @@ How it is pinned
   ``tests/test_model_golden.py`` checks ``lightgcn_norm_adj``, ``igcn_generate_feat``,
   ``igcn_feat_values``, ``dropout_keep_scale``, ``bpr_forward_*`` and ``predict`` below
   against those vectors (indices / maps / row sums / A_hat values bit-exact).
+* BASELINE config 1 (MF + BPRTrainer + eval) is recorded END TO END from the reference's own
+  classes (``e2e_mf_*`` keys of the same fixtures): batches, epoch losses, trained tables,
+  recommended ids, metrics.
 * STILL UNPINNED — the two gspmm callers only: ``lightgcn_get_rep`` (``model.py:96-106``)
   and the product inside ``igcn_get_rep`` (``model.py:423-446``).  The sparse product is
   DGL's ``gspmm(g, 'mul', 'sum', X, w)`` on ``dgl.graph((column, row))`` (call sites

@@ -340,3 +340,104 @@ def test_hip_live_update_against_reference_model(mg, split, tag, ratio):
     with torch.no_grad():
         rep = ig.get_rep()
     assert rep.shape == (full.n_users + full.n_items, 8) and torch.isfinite(rep).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE config 1 end to end: the reference's own MF + BPRTrainer + eval, run by the generator
+# ------------------------------------------------------------------------------------------------
+def _e2e_batches(mg):
+    sizes = mg['e2e_mf_batch_sizes']
+    cuts = np.concatenate([[0], np.cumsum(sizes)])
+    batches = [mg['e2e_mf_batches'][a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    per_epoch = mg['e2e_mf_batches_per_epoch']
+    ecuts = np.concatenate([[0], np.cumsum(per_epoch)])
+    return [batches[a:b] for a, b in zip(ecuts[:-1], ecuts[1:])]
+
+
+def test_reference_mf_run_is_reproduced_by_the_restated_algorithm(mg):
+    """The recorded run (model.py:52-72, trainer.py:222-248, :140-177 executed by the reference itself) against the
+    oracle's loss arithmetic + torch Adam in float64 on the recorded batches: epoch losses (AverageMeter weighting,
+    trainer.py:247), tables after three epochs, recommended ids and metrics."""
+    u = torch.nn.Parameter(torch.from_numpy(mg['e2e_mf_user_emb0']).double())
+    i = torch.nn.Parameter(torch.from_numpy(mg['e2e_mf_item_emb0']).double())
+    opt = torch.optim.Adam([u, i], lr=float(mg['e2e_mf_lr']))
+    l2_reg = float(mg['e2e_mf_l2_reg'])
+    for ep, batches in enumerate(_e2e_batches(mg)):
+        tot, cnt = 0., 0
+        for b in batches:
+            bt = torch.from_numpy(b)
+            ue, pe, ne = u[bt[:, 0]], i[bt[:, 1]], i[bt[:, 2]]
+            l2 = (ue ** 2).sum(1) + (pe ** 2).sum(1) + (ne ** 2).sum(1)
+            loss = torch.nn.functional.softplus((ue * ne).sum(1) - (ue * pe).sum(1)).mean() + l2_reg * l2.mean()
+            opt.zero_grad(); loss.backward(); opt.step()
+            tot += float(loss.detach()) * len(b); cnt += len(b)
+        assert abs(tot / cnt - float(mg['e2e_mf_epoch_losses'][ep])) < 2e-6
+        for b in batches:                                          # sampler semantics of the recorded draws (dataset.py:119-131)
+            assert b.shape[1] == 3 and (b[:, 2] >= 0).all()
+    np.testing.assert_allclose(u.detach().numpy(), mg['e2e_mf_user_emb1'], atol=2e-5)
+    np.testing.assert_allclose(i.detach().numpy(), mg['e2e_mf_item_emb1'], atol=2e-5)
+    # evaluation of the REFERENCE's trained tables by the oracle: ids and metrics
+    lists = {}
+    for name in ('train', 'val', 'test'):
+        lists[name], _ = O.read_data(os.path.join(mg['path'], name + '.txt'))
+    scores = mg['e2e_mf_user_emb1'] @ mg['e2e_mf_item_emb1'].T
+    kmax = int(mg['e2e_mf_topks'].max())
+    for stage in ('val', 'test'):
+        ex = [lists['train'][uu] + (lists['val'][uu] if stage == 'test' else []) for uu in range(mg['n_users'])]
+        rec = O.eval_topk(scores, ex, None, k=kmax)
+        ref = mg['e2e_mf_%s_rec' % stage]
+        same = (rec == ref).all(axis=1)
+        for uu in np.flatnonzero(~same):                           # only where scores tie to fp32 rounding
+            np.testing.assert_allclose(np.sort(scores[uu, rec[uu]]), np.sort(scores[uu, ref[uu]]), rtol=1e-5)
+        assert same.mean() > 0.98
+        m = O.calculate_metrics(lists[stage], ref, [int(k) for k in mg['e2e_mf_topks']])
+        for name in m:
+            for k in m[name]:
+                assert m[name][k] == mg['e2e_mf_%s_%s_%d' % (stage, name, k)]
+
+
+@pytest.mark.gpu
+def test_hip_mf_training_and_evaluation_reproduce_the_reference_run(mg):
+    """BASELINE config 1 (MF + BPRTrainer, config.py:12-18) through the product path — fused loss node, captured steps for
+    the full-size batches, fused Adam, fused score / mask / top-k — on the batches the reference's DataLoader produced:
+    epoch losses <= 2e-6, tables after three epochs <= 2e-5, recommended ids and metrics equal to the reference's."""
+    from igcn_cf_amd.model import get_model
+    from igcn_cf_amd.trainer import get_trainer
+    ds = _dataset(mg['path'])
+    topks = [int(k) for k in mg['e2e_mf_topks']]
+    model = get_model({'name': 'MF', 'embedding_size': 16, 'device': 'cuda'}, ds)
+    with torch.no_grad():
+        model.user_embedding.weight.copy_(_t(mg['e2e_mf_user_emb0'])); model.item_embedding.weight.copy_(_t(mg['e2e_mf_item_emb0']))
+    trainer = get_trainer({'name': 'BPRTrainer', 'optimizer': 'Adam', 'lr': float(mg['e2e_mf_lr']), 'l2_reg': float(mg['e2e_mf_l2_reg']),
+                           'device': 'cuda', 'n_epochs': 3, 'batch_size': 64, 'dataloader_num_workers': 0, 'test_batch_size': 7,
+                           'topks': topks, 'host_metrics': True}, ds, model)
+    model.train()
+    for ep, batches in enumerate(_e2e_batches(mg)):
+        tot, cnt = 0., 0
+        for b in batches:
+            loss = trainer.bpr_step(_t(b))
+            tot += float(loss) * len(b); cnt += len(b)
+        assert abs(tot / cnt - float(mg['e2e_mf_epoch_losses'][ep])) < 2e-6 * max(1., abs(tot / cnt))
+    assert trainer._graph is not None                                  # the 64-triplet batches ran as captured graphs
+    np.testing.assert_allclose(model.user_embedding.weight.detach().cpu().numpy(), mg['e2e_mf_user_emb1'], atol=2e-5)
+    np.testing.assert_allclose(model.item_embedding.weight.detach().cpu().numpy(), mg['e2e_mf_item_emb1'], atol=2e-5)
+    # evaluate the reference's trained tables (so that rounding of the training does not enter): ids and metrics
+    with torch.no_grad():
+        model.user_embedding.weight.copy_(_t(mg['e2e_mf_user_emb1'])); model.item_embedding.weight.copy_(_t(mg['e2e_mf_item_emb1']))
+    scores = mg['e2e_mf_user_emb1'].astype(np.float64) @ mg['e2e_mf_item_emb1'].astype(np.float64).T
+    for stage in ('val', 'test'):
+        _, metrics = trainer.eval(stage)
+        rec = trainer.last_rec_items.cpu().numpy()
+        ref = mg['e2e_mf_%s_rec' % stage]
+        same = (rec == ref).all(axis=1)
+        for uu in np.flatnonzero(~same):
+            np.testing.assert_allclose(np.sort(scores[uu, rec[uu]]), np.sort(scores[uu, ref[uu]]), rtol=1e-5)
+        assert same.mean() > 0.98
+        if same.all():
+            for name in metrics:
+                for k in metrics[name]:
+                    assert metrics[name][k] == mg['e2e_mf_%s_%s_%d' % (stage, name, k)], (stage, name, k)
+        else:
+            for name in metrics:
+                for k in metrics[name]:
+                    assert abs(float(metrics[name][k]) - float(mg['e2e_mf_%s_%s_%d' % (stage, name, k)])) < 1e-3
