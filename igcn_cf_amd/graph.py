@@ -216,7 +216,7 @@ XCD_PLAN_FEATURES = XCD_PLAN   # INMO's template-feature matrix F and its transp
 N_XCD = 8                  # lists of the XCD plan = XCDs of an MI355X (igcn_spmm_csr_f32: xcd_off has N_XCD + 1 entries)
 
 
-def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assign='affinity', list_order='segments_first'):
+def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assign='affinity', list_order='segments_first', n_lists=None):
     """The XCD plan of a CSR matrix: the work of one SpMM launch cut into N_XCD lists, one per XCD, such that a list
     gathers as much as possible from ONE slice of the operand — a slice (1/8 of the operand's rows) fits an XCD's 4 MiB
     L2 where the whole operand does not, and the eight L2s are private (igcn_hip.h: xcd_off).
@@ -237,6 +237,7 @@ def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assi
     lives (in HBM for the device builders: the inductive update rebuilds the graph on a live model).
     Returns (long_rows int32 [n_long, 4], segments int32 [n_seg, 6] — the byte layouts of igcn_long_row /
     igcn_row_segment —, row_order int32, xcd_off int64 [N_XCD + 1], load float64 [N_XCD]) on that device."""
+    NL = int(n_lists or N_XCD)        # lists of the plan (developer A/Bs cut fewer slices; the kernel always walks N_XCD)
     dev = rowptr.device
     i64 = dict(dtype=torch.int64, device=dev)
     n_rows = rowptr.shape[0] - 1
@@ -261,14 +262,14 @@ def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assi
         c = col[e0:e1].to(torch.int64)
         cmin = int(c.min())
         cum = torch.cumsum(torch.bincount(c - cmin), 0)
-        targets = (torch.arange(1, N_XCD, **i64).to(torch.float64) * (float(cum[-1]) / N_XCD))
+        targets = (torch.arange(1, NL, **i64).to(torch.float64) * (float(cum[-1]) / NL))
         bounds = cmin + 1 + torch.searchsorted(cum.to(torch.float64), targets)
-        sl = torch.searchsorted(bounds, c, right=True)                 # slice of every nonzero of the block, 0..N_XCD-1
+        sl = torch.searchsorted(bounds, c, right=True)                 # slice of every nonzero of the block, 0..NL-1
         row_e = torch.repeat_interleave(rows, lens[lo:hi])
         in_cut = cut[row_e]
         pos = e0 + torch.nonzero(in_cut).flatten()                     # nonzeros of the cut rows, in storage order
         if pos.numel():
-            key = row_e[in_cut] * N_XCD + sl[in_cut]
+            key = row_e[in_cut] * NL + sl[in_cut]
             first = torch.ones_like(key, dtype=torch.bool)
             first[1:] = (key[1:] != key[:-1]) | (pos[1:] != pos[:-1] + 1)
             fidx = torch.nonzero(first).flatten()
@@ -279,10 +280,10 @@ def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assi
             within = torch.arange(rep.shape[0], **i64) - torch.repeat_interleave(torch.cumsum(n_chunks, 0) - n_chunks, n_chunks)
             s_start = p_start[rep] + within * segment_len
             s_len = torch.clamp(p_len[rep] - within * segment_len, max=segment_len)
-            seg_parts.append((s_start, s_len, p_key[rep] // N_XCD, p_key[rep] % N_XCD))
+            seg_parts.append((s_start, s_len, p_key[rep] // NL, p_key[rep] % NL))
         # rows that stay whole: nonzeros per slice -> the list they would like and how much of the row it holds
         w_e = ~in_cut
-        cnt = torch.bincount((row_e[w_e] - lo) * N_XCD + sl[w_e], minlength=(hi - lo) * N_XCD).reshape(hi - lo, N_XCD)
+        cnt = torch.bincount((row_e[w_e] - lo) * NL + sl[w_e], minlength=(hi - lo) * NL).reshape(hi - lo, NL)
         cnt = cnt[~cut[lo:hi]]
         best, pref = cnt.max(dim=1)
         per_block.append((whole, pref, best.to(torch.float64) / torch.clamp(lens[whole], min=1).to(torch.float64)))
@@ -308,16 +309,16 @@ def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assi
         long_rows[:, 2] = torch.diff(torch.cat([firsts, torch.tensor([n_seg], **i64)])).int()
 
     # deal the blocks, one after the other, keeping the lists' total work level
-    load = torch.zeros(N_XCD, dtype=torch.float64, device=dev)
-    lists = [[] for _ in range(N_XCD)]
+    load = torch.zeros(NL, dtype=torch.float64, device=dev)
+    lists = [[] for _ in range(NL)]
     inner = torch.tensor(list(blocks[1:-1]), **i64)
     seg_block = torch.searchsorted(inner, seg_row, right=True) if n_seg else seg_row
     for b, (whole, pref, aff) in enumerate(per_block):
         sb = torch.nonzero(seg_block == b).flatten() if n_seg else empty
-        seg_cost = torch.bincount(seg_xcd[sb], weights=(seg_len[sb] + row_cost).to(torch.float64), minlength=N_XCD) \
-            if sb.numel() else torch.zeros(N_XCD, dtype=torch.float64, device=dev)
+        seg_cost = torch.bincount(seg_xcd[sb], weights=(seg_len[sb] + row_cost).to(torch.float64), minlength=NL) \
+            if sb.numel() else torch.zeros(NL, dtype=torch.float64, device=dev)
         cost = (lens[whole] + row_cost).to(torch.float64)
-        level = (load.sum() + seg_cost.sum() + cost.sum()) / N_XCD
+        level = (load.sum() + seg_cost.sum() + cost.sum()) / NL
         quota = torch.clamp(level - load - seg_cost, min=0.)
         if float(quota.sum()) > 0:
             quota = quota * (cost.sum() / quota.sum())
@@ -327,20 +328,20 @@ def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assi
             order = order[torch.sort(pref[order], stable=True).indices]      # by list, strongest affinity first
             po = pref[order]
             run = torch.cumsum(cost[order], 0)
-            before = torch.bincount(po, weights=cost[order], minlength=N_XCD).cumsum(0) - \
-                torch.bincount(po, weights=cost[order], minlength=N_XCD)           # work of the lists before po
+            before = torch.bincount(po, weights=cost[order], minlength=NL).cumsum(0) - \
+                torch.bincount(po, weights=cost[order], minlength=NL)           # work of the lists before po
             fits = (run - before[po]) <= quota[po]
             owner[order[fits]] = po[fits]
         rest = torch.nonzero(owner < 0).flatten()
         if rest.numel():
             rest = rest[torch.sort(-lens[whole[rest]], stable=True).indices]
             got = owner >= 0
-            used = torch.bincount(owner[got], weights=cost[got], minlength=N_XCD) if bool(got.any()) else torch.zeros_like(quota)
+            used = torch.bincount(owner[got], weights=cost[got], minlength=NL) if bool(got.any()) else torch.zeros_like(quota)
             room = torch.clamp(quota - used, min=0.)
             edges = torch.cumsum(room * (cost[rest].sum() / torch.clamp(room.sum(), min=1e-30)), 0)
             mid = torch.cumsum(cost[rest], 0) - cost[rest] / 2
-            owner[rest] = torch.clamp(torch.searchsorted(edges, mid), max=N_XCD - 1)
-        for x in range(N_XCD):
+            owner[rest] = torch.clamp(torch.searchsorted(edges, mid), max=NL - 1)
+        for x in range(NL):
             sx = sb[seg_xcd[sb] == x]
             sx = n_rows + sx[torch.sort(-seg_len[sx], stable=True).indices]
             rx = whole[owner == x]
@@ -355,9 +356,9 @@ def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assi
                 lists[x].append(both)
             else:
                 lists[x] += [sx, rx]
-        load = load + seg_cost + (torch.bincount(owner, weights=cost, minlength=N_XCD) if whole.numel() else 0.)
+        load = load + seg_cost + (torch.bincount(owner, weights=cost, minlength=NL) if whole.numel() else 0.)
     per_list = [torch.cat(l) if l else empty for l in lists]
-    xcd_off = torch.zeros(N_XCD + 1, **i64)
+    xcd_off = torch.zeros(NL + 1, **i64)
     xcd_off[1:] = torch.cumsum(torch.tensor([a.shape[0] for a in per_list], **i64), 0)
     row_order = torch.cat(per_list).to(torch.int32)
     if row_order.shape[0] != n_rows - long_ids.shape[0] + n_seg:
