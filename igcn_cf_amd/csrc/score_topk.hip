@@ -133,14 +133,16 @@ struct TopkPlan {
 
 constexpr int kMinCap = 8, kMaxCap = 16, kQuad = 4;
 
-static inline int topk_groups_per_wave(int d_pad) { return d_pad <= 64 ? 2 : 1; }
+// (the fp16 candidate sweep at d = 128 runs ONE wave per SIMD with 512 registers: both user groups stay)
+static inline bool topk_wide_sweep() { return tuning_get(IGCN_TUNE_TOPK_FAST_WIDE) != 0; }
+static inline int topk_groups_per_wave(int d_pad, bool candidate_sweep = false) { return d_pad <= 64 || (candidate_sweep && d_pad == 128 && topk_wide_sweep()) ? 2 : 1; }
 
 static inline int topk_make_plan(int64_t batch, int64_t n_items, int32_t d, int32_t k, TopkPlan *p, bool candidate_sweep = false) {
     if (batch < 1 || n_items < 1) return IGCN_E_SHAPE;
     if (d < 4 || d > 256 || d % 4 != 0) return IGCN_E_SHAPE;
     if (k < 1 || k > IGCN_MAX_TOPK || k > n_items) return IGCN_E_RANGE;
     p->d_pad = d <= 16 ? 16 : d <= 32 ? 32 : d <= 64 ? 64 : d <= 128 ? 128 : 256;
-    p->ng = topk_groups_per_wave(p->d_pad);
+    p->ng = topk_groups_per_wave(p->d_pad, candidate_sweep);
     const int upw = 32 * p->ng;
     p->groups = (batch + upw - 1) / upw;
     const int64_t L = (n_items + 31) / 32;
@@ -149,9 +151,9 @@ static inline int topk_make_plan(int64_t batch, int64_t n_items, int32_t d, int3
     // CU's 160 KiB; measured: 12 x 13312 B do not fit, 12 x 12800 B do): a wave gets 128 / per_cu of them, holds
     // the heaps (k slots x 64 owner lanes x 8 B) and gives the rest to the staging lists.  The grid must never
     // exceed what is resident: a wave that starts late runs its whole share after everybody else has finished.
-    int per_cu = 8;
+    int per_cu = candidate_sweep && p->d_pad == 128 && topk_wide_sweep() ? 4 : 8;
     const int want = tuning_get(IGCN_TUNE_TOPK_WAVES_PER_CU);
-    if (want == 8 || want == 4 || want == 2 || want == 1) per_cu = want;
+    if ((want == 8 || want == 4 || want == 2 || want == 1) && want <= per_cu) per_cu = want;
     int cap = 0;
     for (; per_cu >= 1; per_cu >>= 1) {
         const int64_t budget = (int64_t)(128 / per_cu) * 1280;
@@ -308,10 +310,12 @@ struct TopkArgs {
 // chain.  MODE 1 (D = 64, FULL): the candidate sweep on the bf16 matrix cores described above.
 // BOUNDED: A.init_thr holds a lower bound of every user's k-th best score (igcn_score_topk_bounded_f32); a variant of
 // its own so that the plain sweeps carry nothing of it (two more live values cost the fp32 sweep 4 %).
+// MODE 2 at D = 128: one wave per SIMD (512 registers: 128 of user planes, 64 of accumulators, 96 of item-tile ring).
 template <int D, int NG, bool FULL, int MODE = 0, bool BOUNDED = false>
-__global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
+__global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) void score_topk_kernel(const TopkArgs A)
 {
-    static_assert(MODE == 0 || (D == 64 && FULL && NG == 2), "the candidate sweeps are built for d = 64");
+    static_assert(MODE == 0 || (FULL && ((D == 64 && NG == 2) || (MODE == 2 && D == 128))), "the candidate sweeps are built for d = 64 (and fp16: d = 128)");
+    constexpr int KS = D / 16;                                   // MODE 1 / 2: k-steps of 16 per row
     static_assert(!BOUNDED || MODE == 0, "a lower bound goes with the exact sweep");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *const heap_base = reinterpret_cast<unsigned long long *>(smem);       // [k][64 owner lanes]
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
         // B operands: user (g, j) of this lane.  Lane half h supplies k = 8q + 4h + c (q < D/8, c < 4): the two
         // lanes of a row read adjacent 16-B pieces, so one load instruction touches 32 lines, not 64.
         float bfrag[NG][MODE == 0 ? D / 2 : 1];
-        float4 ub[MODE != 0 ? NG : 1][2][4];                    // MODE 1: [group][plane][k-step], 8 bf16 each: k = 16 s + 8 h .. + 7
+        float4 ub[MODE != 0 ? NG : 1][2][MODE != 0 ? KS : 1];   // MODE 1 / 2: [group][plane][k-step], 8 halves each: k = 16 s + 8 h .. + 7
         int64_t uid[NG];
         bool user_ok[NG];
 #pragma unroll
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
             } else {
                 const float su = MODE == 2 ? ldexpf(1.f, -scale_exp(__uint_as_float(A.stats[2]))) : 1.f;
 #pragma unroll
-                for (int st = 0; st < 4; ++st) {
+                for (int st = 0; st < KS; ++st) {
                     float4 lo = f4_zero(), hi = f4_zero();
                     if (user_ok[g]) {
                         const float *src = A.user_rows + uid[g] * A.ldu + 16 * st + 8 * h;
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
         // bookkeeping between two blocks waits for (vmcnt counts in order) is ever behind a load just issued.
         // At d = 128 one buffer: each piece is re-loaded as soon as the block has consumed it.
         constexpr bool kTwoBuffers = D <= 64;
-        float4 a[D / 8], a2[kTwoBuffers ? D / 8 : 1];
+        float4 a[D / 8], a2[(kTwoBuffers || MODE == 2) ? D / 8 : 1];
         float4 a3[MODE == 2 ? D / 8 : 1];                         // MODE 2: a third buffer (its tiles are half the size): loads run two tile steps ahead
         auto tile_addr = [&](int t, const char *&tile_ptr, unsigned &off) {
             tile_ptr = reinterpret_cast<const char *>(A.item_rows + (int64_t)t * 32 * ldi);
@@ -511,9 +515,9 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) buf[i] = pk[i * kWave];
             } else if constexpr (MODE == 2) {                      // [k-step]
-                const float4 *pk = A.packed + (int64_t)t * 4 * kWave + lane;
+                const float4 *pk = A.packed + (int64_t)t * KS * kWave + lane;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) buf[i] = pk[i * kWave];
+                for (int i = 0; i < KS; ++i) buf[i] = pk[i * kWave];
             } else {
                 const char *tile_ptr; unsigned off;
                 tile_addr(t, tile_ptr, off);
@@ -545,7 +549,7 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
 #pragma unroll
                 for (int tm = 0; tm < 2; ++tm)                   // the small term (user plane l) first
 #pragma unroll
-                    for (int st = 0; st < 4; ++st)
+                    for (int st = 0; st < KS; ++st)
 #pragma unroll
                         for (int g = 0; g < NG; ++g)
                             acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(a[st]), as_half8(ub[g][1 - tm][st]), acc[g], 0, 0, 0);
@@ -697,7 +701,7 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
         auto tile_step = [&](f32x16 (&cur)[NG], f32x16 (&nxt)[NG], float4 (&ause)[D / 8], float4 (&aload)[D / 8], int tile) {
             const int tile_base = tile * 32;
             build_masks(tile, tile_base);
-            constexpr int kSlots = MODE == 1 ? 12 * NG : MODE == 2 ? 8 * NG : (D / 2) * NG;   // MFMAs of the block
+            constexpr int kSlots = MODE == 1 ? 12 * NG : MODE == 2 ? 2 * KS * NG : (D / 2) * NG;   // MFMAs of the block
             constexpr int kParts = 3 * kQuad * NG;                // selection instructions of the block
             constexpr int kFirst = 4;                             // the first ones wait until the previous block's MFMAs have long retired
             if (tile + 1 < tin1) {
@@ -722,10 +726,10 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
 #ifdef IGCN_X_SAMETILE
                     const float4 *pk = A.packed + lane;           // developer build: every load hits the same lines
 #else
-                    const float4 *pk = A.packed + (int64_t)(tile + 3 < tin1 ? tile + 3 : tin1 - 1) * 4 * kWave + lane;
+                    const float4 *pk = A.packed + (int64_t)(tile + 3 < tin1 ? tile + 3 : tin1 - 1) * KS * kWave + lane;
 #endif
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) aload[i] = pk[i * kWave];
+                    for (int i = 0; i < KS; ++i) aload[i] = pk[i * kWave];
 #endif
                 } else if constexpr (kTwoBuffers) {
 #pragma unroll
@@ -765,11 +769,11 @@ __global__ __launch_bounds__(kWave, 2) void score_topk_kernel(const TopkArgs A)
 #pragma unroll
                     for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
-                        for (int st = 0; st < 4; ++st) {
+                        for (int st = 0; st < KS; ++st) {
 #pragma unroll
                             for (int g = 0; g < NG; ++g) {
                                 nxt[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(ause[st]), as_half8(ub[g][1 - tm][st]), nxt[g], 0, 0, 0);
-                                select_share((tm * 4 + st) * NG + g);
+                                select_share((tm * KS + st) * NG + g);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
@@ -1036,37 +1040,37 @@ __global__ __launch_bounds__(kBlock) void topk_pack_items_kernel(const float *__
     for (int p = 0; p < 2; ++p) packed[((tile * 2 + p) * 4 + s) * kWave + lane] = planes[p];
 }
 
-// stats[0] = max over the items of |row|^2, stats[1] = max |item element| (d = 64: a 16-lane group per row), as the bit
+// stats[0] = max over the items of |row|^2, stats[1] = max |item element| (a group of 2^lg = d / 4 lanes per row: 16 at
+// d = 64, 32 at d = 128), as the bit
 // patterns of non-negative floats; norm2_out (optional): |row|^2 of every row (what the sweep order sorts by).  A small
 // fixed grid walks the table; the maxima are reduced inside the workgroup and ONE lane per workgroup issues the atomics
 // (one atomic per wave from 2 048 waves on the same two words took 43 us).
 // With ids: the rows ids[0..n) of the table, and only the element maximum, into stats[2] (the users of a call).
 __global__ __launch_bounds__(kBlock) void topk_row_stats_kernel(const float *__restrict__ rows, int64_t ld, int64_t n,
-                                                                const int64_t *__restrict__ ids, int of_users,
+                                                                const int64_t *__restrict__ ids, int of_users, int lg,
                                                                 unsigned int *__restrict__ stats, float *__restrict__ norm2_out)
 {
+    const int lpr = 1 << lg;
     __shared__ float sh[2][kBlock / kWave];
     const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     float best_n2 = 0.f, best_el = 0.f;
-    for (int64_t t = t0; (t >> 4) < n + 3; t += stride) {                 // (+3: the four groups of a wave stay together)
-        const int64_t r = t >> 4;
+    for (int64_t t = t0; (t >> lg) < n + 3; t += stride) {                // (+3: the groups of a wave stay together)
+        const int64_t r = t >> lg;
         float n2 = 0.f;
         if (r < n) {
             const int64_t row = ids ? ids[r] : r;
-            const float4 v = *reinterpret_cast<const float4 *>(rows + row * ld + 4 * (t & 15));
+            const float4 v = *reinterpret_cast<const float4 *>(rows + row * ld + 4 * (t & (lpr - 1)));
             n2 = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
             best_el = fmaxf(best_el, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
         }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) n2 += __shfl_xor(n2, o);
-        if (norm2_out && r < n && (t & 15) == 0) norm2_out[r] = n2;
+        for (int o = 1; o < lpr; o <<= 1) n2 += __shfl_xor(n2, o);
+        if (norm2_out && r < n && (t & (lpr - 1)) == 0) norm2_out[r] = n2;
         best_n2 = fmaxf(best_n2, n2);
     }
 #pragma unroll
     for (int o = 1; o < kWave; o <<= 1) best_el = fmaxf(best_el, __shfl_xor(best_el, o));
-#pragma unroll
-    for (int o = 16; o < kWave; o <<= 1) best_n2 = fmaxf(best_n2, __shfl_xor(best_n2, o));
+    for (int o = lpr; o < kWave; o <<= 1) best_n2 = fmaxf(best_n2, __shfl_xor(best_n2, o));
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & (kWave - 1)) == 0) { sh[0][w] = best_n2; sh[1][w] = best_el; }
     __syncthreads();
@@ -1081,18 +1085,18 @@ __global__ __launch_bounds__(kBlock) void topk_row_stats_kernel(const float *__r
     }
 }
 
-// Item table -> one MFMA-ready fp16 plane for MODE 2: [tile][k-step 0..3][lane 0..63] x 16 B, scaled by the power of
-// two that brings the largest element (stats[1]) into [0.5, 1).  One thread per (tile, k-step, lane).
+// Item table -> one MFMA-ready fp16 plane for MODE 2: [tile][k-step 0..ks-1][lane 0..63] x 16 B (ks = d / 16), scaled by
+// the power of two that brings the largest element (stats[1]) into [0.5, 1).  One thread per (tile, k-step, lane).
 __global__ __launch_bounds__(kBlock) void topk_pack_items_f16_kernel(const float *__restrict__ item_rows, int64_t ldi, int64_t n_items,
-                                                                     int n_tiles, const unsigned int *__restrict__ stats,
+                                                                     int n_tiles, int ks, const unsigned int *__restrict__ stats,
                                                                      const int32_t *__restrict__ perm, float4 *__restrict__ packed,
                                                                      const float *__restrict__ norm2, float *__restrict__ tile_bound)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)n_tiles * 4 * kWave) return;
+    if (i >= (int64_t)n_tiles * ks * kWave) return;
     const int lane = (int)(i % kWave);
-    const int s = (int)(i / kWave % 4);
-    const int64_t tile = i / (4 * kWave);
+    const int s = (int)(i / kWave % ks);
+    const int64_t tile = i / (ks * kWave);
     const int64_t item = tile * 32 + (lane & 31);                 // sweep position
     if (tile_bound && lane == 0 && s == 0)
         // the tile's first row is its longest up to the sort's granularity (norms ordered on 18 bits: < 2^-10 apart
@@ -1106,7 +1110,7 @@ __global__ __launch_bounds__(kBlock) void topk_pack_items_f16_kernel(const float
     }
     float4 planes[2];
     split_f16_x8(lo, hi, ldexpf(1.f, -scale_exp(__uint_as_float(stats[1]))), planes);
-    packed[(tile * 4 + s) * kWave + lane] = planes[0];
+    packed[(tile * ks + s) * kWave + lane] = planes[0];
 }
 
 // Second stage of the bf16 path, one wave per user, lane c = candidate c of the sweep (kc = k + kFastExtra <= 64 of
@@ -1122,7 +1126,7 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(const float *__res
                                                               const int64_t *__restrict__ user_ids, int64_t batch,
                                                               const float *__restrict__ item_rows, int64_t ldi,
                                                               const int64_t *__restrict__ cand_idx, const float *__restrict__ cand_val,
-                                                              int kc, int k, const unsigned int *__restrict__ stats, int mode,
+                                                              int kc, int k, int d, const unsigned int *__restrict__ stats, int mode,
                                                               const int32_t *__restrict__ perm,
                                                               int64_t *__restrict__ out_idx, float *__restrict__ out_val,
                                                               int32_t *__restrict__ flagged, float *__restrict__ flagged_thr)
@@ -1143,8 +1147,8 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(const float *__res
     {
         const float *it = item_rows + (real ? item : 0) * ldi;
         float acc = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
+#pragma unroll 8
+        for (int q = 0; q < d / 8; ++q) {
             const float4 ua = *reinterpret_cast<const float4 *>(u + 8 * q), ub = *reinterpret_cast<const float4 *>(u + 8 * q + 4);
             const float4 ia = *reinterpret_cast<const float4 *>(it + 8 * q), ib = *reinterpret_cast<const float4 *>(it + 8 * q + 4);
             acc = fmaf(ia.x, ua.x, acc); acc = fmaf(ib.x, ub.x, acc);
@@ -1180,14 +1184,15 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(const float *__res
         // MODE 1: two bf16 planes each side (8 significant bits each: x = h + l + r, |l| <= 2^-8 |x|, |r| <= 2^-16 |x|), three
         // products kept, l_i l_u and the r terms dropped: 3 * 2^-16 per product, 2^-14 with the accumulation.  MODE 2: items
         // rounded to fp16 once (11 bits: 2^-11 each), users
-        // exact to 2^-22, fp32 accumulation 2^-18: 2^-11 (1 + 2^-5); its approximate scores carry the two tables' scales.
-        const float coef = mode == 2 ? 0x1.08p-11f : 0x1p-14f;
+        // exact to 2^-22, fp32 accumulation of 2 d products 2^-18 (d = 64) / 2^-17 (d = 128): 2^-11 (1 + 2^-5) / 2^-11 (1 + 2^-4);
+        // its approximate scores carry the two tables' scales.
+        const float coef = mode == 2 ? (d > 64 ? 0x1.1p-11f : 0x1.08p-11f) : 0x1p-14f;
         if (mode == 2) a_min = ldexpf(a_min, scale_exp(__uint_as_float(stats[1])) + scale_exp(__uint_as_float(stats[2])));
         float eps = coef * sqrtf(un2 * __uint_as_float(stats[0]));
         // MODE 2: scaled elements below 2^-14 are fp16 subnormals (absolute error <= 2^-25 each, both sides): at most
-        // 2^-18 per score in scaled units = 2^-16 max|i_j| max|u_j| — matters only for a user far smaller than the
-        // largest of the batch, whom it then sends to the fp32 sweep
-        if (mode == 2 && eps > 0.f) eps += 0x1p-16f * __uint_as_float(stats[1]) * __uint_as_float(stats[2]);
+        // 2 d 2^-25 per score in scaled units (2^-18 at d = 64) = 2^-16 (d / 64) max|i_j| max|u_j| — matters only for a
+        // user far smaller than the largest of the batch, whom it then sends to the fp32 sweep
+        if (mode == 2 && eps > 0.f) eps += (d > 64 ? 0x1p-15f : 0x1p-16f) * __uint_as_float(stats[1]) * __uint_as_float(stats[2]);
         // fewer real candidates than slots: the sweep dropped nothing real.  eps == 0 (an all-zero user): scores are exact —
         // enough in an id-order sweep (ties are kept by lower id there too); in a permuted sweep the ties at the end of
         // the candidate list were kept by POSITION, so the user goes to the fp32 sweep (a_min + 0 < e_k fails on a tie).
@@ -1286,8 +1291,9 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
     a.tile_bound = tile_bound; a.unorm2 = unorm2;
 
     if (mode != 0) {
-        if (d != 64 || !packed || (mode == 2 && !stats)) return IGCN_E_SHAPE;
-        rc = mode == 2 ? launch_topk<64, 2, true, 2>(p, st, a) : launch_topk<64, 2, true, 1>(p, st, a);
+        if ((d != 64 && !(mode == 2 && d == 128)) || !packed || (mode == 2 && !stats)) return IGCN_E_SHAPE;
+        if (d == 128) rc = p.ng == 2 ? launch_topk<128, 2, true, 2>(p, st, a) : launch_topk<128, 1, true, 2>(p, st, a);
+        else rc = mode == 2 ? launch_topk<64, 2, true, 2>(p, st, a) : launch_topk<64, 2, true, 1>(p, st, a);
     } else {
         switch (p.d_pad) {
         case 16: rc = d == 16 ? launch_topk<16, 2, true>(p, st, a) : launch_topk<16, 2, false>(p, st, a); break;
@@ -1297,7 +1303,10 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
             if (d == 64 && init_thr) rc = launch_topk<64, 2, true, 0, true>(p, st, a);
             else rc = d == 64 ? launch_topk<64, 2, true>(p, st, a) : launch_topk<64, 2, false>(p, st, a);
             break;
-        case 128: rc = d == 128 ? launch_topk<128, 1, true>(p, st, a) : launch_topk<128, 1, false>(p, st, a); break;
+        case 128:
+            if (d == 128 && init_thr) rc = launch_topk<128, 1, true, 0, true>(p, st, a);
+            else rc = d == 128 ? launch_topk<128, 1, true>(p, st, a) : launch_topk<128, 1, false>(p, st, a);
+            break;
         default: rc = d == 256 ? launch_topk<256, 1, true>(p, st, a) : launch_topk<256, 1, false>(p, st, a); break;
         }
     }
@@ -1343,7 +1352,7 @@ extern "C" int igcn_score_topk_bounded_f32(const float *user_rows, int64_t ldu, 
 static inline int64_t align256(int64_t n) { return (n + 255) / 256 * 256; }
 struct FastLayout { int64_t sweep, packed, cand_idx, cand_val, norm, tile_bound, unorm2, order, total; int kc; TopkOrderLayout ord; };
 static int topk_fast_layout(int64_t batch, int64_t n_items, int32_t d, int32_t k, int64_t excl_rows, int64_t excl_nnz, FastLayout *L) {
-    if (d != 64 || k < 1 || k + kFastExtra > kWave) return IGCN_E_RANGE;
+    if ((d != 64 && d != 128) || k < 1 || k + kFastExtra > kWave) return IGCN_E_RANGE;
     L->kc = k + kFastExtra;
     TopkPlan p;
     const int64_t kc = n_items < L->kc ? n_items : L->kc;        // never more candidates than items
@@ -1394,17 +1403,19 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     float *cand_val = reinterpret_cast<float *>(ws + L.cand_val);
     unsigned int *norm_bits = reinterpret_cast<unsigned int *>(ws + L.norm);
     char *ows = ws + L.order;
-    const int mode = tuning_get(IGCN_TUNE_TOPK_FAST_MODE) == 1 ? 1 : 2;    // 2: one fp16 item plane (default), 1: two bf16 planes
+    // 2: one fp16 item plane (default; the only one at d = 128), 1: two bf16 planes
+    const int mode = tuning_get(IGCN_TUNE_TOPK_FAST_MODE) == 1 && d == 64 ? 1 : 2;
+    const int ks = d / 16, lg = d == 128 ? 5 : 4;
     const bool by_norm = tuning_get(IGCN_TUNE_TOPK_FAST_ORDER) != 0;       // developer knob: 0 = sweep in id order
     hipError_t e = hipMemsetAsync(norm_bits, 0, 16, st);
     if (e == hipSuccess) e = hipMemsetAsync(flagged, 0, 4, st);
     if (e != hipSuccess) return (int)e;
     const int n_tiles = (int)((n_items + 31) / 32);
-    const int64_t pack_threads = (int64_t)n_tiles * 4 * kWave;
-    int64_t stat_blocks = (n_items * 16 + kBlock - 1) / kBlock;
+    const int64_t pack_threads = (int64_t)n_tiles * ks * kWave;
+    int64_t stat_blocks = ((n_items << lg) + kBlock - 1) / kBlock;
     if (stat_blocks > (int64_t)cu_count()) stat_blocks = (int64_t)cu_count();
     hipLaunchKernelGGL(topk_row_stats_kernel, dim3((unsigned)stat_blocks), dim3(kBlock), 0, st, item_rows, ldi, n_items,
-                       (const int64_t *)nullptr, 0, norm_bits, by_norm ? reinterpret_cast<float *>(ows + L.ord.norm2) : (float *)nullptr);
+                       (const int64_t *)nullptr, 0, lg, norm_bits, by_norm ? reinterpret_cast<float *>(ows + L.ord.norm2) : (float *)nullptr);
     const int32_t *perm = nullptr, *excl_pos = nullptr;
     float *tile_bound = reinterpret_cast<float *>(ws + L.tile_bound), *unorm2 = reinterpret_cast<float *>(ws + L.unorm2);
     bool early_exit = false;
@@ -1414,13 +1425,13 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     }
     if (mode == 2) {
         if (!user_rows || ldu < d || ldu % 4 || reinterpret_cast<uintptr_t>(user_rows) % 16) return IGCN_E_SHAPE;
-        int64_t ub = (batch * 16 + kBlock - 1) / kBlock;
+        int64_t ub = ((batch << lg) + kBlock - 1) / kBlock;
         if (ub > (int64_t)cu_count()) ub = (int64_t)cu_count();
         early_exit = by_norm && tuning_get(IGCN_TUNE_TOPK_FAST_EXIT) != 0;     // developer knob: 0 = always sweep to the end
-        hipLaunchKernelGGL(topk_row_stats_kernel, dim3((unsigned)ub), dim3(kBlock), 0, st, user_rows, ldu, batch, user_ids, 1, norm_bits,
+        hipLaunchKernelGGL(topk_row_stats_kernel, dim3((unsigned)ub), dim3(kBlock), 0, st, user_rows, ldu, batch, user_ids, 1, lg, norm_bits,
                            early_exit ? unorm2 : (float *)nullptr);
         hipLaunchKernelGGL(topk_pack_items_f16_kernel, dim3((unsigned)((pack_threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                           item_rows, ldi, n_items, n_tiles, norm_bits, perm, packed,
+                           item_rows, ldi, n_items, n_tiles, ks, norm_bits, perm, packed,
                            early_exit ? reinterpret_cast<const float *>(ows + L.ord.norm2) : (const float *)nullptr,
                            early_exit ? tile_bound : (float *)nullptr);
     } else {
@@ -1437,11 +1448,11 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     if (rc != IGCN_OK) return rc;
     if (L.kc <= 32)
         hipLaunchKernelGGL(topk_rescore_kernel<32>, dim3((unsigned)((batch + 7) / 8)), dim3(kBlock), 0, st, user_rows, ldu, user_ids, batch,
-                           item_rows, ldi, cand_idx, cand_val, L.kc, (int)k, norm_bits, mode, perm, out_idx, out_val, flagged,
+                           item_rows, ldi, cand_idx, cand_val, L.kc, (int)k, (int)d, norm_bits, mode, perm, out_idx, out_val, flagged,
                            flagged_lower_bound);
     else
         hipLaunchKernelGGL(topk_rescore_kernel<64>, dim3((unsigned)((batch + 3) / 4)), dim3(kBlock), 0, st, user_rows, ldu, user_ids, batch,
-                           item_rows, ldi, cand_idx, cand_val, L.kc, (int)k, norm_bits, mode, perm, out_idx, out_val, flagged,
+                           item_rows, ldi, cand_idx, cand_val, L.kc, (int)k, (int)d, norm_bits, mode, perm, out_idx, out_val, flagged,
                            flagged_lower_bound);
     return launch_status();
 }

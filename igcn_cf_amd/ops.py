@@ -513,7 +513,7 @@ def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_co
     """Top-k item ids (best first) and scores for each user row; masked items are
     never returned unless fewer than k unmasked items exist.
 
-    mode 'exact': the fp32 sweep (igcn_score_topk_f32).  'fast' (d = 64, k <= 60): the fp16 candidate sweep + exact fp32
+    mode 'exact': the fp32 sweep (igcn_score_topk_f32).  'fast' (d = 64 or 128, k <= 60): the fp16 candidate sweep + exact fp32
     re-scoring (igcn_score_topk_fast_f32) — the same ids, exact fp32 scores; users whose candidate set cannot be proven
     complete (near-ties at the k-th place; counted on the device, read back here) go through the fp32 sweep.  'auto':
     'fast' where it applies and the problem is large enough to pay for it.
@@ -546,11 +546,11 @@ def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_co
     if banned is not None and (banned.dtype != torch.uint8 or banned.numel() != n_items or not banned.is_cuda):
         raise _lib.IgcnError('banned must be uint8 [n_items] on the GPU')
     L = _lib.lib()
-    fast_ok = d == 64 and k + 4 <= 64 and k <= n_items and B > 0
+    fast_ok = d in (64, 128) and k + 4 <= 64 and k <= n_items and B > 0
     if lower_bound is not None and mode != 'exact':
         raise _lib.IgcnError("lower_bound goes with mode='exact'")
     if mode == 'fast' and not fast_ok:
-        raise _lib.IgcnError('the two-stage top-k path needs d == 64 and k <= 60 (got d=%d k=%d)' % (d, k))
+        raise _lib.IgcnError('the two-stage top-k path needs d == 64 or 128 and k <= 60 (got d=%d k=%d)' % (d, k))
     if mode == 'fast' or (mode == 'auto' and fast_ok and B * n_items >= FAST_TOPK_MIN_WORK):
         return _score_topk_fast(L, user_rows, item_rows, k, user_ids, excl_rowptr, excl_col, banned, B, n_items, d)
     ws_bytes = L.igcn_score_topk_workspace_bytes(B, n_items, d, k)

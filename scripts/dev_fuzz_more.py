@@ -50,7 +50,7 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
         ref = O.eval_topk(s, None, None, k=k)
         for prec in ('fp32',):
             idx, val = score_topk(torch.from_numpy(U).cuda(), torch.from_numpy(I).cuda(), k, user_ids=torch.from_numpy(ids).cuda(),
-                                  mode='fast' if d == 64 and k <= 60 and case % 4 != 3 else 'exact', **kw)
+                                  mode='fast' if d in (64, 128) and k <= 60 and case % 4 != 3 else 'exact', **kw)
             ok = np.array_equal(idx.cpu().numpy(), ref) and np.array_equal(val.cpu().numpy(), np.take_along_axis(s, ref, axis=1))
             if not ok:
                 n_bad += 1
@@ -82,8 +82,9 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
         n_users, n_items = int(rng.integers(1, 3000)), int(rng.integers(70, 30000))
         k = int(rng.integers(1, 61))
         su, si = float(rng.choice([0., 0.5, 1.5])), float(rng.choice([0., 0.5, 1.5]))
-        U = (rng.standard_normal((n_users, 64)) * 0.1 * np.exp(su * rng.standard_normal((n_users, 1)))).astype(np.float32)
-        I = (rng.standard_normal((n_items, 64)) * 0.1 * np.exp(si * rng.standard_normal((n_items, 1)))).astype(np.float32)
+        dd = 128 if case % 3 == 1 else 64
+        U = (rng.standard_normal((n_users, dd)) * 0.1 * np.exp(su * rng.standard_normal((n_users, 1)))).astype(np.float32)
+        I = (rng.standard_normal((n_items, dd)) * 0.1 * np.exp(si * rng.standard_normal((n_items, 1)))).astype(np.float32)
         if case % 5 == 0:
             I[rng.integers(0, n_items, 5)] = I[0]; U[rng.integers(0, n_users)] = 0.
         kw = {}

@@ -41,8 +41,11 @@ def run():
     from scripts.dev_spmm_bench import time_ms
     ds = SyntheticDataset({'name': 'SyntheticDataset', 'preset': 'amazon'})
     g = torch.Generator(device='cuda').manual_seed(0)
-    U = torch.randn(ds.n_users, 64, device='cuda', generator=g) * 0.1
-    I = torch.randn(ds.n_items, 64, device='cuda', generator=g) * 0.1
+    D = int(os.environ.get('D', 64))
+    if os.environ.get('WIDE'):
+        _lib.set_tuning('topk_fast_wide', int(os.environ['WIDE']))
+    U = torch.randn(ds.n_users, D, device='cuda', generator=g) * 0.1
+    I = torch.randn(ds.n_items, D, device='cuda', generator=g) * 0.1
     excl = _merge_sorted_csr(ds.csr('train'), ds.csr('val'))
     rp, cl = _csr_to_device(excl[0], excl[1], 'cuda')
     users = torch.arange(ds.n_users, device='cuda')
@@ -79,7 +82,7 @@ def run():
             for key, v in tune.items():
                 _lib.set_tuning(key, v)
             rec = dict(variant=name, tune=tune)
-            for k in (1, 20):
+            for k in ((20,) if os.environ.get('ONLY_K20') else (1, 20)):
                 for masks in (False, True):
                     kw = dict(excl_rowptr=rp, excl_col=cl) if masks else {}
                     mode = os.environ.get('TOPK_MODE', 'exact')      # 'fast': the two-stage path (ablated builds: garbage lists, timing only)

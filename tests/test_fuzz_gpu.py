@@ -79,8 +79,8 @@ def test_score_topk_fuzz():
             bm = np.zeros(n_items, dtype=np.uint8); bm[ban] = 1
             kw['banned'] = torch.from_numpy(bm).cuda()
         ids = rng.permutation(n_users).astype(np.int64)
-        # d = 64, k <= 60: every other such case through the two-stage path (bf16 candidate sweep + exact re-scoring)
-        mode = 'fast' if d == 64 and k <= 60 and case % 2 == 0 else 'exact'
+        # d = 64 / 128, k <= 60: every other such case through the two-stage path (fp16 candidate sweep + exact re-scoring)
+        mode = 'fast' if d in (64, 128) and k <= 60 and case % 2 == 0 else 'exact'
         _lib.set_tuning('topk_fast_mode', 1 if case % 4 == 0 else None)     # two bf16 planes / one fp16 item plane (default)
         idx, val = score_topk(torch.from_numpy(U).cuda(), torch.from_numpy(I).cuda(), k, user_ids=torch.from_numpy(ids).cuda(),
                               mode=mode, **kw)

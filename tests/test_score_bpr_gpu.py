@@ -78,8 +78,8 @@ def test_score_topk_matches_dense_oracle(d, n_users, n_items, k):
     sub = rng.permutation(n_users)[: max(1, n_users // 2)].astype(np.int64)
     idx, val = score_topk(_dev(U), _dev(I), k, user_ids=_dev(sub))
     _check_topk(scores[sub], idx.cpu().numpy(), val.cpu().numpy(), None, None, k)
-    if d == 64 and k <= 60:
-        # the two-stage path (bf16 candidate sweep + exact fp32 re-scoring): the same lists; integer scores tie in
+    if d in (64, 128) and k <= 60:
+        # the two-stage path (fp16 candidate sweep + exact fp32 re-scoring; d = 64 and 128): the same lists; integer scores tie in
         # droves, so many users here take its fall-back through the fp32 sweep
         idx, val = score_topk(_dev(U), _dev(I), k, user_ids=_dev(users), excl_rowptr=_dev(rowptr), excl_col=_dev(col),
                               banned=_dev(bmask), mode='fast')
@@ -88,14 +88,14 @@ def test_score_topk_matches_dense_oracle(d, n_users, n_items, k):
         _check_topk(scores[sub], idx.cpu().numpy(), val.cpu().numpy(), None, None, k)
 
 
-@pytest.mark.parametrize('mode', ['exact', 'fast', 'fast_bf16'])
+@pytest.mark.parametrize('mode', ['exact', 'fast', 'fast_bf16', 'fast_d128', 'fast_d128_narrow'])
 def test_score_topk_random_floats_match_sets(mode):
     """Gaussian fp32 embeddings: same top-k sets as the float64 ranking except where the
     k-th and (k+1)-th scores are within fp32 rounding of each other — for the fp32 sweep and for the two-stage
     path, whose lists must moreover be those of the fp32 sweep bit for bit."""
     from igcn_cf_amd.ops import score_topk
     rng = np.random.default_rng(1)
-    n_users, n_items, d, k = 512, 30000, 64, 20
+    n_users, n_items, d, k = 512, 30000, (128 if 'd128' in mode else 64), 20
     U = (rng.standard_normal((n_users, d)) * 0.1).astype(np.float32)
     I = (rng.standard_normal((n_items, d)) * 0.1).astype(np.float32)
     I[100] = I[7]; I[20000] = I[7]                       # identical item rows: exact ties, decided by the lower id
@@ -103,6 +103,9 @@ def test_score_topk_random_floats_match_sets(mode):
     from igcn_cf_amd import _lib
     if mode == 'fast_bf16':                              # the candidate sweep on two bf16 planes instead of one fp16 item plane
         _lib.set_tuning('topk_fast_mode', 1)
+        mode = 'fast'
+    if 'd128' in mode:                                   # d = 128: two user groups per wave, one wave per SIMD (default) / one group, two waves
+        _lib.set_tuning('topk_fast_wide', 0 if 'narrow' in mode else None)
         mode = 'fast'
     try:
         idx, val = score_topk(_dev(U), _dev(I), k, mode=mode)
@@ -121,6 +124,7 @@ def test_score_topk_random_floats_match_sets(mode):
                 assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     finally:
         _lib.set_tuning('topk_fast_mode', None)
+        _lib.set_tuning('topk_fast_wide', None)
     idx, val = idx.cpu().numpy(), val.cpu().numpy()
     assert list(idx[5]) == list(range(k))
     s64 = U.astype(np.float64) @ I.astype(np.float64).T
@@ -436,7 +440,8 @@ def test_bpr_column_slices_sum_to_the_full_loss():
             np.testing.assert_allclose(Es.grad.cpu().numpy(), E.grad.cpu().numpy()[:, r * dl:(r + 1) * dl], rtol=1e-4, atol=1e-8)
 
 
-def test_two_stage_sweep_order_and_early_exit_do_not_change_the_lists():
+@pytest.mark.parametrize('d', [64, 128])
+def test_two_stage_sweep_order_and_early_exit_do_not_change_the_lists(d):
     """Round 3: the candidate sweep meets the items by descending norm and stops once no user of a wave can be reached
     by the rows still to come (|score| <= |u| |i|).  On tables whose row norms spread over orders of magnitude — where
     the exit skips most of the sweep — with exclusion lists, banned items, duplicated rows, a zero user, users of very
@@ -445,7 +450,7 @@ def test_two_stage_sweep_order_and_early_exit_do_not_change_the_lists():
     from igcn_cf_amd import _lib
     from igcn_cf_amd.ops import score_topk
     rng = np.random.default_rng(11)
-    n_users, n_items, d, k = 700, 41003, 64, 20
+    n_users, n_items, k = 700, 41003, 20
     U = (rng.standard_normal((n_users, d)) * 0.1 * np.exp(rng.standard_normal((n_users, 1)))).astype(np.float32)
     I = (rng.standard_normal((n_items, d)) * 0.1 * np.exp(1.2 * rng.standard_normal((n_items, 1)))).astype(np.float32)
     I[300] = I[17]; I[40000] = I[17]
