@@ -249,9 +249,10 @@ int igcn_score_topk_bounded_f32(const float *user_rows, int64_t ldu, const int64
                                 int32_t k, const float *lower_bound, int64_t *out_idx, float *out_val,
                                 void *workspace, void *stream);
 
-/* The same evaluation in two stages (d = 64, k <= 60).  Stage 1 sweeps all items on the 16-bit matrix cores — items as
+/* The same evaluation in two stages (d = 64 or 128, k <= 60).  Stage 1 sweeps all items on the 16-bit matrix cores — items as
  * one fp16 plane, users as two, both tables rescaled by a power of two, fp32 accumulate: scores off by at most
- * 2^-11 |u| max|i| (igcn_set_tuning("topk_fast_mode", 1): two bf16 planes each side, three products, 2^-14) — and keeps
+ * 2^-11 |u| max|i| (d = 64 only, igcn_set_tuning("topk_fast_mode", 1): two bf16 planes each side, three products, 2^-14;
+ * d = 128 runs two 32-user groups per wave at ONE wave per SIMD, 396 registers; "topk_fast_wide", 0: one group, two waves) — and keeps
  * the k + 4 best candidates of every user (masks applied as in igcn_score_topk_f32).
  * Stage 2 re-computes the candidates' scores in fp32 in the order the fp32 sweep adds the products, orders them
  * (score, then lower id) and writes the best k: out_idx / out_val as igcn_score_topk_f32 writes them.  A user for
