@@ -65,6 +65,7 @@ def lift_flat(out, extras):
         'eval_mfma_TFLOPs_fp32_sweep': get('eval_roofline', 'achieved'), 'eval_mfma_frac': get('eval_roofline', 'frac'),
         'eval_scoring_ms_fp32_sweep': get('eval_roofline', 'ms'), 'eval_scoring_ms_two_stage': get('eval_two_stage', 'ms'),
         'eval_with_metrics_ms': get('eval_with_metrics_ms'),
+        'eval_d128_scoring_ms_fp32_sweep': get('eval_d128', 'scoring_ms_fp32_sweep'), 'eval_d128_scoring_ms_two_stage': get('eval_d128', 'scoring_ms_two_stage'),
         'hbm_bound_kernel': get('roofline_hbm_bound', 'kernel'), 'hbm_bound_GBps': get('roofline_hbm_bound', 'achieved'),
         'hbm_bound_frac': get('roofline_hbm_bound', 'frac'), 'hbm_bound_ms': get('roofline_hbm_bound', 'avg_launch_ms'),
         'hbm_bound_workload': get('roofline_hbm_bound', 'workload_short'),
@@ -688,6 +689,25 @@ def side_measurements(ds, device, d, K):
                                      'candidates 60 %, draining them into the heaps 22 %, mask bits 14 % of its cycles, the item-tile '
                                      'loads behind them (profiles/r02k_topk_two_stage_ablation.jsonl); includes packing, re-scoring, the '
                                      'host read of the flagged count and the fp32 sweep of the flagged users'}
+    # the same scoring at d = 128 (BASELINE config 5's width) on random tables of the same sizes: fp32 sweep vs two-stage
+    if d != 128:
+        gen = torch.Generator(device=device).manual_seed(128)
+        wide = torch.randn(ds.n_users + ds.n_items, 128, device=device, generator=gen) * 0.1
+
+        def timed_wide(mode, reps):
+            ops.score_topk(wide, wide[ds.n_users:], 20, user_ids=users, mode=mode)
+            k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            k0.record()
+            for _ in range(reps):
+                out_w = ops.score_topk(wide, wide[ds.n_users:], 20, user_ids=users, mode=mode)
+            k1.record()
+            torch.cuda.synchronize()
+            return k0.elapsed_time(k1) / reps, out_w
+        (ms_x, lists_x), (ms_f, lists_f) = timed_wide('exact', 2), timed_wide('fast', 3)
+        res['eval_d128'] = {'scoring_ms_fp32_sweep': ms_x, 'scoring_ms_two_stage': ms_f, 'lists_equal': bool(torch.equal(lists_x[0], lists_f[0])),
+                            'mfma_TFLOPs_fp32_sweep': 2.0 * flops / (ms_x / 1e3) / 1e12, 'users_flagged': ops.score_topk.last_flagged,
+                            'note': 'random N(0, 0.1^2) tables [users + items, 128], k = 20, no masks'}
+        del wide, lists_x, lists_f
     trainer.eval('test')                                   # first call builds the device CSR of the test lists
     model._rep_cache = None
     torch.cuda.synchronize()
