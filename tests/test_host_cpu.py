@@ -380,9 +380,12 @@ def test_trainer_constructor_states_the_scorer_limits():
     BasicTrainer(cfg)
     with pytest.raises(ValueError, match='max\\(topks\\) <= %d' % MAX_TOPK):
         BasicTrainer(dict(cfg, topks=[MAX_TOPK + 1]))
-    m = Model(); m.embedding_size = 192
-    with pytest.raises(ValueError, match='embedding_size'):
-        BasicTrainer(dict(cfg, model=m))
+    m = Model(); m.embedding_size = 192                  # wider than the tuned widths, still taken (<= 256)
+    BasicTrainer(dict(cfg, model=m))
+    for bad in (260, 66):
+        m = Model(); m.embedding_size = bad
+        with pytest.raises(ValueError, match='embedding_size'):
+            BasicTrainer(dict(cfg, model=m))
 
 
 def test_utils_entry_points(golden, tmp_path):
