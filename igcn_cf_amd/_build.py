@@ -13,6 +13,10 @@ SOURCES = [f for f in ('spmm.hip', 'bpr.hip', 'score_topk.hip', 'topk_order.hip'
            if os.path.exists(os.path.join(CSRC, f))]
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-Wall', '-Wno-unused-function',
          '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
+# per source: the d = 128 candidate sweep runs one wave per SIMD with 396 registers; with MFMA results in VGPRs (this option)
+# the selection reads the accumulators where they are, the item tiles and user planes spill over into AGPRs instead
+# (left to itself the allocator puts the accumulators in AGPRs and copies 32 of them to VGPRs every tile step)
+EXTRA_FLAGS = {'score_topk.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form=1']}
 
 
 def _newer(src_list, out):
@@ -33,7 +37,7 @@ def build(force=False, verbose=True):
             raise FileNotFoundError(src)
         obj = os.path.join(CSRC, name.replace('.hip', '.o'))
         if force or _newer([src] + headers, obj):
-            cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(name, []) + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -25,7 +25,7 @@ def build(only=None):
         if only and name not in only:
             continue
         obj = os.path.join(VDIR, name + '.o')
-        subprocess.check_call(['/opt/rocm/bin/hipcc'] + _build.FLAGS + flags + ['-c', os.path.join(_build.CSRC, 'score_topk.hip'), '-o', obj])
+        subprocess.check_call(['/opt/rocm/bin/hipcc'] + _build.FLAGS + _build.EXTRA_FLAGS.get('score_topk.hip', []) + flags + ['-c', os.path.join(_build.CSRC, 'score_topk.hip'), '-o', obj])
         subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o',
                                os.path.join(VDIR, 'lib_%s.so' % name), obj] + objs)
         os.remove(obj)
