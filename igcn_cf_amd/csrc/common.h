@@ -36,10 +36,11 @@ enum {
     IGCN_TUNE_TOPK_WAVES_PER_CU,        // 8, 4, 2 or 1
     IGCN_TUNE_TOPK_CAP,                 // staging slots per lane and group
     IGCN_TUNE_TOPK_STAGGER,             // 0: no static wave priorities
-    IGCN_TUNE_TOPK_FAST_MODE,           // candidate sweep of the two-stage path: 2 = one fp16 item plane (default), 1 = two bf16 planes
+    IGCN_TUNE_TOPK_FAST_MODE,           // candidate sweep of the two-stage path: 3 = one fp16 plane each side (default), 2 = two user planes, 1 = two bf16 planes each
     IGCN_TUNE_TOPK_FAST_ORDER,          // 0: the candidate sweep meets the items in id order (default: by descending norm)
     IGCN_TUNE_TOPK_FAST_EXIT,           // 0: the candidate sweep never stops early (default: Cauchy-Schwarz exit in norm order)
     IGCN_TUNE_TOPK_FAST_WIDE,           // d = 128 candidate sweep: 1 = two user groups per wave, one wave per SIMD; 0 = one group, two waves
+    IGCN_TUNE_TOPK_FAST_EXTRA,          // candidates the sweep keeps beyond k (default by mode; k + extra <= 64)
     IGCN_TUNE_COUNT
 };
 extern int g_tuning[IGCN_TUNE_COUNT];   // defined in spmm.hip; holds value + 1, 0 = unset

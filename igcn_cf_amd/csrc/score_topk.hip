@@ -68,7 +68,7 @@ constexpr int kIdxNone = 0x7fffffff;
 // best candidates per user; topk_rescore_kernel then recomputes their scores exactly in fp32, orders them, and
 // checks that no item the sweep dropped can reach the k-th exact score (else the user is handed to the fp32 sweep).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int kFastExtra = 4;                                    // candidates kept beyond k
+constexpr int kFastExtra = 4;                                    // candidates kept beyond k (default; see topk_fast_extra)
 __device__ __forceinline__ unsigned int bf16_rne_bits(float v) {
     const unsigned int u = __float_as_uint(v);
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
@@ -132,17 +132,38 @@ struct TopkPlan {
 };
 
 constexpr int kMinCap = 8, kMaxCap = 16, kQuad = 4;
+constexpr int kMinCapSweep = 6;      // candidate sweeps: a shallower staging list (more drains) rather than half the resident waves (k + extra = 25..28)
 
 // (the fp16 candidate sweep at d = 128 runs ONE wave per SIMD with 512 registers: both user groups stay)
+// candidates the sweep keeps beyond k: more of them widen the gap the completeness check needs (fewer users handed to
+// the fp32 sweep) and lengthen every list (more heap updates)
+static inline int topk_fast_extra(int k, int mode) {
+    int e = tuning_get(IGCN_TUNE_TOPK_FAST_EXTRA);
+    // one fp16 plane each side doubles the error bound of the sweep: two more candidates keep the users handed to the
+    // fp32 sweep as few (Amazon-like, k = 20: 1 484 of 109 730 with 4 extra, 43 with 6; the sweep's time is the same)
+    if (e < 1) e = mode == 3 ? kFastExtra + 2 : kFastExtra;
+    return k + e > kWave ? kWave - k : e;
+}
+// candidate sweep of the two-stage path: 3 = one fp16 plane each side (default), 2 = one fp16 item plane, two user planes,
+// 1 = two bf16 planes each side (d = 64 only)
+static inline int topk_fast_mode(int d) {
+    const int t = tuning_get(IGCN_TUNE_TOPK_FAST_MODE);
+    return t == 1 && d == 64 ? 1 : t == 2 ? 2 : 3;
+}
 static inline bool topk_wide_sweep() { return tuning_get(IGCN_TUNE_TOPK_FAST_WIDE) != 0; }
-static inline int topk_groups_per_wave(int d_pad, bool candidate_sweep = false) { return d_pad <= 64 || (candidate_sweep && d_pad == 128 && topk_wide_sweep()) ? 2 : 1; }
+// sweep_mode: 0 the fp32 sweep, 1 / 2 / 3 the candidate sweeps (MODE of the kernel)
+static inline bool topk_one_wave_per_simd(int d_pad, int sweep_mode) { return sweep_mode == 2 && d_pad == 128 && topk_wide_sweep(); }
+static inline int topk_groups_per_wave(int d_pad, int sweep_mode = 0) {
+    return d_pad <= 64 || (d_pad == 128 && (sweep_mode == 3 || topk_one_wave_per_simd(d_pad, sweep_mode))) ? 2 : 1;
+}
 
-static inline int topk_make_plan(int64_t batch, int64_t n_items, int32_t d, int32_t k, TopkPlan *p, bool candidate_sweep = false) {
+static inline int topk_make_plan(int64_t batch, int64_t n_items, int32_t d, int32_t k, TopkPlan *p, int sweep_mode = 0) {
+    const bool candidate_sweep = sweep_mode != 0;
     if (batch < 1 || n_items < 1) return IGCN_E_SHAPE;
     if (d < 4 || d > 256 || d % 4 != 0) return IGCN_E_SHAPE;
     if (k < 1 || k > IGCN_MAX_TOPK || k > n_items) return IGCN_E_RANGE;
     p->d_pad = d <= 16 ? 16 : d <= 32 ? 32 : d <= 64 ? 64 : d <= 128 ? 128 : 256;
-    p->ng = topk_groups_per_wave(p->d_pad, candidate_sweep);
+    p->ng = topk_groups_per_wave(p->d_pad, sweep_mode);
     const int upw = 32 * p->ng;
     p->groups = (batch + upw - 1) / upw;
     const int64_t L = (n_items + 31) / 32;
@@ -151,14 +172,14 @@ static inline int topk_make_plan(int64_t batch, int64_t n_items, int32_t d, int3
     // CU's 160 KiB; measured: 12 x 13312 B do not fit, 12 x 12800 B do): a wave gets 128 / per_cu of them, holds
     // the heaps (k slots x 64 owner lanes x 8 B) and gives the rest to the staging lists.  The grid must never
     // exceed what is resident: a wave that starts late runs its whole share after everybody else has finished.
-    int per_cu = candidate_sweep && p->d_pad == 128 && topk_wide_sweep() ? 4 : 8;
+    int per_cu = topk_one_wave_per_simd(p->d_pad, sweep_mode) ? 4 : 8;
     const int want = tuning_get(IGCN_TUNE_TOPK_WAVES_PER_CU);
     if ((want == 8 || want == 4 || want == 2 || want == 1) && want <= per_cu) per_cu = want;
     int cap = 0;
     for (; per_cu >= 1; per_cu >>= 1) {
         const int64_t budget = (int64_t)(128 / per_cu) * 1280;
         cap = (int)((budget - (int64_t)k * kWave * 8) / (p->ng * kWave * 8));
-        if (cap >= kMinCap) break;
+        if (cap >= (candidate_sweep ? kMinCapSweep : kMinCap)) break;
     }
     if (per_cu < 1) return IGCN_E_RANGE;
     if (cap > kMaxCap) cap = kMaxCap;
@@ -314,8 +335,15 @@ struct TopkArgs {
 template <int D, int NG, bool FULL, int MODE = 0, bool BOUNDED = false>
 __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) void score_topk_kernel(const TopkArgs A)
 {
-    static_assert(MODE == 0 || (FULL && ((D == 64 && NG == 2) || (MODE == 2 && D == 128))), "the candidate sweeps are built for d = 64 (and fp16: d = 128)");
-    constexpr int KS = D / 16;                                   // MODE 1 / 2: k-steps of 16 per row
+    static_assert(MODE == 0 || (FULL && ((D == 64 && NG == 2) || ((MODE == 2 || MODE == 3) && D == 128))), "the candidate sweeps are built for d = 64 (and fp16: d = 128)");
+    constexpr int KS = D / 16;                                   // MODE 1 / 2 / 3: k-steps of 16 per row
+    constexpr bool kF16 = MODE == 2 || MODE == 3;                // fp16 candidate sweep; MODE 3: ONE user plane (h only)
+    constexpr int kUserPlanes = MODE == 3 ? 1 : 2;
+    // MODE 3 at d = 128: 64 registers of user plane + 64 of accumulators leave room for 12 item-tile quads, not 16 or 24: a
+    // ring of three HALF tiles (4 k-steps each).  A tile is (lo, hi); while a block multiplies (lo, hi) the third half takes
+    // the next tile's lo at the block's start and lo itself is re-loaded with the next tile's hi as soon as its four
+    // k-steps are consumed: loads run one block ahead, as in the fp32 sweep's two-buffer scheme.
+    constexpr bool kRing12 = MODE == 3 && D == 128;
     static_assert(!BOUNDED || MODE == 0, "a lower bound goes with the exact sweep");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *const heap_base = reinterpret_cast<unsigned long long *>(smem);       // [k][64 owner lanes]
@@ -385,7 +413,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                     bfrag[g][4 * q + 0] = v.x; bfrag[g][4 * q + 1] = v.y; bfrag[g][4 * q + 2] = v.z; bfrag[g][4 * q + 3] = v.w;
                 }
             } else {
-                const float su = MODE == 2 ? ldexpf(1.f, -scale_exp(__uint_as_float(A.stats[2]))) : 1.f;
+                const float su = kF16 ? ldexpf(1.f, -scale_exp(__uint_as_float(A.stats[2]))) : 1.f;
 #pragma unroll
                 for (int st = 0; st < KS; ++st) {
                     float4 lo = f4_zero(), hi = f4_zero();
@@ -395,7 +423,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                         hi = *reinterpret_cast<const float4 *>(src + 4);
                     }
                     float4 planes[2];
-                    if constexpr (MODE == 2) split_f16_x8(lo, hi, su, planes); else split2_x8(lo, hi, planes);
+                    if constexpr (kF16) split_f16_x8(lo, hi, su, planes); else split2_x8(lo, hi, planes);
                     ub[g][0][st] = planes[0]; ub[g][1][st] = planes[1];
                 }
             }
@@ -503,8 +531,8 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
         // bookkeeping between two blocks waits for (vmcnt counts in order) is ever behind a load just issued.
         // At d = 128 one buffer: each piece is re-loaded as soon as the block has consumed it.
         constexpr bool kTwoBuffers = D <= 64;
-        float4 a[D / 8], a2[(kTwoBuffers || MODE == 2) ? D / 8 : 1];
-        float4 a3[MODE == 2 ? D / 8 : 1];                         // MODE 2: a third buffer (its tiles are half the size): loads run two tile steps ahead
+        float4 a[D / 8], a2[(kTwoBuffers || kF16) ? D / 8 : 1];
+        float4 a3[kF16 ? D / 8 : 1];                         // MODE 2: a third buffer (its tiles are half the size): loads run two tile steps ahead
         auto tile_addr = [&](int t, const char *&tile_ptr, unsigned &off) {
             tile_ptr = reinterpret_cast<const char *>(A.item_rows + (int64_t)t * 32 * ldi);
             off = t == n_tiles - 1 ? lane_off_last : lane_off;
@@ -514,7 +542,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                 const float4 *pk = A.packed + (int64_t)t * 8 * kWave + lane;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) buf[i] = pk[i * kWave];
-            } else if constexpr (MODE == 2) {                      // [k-step]
+            } else if constexpr (kF16) {                           // [k-step]
                 const float4 *pk = A.packed + (int64_t)t * KS * kWave + lane;
 #pragma unroll
                 for (int i = 0; i < KS; ++i) buf[i] = pk[i * kWave];
@@ -530,6 +558,11 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
         constexpr int kTermA[3] = {1, 0, 0};
         constexpr int kTermB[3] = {0, 1, 0};
         auto load_a = [&](int t) { load_into(a, t); };
+        auto load_half = [&](float4 (&buf)[D / 8], int t, int half) {      // kRing12: k-steps 4 half .. 4 half + 3 of tile t
+            const float4 *pk = A.packed + ((int64_t)t * KS + 4 * half) * kWave + lane;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) buf[i] = pk[i * kWave];
+        };
         // the chains of one tile, nothing interleaved (prologue of a piece)
         auto chain_plain = [&](f32x16 (&acc)[NG]) {
 #pragma unroll
@@ -545,14 +578,15 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                         for (int g = 0; g < NG; ++g)
                             acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a[kTermA[tm] * 4 + st]),
                                                                              as_bf16x8(ub[g][kTermB[tm]][st]), acc[g], 0, 0, 0);
-            } else if constexpr (MODE == 2) {
+            } else if constexpr (kF16) {
 #pragma unroll
-                for (int tm = 0; tm < 2; ++tm)                   // the small term (user plane l) first
+                for (int tm = 0; tm < kUserPlanes; ++tm)         // the small term (user plane l) first
 #pragma unroll
                     for (int st = 0; st < KS; ++st)
 #pragma unroll
                         for (int g = 0; g < NG; ++g)
-                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(a[st]), as_half8(ub[g][1 - tm][st]), acc[g], 0, 0, 0);
+                            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(kRing12 && st >= 4 ? a2[st - 4] : a[st]),
+                                                                            as_half8(ub[g][kUserPlanes - 1 - tm][st]), acc[g], 0, 0, 0);
             } else {
 #pragma unroll
                 for (int q = 0; q < D / 8; ++q) {
@@ -698,10 +732,10 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
         // t+1.  The chains of tile t+1 (into `nxt`), the loads of tile t+2 (each a[q] as soon as the chains have
         // consumed it) and the selection of tile t are ONE basic block, its schedule written out by hand and
         // pinned (sched_barrier after every MFMA).
-        auto tile_step = [&](f32x16 (&cur)[NG], f32x16 (&nxt)[NG], float4 (&ause)[D / 8], float4 (&aload)[D / 8], int tile) {
+        auto tile_step = [&](f32x16 (&cur)[NG], f32x16 (&nxt)[NG], float4 (&ause)[D / 8], float4 (&aload)[D / 8], int tile, float4 (&ahi)[D / 8]) {
             const int tile_base = tile * 32;
             build_masks(tile, tile_base);
-            constexpr int kSlots = MODE == 1 ? 12 * NG : MODE == 2 ? 2 * KS * NG : (D / 2) * NG;   // MFMAs of the block
+            constexpr int kSlots = MODE == 1 ? 12 * NG : kF16 ? kUserPlanes * KS * NG : (D / 2) * NG;   // MFMAs of the block
             constexpr int kParts = 3 * kQuad * NG;                // selection instructions of the block
             constexpr int kFirst = 4;                             // the first ones wait until the previous block's MFMAs have long retired
             if (tile + 1 < tin1) {
@@ -721,15 +755,16 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
 #pragma unroll
                     for (int i = 0; i < 8; ++i) aload[i] = pk[i * kWave];
 #endif
-                } else if constexpr (MODE == 2) {
+                } else if constexpr (kF16) {
 #ifndef IGCN_X_NOLOADA
 #ifdef IGCN_X_SAMETILE
                     const float4 *pk = A.packed + lane;           // developer build: every load hits the same lines
 #else
-                    const float4 *pk = A.packed + (int64_t)(tile + 3 < tin1 ? tile + 3 : tin1 - 1) * KS * kWave + lane;
+                    const float4 *pk = A.packed + (int64_t)(kRing12 ? (tile + 2 < tin1 ? tile + 2 : tin1 - 1)
+                                                                     : (tile + 3 < tin1 ? tile + 3 : tin1 - 1)) * KS * kWave + lane;
 #endif
 #pragma unroll
-                    for (int i = 0; i < KS; ++i) aload[i] = pk[i * kWave];
+                    for (int i = 0; i < (kRing12 ? 4 : KS); ++i) aload[i] = pk[i * kWave];
 #endif
                 } else if constexpr (kTwoBuffers) {
 #pragma unroll
@@ -765,15 +800,25 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                             }
                         }
                     }
-                } else if constexpr (MODE == 2) {
+                } else if constexpr (kF16) {
 #pragma unroll
-                    for (int tm = 0; tm < 2; ++tm) {
+                    for (int tm = 0; tm < kUserPlanes; ++tm) {
 #pragma unroll
                         for (int st = 0; st < KS; ++st) {
 #pragma unroll
                             for (int g = 0; g < NG; ++g) {
-                                nxt[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(ause[st]), as_half8(ub[g][1 - tm][st]), nxt[g], 0, 0, 0);
+                                nxt[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(kRing12 && st >= 4 ? ahi[st - 4] : ause[st]),
+                                                                                as_half8(ub[g][kUserPlanes - 1 - tm][st]), nxt[g], 0, 0, 0);
                                 select_share((tm * KS + st) * NG + g);
+#ifndef IGCN_X_NOLOADA
+                                if constexpr (kRing12) {
+                                    if (st == 3 && g == NG - 1) {      // lo is consumed: it takes the hi half of the tile after next
+                                        const float4 *pk = A.packed + ((int64_t)(tile + 2 < tin1 ? tile + 2 : tin1 - 1) * KS + 4) * kWave + lane;
+#pragma unroll
+                                        for (int i = 0; i < 4; ++i) ause[i] = pk[i * kWave];
+                                    }
+                                }
+#endif
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                         }
@@ -813,14 +858,20 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
 
         // prologue: scores of the first tile, A operand of the second
         f32x16 acc_a[NG], acc_b[NG];
-        load_a(tin0);
+        if constexpr (kRing12) { load_half(a, tin0, 0); load_half(a2, tin0, 1); } else load_a(tin0);
         chain_plain(acc_a);
-        if constexpr (MODE == 2) {
+        if constexpr (kF16) {
             // ring of three item-tile buffers: step t multiplies tile t + 1 and requests tile t + 3 into the buffer step
             // t - 1 consumed; three steps per turn, the accumulator pair changes roles every step, so the odd turn
             // ends with a copy (32 moves per three tile steps)
-            load_into(a2, tin0 + 1 < tin1 ? tin0 + 1 : tin1 - 1);
-            load_into(a3, tin0 + 2 < tin1 ? tin0 + 2 : tin1 - 1);
+            if constexpr (kRing12) {                           // next tile = (a3, a)
+                const int t1 = tin0 + 1 < tin1 ? tin0 + 1 : tin1 - 1;
+                load_half(a3, t1, 0);
+                load_half(a, t1, 1);
+            } else {
+                load_into(a2, tin0 + 1 < tin1 ? tin0 + 1 : tin1 - 1);
+                load_into(a3, tin0 + 2 < tin1 ? tin0 + 2 : tin1 - 1);
+            }
             for (int tile = tin0; tile < tin1; tile += 3) {
                 if (A.tile_bound && tile > tin0 && (tile - tin0) % 24 == 0) {
                     // Cauchy-Schwarz exit (every 24 tiles): the items come by descending norm, so if no user of this wave
@@ -833,10 +884,16 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                         if (user_ok[g]) alive |= sqrtf(A.unorm2[group * UPW + g * 32 + j]) * reach >= thr[g];
                     if (!__any(alive)) break;
                 }
-                tile_step(acc_a, acc_b, a2, a, tile);
-                if (tile + 1 < tin1) tile_step(acc_b, acc_a, a3, a2, tile + 1);
+                if constexpr (kRing12) {
+                    tile_step(acc_a, acc_b, a3, a2, tile, a);
+                    if (tile + 1 < tin1) tile_step(acc_b, acc_a, a2, a, tile + 1, a3);
+                } else {
+                    tile_step(acc_a, acc_b, a2, a, tile, a);
+                    if (tile + 1 < tin1) tile_step(acc_b, acc_a, a3, a2, tile + 1, a);
+                }
                 if (tile + 2 < tin1) {
-                    tile_step(acc_a, acc_b, a, a3, tile + 2);
+                    if constexpr (kRing12) tile_step(acc_a, acc_b, a, a3, tile + 2, a2);
+                    else tile_step(acc_a, acc_b, a, a3, tile + 2, a);
 #pragma unroll
                     for (int g = 0; g < NG; ++g) acc_a[g] = acc_b[g];
                 }
@@ -845,11 +902,11 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
         if (tin0 + 1 < tin1) load_a(tin0 + 1);
         for (int tile = tin0; tile < tin1; tile += 2) {
             if constexpr (kTwoBuffers) {
-                tile_step(acc_a, acc_b, a, a2, tile);
-                if (tile + 1 < tin1) tile_step(acc_b, acc_a, a2, a, tile + 1);
+                tile_step(acc_a, acc_b, a, a2, tile, a);
+                if (tile + 1 < tin1) tile_step(acc_b, acc_a, a2, a, tile + 1, a);
             } else {
-                tile_step(acc_a, acc_b, a, a, tile);
-                if (tile + 1 < tin1) tile_step(acc_b, acc_a, a, a, tile + 1);
+                tile_step(acc_a, acc_b, a, a, tile, a);
+                if (tile + 1 < tin1) tile_step(acc_b, acc_a, a, a, tile + 1, a);
             }
         }
         }
@@ -1186,13 +1243,14 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(const float *__res
         // rounded to fp16 once (11 bits: 2^-11 each), users
         // exact to 2^-22, fp32 accumulation of 2 d products 2^-18 (d = 64) / 2^-17 (d = 128): 2^-11 (1 + 2^-5) / 2^-11 (1 + 2^-4);
         // its approximate scores carry the two tables' scales.
-        const float coef = mode == 2 ? (d > 64 ? 0x1.1p-11f : 0x1.08p-11f) : 0x1p-14f;
-        if (mode == 2) a_min = ldexpf(a_min, scale_exp(__uint_as_float(stats[1])) + scale_exp(__uint_as_float(stats[2])));
+        // mode 3: users rounded to fp16 once too: 2^-10 (1 + 2^-11) + the accumulation
+        const float coef = mode == 3 ? (d > 64 ? 0x1.08p-10f : 0x1.04p-10f) : mode == 2 ? (d > 64 ? 0x1.1p-11f : 0x1.08p-11f) : 0x1p-14f;
+        if (mode >= 2) a_min = ldexpf(a_min, scale_exp(__uint_as_float(stats[1])) + scale_exp(__uint_as_float(stats[2])));
         float eps = coef * sqrtf(un2 * __uint_as_float(stats[0]));
         // MODE 2: scaled elements below 2^-14 are fp16 subnormals (absolute error <= 2^-25 each, both sides): at most
         // 2 d 2^-25 per score in scaled units (2^-18 at d = 64) = 2^-16 (d / 64) max|i_j| max|u_j| — matters only for a
         // user far smaller than the largest of the batch, whom it then sends to the fp32 sweep
-        if (mode == 2 && eps > 0.f) eps += (d > 64 ? 0x1p-15f : 0x1p-16f) * __uint_as_float(stats[1]) * __uint_as_float(stats[2]);
+        if (mode >= 2 && eps > 0.f) eps += (d > 64 ? 0x1p-15f : 0x1p-16f) * __uint_as_float(stats[1]) * __uint_as_float(stats[2]);
         // fewer real candidates than slots: the sweep dropped nothing real.  eps == 0 (an all-zero user): scores are exact —
         // enough in an id-order sweep (ties are kept by lower id there too); in a permuted sweep the ties at the end of
         // the candidate list were kept by POSITION, so the user goes to the fp32 sweep (a_min + 0 < e_k fails on a tie).
@@ -1258,7 +1316,7 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
     if (!user_rows || !item_rows || !out_idx || !out_val) return IGCN_E_NULL;
     if ((excl_rowptr == nullptr) != (excl_col == nullptr)) return IGCN_E_NULL;
     TopkPlan p;
-    int rc = topk_make_plan(batch, n_items, d, k, &p, mode != 0);
+    int rc = topk_make_plan(batch, n_items, d, k, &p, mode);
     if (rc != IGCN_OK) return rc;
     if (ldu < d || ldi < d || ldu % 4 || ldi % 4 || n_items >= ((int64_t)1 << 31) - 64 || ldi > (1 << 20)) return IGCN_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(user_rows) | reinterpret_cast<uintptr_t>(item_rows)) % 16) return IGCN_E_ALIGN;
@@ -1291,9 +1349,10 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
     a.tile_bound = tile_bound; a.unorm2 = unorm2;
 
     if (mode != 0) {
-        if ((d != 64 && !(mode == 2 && d == 128)) || !packed || (mode == 2 && !stats)) return IGCN_E_SHAPE;
-        if (d == 128) rc = p.ng == 2 ? launch_topk<128, 2, true, 2>(p, st, a) : launch_topk<128, 1, true, 2>(p, st, a);
-        else rc = mode == 2 ? launch_topk<64, 2, true, 2>(p, st, a) : launch_topk<64, 2, true, 1>(p, st, a);
+        if ((d != 64 && !(mode >= 2 && d == 128)) || !packed || (mode >= 2 && !stats)) return IGCN_E_SHAPE;
+        if (d == 128 && mode == 3) rc = launch_topk<128, 2, true, 3>(p, st, a);
+        else if (d == 128) rc = p.ng == 2 ? launch_topk<128, 2, true, 2>(p, st, a) : launch_topk<128, 1, true, 2>(p, st, a);
+        else rc = mode == 3 ? launch_topk<64, 2, true, 3>(p, st, a) : mode == 2 ? launch_topk<64, 2, true, 2>(p, st, a) : launch_topk<64, 2, true, 1>(p, st, a);
     } else {
         switch (p.d_pad) {
         case 16: rc = d == 16 ? launch_topk<16, 2, true>(p, st, a) : launch_topk<16, 2, false>(p, st, a); break;
@@ -1353,11 +1412,11 @@ static inline int64_t align256(int64_t n) { return (n + 255) / 256 * 256; }
 struct FastLayout { int64_t sweep, packed, cand_idx, cand_val, norm, tile_bound, unorm2, order, total; int kc; TopkOrderLayout ord; };
 static int topk_fast_layout(int64_t batch, int64_t n_items, int32_t d, int32_t k, int64_t excl_rows, int64_t excl_nnz, FastLayout *L) {
     if ((d != 64 && d != 128) || k < 1 || k + kFastExtra > kWave) return IGCN_E_RANGE;
-    L->kc = k + kFastExtra;
+    L->kc = k + topk_fast_extra(k, topk_fast_mode(d));
     TopkPlan p;
     const int64_t kc = n_items < L->kc ? n_items : L->kc;        // never more candidates than items
     L->kc = (int)kc;
-    int rc = topk_make_plan(batch, n_items, d, L->kc, &p, true);
+    int rc = topk_make_plan(batch, n_items, d, L->kc, &p, topk_fast_mode(d));
     if (rc != IGCN_OK) return rc;
     rc = topk_order_layout(n_items, excl_rows, excl_nnz, &L->ord);
     if (rc != IGCN_OK) return rc;
@@ -1404,7 +1463,7 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     unsigned int *norm_bits = reinterpret_cast<unsigned int *>(ws + L.norm);
     char *ows = ws + L.order;
     // 2: one fp16 item plane (default; the only one at d = 128), 1: two bf16 planes
-    const int mode = tuning_get(IGCN_TUNE_TOPK_FAST_MODE) == 1 && d == 64 ? 1 : 2;
+    const int mode = topk_fast_mode(d);
     const int ks = d / 16, lg = d == 128 ? 5 : 4;
     const bool by_norm = tuning_get(IGCN_TUNE_TOPK_FAST_ORDER) != 0;       // developer knob: 0 = sweep in id order
     hipError_t e = hipMemsetAsync(norm_bits, 0, 16, st);
@@ -1423,7 +1482,7 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
         rc = topk_order_build(L.ord, ows, n_items, excl_rowptr, excl_col, excl_rows, excl_nnz, st, &perm, &excl_pos);
         if (rc != IGCN_OK) return rc;
     }
-    if (mode == 2) {
+    if (mode >= 2) {
         if (!user_rows || ldu < d || ldu % 4 || reinterpret_cast<uintptr_t>(user_rows) % 16) return IGCN_E_SHAPE;
         int64_t ub = ((batch << lg) + kBlock - 1) / kBlock;
         if (ub > (int64_t)cu_count()) ub = (int64_t)cu_count();

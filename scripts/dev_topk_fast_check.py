@@ -14,6 +14,8 @@ D = int(os.environ.get('D', 64))                                         # 64 or
 from igcn_cf_amd import _lib
 if os.environ.get('FAST_MODE'):
     _lib.set_tuning('topk_fast_mode', int(os.environ['FAST_MODE']))      # 1: two bf16 planes, 2 (default): one fp16 item plane
+if os.environ.get('EXTRA'):
+    _lib.set_tuning('topk_fast_extra', int(os.environ['EXTRA']))
 if os.environ.get('WIDE'):
     _lib.set_tuning('topk_fast_wide', int(os.environ['WIDE']))           # d = 128: 1 = two groups per wave, one wave per SIMD
 # 1. small exact-arithmetic case (integers: massive ties -> every user must fall back and still be right)

@@ -81,7 +81,8 @@ def test_score_topk_fuzz():
         ids = rng.permutation(n_users).astype(np.int64)
         # d = 64 / 128, k <= 60: every other such case through the two-stage path (fp16 candidate sweep + exact re-scoring)
         mode = 'fast' if d in (64, 128) and k <= 60 and case % 2 == 0 else 'exact'
-        _lib.set_tuning('topk_fast_mode', 1 if case % 4 == 0 else None)     # two bf16 planes / one fp16 item plane (default)
+        # two bf16 planes each side / one fp16 item plane + two user planes / one fp16 plane each side (default)
+        _lib.set_tuning('topk_fast_mode', 1 if case % 4 == 0 else 2 if case % 8 == 2 else None)
         idx, val = score_topk(torch.from_numpy(U).cuda(), torch.from_numpy(I).cuda(), k, user_ids=torch.from_numpy(ids).cuda(),
                               mode=mode, **kw)
         s = scores[ids].copy()

@@ -88,7 +88,7 @@ def test_score_topk_matches_dense_oracle(d, n_users, n_items, k):
         _check_topk(scores[sub], idx.cpu().numpy(), val.cpu().numpy(), None, None, k)
 
 
-@pytest.mark.parametrize('mode', ['exact', 'fast', 'fast_bf16', 'fast_d128', 'fast_d128_narrow'])
+@pytest.mark.parametrize('mode', ['exact', 'fast', 'fast_bf16', 'fast_f16x2', 'fast_d128', 'fast_d128_f16x2', 'fast_d128_f16x2_narrow'])
 def test_score_topk_random_floats_match_sets(mode):
     """Gaussian fp32 embeddings: same top-k sets as the float64 ranking except where the
     k-th and (k+1)-th scores are within fp32 rounding of each other — for the fp32 sweep and for the two-stage
@@ -101,11 +101,14 @@ def test_score_topk_random_floats_match_sets(mode):
     I[100] = I[7]; I[20000] = I[7]                       # identical item rows: exact ties, decided by the lower id
     U[5] = 0.0                                           # an all-zero user: every score ties at 0
     from igcn_cf_amd import _lib
-    if mode == 'fast_bf16':                              # the candidate sweep on two bf16 planes instead of one fp16 item plane
+    # candidate sweep: one fp16 plane each side (default) / two bf16 planes each side (d = 64) / one fp16 item plane and two
+    # user planes — at d = 128 that one runs two user groups per wave at one wave per SIMD, or ('narrow') one group at two waves
+    if mode == 'fast_bf16':
         _lib.set_tuning('topk_fast_mode', 1)
-        mode = 'fast'
-    if 'd128' in mode:                                   # d = 128: two user groups per wave, one wave per SIMD (default) / one group, two waves
+    if 'f16x2' in mode:
+        _lib.set_tuning('topk_fast_mode', 2)
         _lib.set_tuning('topk_fast_wide', 0 if 'narrow' in mode else None)
+    if mode.startswith('fast'):
         mode = 'fast'
     try:
         idx, val = score_topk(_dev(U), _dev(I), k, mode=mode)
@@ -468,9 +471,10 @@ def test_two_stage_sweep_order_and_early_exit_do_not_change_the_lists(d):
     kw = dict(user_ids=_dev(users), excl_rowptr=_dev(rowptr), excl_col=_dev(col), banned=_dev(bmask))
     ref = score_topk(_dev(U), _dev(I), k, mode='exact', **kw)
     try:
-        for order, ex_it in ((None, None), (None, 0), (0, None)):
+        for order, ex_it, planes in ((None, None, None), (None, 0, None), (0, None, None), (None, None, 2)):
             _lib.set_tuning('topk_fast_order', order)
             _lib.set_tuning('topk_fast_exit', ex_it)
+            _lib.set_tuning('topk_fast_mode', planes)
             got = score_topk(_dev(U), _dev(I), k, mode='fast', **kw)
             assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (order, ex_it)
             got = score_topk(_dev(U), _dev(I), k, mode='fast')          # no masks
@@ -479,3 +483,4 @@ def test_two_stage_sweep_order_and_early_exit_do_not_change_the_lists(d):
     finally:
         _lib.set_tuning('topk_fast_order', None)
         _lib.set_tuning('topk_fast_exit', None)
+        _lib.set_tuning('topk_fast_mode', None)
