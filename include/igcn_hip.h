@@ -39,8 +39,10 @@ int         igcn_abi_version(void);
 const char *igcn_error_string(int code);
 
 /* Developer / test knobs of the launch heuristics (no reference counterpart).  name: "spmm_blocks_per_cu",
- * "spmm_multirow", "topk_slots", "topk_waves_per_cu", "topk_cap", "topk_stagger", "topk_fast_order", "topk_fast_mode" (candidate sweep of
- * igcn_score_topk_fast_f32: 2 = one fp16 item plane, 1 = two bf16 planes); value < 0 restores the library
+ * "spmm_multirow", "topk_slots", "topk_waves_per_cu", "topk_cap", "topk_stagger", "topk_fast_order", "topk_fast_exit",
+ * "topk_fast_wide", "topk_fast_extra" (candidates kept beyond k), "topk_fast_mode" (candidate sweep of
+ * igcn_score_topk_fast_f32: 3 = one fp16 plane each side, the default; 2 = two fp16 user planes; 1 = two bf16 planes each side,
+ * d = 64 only); value < 0 restores the library
  * default.  Results never depend on them (tests/test_spmm_gpu.py::test_launch_shape_does_not_change_results).
  * Not thread-safe against concurrent launches.  Returns IGCN_E_RANGE for an unknown name. */
 int igcn_set_tuning(const char *name, int32_t value);
@@ -249,11 +251,12 @@ int igcn_score_topk_bounded_f32(const float *user_rows, int64_t ldu, const int64
                                 int32_t k, const float *lower_bound, int64_t *out_idx, float *out_val,
                                 void *workspace, void *stream);
 
-/* The same evaluation in two stages (d = 64 or 128, k <= 60).  Stage 1 sweeps all items on the 16-bit matrix cores — items as
- * one fp16 plane, users as two, both tables rescaled by a power of two, fp32 accumulate: scores off by at most
- * 2^-11 |u| max|i| (d = 64 only, igcn_set_tuning("topk_fast_mode", 1): two bf16 planes each side, three products, 2^-14;
- * d = 128 runs two 32-user groups per wave at ONE wave per SIMD, 396 registers; "topk_fast_wide", 0: one group, two waves) — and keeps
- * the k + 4 best candidates of every user (masks applied as in igcn_score_topk_f32).
+/* The same evaluation in two stages (d = 64 or 128, k <= 60).  Stage 1 sweeps all items on the 16-bit matrix cores — items
+ * and users as ONE fp16 plane each, both tables rescaled by a power of two, fp32 accumulate: scores off by at most
+ * 2^-10 |u| max|i| (igcn_set_tuning("topk_fast_mode", 2): users as two fp16 planes, 2^-11, twice the MFMAs — at d = 128
+ * two 32-user groups per wave at ONE wave per SIMD, or with "topk_fast_wide" 0 one group at two waves; "topk_fast_mode" 1,
+ * d = 64 only: two bf16 planes each side, three products, 2^-14) — and keeps the k + 6 best candidates of every user
+ * (k + 4 in modes 1 and 2; masks applied as in igcn_score_topk_f32).
  * Stage 2 re-computes the candidates' scores in fp32 in the order the fp32 sweep adds the products, orders them
  * (score, then lower id) and writes the best k: out_idx / out_val as igcn_score_topk_f32 writes them.  A user for
  * whom an item dropped by stage 1 could still reach the k-th exact score (its bound does not stay below it: near-ties
