@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_PKG, 'libigcn_hip.so')
 
 MAX_ADDS = 8
 MAX_TOPK = 256
+MAX_METRIC_CUTS = 8
 
 c_i64_p = C.POINTER(C.c_int64)
 vp = C.c_void_p
@@ -54,6 +55,8 @@ SIGNATURES = {
     'igcn_score_topk_fast_f32': (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32,
                                            vp, vp, C.c_int64, C.c_int64, vp, C.c_int32, vp, vp, vp, vp, vp, vp]),
     'igcn_hit_matrix': (C.c_int, [vp, C.c_int64, C.c_int32, vp, vp, vp, vp]),
+    'igcn_eval_metrics_workspace_bytes': (C.c_int64, [C.c_int64]),
+    'igcn_eval_metrics': (C.c_int, [vp, C.c_int64, C.c_int32, vp, vp, vp, C.c_int32, vp, vp, vp]),
     'igcn_bpr_sample': (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, vp, vp]),
     'igcn_bpr_sample_nodes': (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_int64, vp, vp]),
     'igcn_rows_finish_f32': (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int32, vp, C.c_float, vp]),

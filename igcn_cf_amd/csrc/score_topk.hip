@@ -1074,6 +1074,74 @@ __global__ void hit_matrix_kernel(const int64_t *__restrict__ rec, int64_t n_use
     hit[i] = (lo < end && eval_col[lo] == item) ? 1.f : 0.f;
 }
 
+// calculate_metrics (trainer.py:109-138) in one pass over the recommended lists: per user the membership tests of
+// hit_matrix_kernel, then for every cut-off k_t: hits / k_t, hits / |list|, DCG / IDCG in float32 as the reference forms
+// them; users with an empty list do not count (trainer.py:133).  Sums over users in float64: per-workgroup partial sums
+// to the workspace, added up in workgroup order by the last kernel — the same bits on every run, no float atomics.
+struct MetricCuts { int k[IGCN_MAX_METRIC_CUTS]; int n; };
+__global__ __launch_bounds__(kBlock) void eval_metrics_kernel(const int64_t *__restrict__ rec, int64_t n_users, int k_rec,
+                                                              const int64_t *__restrict__ eval_rowptr, const int32_t *__restrict__ eval_col,
+                                                              const MetricCuts cuts, double *__restrict__ partial)
+{
+    constexpr int NV = 3 * IGCN_MAX_METRIC_CUTS + 1;
+    __shared__ double sh[kBlock / kWave][NV];
+    const int64_t u = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    double v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = 0.0;
+    if (u < n_users) {
+        const int64_t lo0 = eval_rowptr[u], end = eval_rowptr[u + 1];
+        const int len = (int)(end - lo0);
+        if (len > 0 && eval_col) {
+            float hits[IGCN_MAX_METRIC_CUTS], dcg[IGCN_MAX_METRIC_CUTS], idcg[IGCN_MAX_METRIC_CUTS];
+#pragma unroll
+            for (int t = 0; t < IGCN_MAX_METRIC_CUTS; ++t) hits[t] = dcg[t] = idcg[t] = 0.f;
+            for (int j = 0; j < k_rec; ++j) {
+                const int64_t item = rec[u * k_rec + j];
+                int64_t lo = lo0, hi = end;
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (eval_col[mid] < item) lo = mid + 1; else hi = mid;
+                }
+                const float h = (lo < end && eval_col[lo] == item) ? 1.f : 0.f;
+                const float denom = log2f((float)(j + 2));
+                const float hd = h / denom, id = (j < len ? 1.f : 0.f) / denom;
+#pragma unroll
+                for (int t = 0; t < IGCN_MAX_METRIC_CUTS; ++t)
+                    if (t < cuts.n && j < cuts.k[t]) { hits[t] += h; dcg[t] += hd; idcg[t] += id; }
+            }
+#pragma unroll
+            for (int t = 0; t < IGCN_MAX_METRIC_CUTS; ++t)
+                if (t < cuts.n) {
+                    v[3 * t] = (double)(hits[t] / (float)cuts.k[t]);
+                    v[3 * t + 1] = (double)(hits[t] / (float)len);
+                    v[3 * t + 2] = (double)(dcg[t] / idcg[t]);
+                }
+            v[NV - 1] = 1.0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double x = v[i];
+        for (int o = kWave / 2; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        if ((threadIdx.x & (kWave - 1)) == 0) sh[threadIdx.x >> 6][i] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double x = 0.0;
+        for (int w = 0; w < kBlock / kWave; ++w) x += sh[w][threadIdx.x];
+        partial[(int64_t)blockIdx.x * NV + threadIdx.x] = x;
+    }
+}
+__global__ __launch_bounds__(kWave) void eval_metrics_finish_kernel(const double *__restrict__ partial, int64_t n_blocks, double *__restrict__ out)
+{
+    constexpr int NV = 3 * IGCN_MAX_METRIC_CUTS + 1;
+    if (threadIdx.x >= NV) return;
+    double x = 0.0;
+    for (int64_t b = 0; b < n_blocks; ++b) x += partial[b * NV + threadIdx.x];
+    out[threadIdx.x] = x;
+}
+
 // Item table -> MFMA-ready bf16 planes for MODE 1: [tile][plane 0..1][k-step 0..3][lane 0..63] x 16 B, lane (j, kg)
 // holding k = 16 s + 8 kg .. + 7 of item 32 tile + j (rows past the end: zeros).  One thread per (tile, k-step, lane).
 __global__ __launch_bounds__(kBlock) void topk_pack_items_kernel(const float *__restrict__ item_rows, int64_t ldi, int64_t n_items,
@@ -1534,6 +1602,32 @@ extern "C" int igcn_debug_topk_stats(unsigned long long *host8, int reset)
     return (int)e;
 }
 #endif
+
+extern "C" int64_t igcn_eval_metrics_workspace_bytes(int64_t n_users)
+{
+    if (n_users < 0) return -1;
+    return ((n_users + kBlock - 1) / kBlock + 1) * (3 * IGCN_MAX_METRIC_CUTS + 1) * 8;
+}
+
+extern "C" int igcn_eval_metrics(const int64_t *rec, int64_t n_users, int32_t k_rec, const int64_t *eval_rowptr, const int32_t *eval_col,
+                                 const int32_t *topks_host, int32_t n_topks, double *out, void *workspace, void *stream)
+{
+    if (!rec || !eval_rowptr || !topks_host || !out || !workspace) return IGCN_E_NULL;
+    if (n_users < 1 || k_rec < 1 || n_topks < 1 || n_topks > IGCN_MAX_METRIC_CUTS) return IGCN_E_SHAPE;
+    MetricCuts cuts{};
+    cuts.n = n_topks;
+    for (int t = 0; t < n_topks; ++t) {
+        if (topks_host[t] < 1 || topks_host[t] > k_rec) return IGCN_E_RANGE;
+        cuts.k[t] = topks_host[t];
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t n_blocks = (n_users + kBlock - 1) / kBlock;
+    if (n_blocks >= ((int64_t)1 << 31)) return IGCN_E_SHAPE;
+    double *partial = static_cast<double *>(workspace);
+    hipLaunchKernelGGL(eval_metrics_kernel, dim3((unsigned)n_blocks), dim3(kBlock), 0, st, rec, n_users, (int)k_rec, eval_rowptr, eval_col, cuts, partial);
+    hipLaunchKernelGGL(eval_metrics_finish_kernel, dim3(1), dim3(kWave), 0, st, (const double *)partial, n_blocks, out);
+    return launch_status();
+}
 
 extern "C" int igcn_hit_matrix(const int64_t *rec, int64_t n_users, int32_t k,
                                const int64_t *eval_rowptr, const int32_t *eval_col, float *hit, void *stream)

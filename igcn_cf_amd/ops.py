@@ -622,6 +622,26 @@ def hit_matrix(rec, eval_rowptr, eval_col):
     return hit
 
 
+def eval_metric_sums(rec, eval_rowptr, eval_col, topks):
+    """calculate_metrics (trainer.py:109-138) fused (igcn_eval_metrics): numpy float64 [len(topks), 3] of the sums over
+    the users with a non-empty list of (hits / k, hits / |list|, DCG / IDCG), and the number of such users.  One launch
+    pair and one small copy instead of the hit matrix + ~25 reductions per cut-off."""
+    _require_i64(rec, 'rec')
+    _require_i64(eval_rowptr, 'eval_rowptr')
+    if len(topks) > _lib.MAX_METRIC_CUTS:
+        raise _lib.IgcnError('at most %d cut-offs per call' % _lib.MAX_METRIC_CUTS)
+    rec = rec.contiguous()
+    L = _lib.lib()
+    ws = torch.empty(max(int(L.igcn_eval_metrics_workspace_bytes(rec.shape[0])), 8), dtype=torch.uint8, device=rec.device)
+    out = torch.empty(3 * _lib.MAX_METRIC_CUTS + 1, dtype=torch.float64, device=rec.device)
+    cuts = (C.c_int32 * len(topks))(*[int(k) for k in topks])
+    col_ptr = eval_col.data_ptr() if eval_col is not None and eval_col.numel() else None
+    _lib.check(L.igcn_eval_metrics(rec.data_ptr(), rec.shape[0], rec.shape[1], eval_rowptr.data_ptr(), col_ptr,
+                                   C.addressof(cuts), len(topks), out.data_ptr(), ws.data_ptr(), _lib.current_stream()), 'igcn_eval_metrics')
+    host = out.cpu().numpy()
+    return host[:3 * len(topks)].reshape(len(topks), 3), float(host[-1])
+
+
 def bpr_sample(train_rowptr, train_col, nonempty_users, n_items, batch, seed, out=None):
     """int64 [batch, 3] (user, pos, neg) drawn on the device (igcn_bpr_sample).  out: as bpr_sample_nodes."""
     _require_i64(train_rowptr, 'train_rowptr')

@@ -26,7 +26,7 @@ import torch
 from torch.optim import SGD, Adam  # noqa: F401  (resolved by name, trainer.py:43-45)
 
 from . import ops
-from ._lib import MAX_TOPK
+from ._lib import MAX_METRIC_CUTS, MAX_TOPK
 from .dataset import AuxiliaryDataset
 
 
@@ -394,6 +394,17 @@ class BasicTrainer:
             out['NDCG'][k] = ndcg[scored].mean()
         return out
 
+    def _metrics_device(self, rec, eval_rowptr, eval_col):
+        """trainer.py:109-138 as one fused pass over the recommended lists (igcn_eval_metrics): per user in float32 as the
+        reference forms them, the mean over users in float64; only 3 * len(topks) + 1 numbers cross PCIe."""
+        sums, n_valid = ops.eval_metric_sums(rec, eval_rowptr, eval_col, self.topks)
+        results = {'Precision': {}, 'Recall': {}, 'NDCG': {}}
+        with np.errstate(invalid='ignore', divide='ignore'):
+            for i, k in enumerate(self.topks):
+                for j, name in enumerate(('Precision', 'Recall', 'NDCG')):
+                    results[name][k] = np.float32(np.float64(sums[i, j]) / np.float64(n_valid))   # no evaluated user: nan
+        return results
+
     def _metrics_from_hits_device(self, hit, eval_len):
         """The reductions of trainer.py:116-137 on the device (float32, same formulas): only the
         final scalars cross PCIe.  Used by eval(); calculate_metrics() keeps the numpy path, whose
@@ -484,11 +495,13 @@ class BasicTrainer:
         self.model.eval()
         rec = self.recommend_all(val_or_test, banned_items)
         rp, cl, lens = _eval_lists if _eval_lists is not None else self._eval_lists_device(val_or_test)
-        hit = ops.hit_matrix(rec.contiguous(), rp, cl)
         if self.config.get('host_metrics', False):
+            hit = ops.hit_matrix(rec.contiguous(), rp, cl)
             metrics = self._metrics_from_hits(hit.cpu().numpy(), lens.cpu().numpy().astype(np.int32))
+        elif len(self.topks) <= MAX_METRIC_CUTS and rec.shape[0] > 0:
+            metrics = self._metrics_device(rec, rp, cl)
         else:
-            metrics = self._metrics_from_hits_device(hit, lens)
+            metrics = self._metrics_from_hits_device(ops.hit_matrix(rec.contiguous(), rp, cl), lens)
         self.last_rec_items = rec
 
         def row(name):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IGCN_ABI_VERSION 5
+#define IGCN_ABI_VERSION 6
 
 #define IGCN_OK            0
 #define IGCN_E_NULL       -1   /* a required pointer is NULL               */
@@ -285,6 +285,19 @@ int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, const int64_t 
 int igcn_hit_matrix(const int64_t *rec, int64_t n_users, int32_t k,
                     const int64_t *eval_rowptr, const int32_t *eval_col,
                     float *hit, void *stream);
+
+/* calculate_metrics (trainer.py:109-138) without the hit matrix: for every cut-off topks_host[t] (host array, n_topks <=
+ * IGCN_MAX_METRIC_CUTS, each <= k_rec) the SUMS over the users with a non-empty list of  hits / k,  hits / |list|,
+ * DCG / IDCG  (per user in float32 as the reference forms them, summed in float64 in a fixed order):
+ *   out[3 t], out[3 t + 1], out[3 t + 2]  (device, double [3 * IGCN_MAX_METRIC_CUTS + 1]),  out[3 * IGCN_MAX_METRIC_CUTS] = that number
+ * of users; Precision / Recall / NDCG @ k_t are the sums divided by it (0 / 0 = nan, the reference's empty mean).
+ * rec int64 [n_users, k_rec] = the recommended ids; eval lists as for igcn_hit_matrix (eval_col NULL: all empty).
+ * workspace: igcn_eval_metrics_workspace_bytes(n_users) bytes, 8-byte aligned. */
+#define IGCN_MAX_METRIC_CUTS 8
+int64_t igcn_eval_metrics_workspace_bytes(int64_t n_users);
+int igcn_eval_metrics(const int64_t *rec, int64_t n_users, int32_t k_rec,
+                      const int64_t *eval_rowptr, const int32_t *eval_col,
+                      const int32_t *topks_host, int32_t n_topks, double *out, void *workspace, void *stream);
 
 /* Device-side BPR negative sampler (dataset.py:119-131): for each of `batch`
  * draws, a uniform user with a non-empty train list, a uniform positive from

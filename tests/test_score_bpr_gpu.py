@@ -484,3 +484,43 @@ def test_two_stage_sweep_order_and_early_exit_do_not_change_the_lists(d):
         _lib.set_tuning('topk_fast_order', None)
         _lib.set_tuning('topk_fast_exit', None)
         _lib.set_tuning('topk_fast_mode', None)
+
+
+def test_fused_eval_metrics_match_the_reference_formulas(golden):
+    """igcn_eval_metrics (one pass over the recommended lists) against calculate_metrics' numpy restatement — which the
+    reference-produced fixtures pin bit for bit (test_hit_matrix_and_metrics_golden) — on the golden recommendations and on
+    random lists with empty users, several cut-offs, cut-off == list width; and the all-empty split (nan)."""
+    from igcn_cf_amd import ops
+    from igcn_cf_amd.trainer import BasicTrainer
+    rng = np.random.default_rng(3)
+
+    def check(lists, rec, topks, n_items):
+        class DS:
+            n_users = len(lists)
+        DS.n_items = n_items
+        tr = BasicTrainer({'name': 'BasicTrainer', 'dataset': DS(), 'model': None, 'topks': topks, 'device': 'cuda',
+                           'n_epochs': 0, 'test_batch_size': 7})
+        with np.errstate(all='ignore'):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                want = tr.calculate_metrics(lists, rec)
+        rowptr = np.zeros(len(lists) + 1, dtype=np.int64)
+        np.cumsum([len(x) for x in lists], out=rowptr[1:])
+        col = np.array([i for x in lists for i in sorted(x)], dtype=np.int32)
+        got = tr._metrics_device(_dev(rec.astype(np.int64)), _dev(rowptr), _dev(col) if col.size else None)
+        for name in want:
+            for k in topks:
+                a, b = float(got[name][k]), float(want[name][k])
+                assert (np.isnan(a) and np.isnan(b)) or abs(a - b) < 1e-6, (name, k, a, b)
+
+    lists = _lists(golden)
+    topks = [int(k) for k in golden['eval_topks']]
+    for tag, stage in (('train', 'train'), ('val', 'val'), ('test', 'test'), ('testban', 'test')):
+        check(lists[stage], np.asarray(golden['eval_%s_rec' % tag]), topks, int(golden['n_items']))
+    n_users, n_items = 5000, 700
+    lists = [sorted(rng.choice(n_items, size=int(rng.integers(0, 40)) if u % 7 else 0, replace=False).tolist()) for u in range(n_users)]
+    rec = np.stack([rng.permutation(n_items)[:50] for _ in range(n_users)])
+    check(lists, rec, [1, 5, 20, 50], n_items)
+    check(lists, rec[:, :20], [20], n_items)
+    check([[] for _ in range(300)], rec[:300, :10], [5, 10], n_items)
