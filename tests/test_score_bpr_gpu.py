@@ -471,19 +471,23 @@ def test_two_stage_sweep_order_and_early_exit_do_not_change_the_lists(d):
     kw = dict(user_ids=_dev(users), excl_rowptr=_dev(rowptr), excl_col=_dev(col), banned=_dev(bmask))
     ref = score_topk(_dev(U), _dev(I), k, mode='exact', **kw)
     try:
-        for order, ex_it, planes in ((None, None, None), (None, 0, None), (0, None, None), (None, None, 2)):
+        # (sweep order, early exit, user planes, candidates kept beyond k): library defaults = None
+        for order, ex_it, planes, extra in ((None, None, None, None), (None, 0, None, None), (0, None, None, None), (None, None, 2, None),
+                                           (None, None, None, 1), (None, None, None, 8), (None, None, 2, 7)):
             _lib.set_tuning('topk_fast_order', order)
             _lib.set_tuning('topk_fast_exit', ex_it)
             _lib.set_tuning('topk_fast_mode', planes)
+            _lib.set_tuning('topk_fast_extra', extra)
             got = score_topk(_dev(U), _dev(I), k, mode='fast', **kw)
-            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (order, ex_it)
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (order, ex_it, planes, extra)
             got = score_topk(_dev(U), _dev(I), k, mode='fast')          # no masks
             ref0 = score_topk(_dev(U), _dev(I), k, mode='exact')
-            assert torch.equal(got[0], ref0[0]) and torch.equal(got[1], ref0[1]), (order, ex_it)
+            assert torch.equal(got[0], ref0[0]) and torch.equal(got[1], ref0[1]), (order, ex_it, planes, extra)
     finally:
         _lib.set_tuning('topk_fast_order', None)
         _lib.set_tuning('topk_fast_exit', None)
         _lib.set_tuning('topk_fast_mode', None)
+        _lib.set_tuning('topk_fast_extra', None)
 
 
 def test_fused_eval_metrics_match_the_reference_formulas(golden):
