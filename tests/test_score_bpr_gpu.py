@@ -528,3 +528,36 @@ def test_fused_eval_metrics_match_the_reference_formulas(golden):
     check(lists, rec, [1, 5, 20, 50], n_items)
     check(lists, rec[:, :20], [20], n_items)
     check([[] for _ in range(300)], rec[:300, :10], [5, 10], n_items)
+
+
+@pytest.mark.parametrize('d', [64, 128])
+def test_two_stage_evaluation_at_full_amazon_size_is_the_fp32_sweep(d):
+    """BASELINE's evaluation shape (109 730 users x 96 421 items, k = 20, train + val lists excluded) at both widths the
+    two-stage path takes: ids and scores of the fp32 sweep bit for bit; the lists hold no excluded item, are ordered, and
+    re-scored in float64 they are the float64 top-20 up to fp32 rounding (a sample of users)."""
+    from igcn_cf_amd.dataset import SyntheticDataset
+    from igcn_cf_amd.ops import score_topk
+    from igcn_cf_amd.trainer import _csr_to_device, _merge_sorted_csr
+    ds = SyntheticDataset({'name': 'SyntheticDataset', 'preset': 'amazon'})
+    g = torch.Generator(device='cuda').manual_seed(d)
+    U = torch.randn(ds.n_users, d, device='cuda', generator=g) * 0.1
+    I = torch.randn(ds.n_items, d, device='cuda', generator=g) * 0.1
+    excl = _merge_sorted_csr(ds.csr('train'), ds.csr('val'))
+    rp, cl = _csr_to_device(excl[0], excl[1], 'cuda')
+    a = score_topk(U, I, 20, excl_rowptr=rp, excl_col=cl, mode='fast')
+    flagged = score_topk.last_flagged
+    b = score_topk(U, I, 20, excl_rowptr=rp, excl_col=cl, mode='exact')
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert flagged < ds.n_users // 50                     # the fall-back stays the exception (43 / 173 users on this data)
+    assert bool((a[1][:, :-1] >= a[1][:, 1:]).all())
+    sample = torch.arange(0, ds.n_users, 997, device='cuda')
+    s64 = U[sample].double() @ I.double().T
+    rows = torch.repeat_interleave(torch.arange(ds.n_users, device='cuda'), rp[1:] - rp[:-1])
+    keep = torch.isin(rows, sample)
+    pos = torch.searchsorted(sample, rows[keep])
+    s64[pos, cl[keep].long()] = -float('inf')
+    assert bool((torch.gather(s64, 1, a[0][sample]) > -float('inf')).all())          # nothing excluded was recommended
+    top = torch.topk(s64, 20, dim=1).values
+    got = torch.gather(s64, 1, a[0][sample])
+    assert float((top - got).abs().max()) < 1e-6
+
