@@ -58,6 +58,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // global pointer the compiler emits a vector load + s_waitcnt vmcnt(0) + readfirstlane, and that wait also drains every
 // item tile in flight.  Only for memory no kernel of the same launch writes (the banned items packed by a pre-kernel).
 typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
+typedef const __attribute__((address_space(4))) float *const_f32_ptr;
 
 constexpr int kIdxNone = 0x7fffffff;
 
@@ -132,6 +133,11 @@ struct TopkPlan {
 };
 
 constexpr int kMinCap = 8, kMaxCap = 16, kQuad = 4;
+// Candidate sweep, early exit: a wave alive after this many tiles hands its remaining users to the fp32 sweep once three
+// quarters of the waves have left.  Trained LightGCN tables (Amazon-like, epochs 2-3): stragglers hold ~20-40 users with low
+// thresholds and crawl at ~6 us a tile; 96: scoring 1.4 ms, 192: 1.8 ms, never: 3.4 ms; after the first epoch (every wave
+// leaves within ~50 tiles) 96 hands over one user for nothing (+0.1 ms on 0.4 ms).
+constexpr int kGiveUpAfterTiles = 96;
 constexpr int kMinCapSweep = 6;      // candidate sweeps: a shallower staging list (more drains) rather than half the resident waves (k + extra = 25..28)
 
 // (the fp16 candidate sweep at d = 128 runs ONE wave per SIMD with 512 registers: both user groups stay)
@@ -325,6 +331,8 @@ struct TopkArgs {
     // tile; unorm2[b] = |u_b|^2.  |approximate score| <= s_u |u| tile_bound: once no user of the wave can be reached, the
     // rest of the sweep is skipped.  NULL: no early exit.
     const float *tile_bound; const float *unorm2;
+    // early exit bookkeeping (MODE 2 / 3, NULL: none): waves that left early; users a wave gave up on (see the sweep loop)
+    unsigned int *exit_count; uint8_t *unfinished;
 };
 
 // FULL: d == D, no k-slice of a row is padding.  NG: 32-user groups of a wave.  MODE 0: fp32 MFMA, the exact fmaf
@@ -872,17 +880,49 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                 load_into(a2, tin0 + 1 < tin1 ? tin0 + 1 : tin1 - 1);
                 load_into(a3, tin0 + 2 < tin1 ? tin0 + 2 : tin1 - 1);
             }
+            unsigned gone_next = 0u;
+            float ureach[NG];                                  // s_u |u| of this lane's users: what a unit row can score at most
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                ureach[g] = A.tile_bound && user_ok[g] ? sqrtf(A.unorm2[group * UPW + g * 32 + j]) * ldexpf(1.f, -scale_exp(__uint_as_float(A.stats[2]))) : 0.f;
             for (int tile = tin0; tile < tin1; tile += 3) {
                 if (A.tile_bound && tile > tin0 && (tile - tin0) % 24 == 0) {
                     // Cauchy-Schwarz exit (every 24 tiles): the items come by descending norm, so if no user of this wave
                     // can still be reached by a row as long as this tile's longest, none of the remaining tiles matters
                     // (a user whose list is not full yet has thr = -inf and keeps the sweep alive)
-                    const float reach = A.tile_bound[tile] * ldexpf(1.f, -scale_exp(__uint_as_float(A.stats[2])));
-                    bool alive = false;
+                    // the thresholds in registers date from the last drain: early in the sweep, where they still move fast
+                    // and where most waves of a trained model leave, they are refreshed first
+                    if (tile - tin0 <= 192) flush();
+                    // (a scalar load: the table was written by the packing kernel; a vector load here would wait for every
+                    // item tile in flight)
+                    const float reach = ((const_f32_ptr)(uintptr_t)A.tile_bound)[tile];
+                    bool alive[NG], any_alive = false;
 #pragma unroll
-                    for (int g = 0; g < NG; ++g)
-                        if (user_ok[g]) alive |= sqrtf(A.unorm2[group * UPW + g * 32 + j]) * reach >= thr[g];
-                    if (!__any(alive)) break;
+                    for (int g = 0; g < NG; ++g) {
+                        alive[g] = user_ok[g] && ureach[g] * reach >= thr[g];
+                        any_alive |= alive[g];
+                    }
+                    if (!__any(any_alive)) {
+                        if (A.exit_count && lane == 0) atomicAdd(A.exit_count, 1u);
+                        break;
+                    }
+                    // Giving up: a wave that is still alive long after three quarters of the waves have left would hold the
+                    // kernel (one wave alone needs as long for a whole sweep as the full chip for all of them) for the sake
+                    // of a few users.  Those users are handed to the fp32 sweep instead (re-scoring flags them; their
+                    // candidates so far bound it from below), which is planned across the whole chip.  Which users take
+                    // that way depends on timing; the lists do not.  With nobody leaving early (norms all alike) nobody gives up.
+                    // (not before kGiveUpAfterTiles: handing users over costs a launch of its own, ~0.15 ms; the count is the one read at
+                    // the previous check — its latency would otherwise stall the wave at every check)
+                    const unsigned gone = gone_next;
+                    if (A.exit_count) gone_next = __hip_atomic_load(A.exit_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (A.exit_count && tile - tin0 >= kGiveUpAfterTiles) {
+                        if ((uint64_t)gone * 4 >= (uint64_t)gridDim.x * 3) {
+#pragma unroll
+                            for (int g = 0; g < NG; ++g)
+                                if (alive[g] && h == 0) A.unfinished[group * UPW + g * 32 + j] = 1;
+                            break;
+                        }
+                    }
                 }
                 if constexpr (kRing12) {
                     tile_step(acc_a, acc_b, a3, a2, tile, a);
@@ -1254,7 +1294,8 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(const float *__res
                                                               int kc, int k, int d, const unsigned int *__restrict__ stats, int mode,
                                                               const int32_t *__restrict__ perm,
                                                               int64_t *__restrict__ out_idx, float *__restrict__ out_val,
-                                                              int32_t *__restrict__ flagged, float *__restrict__ flagged_thr)
+                                                              int32_t *__restrict__ flagged, float *__restrict__ flagged_thr,
+                                                              const uint8_t *__restrict__ unfinished)
 {
     constexpr int UPW = kWave / LANES;                            // users per wave
     const int lane = threadIdx.x & (LANES - 1);
@@ -1324,7 +1365,9 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(const float *__res
         // the candidate list were kept by POSITION, so the user goes to the fp32 sweep (a_min + 0 < e_k fails on a tie).
         // Fewer than k real candidates: the list ends with masked fill-ins, which the fp32 sweep picks by lower id and a
         // permuted sweep by lower position: that user goes to the fp32 sweep too.
-        const bool ok = (n_real < kc && (!perm || n_real >= k)) || (eps == 0.f && !perm) || a_min + eps < e_k;
+        // (unfinished: the sweep gave up on this user before its end — nothing is known about the items it did not see)
+        const bool ok = !(unfinished && unfinished[b]) &&
+                        ((n_real < kc && (!perm || n_real >= k)) || (eps == 0.f && !perm) || a_min + eps < e_k);
         if (!ok) {
             // e_k, the k-th exact score among real (unmasked) candidates, is a lower bound of the user's k-th best:
             // the fp32 sweep that re-does this user starts from it instead of from an empty list
@@ -1379,7 +1422,8 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
                     const int64_t *excl_rowptr, const int32_t *excl_col, const uint8_t *banned,
                     int32_t k, int64_t *out_idx, float *out_val, void *workspace, const float4 *packed,
                     const unsigned int *stats, hipStream_t st, const int32_t *perm = nullptr, const float *init_thr = nullptr,
-                    const float *tile_bound = nullptr, const float *unorm2 = nullptr)
+                    const float *tile_bound = nullptr, const float *unorm2 = nullptr, unsigned int *exit_count = nullptr,
+                    uint8_t *unfinished = nullptr)
 {
     if (!user_rows || !item_rows || !out_idx || !out_val) return IGCN_E_NULL;
     if ((excl_rowptr == nullptr) != (excl_col == nullptr)) return IGCN_E_NULL;
@@ -1415,6 +1459,7 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
     a.stats = stats;
     a.init_thr = init_thr;
     a.tile_bound = tile_bound; a.unorm2 = unorm2;
+    a.exit_count = exit_count; a.unfinished = unfinished;
 
     if (mode != 0) {
         if ((d != 64 && !(mode >= 2 && d == 128)) || !packed || (mode >= 2 && !stats)) return IGCN_E_SHAPE;
@@ -1477,7 +1522,7 @@ extern "C" int igcn_score_topk_bounded_f32(const float *user_rows, int64_t ldu, 
 // ---- the two-stage evaluation: bf16 candidate sweep + exact fp32 re-scoring (d = 64, k <= 60) --------------------
 // workspace: [sweep workspace for k + 4][item planes][candidate ids][candidate scores][max |item|^2], each 256-aligned
 static inline int64_t align256(int64_t n) { return (n + 255) / 256 * 256; }
-struct FastLayout { int64_t sweep, packed, cand_idx, cand_val, norm, tile_bound, unorm2, order, total; int kc; TopkOrderLayout ord; };
+struct FastLayout { int64_t sweep, packed, cand_idx, cand_val, norm, tile_bound, unorm2, exit_state, order, total; int kc; TopkOrderLayout ord; };
 static int topk_fast_layout(int64_t batch, int64_t n_items, int32_t d, int32_t k, int64_t excl_rows, int64_t excl_nnz, FastLayout *L) {
     if ((d != 64 && d != 128) || k < 1 || k + kFastExtra > kWave) return IGCN_E_RANGE;
     L->kc = k + topk_fast_extra(k, topk_fast_mode(d));
@@ -1495,7 +1540,8 @@ static int topk_fast_layout(int64_t batch, int64_t n_items, int32_t d, int32_t k
     L->norm = L->cand_val + align256(batch * L->kc * 4);
     L->tile_bound = L->norm + 256;
     L->unorm2 = L->tile_bound + align256((int64_t)p.n_tiles * 4);
-    L->order = L->unorm2 + align256(batch * 4);
+    L->exit_state = L->unorm2 + align256(batch * 4);                  // [256 B: waves that left early][batch B: users given up on]
+    L->order = L->exit_state + 256 + align256(batch);
     L->total = L->order + L->ord.total;
     return IGCN_OK;
 }
@@ -1567,20 +1613,30 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     }
     rc = launch_status();
     if (rc != IGCN_OK) return rc;
+    // waves that outlast three quarters of the others hand their remaining users to the fp32 sweep (developer knob
+    // "topk_fast_give_up" 0: every wave runs until it can leave or its sweep ends)
+    const bool give_up = early_exit && tuning_get(IGCN_TUNE_TOPK_FAST_GIVE_UP) != 0;
+    unsigned int *exit_count = reinterpret_cast<unsigned int *>(ws + L.exit_state);
+    uint8_t *unfinished = reinterpret_cast<uint8_t *>(ws + L.exit_state + 256);
+    if (give_up) {
+        e = hipMemsetAsync(ws + L.exit_state, 0, (size_t)(256 + batch), st);
+        if (e != hipSuccess) return (int)e;
+    }
     // the sweep runs in position space: its exclusion lists and banned bits are those of the positions, and the
     // candidate ids it returns are positions (mapped back by the re-scoring kernel)
     rc = topk_run(mode, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, d, excl_rowptr, by_norm && excl_rowptr ? excl_pos : excl_col,
                   banned, L.kc, cand_idx, cand_val, ws + L.sweep, packed, norm_bits, st, perm, nullptr,
-                  early_exit ? tile_bound : nullptr, early_exit ? unorm2 : nullptr);
+                  early_exit ? tile_bound : nullptr, early_exit ? unorm2 : nullptr, give_up ? exit_count : nullptr,
+                  give_up ? unfinished : nullptr);
     if (rc != IGCN_OK) return rc;
     if (L.kc <= 32)
         hipLaunchKernelGGL(topk_rescore_kernel<32>, dim3((unsigned)((batch + 7) / 8)), dim3(kBlock), 0, st, user_rows, ldu, user_ids, batch,
                            item_rows, ldi, cand_idx, cand_val, L.kc, (int)k, (int)d, norm_bits, mode, perm, out_idx, out_val, flagged,
-                           flagged_lower_bound);
+                           flagged_lower_bound, give_up ? (const uint8_t *)unfinished : (const uint8_t *)nullptr);
     else
         hipLaunchKernelGGL(topk_rescore_kernel<64>, dim3((unsigned)((batch + 3) / 4)), dim3(kBlock), 0, st, user_rows, ldu, user_ids, batch,
                            item_rows, ldi, cand_idx, cand_val, L.kc, (int)k, (int)d, norm_bits, mode, perm, out_idx, out_val, flagged,
-                           flagged_lower_bound);
+                           flagged_lower_bound, give_up ? (const uint8_t *)unfinished : (const uint8_t *)nullptr);
     return launch_status();
 }
 

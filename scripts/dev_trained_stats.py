@@ -1,0 +1,46 @@
+"""Developer: event counts of the candidate sweep (stats build of the library) on TRAINED LightGCN tables, epoch by epoch:
+tiles swept per wave (early exit), hit quads, staged candidates, flushes."""
+import ctypes as C, json, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import igcn_cf_amd._lib as _lib
+from igcn_cf_amd.dataset import SyntheticDataset
+from igcn_cf_amd.model import get_model
+from igcn_cf_amd.ops import score_topk
+from igcn_cf_amd.trainer import get_trainer
+dev = torch.device('cuda')
+ds = SyntheticDataset({'name': 'SyntheticDataset', 'preset': 'amazon', 'seed': 2021, 'device': dev})
+torch.manual_seed(2021)
+model = get_model({'name': 'LightGCN', 'embedding_size': 64, 'n_layers': 3, 'device': dev}, ds)
+trainer = get_trainer({'name': 'BPRTrainer', 'optimizer': 'Adam', 'lr': 1e-3, 'l2_reg': 1e-5, 'device': dev, 'n_epochs': 1,
+                       'batch_size': 2048, 'dataloader_num_workers': 0, 'test_batch_size': 512, 'topks': [20]}, ds, model)
+users = torch.arange(ds.n_users, device=dev)
+main_handle, main_bound = _lib.lib(), None
+stats = C.CDLL(os.path.join(ROOT, 'igcn_cf_amd', '_variants', 'lib_stats.so'))
+buf = (C.c_ulonglong * 12)()
+for epoch in range(4):
+    model.eval()
+    with torch.no_grad():
+        rep = model.get_rep().clone()
+    U, I = rep[:ds.n_users], rep[ds.n_users:]
+    saved = (_lib._handle, _lib._bound)
+    _lib._handle, _lib._bound = stats, {}
+    score_topk(U, I, 20, user_ids=users, mode='fast')
+    stats.igcn_debug_topk_stats(buf, 1)
+    score_topk(U, I, 20, user_ids=users, mode='fast')
+    stats.igcn_debug_topk_stats(buf, 1)
+    t = list(buf)
+    import numpy as np
+    wt = (C.c_ulonglong * (3 * 2048))()
+    stats.igcn_debug_topk_wave_times(wt, 2048)
+    w = np.array(list(wt), dtype=np.uint64).reshape(2048, 3)[:1715]
+    life = (w[:, 1] - w[:, 0]).astype(np.float64) / 100          # us
+    start = (w[:, 0] - w[:, 0].min()).astype(np.float64) / 100
+    _lib._handle, _lib._bound = saved
+    print(json.dumps(dict(epochs_trained=epoch, waves=t[6], tiles_per_wave=round(t[0] / max(t[6], 1), 1), tiles_with_hits_per_wave=round(t[1] / max(t[6], 1), 1),
+                          hit_quads_per_wave=round(t[2] / max(t[6], 1), 1), flushes_per_wave=round(t[3] / max(t[6], 1), 1),
+                          staged_per_wave=round(t[5] / max(t[6], 1), 1), wave_life_us_quantiles_10_50_75_90_99_max=[round(float(np.percentile(life, q)), 1) for q in (10, 50, 75, 90, 99, 100)],
+                          wave_start_us_max=round(float(start.max()), 1))), flush=True)
+    model.train()
+    trainer.train_one_epoch()

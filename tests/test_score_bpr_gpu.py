@@ -447,7 +447,7 @@ def test_bpr_column_slices_sum_to_the_full_loss():
 def test_two_stage_sweep_order_and_early_exit_do_not_change_the_lists(d):
     """Round 3: the candidate sweep meets the items by descending norm and stops once no user of a wave can be reached
     by the rows still to come (|score| <= |u| |i|).  On tables whose row norms spread over orders of magnitude — where
-    the exit skips most of the sweep — with exclusion lists, banned items, duplicated rows, a zero user, users of very
+    the exit skips most of the sweep and the last waves hand their remaining users to the fp32 sweep — with exclusion lists, banned items, duplicated rows, a zero user, users of very
     different scale and a ragged item count: the lists are those of the fp32 sweep, bit for bit, with the order and
     the exit switched on and off."""
     from igcn_cf_amd import _lib
@@ -471,23 +471,26 @@ def test_two_stage_sweep_order_and_early_exit_do_not_change_the_lists(d):
     kw = dict(user_ids=_dev(users), excl_rowptr=_dev(rowptr), excl_col=_dev(col), banned=_dev(bmask))
     ref = score_topk(_dev(U), _dev(I), k, mode='exact', **kw)
     try:
-        # (sweep order, early exit, user planes, candidates kept beyond k): library defaults = None
-        for order, ex_it, planes, extra in ((None, None, None, None), (None, 0, None, None), (0, None, None, None), (None, None, 2, None),
-                                           (None, None, None, 1), (None, None, None, 8), (None, None, 2, 7)):
+        # (sweep order, early exit, user planes, candidates kept beyond k, stragglers give up): library defaults = None
+        for order, ex_it, planes, extra, give_up in ((None, None, None, None, None), (None, 0, None, None, None), (0, None, None, None, None),
+                                                    (None, None, 2, None, None), (None, None, None, 1, None), (None, None, None, 8, 0),
+                                                    (None, None, 2, 7, None), (None, None, None, None, 0)):
             _lib.set_tuning('topk_fast_order', order)
             _lib.set_tuning('topk_fast_exit', ex_it)
             _lib.set_tuning('topk_fast_mode', planes)
             _lib.set_tuning('topk_fast_extra', extra)
+            _lib.set_tuning('topk_fast_give_up', give_up)
             got = score_topk(_dev(U), _dev(I), k, mode='fast', **kw)
-            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (order, ex_it, planes, extra)
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (order, ex_it, planes, extra, give_up)
             got = score_topk(_dev(U), _dev(I), k, mode='fast')          # no masks
             ref0 = score_topk(_dev(U), _dev(I), k, mode='exact')
-            assert torch.equal(got[0], ref0[0]) and torch.equal(got[1], ref0[1]), (order, ex_it, planes, extra)
+            assert torch.equal(got[0], ref0[0]) and torch.equal(got[1], ref0[1]), (order, ex_it, planes, extra, give_up)
     finally:
         _lib.set_tuning('topk_fast_order', None)
         _lib.set_tuning('topk_fast_exit', None)
         _lib.set_tuning('topk_fast_mode', None)
         _lib.set_tuning('topk_fast_extra', None)
+        _lib.set_tuning('topk_fast_give_up', None)
 
 
 def test_fused_eval_metrics_match_the_reference_formulas(golden):
@@ -560,4 +563,40 @@ def test_two_stage_evaluation_at_full_amazon_size_is_the_fp32_sweep(d):
     top = torch.topk(s64, 20, dim=1).values
     got = torch.gather(s64, 1, a[0][sample])
     assert float((top - got).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize('d', [64, 128])
+def test_two_stage_stragglers_hand_their_users_to_the_fp32_sweep(d):
+    """The state of a trained recommender: every user likes the long (popular) rows, so nearly every wave of the candidate
+    sweep leaves after a few tiles — except the waves that hold one of a few users whose scores are all small, which would
+    crawl through the whole table alone.  Those give up once three quarters of the waves are gone and their users are
+    re-done by the fp32 sweep: the lists are the fp32 sweep's all the same, with and without giving up, with masks."""
+    from igcn_cf_amd import _lib
+    from igcn_cf_amd.ops import score_topk
+    rng = np.random.default_rng(17)
+    n_users, n_items, k = 6400, 40000, 20
+    pop = rng.standard_normal(d).astype(np.float32)
+    pop /= np.linalg.norm(pop)
+    scale = np.exp(1.0 * rng.standard_normal((n_items, 1))).astype(np.float32)
+    I = (0.05 * rng.standard_normal((n_items, d)) + 0.3 * scale * pop[None, :]).astype(np.float32)
+    U = (0.05 * rng.standard_normal((n_users, d)) + 1.0 * pop[None, :]).astype(np.float32)
+    odd = rng.choice(n_users, size=25, replace=False)
+    U[odd] = (0.3 * rng.standard_normal((25, d))).astype(np.float32)                       # no taste for the popular rows
+    ex = [sorted(rng.choice(n_items, size=int(rng.integers(0, 30)), replace=False).tolist()) for _ in range(n_users)]
+    rowptr = np.zeros(n_users + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in ex], out=rowptr[1:])
+    col = np.array([i for x in ex for i in x], dtype=np.int32)
+    kw = dict(excl_rowptr=_dev(rowptr), excl_col=_dev(col))
+    Ud, Id = _dev(U), _dev(I)
+    ref = score_topk(Ud, Id, k, mode='exact', **kw)
+    try:
+        for give_up in (None, 0):
+            _lib.set_tuning('topk_fast_give_up', give_up)
+            got = score_topk(Ud, Id, k, mode='fast', **kw)
+            flagged = score_topk.last_flagged
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), give_up
+            if give_up is None:
+                assert 1 <= flagged <= 400, flagged               # the stragglers' users, not whole waves' worth of the batch
+    finally:
+        _lib.set_tuning('topk_fast_give_up', None)
 
