@@ -65,6 +65,7 @@ def lift_flat(out, extras):
         'eval_mfma_TFLOPs_fp32_sweep': get('eval_roofline', 'achieved'), 'eval_mfma_frac': get('eval_roofline', 'frac'),
         'eval_scoring_ms_fp32_sweep': get('eval_roofline', 'ms'), 'eval_scoring_ms_two_stage': get('eval_two_stage', 'ms'),
         'eval_with_metrics_ms': get('eval_with_metrics_ms'),
+        'eval_ms_after_2_epochs': get('eval_trained', 'eval_ms'), 'eval_ms_after_2_epochs_fp32_sweep': get('eval_trained', 'eval_ms_fp32_sweep'),
         'eval_d128_scoring_ms_fp32_sweep': get('eval_d128', 'scoring_ms_fp32_sweep'), 'eval_d128_scoring_ms_two_stage': get('eval_d128', 'scoring_ms_two_stage'),
         'hbm_bound_kernel': get('roofline_hbm_bound', 'kernel'), 'hbm_bound_GBps': get('roofline_hbm_bound', 'achieved'),
         'hbm_bound_frac': get('roofline_hbm_bound', 'frac'), 'hbm_bound_ms': get('roofline_hbm_bound', 'avg_launch_ms'),
@@ -708,6 +709,25 @@ def side_measurements(ds, device, d, K):
                             'mfma_TFLOPs_fp32_sweep': 2.0 * flops / (ms_x / 1e3) / 1e12, 'users_flagged': ops.score_topk.last_flagged,
                             'note': 'random N(0, 0.1^2) tables [users + items, 128], k = 20, no masks'}
         del wide, lists_x, lists_f
+    # the evaluation a training run actually performs: on TRAINED tables (two epochs here), where popular items carry long rows,
+    # most waves of the candidate sweep leave after a few tiles and the stragglers hand their users to the fp32 sweep
+    if not os.environ.get('IGCN_BENCH_NO_TRAINED_EVAL'):
+        backup = {k_: v.detach().clone() for k_, v in model.state_dict().items()}
+        model.train()
+        t_train = time.perf_counter()
+        for _ in range(2):
+            trainer.train_one_epoch()
+        torch.cuda.synchronize()
+        t_train = time.perf_counter() - t_train
+        model.eval()
+        med_t, best_t, rec_t = eval_ms('auto', reps=5)
+        med_tx, _, rec_tx = eval_ms('exact', reps=3)
+        res['eval_trained'] = {'eval_ms': med_t, 'eval_ms_min': best_t, 'eval_ms_fp32_sweep': med_tx, 'lists_equal_both_paths': bool(torch.equal(rec_t, rec_tx)),
+                               'users_handed_to_the_fp32_sweep': ops.score_topk.last_flagged, 'two_epochs_s': t_train,
+                               'note': 'LightGCN after two epochs of BPR on the same split (Adam 1e-3, B = 2048); propagation recomputed in every call'}
+        model.load_state_dict(backup)
+        model._rep_cache = None
+        model.eval()
     trainer.eval('test')                                   # first call builds the device CSR of the test lists
     model._rep_cache = None
     torch.cuda.synchronize()
