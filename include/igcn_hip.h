@@ -40,7 +40,7 @@ const char *igcn_error_string(int code);
 
 /* Developer / test knobs of the launch heuristics (no reference counterpart).  name: "spmm_blocks_per_cu",
  * "spmm_multirow", "topk_slots", "topk_waves_per_cu", "topk_cap", "topk_stagger", "topk_fast_order", "topk_fast_exit",
- * "topk_fast_wide", "topk_fast_extra" (candidates kept beyond k), "topk_fast_mode" (candidate sweep of
+ * "topk_fast_wide", "topk_fast_extra" (candidates kept beyond k), "topk_fast_give_up" (0: no wave hands users over), "topk_fast_mode" (candidate sweep of
  * igcn_score_topk_fast_f32: 3 = one fp16 plane each side, the default; 2 = two fp16 user planes; 1 = two bf16 planes each side,
  * d = 64 only); value < 0 restores the library
  * default.  Results never depend on them (tests/test_spmm_gpu.py::test_launch_shape_does_not_change_results).
@@ -270,6 +270,9 @@ int igcn_score_topk_bounded_f32(const float *user_rows, int64_t ldu, const int64
  * workspace (rocPRIM radix sorts), which is why the exclusion CSR's size is passed: excl_rows = rows of excl_rowptr
  * (every user id of the batch < excl_rows), excl_nnz = its entries; both 0 when excl_rowptr is NULL.  The lists
  * returned do not depend on the order.  igcn_set_tuning("topk_fast_order", 0) sweeps in id order.
+ * In that order a wave leaves the sweep once no row still to come can reach any of its users (|score| <= |u| |i|), and a
+ * wave that outlasts three quarters of the others hands the users it could not finish to the flagged list as well
+ * (ABI v6; which users take that way depends on timing, the lists do not).
  * workspace: igcn_score_topk_fast_workspace_bytes(...) bytes, 256-byte aligned. */
 int64_t igcn_score_topk_fast_workspace_bytes(int64_t batch, int64_t n_items, int32_t d, int32_t k,
                                              int64_t excl_rows, int64_t excl_nnz);
