@@ -134,10 +134,11 @@ struct TopkPlan {
 
 constexpr int kMinCap = 8, kMaxCap = 16, kQuad = 4;
 // Candidate sweep, early exit: a wave alive after this many tiles hands its remaining users to the fp32 sweep once three
-// quarters of the waves have left.  Trained LightGCN tables (Amazon-like, epochs 2-3): stragglers hold ~20-40 users with low
-// thresholds and crawl at ~6 us a tile; 96: scoring 1.4 ms, 192: 1.8 ms, never: 3.4 ms; after the first epoch (every wave
-// leaves within ~50 tiles) 96 hands over one user for nothing (+0.1 ms on 0.4 ms).
-constexpr int kGiveUpAfterTiles = 96;
+// quarters of the waves have left AND one of its users is far from done (reach >= 1.5 x threshold: a wave about to leave by
+// itself stays).  Trained LightGCN tables (Amazon-like, epochs 2-3): the stragglers hold ~20-40 users with low thresholds
+// and crawl at ~6 us a tile; scoring 1.3-1.45 ms with 48 (the same with 24), 1.5-1.7 with 96, 1.8-2.0 with 192, 3.4-3.8
+// when nobody gives up; after the first epoch (every wave leaves within ~50 tiles) nobody is handed over (0.41 ms).
+constexpr int kGiveUpAfterTiles = 48;
 constexpr int kMinCapSweep = 6;      // candidate sweeps: a shallower staging list (more drains) rather than half the resident waves (k + extra = 25..28)
 
 // (the fp16 candidate sweep at d = 128 runs ONE wave per SIMD with 512 registers: both user groups stay)
@@ -896,11 +897,13 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                     // (a scalar load: the table was written by the packing kernel; a vector load here would wait for every
                     // item tile in flight)
                     const float reach = ((const_f32_ptr)(uintptr_t)A.tile_bound)[tile];
-                    bool alive[NG], any_alive = false;
+                    bool alive[NG], any_alive = false, far = false;
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
                         alive[g] = user_ok[g] && ureach[g] * reach >= thr[g];
                         any_alive |= alive[g];
+                        // far from done: the rows would have to get another third shorter (norms fall slowly in the tail)
+                        far |= alive[g] && ureach[g] * reach >= 1.5f * thr[g];
                     }
                     if (!__any(any_alive)) {
                         if (A.exit_count && lane == 0) atomicAdd(A.exit_count, 1u);
@@ -916,7 +919,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                     const unsigned gone = gone_next;
                     if (A.exit_count) gone_next = __hip_atomic_load(A.exit_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (A.exit_count && tile - tin0 >= kGiveUpAfterTiles) {
-                        if ((uint64_t)gone * 4 >= (uint64_t)gridDim.x * 3) {
+                        if ((uint64_t)gone * 4 >= (uint64_t)gridDim.x * 3 && __any(far)) {   // (a wave about to leave by itself stays)
 #pragma unroll
                             for (int g = 0; g < NG; ++g)
                                 if (alive[g] && h == 0) A.unfinished[group * UPW + g * 32 + j] = 1;
