@@ -160,17 +160,22 @@ static inline int topk_fast_mode(int d) {
 static inline bool topk_wide_sweep() { return tuning_get(IGCN_TUNE_TOPK_FAST_WIDE) != 0; }
 // sweep_mode: 0 the fp32 sweep, 1 / 2 / 3 the candidate sweeps (MODE of the kernel)
 static inline bool topk_one_wave_per_simd(int d_pad, int sweep_mode) { return sweep_mode == 2 && d_pad == 128 && topk_wide_sweep(); }
-static inline int topk_groups_per_wave(int d_pad, int sweep_mode = 0) {
+// sweep_mode -1: the bounded fp32 sweep (igcn_score_topk_bounded_f32).  Its batches are the few users the two-stage path hands
+// back: at d = 64 one 32-user group per wave then — a 64-user wave-group cut into the <= 58 pieces the merge takes cannot fill
+// the chip below ~2 000 users, half-size groups give twice the waves for the same work (20-40 users: 243 -> ~130 us).
+constexpr int64_t kNarrowBoundedBatch = 2048;
+static inline int topk_groups_per_wave(int d_pad, int sweep_mode = 0, int64_t batch = 0) {
+    if (sweep_mode == -1 && d_pad == 64 && batch <= kNarrowBoundedBatch) return 1;
     return d_pad <= 64 || (d_pad == 128 && (sweep_mode == 3 || topk_one_wave_per_simd(d_pad, sweep_mode))) ? 2 : 1;
 }
 
 static inline int topk_make_plan(int64_t batch, int64_t n_items, int32_t d, int32_t k, TopkPlan *p, int sweep_mode = 0) {
-    const bool candidate_sweep = sweep_mode != 0;
+    const bool candidate_sweep = sweep_mode > 0;
     if (batch < 1 || n_items < 1) return IGCN_E_SHAPE;
     if (d < 4 || d > 256 || d % 4 != 0) return IGCN_E_SHAPE;
     if (k < 1 || k > IGCN_MAX_TOPK || k > n_items) return IGCN_E_RANGE;
     p->d_pad = d <= 16 ? 16 : d <= 32 ? 32 : d <= 64 ? 64 : d <= 128 ? 128 : 256;
-    p->ng = topk_groups_per_wave(p->d_pad, sweep_mode);
+    p->ng = topk_groups_per_wave(p->d_pad, sweep_mode, batch);
     const int upw = 32 * p->ng;
     p->groups = (batch + upw - 1) / upw;
     const int64_t L = (n_items + 31) / 32;
@@ -1414,9 +1419,10 @@ using namespace igcn;
 
 extern "C" int64_t igcn_score_topk_workspace_bytes(int64_t batch, int64_t n_items, int32_t d, int32_t k)
 {
-    TopkPlan p;
-    if (topk_make_plan(batch, n_items, d, k, &p) != IGCN_OK) return -1;
-    return topk_merge_bytes(p, batch, k) + (int64_t)p.n_tiles * 4;       // + the banned items as one word per tile
+    TopkPlan p, pb;                                                       // (the bounded sweep may plan narrower groups: the larger of the two)
+    if (topk_make_plan(batch, n_items, d, k, &p) != IGCN_OK || topk_make_plan(batch, n_items, d, k, &pb, -1) != IGCN_OK) return -1;
+    const int64_t mb = topk_merge_bytes(p, batch, k), mbb = topk_merge_bytes(pb, batch, k);
+    return (mb > mbb ? mb : mbb) + (int64_t)p.n_tiles * 4;               // + the banned items as one word per tile
 }
 
 // One sweep: MODE 0 the exact fp32 one, MODE 1 the bf16 candidate sweep (d = 64, `packed` = the item planes).
@@ -1431,7 +1437,7 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
     if (!user_rows || !item_rows || !out_idx || !out_val) return IGCN_E_NULL;
     if ((excl_rowptr == nullptr) != (excl_col == nullptr)) return IGCN_E_NULL;
     TopkPlan p;
-    int rc = topk_make_plan(batch, n_items, d, k, &p, mode);
+    int rc = topk_make_plan(batch, n_items, d, k, &p, mode == 0 && init_thr ? -1 : mode);
     if (rc != IGCN_OK) return rc;
     if (ldu < d || ldi < d || ldu % 4 || ldi % 4 || n_items >= ((int64_t)1 << 31) - 64 || ldi > (1 << 20)) return IGCN_E_SHAPE;
     if ((reinterpret_cast<uintptr_t>(user_rows) | reinterpret_cast<uintptr_t>(item_rows)) % 16) return IGCN_E_ALIGN;
@@ -1475,7 +1481,7 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
         case 32: rc = d == 32 ? launch_topk<32, 2, true>(p, st, a) : launch_topk<32, 2, false>(p, st, a); break;
         case 64:
             // the bound is an optimisation: the variants without it (other widths) simply do not use it
-            if (d == 64 && init_thr) rc = launch_topk<64, 2, true, 0, true>(p, st, a);
+            if (d == 64 && init_thr) rc = p.ng == 1 ? launch_topk<64, 1, true, 0, true>(p, st, a) : launch_topk<64, 2, true, 0, true>(p, st, a);
             else rc = d == 64 ? launch_topk<64, 2, true>(p, st, a) : launch_topk<64, 2, false>(p, st, a);
             break;
         case 128:
