@@ -16,6 +16,9 @@
 //   excl_pos  = the exclusion CSR's entries as sweep positions, ascending inside every row (the sweep walks each
 //               user's list with a cursor): inv[col], then one segmented radix sort (rocPRIM) over the rows — a global
 //               sort of (row << 32 | position) keys took 6 passes x 29 us on the Amazon-like lists and ate the gain.
+//               (Tried and dropped, round 3: hand-written per-row sorts — rank counting across a (half-)wave for short
+//               rows, bitonic networks in LDS for longer ones: 185-370 us against rocPRIM's 115 us + a host read; one
+//               wave per 23-entry row is three dependent memory round trips and little else.)
 // The norms are sorted on their upper 18 bits (exponent + 10 significant bits): any order is valid, a finer one buys
 // nothing, and the sort is two passes shorter.
 #include <rocprim/device/device_radix_sort.hpp>

@@ -600,3 +600,30 @@ def test_two_stage_stragglers_hand_their_users_to_the_fp32_sweep(d):
     finally:
         _lib.set_tuning('topk_fast_give_up', None)
 
+
+def test_two_stage_exclusion_lists_of_every_length_class():
+    """The candidate sweep walks each user's exclusion list in SWEEP positions, sorted row by row on the device (a segmented
+    radix sort): empty lists, short ones, lists of thousands of entries and one that leaves exactly k items.  The lists are
+    the fp32 sweep's."""
+    from igcn_cf_amd.ops import score_topk
+    rng = np.random.default_rng(23)
+    n_users, n_items, d, k = 300, 45000, 64, 20
+    U = (rng.standard_normal((n_users, d)) * 0.1).astype(np.float32)
+    I = (rng.standard_normal((n_items, d)) * 0.1 * np.exp(0.5 * rng.standard_normal((n_items, 1)))).astype(np.float32)
+    sizes = rng.integers(0, 64, size=n_users)
+    sizes[::7] = rng.integers(65, 2049, size=len(sizes[::7]))
+    sizes[3], sizes[10], sizes[50], sizes[100], sizes[200] = 2049, 16384, 16385, 30000, n_items - k
+    sizes[5], sizes[6], sizes[77] = 0, 64, 2048
+    ex = [np.sort(rng.choice(n_items, size=int(m), replace=False)) for m in sizes]
+    rowptr = np.zeros(n_users + 1, dtype=np.int64)
+    np.cumsum(sizes, out=rowptr[1:])
+    col = np.concatenate(ex).astype(np.int32)
+    kw = dict(excl_rowptr=_dev(rowptr), excl_col=_dev(col))
+    a = score_topk(_dev(U), _dev(I), k, mode='fast', **kw)
+    b = score_topk(_dev(U), _dev(I), k, mode='exact', **kw)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    got = a[0].cpu().numpy()
+    for u in (3, 10, 50, 100, 200, 6, 77):
+        assert not np.isin(got[u], ex[u]).any(), u
+    assert set(got[200].tolist()) == set(np.setdiff1d(np.arange(n_items), ex[200]).tolist())     # exactly the k items left
+
