@@ -164,8 +164,13 @@ static inline bool topk_one_wave_per_simd(int d_pad, int sweep_mode) { return sw
 // back: at d = 64 one 32-user group per wave then — a 64-user wave-group cut into the <= 58 pieces the merge takes cannot fill
 // the chip below ~2 000 users, half-size groups give twice the waves for the same work (20-40 users: 243 -> ~130 us).
 constexpr int64_t kNarrowBoundedBatch = 2048;
+static inline bool topk_narrow_small_batches() { return tuning_get(IGCN_TUNE_TOPK_FAST_NARROW) != 0; }
 static inline int topk_groups_per_wave(int d_pad, int sweep_mode = 0, int64_t batch = 0) {
     if (sweep_mode == -1 && d_pad == 64 && batch <= kNarrowBoundedBatch) return 1;
+    // The candidate sweep of a batch that cannot give every second wave slot a 64-user group is cut into pieces, and a piece's
+    // time is mostly the warm-up of its users' lists (k ln(n / k) candidates each, most of them in the first thousands of
+    // items, whatever the piece's length): 32-user groups halve that per wave and double the waves.
+    if (sweep_mode == 3 && d_pad == 64 && topk_narrow_small_batches() && (batch + 63) / 64 * 2 < 8 * (int64_t)cu_count()) return 1;
     return d_pad <= 64 || (d_pad == 128 && (sweep_mode == 3 || topk_one_wave_per_simd(d_pad, sweep_mode))) ? 2 : 1;
 }
 
@@ -349,7 +354,7 @@ struct TopkArgs {
 template <int D, int NG, bool FULL, int MODE = 0, bool BOUNDED = false>
 __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) void score_topk_kernel(const TopkArgs A)
 {
-    static_assert(MODE == 0 || (FULL && ((D == 64 && NG == 2) || ((MODE == 2 || MODE == 3) && D == 128))), "the candidate sweeps are built for d = 64 (and fp16: d = 128)");
+    static_assert(MODE == 0 || (FULL && ((D == 64 && (NG == 2 || MODE == 3)) || ((MODE == 2 || MODE == 3) && D == 128))), "the candidate sweeps are built for d = 64 (and fp16: d = 128)");
     constexpr int KS = D / 16;                                   // MODE 1 / 2 / 3: k-steps of 16 per row
     constexpr bool kF16 = MODE == 2 || MODE == 3;                // fp16 candidate sweep; MODE 3: ONE user plane (h only)
     constexpr int kUserPlanes = MODE == 3 ? 1 : 2;
@@ -751,7 +756,9 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
             build_masks(tile, tile_base);
             constexpr int kSlots = MODE == 1 ? 12 * NG : kF16 ? kUserPlanes * KS * NG : (D / 2) * NG;   // MFMAs of the block
             constexpr int kParts = 3 * kQuad * NG;                // selection instructions of the block
-            constexpr int kFirst = 4;                             // the first ones wait until the previous block's MFMAs have long retired
+            // the first ones wait until the previous block's MFMAs have long retired (a block of only 4 MFMAs — one 32-user group,
+            // one fp16 plane per side at d = 64 — keeps two for that: the staging code between two blocks adds to the distance)
+            constexpr int kFirst = kSlots >= 8 ? 4 : 2;
             if (tile + 1 < tin1) {
                 const char *tile_ptr = nullptr; unsigned off = 0;
                 if constexpr (MODE == 0) tile_addr(tile + 2 < tin1 ? tile + 2 : tin1 - 1, tile_ptr, off);   // (re-reads the last tile at the end)
@@ -1474,7 +1481,7 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
         if ((d != 64 && !(mode >= 2 && d == 128)) || !packed || (mode >= 2 && !stats)) return IGCN_E_SHAPE;
         if (d == 128 && mode == 3) rc = launch_topk<128, 2, true, 3>(p, st, a);
         else if (d == 128) rc = p.ng == 2 ? launch_topk<128, 2, true, 2>(p, st, a) : launch_topk<128, 1, true, 2>(p, st, a);
-        else rc = mode == 3 ? launch_topk<64, 2, true, 3>(p, st, a) : mode == 2 ? launch_topk<64, 2, true, 2>(p, st, a) : launch_topk<64, 2, true, 1>(p, st, a);
+        else rc = mode == 3 ? (p.ng == 1 ? launch_topk<64, 1, true, 3>(p, st, a) : launch_topk<64, 2, true, 3>(p, st, a)) : mode == 2 ? launch_topk<64, 2, true, 2>(p, st, a) : launch_topk<64, 2, true, 1>(p, st, a);
     } else {
         switch (p.d_pad) {
         case 16: rc = d == 16 ? launch_topk<16, 2, true>(p, st, a) : launch_topk<16, 2, false>(p, st, a); break;

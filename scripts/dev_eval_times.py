@@ -6,7 +6,7 @@ from igcn_cf_amd.dataset import SyntheticDataset
 from igcn_cf_amd.model import get_model
 from igcn_cf_amd.trainer import get_trainer
 dev = torch.device('cuda')
-ds = SyntheticDataset({'name': 'SyntheticDataset', 'preset': 'amazon', 'seed': 2021, 'device': dev})
+ds = SyntheticDataset({'name': 'SyntheticDataset', 'preset': os.environ.get('PRESET', 'amazon'), 'seed': 2021, 'device': dev})
 torch.manual_seed(2021)
 model = get_model({'name': 'LightGCN', 'embedding_size': 64, 'n_layers': 3, 'device': dev}, ds)
 trainer = get_trainer({'name': 'BPRTrainer', 'optimizer': 'Adam', 'lr': 1e-3, 'l2_reg': 1e-5, 'device': dev, 'n_epochs': 1,

@@ -99,6 +99,7 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
         ids = torch.from_numpy(rng.permutation(n_users).astype(np.int64)).cuda()
         Ut, It = torch.from_numpy(U).cuda(), torch.from_numpy(I).cuda()
         _lib.set_tuning('topk_fast_mode', 2 if case % 4 == 3 else None)
+        _lib.set_tuning('topk_fast_narrow', 0 if case % 3 == 2 else None)
         _lib.set_tuning('topk_fast_extra', int(rng.integers(1, 9)) if case % 5 == 4 else None)
         a = score_topk(Ut, It, k, user_ids=ids, mode='fast', **kw)
         b = score_topk(Ut, It, k, user_ids=ids, mode='exact', **kw)

@@ -88,7 +88,7 @@ def test_score_topk_matches_dense_oracle(d, n_users, n_items, k):
         _check_topk(scores[sub], idx.cpu().numpy(), val.cpu().numpy(), None, None, k)
 
 
-@pytest.mark.parametrize('mode', ['exact', 'fast', 'fast_bf16', 'fast_f16x2', 'fast_d128', 'fast_d128_f16x2', 'fast_d128_f16x2_narrow'])
+@pytest.mark.parametrize('mode', ['exact', 'fast', 'fast_64_user_groups', 'fast_bf16', 'fast_f16x2', 'fast_d128', 'fast_d128_f16x2', 'fast_d128_f16x2_narrow'])
 def test_score_topk_random_floats_match_sets(mode):
     """Gaussian fp32 embeddings: same top-k sets as the float64 ranking except where the
     k-th and (k+1)-th scores are within fp32 rounding of each other — for the fp32 sweep and for the two-stage
@@ -105,6 +105,8 @@ def test_score_topk_random_floats_match_sets(mode):
     # user planes — at d = 128 that one runs two user groups per wave at one wave per SIMD, or ('narrow') one group at two waves
     if mode == 'fast_bf16':
         _lib.set_tuning('topk_fast_mode', 1)
+    if mode == 'fast_64_user_groups':                    # (a batch this small runs 32-user wave-groups by default)
+        _lib.set_tuning('topk_fast_narrow', 0)
     if 'f16x2' in mode:
         _lib.set_tuning('topk_fast_mode', 2)
         _lib.set_tuning('topk_fast_wide', 0 if 'narrow' in mode else None)
@@ -128,6 +130,7 @@ def test_score_topk_random_floats_match_sets(mode):
     finally:
         _lib.set_tuning('topk_fast_mode', None)
         _lib.set_tuning('topk_fast_wide', None)
+        _lib.set_tuning('topk_fast_narrow', None)
     idx, val = idx.cpu().numpy(), val.cpu().numpy()
     assert list(idx[5]) == list(range(k))
     s64 = U.astype(np.float64) @ I.astype(np.float64).T
@@ -590,8 +593,9 @@ def test_two_stage_stragglers_hand_their_users_to_the_fp32_sweep(d):
     Ud, Id = _dev(U), _dev(I)
     ref = score_topk(Ud, Id, k, mode='exact', **kw)
     try:
-        for give_up in (None, 0):
+        for give_up, narrow in ((None, None), (0, None), (None, 0)):
             _lib.set_tuning('topk_fast_give_up', give_up)
+            _lib.set_tuning('topk_fast_narrow', narrow)            # 0: 64-user wave-groups although the batch is small
             got = score_topk(Ud, Id, k, mode='fast', **kw)
             flagged = score_topk.last_flagged
             assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), give_up
@@ -599,6 +603,7 @@ def test_two_stage_stragglers_hand_their_users_to_the_fp32_sweep(d):
                 assert 1 <= flagged <= 400, flagged               # the stragglers' users, not whole waves' worth of the batch
     finally:
         _lib.set_tuning('topk_fast_give_up', None)
+        _lib.set_tuning('topk_fast_narrow', None)
 
 
 def test_two_stage_exclusion_lists_of_every_length_class():
