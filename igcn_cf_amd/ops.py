@@ -505,7 +505,10 @@ def bpr_loss_terms(u_tab, p_tab, l2u_tab, l2p_tab, w, users, pos, neg, item_offs
     return BprLossFn.apply(u_tab, p_tab, l2u_tab, l2p_tab, w, users, pos, neg, item_offset, l2_item_offset, reduce_fn)
 
 
-FAST_TOPK_MIN_WORK = 1 << 26      # users x items from which the two-stage path pays for its packing pass and its host check
+# users x items from which the two-stage path pays for its order / packing passes and its host check (random-init tables,
+# MI355X, profiles/r03ai_*: 8 192 users x 96 k items 1.13 against 1.35 ms, 4 096 users 0.89 against 0.84 ms; 16 384 x 41 k
+# 1.02 against 1.25 ms, 8 192 x 41 k 0.85 against 0.78 ms)
+FAST_TOPK_MIN_WORK = 1 << 29
 
 
 def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_col=None, banned=None, batch=None, mode='auto',

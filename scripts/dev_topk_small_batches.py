@@ -7,8 +7,11 @@ import bench
 from igcn_cf_amd import _lib
 from igcn_cf_amd.ops import score_topk
 g = torch.Generator(device='cuda').manual_seed(0)
-for tag, nu, ni in (('gowalla', 29858, 40988), ('yelp', 75173, 42706), ('amazon users / 8', 13716, 96421), ('amazon users / 2', 54865, 96421),
-                    ('amazon', 109730, 96421), ('one test batch', 512, 96421)):
+CASES = (('gowalla', 29858, 40988), ('yelp', 75173, 42706), ('amazon users / 8', 13716, 96421), ('amazon users / 2', 54865, 96421),
+                    ('amazon', 109730, 96421), ('one test batch', 512, 96421))
+if len(sys.argv) > 1 and sys.argv[1] == 'crossover':
+    CASES = tuple(('%d users x %d items' % (b, n), b, n) for n in (96421, 40988, 10000) for b in (1024, 2048, 4096, 8192, 16384))
+for tag, nu, ni in CASES:
     U = torch.randn(nu, 64, device='cuda', generator=g) * 0.1
     I = torch.randn(ni, 64, device='cuda', generator=g) * 0.1
     rec = dict(case=tag, users=nu, items=ni)
