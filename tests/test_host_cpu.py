@@ -533,3 +533,19 @@ def test_generated_bipartite_graph_rank_shares_match_the_host_builder():
             np.testing.assert_array_equal(csr.val.numpy()[lp[j]:lp[j + 1]], val[rowptr[gr]:rowptr[gr + 1]])
         assert abs(csr.nnz / (rowptr[-1] / world) - 1) < 0.05                                    # nnz-balanced
     assert total == rowptr[-1] == g.nnz
+
+
+def test_xcd_plan_with_fewer_lists(golden):
+    """graph.xcd_plan(n_lists=4) (developer A/Bs: fewer, larger operand slices): four lists, the same cover."""
+    from igcn_cf_amd.graph import normalized_adjacency_host, xcd_plan
+    nu, ni = int(golden['n_users']), int(golden['n_items'])
+    n = nu + ni
+    rowptr, col, _ = normalized_adjacency_host(golden['train_array'], nu, ni)
+    lr, sg, order, off, load = xcd_plan(torch.from_numpy(rowptr), torch.from_numpy(col), [0, nu, n], 3, 4, n_lists=4)
+    assert off.shape[0] == 5 and load.shape[0] == 4 and int(off[-1]) == order.shape[0]
+    lens = np.diff(rowptr)
+    order = order.numpy()
+    assert sorted(order[order < n].tolist()) == np.flatnonzero(lens <= 3).tolist()
+    assert sorted((order[order >= n] - n).tolist()) == list(range(sg.shape[0]))
+    assert int(sg[:, 2].sum()) == int(lens[lens > 3].sum())
+
