@@ -76,6 +76,11 @@ def lift_flat(out, extras):
         'igcn_train_step_ms_yelp': get('igcn_step', 'train_step_ms'),
         'inductive_update_plus_eval_s': get('inductive_update', 'update_plus_eval_s'),
         'propagation_uniform_graph_edges_per_s': get('propagation_uniform_random_graph', 'edges_per_s'),
+        # N > 1 (same graph at every N): the no-exchange column sharding beside the headline's row sharding, the row-sharded
+        # training step, the user-sharded evaluation
+        'column_sharded_edges_per_s': get('column_sharded', 'edges_per_s'), 'column_sharded_ms_per_step': get('column_sharded', 'ms_per_step'),
+        'row_sharded_train_step_ms': get('row_sharded_train_step_ms'),
+        'user_sharded_eval_users_per_s': get('user_sharded_eval', 'eval_users_per_s'), 'user_sharded_eval_ms': get('user_sharded_eval', 'eval_ms'),
     }
     out.update({k: v for k, v in flat.items() if v is not None})
     r = out.get('roofline')
