@@ -1279,7 +1279,7 @@ __global__ __launch_bounds__(kBlock) void topk_pack_items_f16_kernel(const float
     const int64_t tile = i / (ks * kWave);
     const int64_t item = tile * 32 + (lane & 31);                 // sweep position
     if (tile_bound && lane == 0 && s == 0)
-        // the tile's first row is its longest up to the sort's granularity (norms ordered on 18 bits: < 2^-10 apart
+        // the tile's first row is its longest up to the sort's granularity (norms ordered on 16 bits: < 2^-8 apart
         // in |row|^2 inside a bucket); 1 % covers that, the fp16 rounding of the plane and the fp32 accumulation
         tile_bound[tile] = 1.01f * sqrtf(norm2[perm[item]]) * ldexpf(1.f, -scale_exp(__uint_as_float(stats[1])));
     float4 lo = f4_zero(), hi = f4_zero();

@@ -19,7 +19,7 @@
 //               (Tried and dropped, round 3: hand-written per-row sorts — rank counting across a (half-)wave for short
 //               rows, bitonic networks in LDS for longer ones: 185-370 us against rocPRIM's 115 us + a host read; one
 //               wave per 23-entry row is three dependent memory round trips and little else.)
-// The norms are sorted on their upper 18 bits (exponent + 10 significant bits): any order is valid, a finer one buys
+// The norms are sorted on their upper 16 bits (exponent + 8 significant bits: two radix passes): any order is valid, a finer one buys
 // nothing, and the sort is two passes shorter.
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kBlock) void excl_positions_kernel(const int32_t *_
 }
 
 static int bits_for(int64_t n) { int b = 1; while (b < 31 && ((int64_t)1 << b) < n) ++b; return b; }
-constexpr int kNormBeginBit = 13;                    // float bits [13, 31): exponent + 10 significant bits (the sign is 0)
+constexpr int kNormBeginBit = 15;                    // float bits [15, 31): exponent + 8 significant bits (the sign is 0)
 
 int topk_order_layout(int64_t n_items, int64_t excl_rows, int64_t excl_nnz, TopkOrderLayout *L)
 {
