@@ -344,6 +344,7 @@ struct TopkArgs {
     const float *tile_bound; const float *unorm2;
     // early exit bookkeeping (MODE 2 / 3, NULL: none): waves that left early; users a wave gave up on (see the sweep loop)
     unsigned int *exit_count; uint8_t *unfinished;
+    unsigned int *shared_thr;   // NULL, or per batch position the best k-th-best any piece of the user's sweep has published (see flush())
 };
 
 // FULL: d == D, no k-slice of a row is padding.  NG: 32-user groups of a wave.  MODE 0: fp32 MFMA, the exact fmaf
@@ -529,6 +530,19 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                 thr[g] = !user_ok[g] ? INFINITY : r ? key_score(r) : -INFINITY;   // list not full yet: everything may enter
                 // ... that reaches the caller's lower bound (the list fills from the items above it: there are >= k)
                 if constexpr (BOUNDED) { if (user_ok[g]) thr[g] = fmaxf(thr[g], A.init_thr[group * UPW + g * 32 + j]); }
+            }
+            if constexpr (MODE == 3 && D == 64) if (A.shared_thr) {      // (compiled into the default candidate sweep only: registers)
+                // The pieces a user's sweep is cut into run at the same time, each with a list of its own: they share their
+                // thresholds.  A piece's k-th best is a lower bound of the user's k-th best over the whole table, so every
+                // piece may use the largest one any of them has reached — the pieces over the short rows then stop staging
+                // almost at once instead of warming up a list nobody will look at.  (Sortable score bits, atomicMax; 0 = none.)
+                const int64_t b_own = group * UPW + lane;
+                if (owner && root && b_own < A.batch) atomicMax(A.shared_thr + b_own, (unsigned int)(root >> 32));
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const unsigned int sh = user_ok[g] ? A.shared_thr[group * UPW + g * 32 + j] : 0u;
+                    if (sh) thr[g] = fmaxf(thr[g], key_score((unsigned long long)sh << 32));
+                }
             }
 #ifdef IGCN_TOPK_STATS
             asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(thr[0]) : "memory");
@@ -1439,7 +1453,7 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
                     int32_t k, int64_t *out_idx, float *out_val, void *workspace, const float4 *packed,
                     const unsigned int *stats, hipStream_t st, const int32_t *perm = nullptr, const float *init_thr = nullptr,
                     const float *tile_bound = nullptr, const float *unorm2 = nullptr, unsigned int *exit_count = nullptr,
-                    uint8_t *unfinished = nullptr)
+                    uint8_t *unfinished = nullptr, unsigned int *shared_thr = nullptr)
 {
     if (!user_rows || !item_rows || !out_idx || !out_val) return IGCN_E_NULL;
     if ((excl_rowptr == nullptr) != (excl_col == nullptr)) return IGCN_E_NULL;
@@ -1476,6 +1490,7 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
     a.init_thr = init_thr;
     a.tile_bound = tile_bound; a.unorm2 = unorm2;
     a.exit_count = exit_count; a.unfinished = unfinished;
+    a.shared_thr = p.p_max > 1 ? shared_thr : nullptr;          // (only pieces have anything to share)
 
     if (mode != 0) {
         if ((d != 64 && !(mode >= 2 && d == 128)) || !packed || (mode >= 2 && !stats)) return IGCN_E_SHAPE;
@@ -1557,7 +1572,7 @@ static int topk_fast_layout(int64_t batch, int64_t n_items, int32_t d, int32_t k
     L->tile_bound = L->norm + 256;
     L->unorm2 = L->tile_bound + align256((int64_t)p.n_tiles * 4);
     L->exit_state = L->unorm2 + align256(batch * 4);                  // [256 B: waves that left early][batch B: users given up on]
-    L->order = L->exit_state + 256 + align256(batch);
+    L->order = L->exit_state + 256 + align256(batch) + align256(batch * 4);   // (+ the thresholds the pieces of a sweep share)
     L->total = L->order + L->ord.total;
     return IGCN_OK;
 }
@@ -1639,8 +1654,10 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     const bool give_up = early_exit && sweep_plan.rest_tiles == 0 && tuning_get(IGCN_TUNE_TOPK_FAST_GIVE_UP) != 0;
     unsigned int *exit_count = reinterpret_cast<unsigned int *>(ws + L.exit_state);
     uint8_t *unfinished = reinterpret_cast<uint8_t *>(ws + L.exit_state + 256);
-    if (give_up) {
-        e = hipMemsetAsync(ws + L.exit_state, 0, (size_t)(256 + batch), st);
+    unsigned int *shared_thr = reinterpret_cast<unsigned int *>(ws + L.exit_state + 256 + align256(batch));
+    const bool share = sweep_plan.p_max > 1 && mode == 3 && d == 64 && tuning_get(IGCN_TUNE_TOPK_FAST_SHARE) != 0;
+    if (give_up || share) {
+        e = hipMemsetAsync(ws + L.exit_state, 0, (size_t)(256 + align256(batch) + (share ? batch * 4 : 0)), st);
         if (e != hipSuccess) return (int)e;
     }
     // the sweep runs in position space: its exclusion lists and banned bits are those of the positions, and the
@@ -1648,7 +1665,7 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     rc = topk_run(mode, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, d, excl_rowptr, by_norm && excl_rowptr ? excl_pos : excl_col,
                   banned, L.kc, cand_idx, cand_val, ws + L.sweep, packed, norm_bits, st, perm, nullptr,
                   early_exit ? tile_bound : nullptr, early_exit ? unorm2 : nullptr, give_up ? exit_count : nullptr,
-                  give_up ? unfinished : nullptr);
+                  give_up ? unfinished : nullptr, share ? shared_thr : nullptr);
     if (rc != IGCN_OK) return rc;
     if (L.kc <= 32)
         hipLaunchKernelGGL(topk_rescore_kernel<32>, dim3((unsigned)((batch + 7) / 8)), dim3(kBlock), 0, st, user_rows, ldu, user_ids, batch,

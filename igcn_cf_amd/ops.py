@@ -506,9 +506,9 @@ def bpr_loss_terms(u_tab, p_tab, l2u_tab, l2p_tab, w, users, pos, neg, item_offs
 
 
 # users x items from which the two-stage path pays for its order / packing passes and its host check (random-init tables,
-# MI355X, profiles/r03ai_*: 8 192 users x 96 k items 1.13 against 1.35 ms, 4 096 users 0.89 against 0.84 ms; 16 384 x 41 k
-# 1.02 against 1.25 ms, 8 192 x 41 k 0.85 against 0.78 ms)
-FAST_TOPK_MIN_WORK = 1 << 29
+# MI355X, profiles/r03ai_*, with the pieces of a cut sweep sharing their thresholds: 2 048 users x 96 k items 0.49 against 0.57 ms,
+# 1 024 users 0.43 against 0.47; 4 096 x 41 k 0.54 against 0.52, 2 048 x 41 k 0.46 against 0.42; 16 384 x 10 k 0.56 against 0.56)
+FAST_TOPK_MIN_WORK = 1 << 27
 
 
 def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_col=None, banned=None, batch=None, mode='auto',

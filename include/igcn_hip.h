@@ -41,7 +41,8 @@ const char *igcn_error_string(int code);
 /* Developer / test knobs of the launch heuristics (no reference counterpart).  name: "spmm_blocks_per_cu",
  * "spmm_multirow", "topk_slots", "topk_waves_per_cu", "topk_cap", "topk_stagger", "topk_fast_order", "topk_fast_exit",
  * "topk_fast_wide", "topk_fast_extra" (candidates kept beyond k), "topk_fast_give_up" (0: no wave hands users over),
- * "topk_fast_narrow" (0: small batches keep 64-user wave-groups), "topk_fast_mode" (candidate sweep of
+ * "topk_fast_narrow" (0: small batches keep 64-user wave-groups), "topk_fast_share" (0: the pieces of a cut sweep
+ * keep their thresholds to themselves), "topk_fast_mode" (candidate sweep of
  * igcn_score_topk_fast_f32: 3 = one fp16 plane each side, the default; 2 = two fp16 user planes; 1 = two bf16 planes each side,
  * d = 64 only); value < 0 restores the library
  * default.  Results never depend on them (tests/test_spmm_gpu.py::test_launch_shape_does_not_change_results).

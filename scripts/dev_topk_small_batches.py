@@ -16,11 +16,14 @@ for tag, nu, ni in CASES:
     I = torch.randn(ni, 64, device='cuda', generator=g) * 0.1
     rec = dict(case=tag, users=nu, items=ni)
     ref = score_topk(U, I, 20, mode='exact')
-    for narrow in (None, 0):
+    for tag, narrow, share in (('default', None, None), ('pieces_do_not_share_thresholds', None, 0), ('64_user_groups', 0, None)):
         _lib.set_tuning('topk_fast_narrow', narrow)
+        _lib.set_tuning('topk_fast_share', share)
         a = score_topk(U, I, 20, mode='fast')
-        assert torch.equal(a[0], ref[0]) and torch.equal(a[1], ref[1])
-        rec['ms_%s' % ('32_user_groups_when_small' if narrow is None else '64_user_groups')] = round(min(bench.time_ms(lambda: score_topk(U, I, 20, mode='fast'), 5, 2) for _ in range(2)), 3)
+        assert torch.equal(a[0], ref[0]) and torch.equal(a[1], ref[1]), tag
+        rec['ms_' + tag] = round(min(bench.time_ms(lambda: score_topk(U, I, 20, mode='fast'), 5, 2) for _ in range(2)), 3)
+        rec['flagged_' + tag] = score_topk.last_flagged
     _lib.set_tuning('topk_fast_narrow', None)
+    _lib.set_tuning('topk_fast_share', None)
     rec['ms_fp32_sweep'] = round(bench.time_ms(lambda: score_topk(U, I, 20, mode='exact'), 3, 1), 3)
     print(json.dumps(rec), flush=True)

@@ -84,6 +84,7 @@ def test_score_topk_fuzz():
         # two bf16 planes each side / one fp16 item plane + two user planes / one fp16 plane each side (default)
         _lib.set_tuning('topk_fast_mode', 1 if case % 4 == 0 else 2 if case % 8 == 2 else None)
         _lib.set_tuning('topk_fast_narrow', 0 if case % 16 == 6 else None)           # 64-user wave-groups on a small batch
+        _lib.set_tuning('topk_fast_share', 0 if case % 16 == 14 else None)          # pieces keep their thresholds to themselves
         idx, val = score_topk(torch.from_numpy(U).cuda(), torch.from_numpy(I).cuda(), k, user_ids=torch.from_numpy(ids).cuda(),
                               mode=mode, **kw)
         s = scores[ids].copy()
@@ -99,3 +100,4 @@ def test_score_topk_fuzz():
     _lib.set_tuning('topk_slots', None)
     _lib.set_tuning('topk_fast_mode', None)
     _lib.set_tuning('topk_fast_narrow', None)
+    _lib.set_tuning('topk_fast_share', None)

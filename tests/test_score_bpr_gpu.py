@@ -88,7 +88,7 @@ def test_score_topk_matches_dense_oracle(d, n_users, n_items, k):
         _check_topk(scores[sub], idx.cpu().numpy(), val.cpu().numpy(), None, None, k)
 
 
-@pytest.mark.parametrize('mode', ['exact', 'fast', 'fast_64_user_groups', 'fast_bf16', 'fast_f16x2', 'fast_d128', 'fast_d128_f16x2', 'fast_d128_f16x2_narrow'])
+@pytest.mark.parametrize('mode', ['exact', 'fast', 'fast_64_user_groups', 'fast_no_sharing', 'fast_bf16', 'fast_f16x2', 'fast_d128', 'fast_d128_f16x2', 'fast_d128_f16x2_narrow'])
 def test_score_topk_random_floats_match_sets(mode):
     """Gaussian fp32 embeddings: same top-k sets as the float64 ranking except where the
     k-th and (k+1)-th scores are within fp32 rounding of each other — for the fp32 sweep and for the two-stage
@@ -107,6 +107,8 @@ def test_score_topk_random_floats_match_sets(mode):
         _lib.set_tuning('topk_fast_mode', 1)
     if mode == 'fast_64_user_groups':                    # (a batch this small runs 32-user wave-groups by default)
         _lib.set_tuning('topk_fast_narrow', 0)
+    if mode == 'fast_no_sharing':                        # (the pieces of this small batch's sweeps share thresholds by default)
+        _lib.set_tuning('topk_fast_share', 0)
     if 'f16x2' in mode:
         _lib.set_tuning('topk_fast_mode', 2)
         _lib.set_tuning('topk_fast_wide', 0 if 'narrow' in mode else None)
@@ -131,6 +133,7 @@ def test_score_topk_random_floats_match_sets(mode):
         _lib.set_tuning('topk_fast_mode', None)
         _lib.set_tuning('topk_fast_wide', None)
         _lib.set_tuning('topk_fast_narrow', None)
+        _lib.set_tuning('topk_fast_share', None)
     idx, val = idx.cpu().numpy(), val.cpu().numpy()
     assert list(idx[5]) == list(range(k))
     s64 = U.astype(np.float64) @ I.astype(np.float64).T
