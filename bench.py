@@ -67,9 +67,23 @@ def lift_flat(out, extras):
         'eval_with_metrics_ms': get('eval_with_metrics_ms'),
         'eval_ms_after_2_epochs': get('eval_trained', 'eval_ms'), 'eval_ms_after_2_epochs_fp32_sweep': get('eval_trained', 'eval_ms_fp32_sweep'),
         'eval_d128_scoring_ms_fp32_sweep': get('eval_d128', 'scoring_ms_fp32_sweep'), 'eval_d128_scoring_ms_two_stage': get('eval_d128', 'scoring_ms_two_stage'),
-        'hbm_bound_kernel': get('roofline_hbm_bound', 'kernel'), 'hbm_bound_GBps': get('roofline_hbm_bound', 'achieved'),
-        'hbm_bound_frac': get('roofline_hbm_bound', 'frac'), 'hbm_bound_ms': get('roofline_hbm_bound', 'avg_launch_ms'),
+        # the HBM-bound leg (config 5, rank 0 of 8): counter bytes / time first (what left L2, rocprofv3 pass on file), the
+        # algorithmic figure (SURVEY 8(d) bytes; exceeds what HBM streams when gathers hit caches) under its own name
+        'hbm_bound_kernel': get('roofline_hbm_bound', 'kernel'), 'hbm_bound_ms': get('roofline_hbm_bound', 'avg_launch_ms'),
         'hbm_bound_workload': get('roofline_hbm_bound', 'workload_short'),
+        'hbm_bound_counter_GBps': get('roofline_hbm_bound', 'counter_GBps'), 'hbm_bound_counter_frac': get('roofline_hbm_bound', 'counter_frac'),
+        'hbm_bound_counter_frac_of_measured_stream': get('roofline_hbm_bound', 'counter_frac_of_measured_stream'),
+        'hbm_bound_algorithmic_GBps': get('roofline_hbm_bound', 'algorithmic_GBps'), 'hbm_bound_algorithmic_frac': get('roofline_hbm_bound', 'algorithmic_frac'),
+        'hbm_bound_item_block_ms': get('roofline_hbm_bound', 'blocks', 'item_block', 'ms'),
+        'hbm_bound_item_block_GBps': get('roofline_hbm_bound', 'blocks', 'item_block', 'counter_GBps'),
+        'hbm_bound_item_block_frac': get('roofline_hbm_bound', 'blocks', 'item_block', 'counter_frac'),
+        'hbm_bound_item_block_frac_of_measured_stream': get('roofline_hbm_bound', 'blocks', 'item_block', 'counter_frac_of_measured_stream'),
+        'hbm_bound_item_block_algorithmic_GBps': get('roofline_hbm_bound', 'blocks', 'item_block', 'algorithmic_GBps'),
+        'hbm_bound_user_block_ms': get('roofline_hbm_bound', 'blocks', 'user_block', 'ms'),
+        'hbm_bound_user_block_GBps': get('roofline_hbm_bound', 'blocks', 'user_block', 'counter_GBps'),
+        'hbm_bound_user_block_algorithmic_GBps': get('roofline_hbm_bound', 'blocks', 'user_block', 'algorithmic_GBps'),
+        'hbm_stream_read_GBps': get('roofline_hbm_bound', 'stream_read_GBps'), 'hbm_stream_copy_GBps': get('roofline_hbm_bound', 'stream_copy_GBps'),
+        'hbm_random_row_guide_GBps': 5700.0 if get('roofline_hbm_bound') else None,      # MI355X_MICROARCH.md: once-read random rows, 5.5-5.8 TB/s
         'hbm_bound_rank_ms_min': get('roofline_hbm_bound', 'rank_ms_min'), 'hbm_bound_rank_ms_max': get('roofline_hbm_bound', 'rank_ms_max'),
         'train_step_ms': get('train_step_ms'), 'train_step_ms_gowalla_hip_graph': get('launch_bound_config', 'train_step_ms_hip_graph'),
         'mf_train_step_ms_gowalla': get('launch_bound_config', 'mf_train_step_ms_hip_graph'),
@@ -82,10 +96,20 @@ def lift_flat(out, extras):
         'row_sharded_train_step_ms': get('row_sharded_train_step_ms'),
         'user_sharded_eval_users_per_s': get('user_sharded_eval', 'eval_users_per_s'), 'user_sharded_eval_ms': get('user_sharded_eval', 'eval_ms'),
     }
+    # BASELINE config 5 across ranks ('halves' exchange, K = 3, d = 128; at N = 1 the whole graph on the one GPU)
+    c5 = get('config5_sharded')
+    if isinstance(c5, dict):
+        flat.update({'config5_' + k: v for k, v in c5.items() if isinstance(v, (int, float, bool)) or (isinstance(v, str) and len(v) <= 120)})
     out.update({k: v for k, v in flat.items() if v is not None})
     r = out.get('roofline')
     if isinstance(r, dict):
-        for k in ('eval_mfma_frac', 'hbm_bound_frac', 'hbm_bound_GBps', 'hbm_bound_kernel'):
+        # the driver keeps the VALUES of the nested roofline object (of other extra keys only the names): the second half of
+        # BASELINE's metric (eval users/s), the MFMA fraction, the HBM-bound leg and the steps ride along here
+        for k in ('eval_users_per_s', 'eval_users_per_s_fp32_sweep', 'eval_ms', 'eval_ms_after_2_epochs', 'eval_mfma_frac', 'train_step_ms',
+                  'hbm_bound_kernel', 'hbm_bound_ms', 'hbm_bound_counter_GBps', 'hbm_bound_counter_frac', 'hbm_bound_algorithmic_GBps',
+                  'hbm_bound_algorithmic_frac', 'hbm_bound_item_block_GBps', 'hbm_bound_item_block_frac',
+                  'hbm_bound_item_block_frac_of_measured_stream', 'hbm_stream_read_GBps', 'hbm_stream_copy_GBps',
+                  'config5_pass_ms', 'config5_edges_per_s', 'config5_exposed_exchange_ms', 'config5_local_spmm_ms'):
             if flat.get(k) is not None:
                 r[k] = flat[k]
 
@@ -101,7 +125,42 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the eval / train-step side measurements')
     ap.add_argument('--no-hbm-leg', action='store_true', help='skip the HBM-bound config-5 shard leg (extras.roofline_hbm_bound)')
+    ap.add_argument('--no-config5', action='store_true', help='skip BASELINE config 5 across the ranks of this job (extras.config5_sharded)')
     return ap.parse_args()
+
+
+def spawn_ranks(args, json_fd):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes (python -m
+    torch.distributed.run, the driver's own N > 1 command), relay rank 0's JSON line, return the children's status.
+    This process has made no GPU call (torch.cuda.device_count() does not initialise the runtime on this image) and
+    makes none: a process that touched the GPU must never exec or fork GPU work."""
+    import socket
+    import subprocess
+    env = dict(os.environ)
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and env.get('IGCN_BENCH_ONE_GPU') != '1':
+        sys.stderr.write('bench.py --gpus %d: %d GPU(s) visible.  IGCN_BENCH_ONE_GPU=1 rehearses the N > 1 code path with every '
+                         'rank on cuda:0 over gloo (its timings are not measurements).\n' % (args.gpus, n_dev))
+        return 2
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE)
+    line = None
+    for raw in proc.stdout:
+        text = raw.decode('utf-8', 'replace')
+        if text.startswith('{'):
+            line = text
+        else:
+            sys.stderr.write(text)
+    rc = proc.wait()
+    if line is not None:
+        os.write(json_fd, line.encode())
+    return rc
 
 
 def main():
@@ -110,6 +169,8 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(args, json_fd))      # plain `python bench.py --gpus N`: this process becomes the launcher
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -250,7 +311,8 @@ def main():
             'probe_gathered_row_GBps_uniform_random': g['gathered_row_GBps_uniform_random'],
             'frac_of_compulsory': b_min / b_alg, 'rank': rank, 'world': world}
     if not sharded:
-        roof['hbm_copy_measured_GBps'] = measured_copy_GBps(device)
+        st = measured_stream(device)
+        roof['hbm_stream_read_GBps'], roof['hbm_stream_copy_GBps'] = st['read_GBps'], st['copy_GBps']
         t = stored_traffic(kernel_name, args.preset, nnz, d)
         roof['traffic'] = t['bytes'] if t else None
         roof['traffic_source'] = t['source'] if t else 'no PMC pass on file for this kernel/workload'
@@ -262,6 +324,7 @@ def main():
         roof['traffic'] = None
     out['roofline'] = roof
     extras = {}
+    stream_probe = None if sharded else st
     if sharded and not args.no_extras:
         extras = sharded_side_measurements(ds, device, d, K, rank, world, rowptr, col, val, emb_host, barrier_sync, job_max)
     if not sharded and not args.no_extras:
@@ -270,7 +333,14 @@ def main():
     if not sharded and not args.no_hbm_leg:
         del csr, x0
         torch.cuda.empty_cache()
-        extras['roofline_hbm_bound'] = hbm_bound_leg(device)
+        extras['roofline_hbm_bound'] = hbm_bound_leg(device, stream_probe=stream_probe)
+        torch.cuda.empty_cache()
+    if not args.no_config5:
+        # BASELINE config 5 across the ranks of this job (N = 1: the whole graph on the one GPU)
+        if sharded:
+            del prop, eu, ei
+        torch.cuda.empty_cache()
+        extras['config5_sharded'] = config5_sharded_leg(device, rank, world, rehearsal, barrier_sync, job_max)
     extras['gather_roof'] = g
     out['extras'] = extras
     lift_flat(out, extras)
@@ -341,6 +411,88 @@ def sharded_side_measurements(ds, device, d, K, rank, world, rowptr, col, val, e
     return res
 
 
+def config5_sharded_leg(device, rank, world, rehearsal, barrier_sync, job_max, K=3, d=128, reps=3):
+    """BASELINE config 5 ACROSS the ranks of this job: the bipartite 10 M x 2 M x ~500 M-edge graph (the same seeded device
+    generator on every rank), rows of A_hat cut with ShardLayout.balanced(world); every rank builds ONLY its own two
+    blocks in HBM (synth.rank_blocks: padded rows, padded column ids — no CSR of the whole graph anywhere), then K = 3
+    layers at d = 128 under the 'halves' exchange: per layer two local SpMMs and two all-gathers (RCCL over xGMI), each
+    all-gather in flight under the OTHER half's SpMM, the layer mean in the last launches' epilogue
+    (dist.RowShardedPropagator; the layer sharded is model.py:96-106).  A step = X_0 exchange + the K-layer pass.
+    At world = 1 the same code runs the whole graph on the one GPU (the N = 1 point of this leg's curve).
+    rehearsal (every rank on cuda:0, gloo): a reduced graph (1 M x 200 k x ~50 M edges); timings are not measurements."""
+    from igcn_cf_amd.dist import RowShardedPropagator, ShardLayout
+    from igcn_cf_amd.synth import BipartiteGraphDevice, check_rows_f64
+    from igcn_cf_amd import ops
+    sizes = (1_000_000, 200_000, 50_000_000) if rehearsal else (10_000_000, 2_000_000, 500_000_000)
+    t0 = time.perf_counter()
+    g = BipartiteGraphDevice(*sizes, device, seed=2021)
+    layout = ShardLayout.balanced(g.rowptr_host(), g.n_users, g.n_items, world)
+    blocks = g.rank_blocks(layout, rank)
+    n_users, n_items, n_edges, nnz = g.n_users, g.n_items, g.n_edges, g.nnz
+    del g                                                             # the pair list (8 GB at full size) is not needed again
+    torch.cuda.empty_cache()
+    prop = RowShardedPropagator(None, n_users, n_items, K, rank, world, device, exchange='halves', layout=layout, local_blocks=blocks,
+                                global_nnz=nnz)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    (ulo, uhi), (ilo, ihi) = layout.user_rows(rank), layout.item_rows(rank)
+    gen = torch.Generator(device=device).manual_seed(100 + rank)
+    eu = torch.randn(uhi - ulo, d, device=device, generator=gen) * 0.1
+    ei = torch.randn(ihi - ilo, d, device=device, generator=gen) * 0.1
+
+    def step():
+        prop.load_local_embedding(eu, ei)
+        return prop.propagate()
+
+    def timed(fn, n, warm):
+        for _ in range(warm):
+            fn()
+        barrier_sync()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        barrier_sync()
+        return job_max(time.perf_counter() - t) / n * 1e3
+    pass_ms = timed(step, reps, 2)
+    # one layer's local products alone (same operands, same stream, no collective): plain launches and the epilogue launches
+    own, rep = prop._buffers(d)
+    parts = {'u': prop.csr_u, 'i': prop.csr_i}
+    s = 1.0 / (K + 1)
+    ms = {}
+    for p_, csr in parts.items():
+        ms[p_] = time_ms(lambda: ops.spmm(csr, rep[0], out=prop._part(own[1], p_)), reps, 1)
+        ms[p_ + '_last'] = time_ms(lambda: ops.spmm(csr, rep[0], out=prop._part(own[K], p_), adds=[prop._part(o, p_) for o in own[:K]],
+                                                    out_scale=s, add_scale=s), reps, 1)
+    local_ms = (K - 1) * (ms['u'] + ms['i']) + ms['u_last'] + ms['i_last']
+    # the pass's all-gathers alone (X_0 + K - 1 layers, two halves each), nothing computed beside them
+    def gathers():
+        for _ in range(K):
+            ws = [prop._allgather(prop._section(rep[0], p_), prop._part(own[0], p_), True) for p_ in ('u', 'i')]
+            for w in ws:
+                if w is not None:
+                    w.wait()
+    gather_ms = timed(gathers, reps, 1)
+    rows = torch.randint(0, max(uhi - ulo, 1), (16,), device=device, generator=gen).tolist()
+    prop.load_local_embedding(eu, ei)
+    y = ops.spmm(prop.csr_u, rep[0])
+    err = check_rows_f64(prop.csr_u, rep[0], y, rows)
+    b_alg = prop.local_nnz * (8 + 4 * d) + (layout.bu + layout.bi) * (4 * d + 4)       # one layer on this rank
+    local_layer_ms = local_ms / K
+    out = {'label': ('REHEARSAL (all ranks on one GPU, gloo, reduced graph): not a measurement' if rehearsal else
+                     'config 5 across %d rank(s), halves exchange, K=%d d=%d' % (world, K, d)),
+           'world': world, 'users': n_users, 'items': n_items, 'edges': n_edges, 'nnz': nnz, 'd': d, 'n_layers': K,
+           'pass_ms': pass_ms, 'edges_per_s': K * nnz / (pass_ms / 1e3),
+           'local_spmm_ms': local_ms, 'exposed_exchange_ms': max(pass_ms - local_ms, 0.0), 'allgathers_alone_ms': gather_ms,
+           'user_block_ms': ms['u'], 'item_block_ms': ms['i'], 'user_block_last_layer_ms': ms['u_last'], 'item_block_last_layer_ms': ms['i_last'],
+           'local_nnz': prop.local_nnz, 'rank_algorithmic_GBps': b_alg / local_layer_ms / 1e6,
+           'rank_algorithmic_frac_of_hbm_peak': b_alg / local_layer_ms / 1e6 / HBM_PEAK_GBPS,
+           'exchanged_bytes_per_rank_per_pass': K * (world - 1) * (layout.bu + layout.bi) * d * 4,
+           'build_s': build_s, 'sample_rel_err_vs_f64': err,
+           'note': 'pass = X_0 exchange + K layers; local_spmm_ms = the 2K local launches timed alone (rank %d); exposed_exchange_ms = '
+                   'pass - local (what the overlap did not hide, plus waits on slower ranks); max over ranks where collective' % rank}
+    return out
+
+
 def uniform_graph_pass(device, preset, d, K):
     """The same pass on a graph of the same size whose items are drawn uniformly (zipf_a = 0): no hot item rows for L2
     to keep, no long rows — the worst-case locality variant SURVEY 8(d) asks for next to the popularity-skewed headline."""
@@ -369,12 +521,30 @@ def time_ms(fn, reps, warm):
     return e0.elapsed_time(e1) / reps
 
 
-def measured_copy_GBps(device):
-    """What a plain device copy reaches on THIS box (read + write bytes)."""
-    src = torch.empty(1 << 28, dtype=torch.float32, device=device)
+def measured_stream(device, gib=2, reps=10):
+    """What THIS box streams (csrc/roof_probe.hip: 16 bytes per lane, four loads in flight, grid-stride): read-only and
+    copy over 2 GiB buffers — far beyond the 256 MiB Infinity Cache —, the best of several grids, >= 10 launches each."""
+    lib = roof_lib()
+    n4 = gib * (1 << 30) // 16
+    src = torch.ones(4 * n4, dtype=torch.float32, device=device)
     dst = torch.empty_like(src)
-    ms = time_ms(lambda: dst.copy_(src), 5, 1)
-    return 2 * src.numel() * 4 / ms / 1e6
+    stream = torch.cuda.current_stream().cuda_stream
+    out = {'buffer_GiB': gib, 'launches_per_grid': reps}
+    for mode, key, nbytes in ((0, 'read', 16 * n4), (1, 'copy', 32 * n4)):
+        grids = {}
+        for variant, vname in ((0, '4 in flight'), (1, '8 in flight'), (2, '4 in flight, nt'), (3, '8 in flight, nt')):
+            for wg_per_cu in (4, 8, 16, 32, 64):
+                blocks = 256 * wg_per_cu
+
+                def run():
+                    rc = lib.igcn_roof_stream_f32(src.data_ptr(), dst.data_ptr(), n4, mode, variant, blocks, stream)
+                    if rc != 0:
+                        raise RuntimeError('igcn_roof_stream_f32 failed: %d' % rc)
+                grids['%s, %d workgroups' % (vname, blocks)] = nbytes / time_ms(run, reps, 2) / 1e6
+        best = max(grids, key=grids.get)
+        out[key + '_GBps'], out[key + '_best_variant'] = grids[best], best
+        out[key + '_GBps_by_variant'] = grids
+    return out
 
 
 _roof_lib = None
@@ -389,6 +559,8 @@ def roof_lib():
         lib.igcn_roof_gather_f32.restype = C.c_int
         lib.igcn_roof_gather_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                              C.c_int64, C.c_int32, C.c_int64, C.c_void_p]
+        lib.igcn_roof_stream_f32.restype = C.c_int
+        lib.igcn_roof_stream_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_void_p]
         _roof_lib = lib
     return _roof_lib
 
@@ -440,12 +612,45 @@ def stored_traffic(kernel_name, preset, nnz, d):
                       % t.get('tag', '?')}
 
 
-def hbm_bound_leg(device, reps=5, ranks=(0,)):
+def stored_config5_traffic(nnz, d):
+    """Counter-measured bytes beyond L2 per launch (2 x FETCH_SIZE + WRITE_SIZE, MI355X_MICROARCH.md's gfx950 correction) of the
+    config-5 rank share, of its user block alone and of its item block alone — from the committed rocprofv3 --pmc passes
+    (profiles/pmc_traffic_config5.json, scripts/profile_config5.sh), only if they were taken on this very share."""
+    try:
+        t = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic_config5.json')))
+    except Exception:
+        return None
+    if t.get('d') != d or t.get('launches', {}).get('whole', {}).get('nnz') != nnz:
+        return None
+    return t
+
+
+def split_share(csr, n_user_rows):
+    """The two row blocks of a rank share [user rows; item rows] as matrices of their own (views of the same col / val):
+    what the 'halves' exchange launches one after the other (dist.RowShardedPropagator.csr_u / csr_i)."""
+    from igcn_cf_amd.graph import CsrMatrix
+    e_u = int(csr.rowptr_host[n_user_rows])
+    cu = CsrMatrix.from_device(csr.rowptr[:n_user_rows + 1].clone(), csr.col[:e_u], csr.val[:e_u], (n_user_rows, csr.shape[1]),
+                               order_blocks=[0, n_user_rows])
+    ni = csr.shape[0] - n_user_rows
+    ci = CsrMatrix.from_device(csr.rowptr[n_user_rows:] - e_u, csr.col[e_u:], csr.val[e_u:], (ni, csr.shape[1]), order_blocks=[0, ni])
+    return cu, ci
+
+
+def hbm_bound_leg(device, reps=5, ranks=(0,), stream_probe=None):
     """The HBM-bound leg: BASELINE config 5 as written — the bipartite 10 M x 2 M x ~500 M-edge graph generated in HBM
     (igcn_cf_amd/synth.py, SURVEY 8(d) generator rules), cut with ShardLayout.balanced(world = 8); rank 0's share (its
     user block gathering item rows + its item block gathering user rows, ~125 M nonzeros) against the full replicated
     operand X (12 M x 128 fp32 = 6.1 GB, far beyond the Infinity Cache).  One launch of igcn_spmm_csr_f32
-    (spmm_csr_rows_kernel<32,false>) per share; `ranks` = the shares to run (scripts/dev_config5_shares.py runs all 8)."""
+    (spmm_csr_rows_kernel<32,false>) per share; `ranks` = the shares to run (scripts/dev_config5_shares.py runs all 8).
+
+    Three rates per launch, never mixed: ALGORITHMIC bytes / time (every gathered row counted, cache-served
+    or not — can exceed what HBM streams); COUNTER bytes / time (2 x FETCH_SIZE + WRITE_SIZE of the committed rocprofv3
+    pass of this share: what left L2 — Infinity-Cache hits included, the guide says — over THIS run's time); and both
+    against the 8 TB/s spec and against what this box streams (measured_stream).  The two row blocks are also timed as
+    launches of their own: the item block gathers from the 10 M user rows (5.1 GB, each row read ~once: nothing to
+    cache — the truly HBM-bound half), the user block from the 2 M item rows (1.0 GB with a Zipf-Mandelbrot head that
+    the Infinity Cache keeps)."""
     from igcn_cf_amd.dist import ShardLayout
     from igcn_cf_amd.synth import BipartiteGraphDevice, check_rows_f64
     from igcn_cf_amd import ops
@@ -475,8 +680,20 @@ def hbm_bound_leg(device, reps=5, ranks=(0,)):
     csr, y, b_alg, ms, err = first
     gr = gather_roof(device, csr.col, csr.val, x, csr.shape[0], d, reps=3)
     ach = b_alg / ms / 1e6
-    out = {'bound': 'hbm', 'kernel': 'spmm_csr_rows_kernel<32,false>', 'achieved': ach, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s',
-           'frac': ach / HBM_PEAK_GBPS, 'avg_launch_ms': ms, 'algorithmic_bytes_per_launch': b_alg,
+    # the two row blocks as launches of their own (what the 'halves' exchange runs one after the other)
+    nu_l = per_rank[0]['user_rows']
+    blocks = {}
+    for name, blk, yb in zip(('user_block', 'item_block'), split_share(csr, nu_l), (y[:nu_l], y[nu_l:])):
+        ms_b = min(time_ms(lambda: ops.spmm(blk, x, out=yb), reps, 2) for _ in range(2))
+        alg_b = blk.nnz * (8 + 4 * d) + blk.shape[0] * (4 * d + 4)
+        blocks[name] = {'rows': blk.shape[0], 'nnz': blk.nnz, 'ms': ms_b, 'algorithmic_bytes': alg_b, 'algorithmic_GBps': alg_b / ms_b / 1e6,
+                        'gathers_from': ('the 2 M item rows (1.0 GB, popularity-skewed: hot head in the Infinity Cache)' if name == 'user_block'
+                                         else 'the 10 M user rows (5.1 GB, near-uniform: nothing to cache)')}
+    st = stream_probe or measured_stream(device)
+    out = {'kernel': 'spmm_csr_rows_kernel<32,false>', 'unit': 'GB/s', 'peak': HBM_PEAK_GBPS, 'avg_launch_ms': ms,
+           'algorithmic_bytes_per_launch': b_alg, 'algorithmic_GBps': ach, 'algorithmic_frac': ach / HBM_PEAK_GBPS,
+           'algorithmic_note': 'SURVEY 8(d) bytes (every gathered row counted) / time: exceeds what HBM streams when gathers hit caches',
+           'stream_read_GBps': st['read_GBps'], 'stream_copy_GBps': st['copy_GBps'],
            'workload': 'BASELINE config 5: bipartite %d users x %d items x %d edges (synthetic, Zipf-Mandelbrot items, log-normal '
                        'user degrees >= 7), d=128, rank %d of 8 under nnz-balanced row sharding: %d user rows + %d item rows, %d '
                        'nonzeros, operand %d x %d fp32 = %.1f GB' % (g.n_users, g.n_items, g.n_edges, ranks[0], per_rank[0]['user_rows'],
@@ -485,7 +702,26 @@ def hbm_bound_leg(device, reps=5, ranks=(0,)):
                              % (g.n_edges / 1e6, ranks[0], csr.nnz // 1000000),
            'gedges_per_s': csr.nnz / ms / 1e6, 'sample_rel_err_vs_f64': err, 'graph_generation_s': gen_s,
            'frac_of_measured_gather_roof': gr['best_ms'] / ms, 'gather_roof_ms': gr['best_ms'], 'per_rank': per_rank,
-           'rank_ms_min': min(p['ms'] for p in per_rank), 'rank_ms_max': max(p['ms'] for p in per_rank)}
+           'rank_ms_min': min(p['ms'] for p in per_rank), 'rank_ms_max': max(p['ms'] for p in per_rank), 'blocks': blocks}
+    t = stored_config5_traffic(csr.nnz, d)
+    if t:
+        src = 'profiles/pmc_traffic_config5.json (%s): rocprofv3 --pmc passes, 2*FETCH+WRITE per launch' % t.get('tag', '?')
+        for name, rec, ms_x in (('whole', out, ms), ('user_block', blocks['user_block'], blocks['user_block']['ms']),
+                                ('item_block', blocks['item_block'], blocks['item_block']['ms'])):
+            c = t['launches'].get(name)
+            if not c or (name != 'whole' and c.get('nnz') != rec['nnz']):
+                continue
+            gbps = c['bytes'] / ms_x / 1e6
+            rec.update({'counter_bytes_per_launch': c['bytes'], 'counter_GBps': gbps, 'counter_frac': gbps / HBM_PEAK_GBPS,
+                        'counter_frac_of_measured_stream': gbps / st['read_GBps'], 'l2_hit_rate': c.get('l2_hit_rate'),
+                        'counter_over_algorithmic': c['bytes'] / rec['algorithmic_bytes' if name != 'whole' else 'algorithmic_bytes_per_launch']})
+        out['counter_source'] = src
+    # the figure to quote: counter bytes / time / peak where a pass of this share is on file, of the item block first
+    ib = blocks['item_block']
+    out['achieved'] = ib.get('counter_GBps', out.get('counter_GBps'))
+    out['frac'] = None if out['achieved'] is None else out['achieved'] / HBM_PEAK_GBPS
+    out['bound'] = 'hbm' if t else 'hbm (no counter pass on file for this share: algorithmic figures only)'
+    out['frac_note'] = 'item block: (2*FETCH_SIZE + WRITE_SIZE) / launch time / 8 TB/s; whole-share and user-block figures beside it'
     return out
 
 

@@ -139,6 +139,8 @@ constexpr int kMinCap = 8, kMaxCap = 16, kQuad = 4;
 // and crawl at ~6 us a tile; scoring 1.3-1.45 ms with 48 (the same with 24), 1.5-1.7 with 96, 1.8-2.0 with 192, 3.4-3.8
 // when nobody gives up; after the first epoch (every wave leaves within ~50 tiles) nobody is handed over (0.41 ms).
 constexpr int kGiveUpAfterTiles = 48;
+constexpr int kExitSlots = 64;       // counters of early leavers, one per whole sweep of a wave (256 B of the call's workspace)
+__device__ __forceinline__ int exit_slot(int64_t job) { return job < kExitSlots ? (int)job : kExitSlots - 1; }
 constexpr int kMinCapSweep = 6;      // candidate sweeps: a shallower staging list (more drains) rather than half the resident waves (k + extra = 25..28)
 
 // (the fp16 candidate sweep at d = 128 runs ONE wave per SIMD with 512 registers: both user groups stay)
@@ -932,7 +934,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                         far |= alive[g] && ureach[g] * reach >= 1.5f * thr[g];
                     }
                     if (!__any(any_alive)) {
-                        if (A.exit_count && lane == 0) atomicAdd(A.exit_count, 1u);
+                        if (A.exit_count && job < A.n_whole && lane == 0) atomicAdd(A.exit_count + exit_slot(job), 1u);
                         break;
                     }
                     // Giving up: a wave that is still alive long after three quarters of the waves have left would hold the
@@ -942,10 +944,18 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                     // that way depends on timing; the lists do not.  With nobody leaving early (norms all alike) nobody gives up.
                     // (not before kGiveUpAfterTiles: handing users over costs a launch of its own, ~0.15 ms; the count is the one read at
                     // the previous check — its latency would otherwise stall the wave at every check)
+                    // One counter per JOB (a wave's j-th whole sweep; kExitSlots of them, later jobs share the last): the leavers of
+                    // a wave's first sweep must not count against its second (above 2 048 slots x 64 users per call
+                    // every wave of job 1 that was alive at tile 48 handed its users over).  Only waves that LEFT EARLY or gave up
+                    // are counted, not the ones that reached the end of the table: with those counted too, the last quarter
+                    // of a random-init sweep — where all waves end together — gave up a few tiles before its end
+                    // (measured: scoring 3.4 -> 5.0 ms, profiles/r04a_*).
                     const unsigned gone = gone_next;
-                    if (A.exit_count) gone_next = __hip_atomic_load(A.exit_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (A.exit_count && tile - tin0 >= kGiveUpAfterTiles) {
+                    const bool counting = A.exit_count && job < A.n_whole;
+                    if (counting) gone_next = __hip_atomic_load(A.exit_count + exit_slot(job), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (counting && tile - tin0 >= kGiveUpAfterTiles) {
                         if ((uint64_t)gone * 4 >= (uint64_t)gridDim.x * 3 && __any(far)) {   // (a wave about to leave by itself stays)
+                            if (lane == 0) atomicAdd(A.exit_count + exit_slot(job), 1u);
 #pragma unroll
                             for (int g = 0; g < NG; ++g)
                                 if (alive[g] && h == 0) A.unfinished[group * UPW + g * 32 + j] = 1;
@@ -1651,7 +1661,8 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     TopkPlan sweep_plan;
     rc = topk_make_plan(batch, n_items, d, L.kc, &sweep_plan, mode);
     if (rc != IGCN_OK) return rc;
-    const bool give_up = early_exit && sweep_plan.rest_tiles == 0 && tuning_get(IGCN_TUNE_TOPK_FAST_GIVE_UP) != 0;
+    // (whole sweeps only — `n_whole` of them per wave, counted job by job; the pieces of a rest never give up)
+    const bool give_up = early_exit && sweep_plan.n_whole >= 1 && tuning_get(IGCN_TUNE_TOPK_FAST_GIVE_UP) != 0;
     unsigned int *exit_count = reinterpret_cast<unsigned int *>(ws + L.exit_state);
     uint8_t *unfinished = reinterpret_cast<uint8_t *>(ws + L.exit_state + 256);
     unsigned int *shared_thr = reinterpret_cast<unsigned int *>(ws + L.exit_state + 256 + align256(batch));

@@ -61,7 +61,7 @@ class _SplitLists(list):
         locals()[_n] = _notifying(_n)
     del _n
 
-    def __reduce__(self):                      # pickles / copies as a plain list
+    def __reduce__(self):                      # pickles / copies as a plain list; BasicDataset._get_list wraps it again
         return (list, (list(self),))
 
 
@@ -71,7 +71,9 @@ class BasicDataset:
     train_data / val_data / test_data are properties: assigning a new list-of-lists bumps the split's
     version (what the trainers key their device copies on) and drops its cached CSR views, and so does
     assigning to / deleting from / appending to the list of a split (dataset.test_data[user] = [], as
-    trainer.py:183-184 does).  Only code that edits one user's INNER list in place must call invalidate(which)."""
+    trainer.py:183-184 does).  Only code that edits one user's INNER list in place must call invalidate(which).
+    One difference from the reference's plain attributes: assignment COPIES the outer list (dataset.test_data = lst;
+    lst[u] = [] afterwards is not seen — edit dataset.test_data[u] instead).  Tracking survives pickle / deepcopy."""
 
     SPLITS = ('train', 'val', 'test')
 
@@ -89,7 +91,12 @@ class BasicDataset:
 
     # ---- list views <-> CSR views ------------------------------------------------
     def _get_list(self, name):
-        return self._lists.get(name)
+        cur = self._lists.get(name)
+        if cur is not None and not isinstance(cur, _SplitLists):
+            # a dataset that went through pickle / deepcopy / mp.spawn carries its splits as plain lists (_SplitLists
+            # reduces to one: its callback is bound to the ORIGINAL dataset): track them again on first access
+            cur = self._lists[name] = self._track(name, cur)
+        return cur
 
     def _track(self, name, value):
         return _SplitLists(value, lambda: self.invalidate(name))

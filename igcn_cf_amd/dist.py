@@ -27,7 +27,7 @@ the scheme BASELINE.json's north_star asks for at Amazon-book scale and above:
 
 `spmm_fn` is the local product; the product path uses the HIP kernel (ops.spmm).  The CPU
 tests inject a checker implementation to exercise the partitioning / exchange logic under
-gloo with world_size 2.  Nothing here has run on more than one physical GPU yet.
+gloo with world_size 2.  Nothing here has run on more than one physical GPU yet (gpurun boxes have one).
 """
 import numpy as np
 import torch
@@ -103,6 +103,22 @@ class ShardLayout:
         return np.where(is_item, self.pu + rank * self.bi + (local - self.bu), rank * self.bu + local)
 
 
+    def pad_index_torch(self, node):
+        """pad_index for an int64 tensor of global node ids, on the tensor's device (the device builders of the local blocks)."""
+        dev = node.device
+        ub = torch.from_numpy(self.user_bounds).to(dev)
+        ib = torch.from_numpy(self.item_bounds).to(dev)
+        is_item = node >= self.n_users
+        it = torch.where(is_item, node - self.n_users, torch.zeros_like(node))
+        us = torch.where(is_item, torch.zeros_like(node), node)
+        ru = (torch.searchsorted(ub, us, right=True) - 1).clamp_(max=self.world - 1)
+        ri = (torch.searchsorted(ib, it, right=True) - 1).clamp_(max=self.world - 1)
+        lu, li = us - ub[ru], it - ib[ri]
+        if self.fused:
+            return torch.where(is_item, ri * self.block + self.bu + li, ru * self.block + lu)
+        return torch.where(is_item, self.pu + ri * self.bi + li, ru * self.bu + lu)
+
+
 def local_blocks_host(rowptr, col, val, layout, rank):
     """Rows of the global CSR owned by `rank`, as two CSR blocks (user rows, item rows) of
     exactly bu / bi rows (padding rows empty), padded column ids."""
@@ -117,22 +133,47 @@ def local_blocks_host(rowptr, col, val, layout, rank):
 
 
 class RowShardedPropagator:
+    """adjacency / train_array: the whole A_hat on the host, cut here (Amazon-book size: 36 MB).  At sizes where no rank can
+    hold the whole matrix (BASELINE config 5: 1 G nonzeros) pass `layout` + `local_blocks` instead — the rank's own blocks,
+    already in HBM with padded column ids (synth.BipartiteGraphDevice.rank_blocks): (csr_users, csr_items) for 'halves',
+    (csr,) for 'fused' — and `global_nnz`; nothing of the whole graph is then touched here."""
+
     def __init__(self, train_array, n_users, n_items, n_layers, rank, world, device, group=None,
-                 spmm_fn=None, csr_factory=None, adjacency=None, exchange=None, balance=True):
-        rowptr, col, val = adjacency if adjacency is not None else normalized_adjacency_host(train_array, n_users, n_items)
+                 spmm_fn=None, csr_factory=None, adjacency=None, exchange=None, balance=True,
+                 layout=None, local_blocks=None, global_nnz=None):
         if exchange is None:
             exchange = 'fused' if (n_users + n_items) * 256 <= FUSED_EXCHANGE_MAX_BYTES else 'halves'
         if exchange not in ('fused', 'halves'):
             raise ValueError("exchange must be 'fused' or 'halves'")
         self.exchange = exchange
         fused = exchange == 'fused'
-        self.layout = ShardLayout.balanced(rowptr, n_users, n_items, world, fused) if balance else \
-            ShardLayout(n_users, n_items, world, fused=fused)
         self.n_layers, self.rank, self.world, self.group = n_layers, rank, world, group
         self.device = torch.device(device)
         if spmm_fn is None:
             from . import ops
             spmm_fn = ops.spmm
+        self.spmm = spmm_fn
+        self._d = None
+        if local_blocks is not None:
+            if layout is None or layout.fused != fused or layout.world != world:
+                raise ValueError('local_blocks need the ShardLayout they were cut with (same world, same exchange)')
+            if len(local_blocks) != (1 if fused else 2):
+                raise ValueError("local_blocks: (csr,) for 'fused', (csr_users, csr_items) for 'halves'")
+            self.layout = L = layout
+            shapes = [(L.block, L.n_pad)] if fused else [(L.bu, L.n_pad), (L.bi, L.n_pad)]
+            for blk, shape in zip(local_blocks, shapes):
+                if tuple(blk.shape) != shape:
+                    raise ValueError('local block of shape %s, layout needs %s' % (tuple(blk.shape), shape))
+            if fused:
+                self.csr, = local_blocks
+            else:
+                self.csr_u, self.csr_i = local_blocks
+            self.local_nnz = int(sum(blk.nnz for blk in local_blocks))
+            self.global_nnz = None if global_nnz is None else int(global_nnz)
+            return
+        rowptr, col, val = adjacency if adjacency is not None else normalized_adjacency_host(train_array, n_users, n_items)
+        self.layout = ShardLayout.balanced(rowptr, n_users, n_items, world, fused) if balance else \
+            ShardLayout(n_users, n_items, world, fused=fused)
         if csr_factory is None:
             from .graph import XCD_PLAN, CsrMatrix
             # 'fused' (operand of tens of MB, slices of it fit an XCD's L2): the XCD plan, as on one GPU; 'halves'
@@ -140,7 +181,6 @@ class RowShardedPropagator:
             plan = XCD_PLAN if exchange == 'fused' else None
             csr_factory = lambda rp, c, v, shape, blocks=None: CsrMatrix(rp, c, v, shape, self.device, order_blocks=blocks,
                                                                          xcd_plan=plan)
-        self.spmm = spmm_fn
         (urp, ucol, uval), (irp, icol, ival) = local_blocks_host(rowptr, col, val, self.layout, rank)
         L = self.layout
         self.local_nnz = int(urp[-1] + irp[-1])
@@ -152,7 +192,6 @@ class RowShardedPropagator:
         else:
             self.csr_u = self._make_csr(csr_factory, urp, ucol, uval, (L.bu, L.n_pad), [0, L.bu])
             self.csr_i = self._make_csr(csr_factory, irp, icol, ival, (L.bi, L.n_pad), [0, L.bi])
-        self._d = None
 
     @staticmethod
     def _make_csr(factory, rp, col, val, shape, blocks):

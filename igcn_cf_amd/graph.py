@@ -358,8 +358,10 @@ def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assi
                 lists[x] += [sx, rx]
         load = load + seg_cost + (torch.bincount(owner, weights=cost, minlength=NL) if whole.numel() else 0.)
     per_list = [torch.cat(l) if l else empty for l in lists]
-    xcd_off = torch.zeros(NL + 1, **i64)
-    xcd_off[1:] = torch.cumsum(torch.tensor([a.shape[0] for a in per_list], **i64), 0)
+    # the kernels always walk N_XCD lists (xcd_off[(blockIdx.x & 7) + 1]): fewer lists of a developer A/B are padded with empty ones
+    xcd_off = torch.zeros(max(NL, N_XCD) + 1, **i64)
+    xcd_off[1:NL + 1] = torch.cumsum(torch.tensor([a.shape[0] for a in per_list], **i64), 0)
+    xcd_off[NL + 1:] = xcd_off[NL]
     row_order = torch.cat(per_list).to(torch.int32)
     if row_order.shape[0] != n_rows - long_ids.shape[0] + n_seg:
         raise AssertionError('XCD plan lost or duplicated work items')

@@ -520,8 +520,9 @@ def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_co
     re-scoring (igcn_score_topk_fast_f32) — the same ids, exact fp32 scores; users whose candidate set cannot be proven
     complete (near-ties at the k-th place; counted on the device, read back here) go through the fp32 sweep.  'auto':
     'fast' where it applies and the problem is large enough to pay for it.
-    lower_bound (mode 'exact' only): float32 [B] on the GPU, per user a VALID lower bound of its k-th best score
-    (igcn_score_topk_bounded_f32): only items that reach it are looked at."""
+    lower_bound (mode 'exact' only): float32 [B] on the GPU, per user a lower bound of its k-th best score
+    (igcn_score_topk_bounded_f32): only items that reach it are looked at.  A bound that turns out too high costs time,
+    not correctness: a list it left short is redone by the plain fp32 sweep."""
     if mode not in ('auto', 'exact', 'fast'):
         raise ValueError("mode must be 'auto', 'exact' or 'fast'")
     _require_gpu_f32(user_rows, 'user_rows')
@@ -571,6 +572,17 @@ def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_co
             item_rows.data_ptr(), item_rows.stride(0), n_items, d,
             _lib.ptr(excl_rowptr), _lib.ptr(excl_col), _lib.ptr(banned), k, lower_bound.data_ptr(),
             out_idx.data_ptr(), out_val.data_ptr(), ws.data_ptr(), _lib.current_stream()), 'igcn_score_topk_bounded_f32')
+        # A bound above a user's true k-th best score (an invalid one, or one that is an ulp high) leaves that user's list
+        # short instead of wrong: such users — and the ones who really have fewer than k unmasked items — go through the
+        # plain fp32 sweep again.  One small host read, on a path that is only taken for a handful of users.
+        short = out_idx[:, k - 1] < 0
+        if bool(short.any()):
+            pos = torch.nonzero(short).flatten()
+            ids = user_ids[pos] if user_ids is not None else pos
+            idx_s, val_s = score_topk(user_rows, item_rows, k, user_ids=ids.contiguous(), excl_rowptr=excl_rowptr, excl_col=excl_col,
+                                      banned=banned, mode='exact')
+            out_idx[pos] = idx_s
+            out_val[pos] = val_s
         return out_idx, out_val
     _lib.check(L.igcn_score_topk_f32(
         user_rows.data_ptr(), user_rows.stride(0), _lib.ptr(user_ids), B,

@@ -63,15 +63,17 @@ class BipartiteGraphDevice:
         table = np.power(np.maximum(np.arange(max_deg + 1, dtype=np.float32), np.float32(1.)), np.float32(-0.5)).astype(np.float32)
         return torch.from_numpy(table).to(self.device)[deg]
 
-    def rank_share(self, layout, rank, xcd_plan=None):
-        """(CsrMatrix of the rank's rows [its user block; its item block] with GLOBAL column ids, int64 global row ids)."""
+    def _share_arrays(self, layout, rank):
+        """The rank's two row blocks with GLOBAL column ids: ((counts, col int64, val) of its user rows — which gather item
+        rows —, the same of its item rows).  Values fl(fl(d_r * 1) * d_c), the reference's order (model.py:90-92)."""
         (ulo, uhi), (ilo, ihi) = layout.user_rows(rank), layout.item_rows(rank)
         dinv = self.inv_sqrt_degree()
         n = self.n
         # user rows: the pair list is sorted by (user, item): the rank's pairs are one contiguous run
         bounds = torch.searchsorted(self.users, torch.tensor([ulo, uhi], device=self.device))
         s, e = int(bounds[0]), int(bounds[1])
-        u_rows, u_cols = self.users[s:e] - ulo, self.items[s:e] + self.n_users
+        u_cols = self.items[s:e] + self.n_users
+        u_val = (dinv[self.users[s:e]] * 1.0) * dinv[u_cols]
         # item rows: pairs whose item lies in the block, sorted by (item, user)
         m = (self.items >= ilo) & (self.items < ihi)
         key = (self.items[m] - ilo) * n + self.users[m]
@@ -79,17 +81,50 @@ class BipartiteGraphDevice:
         i_rows = torch.div(key, n, rounding_mode='floor')
         i_cols = key - i_rows * n
         del key, m
+        i_val = (dinv[self.n_users + ilo + i_rows] * 1.0) * dinv[i_cols]
+        return (self.deg_u[ulo:uhi], u_cols, u_val), (self.deg_i[ilo:ihi], i_cols, i_val)
+
+    def rank_share(self, layout, rank, xcd_plan=None):
+        """(CsrMatrix of the rank's rows [its user block; its item block] with GLOBAL column ids, int64 global row ids)."""
+        (ulo, uhi), (ilo, ihi) = layout.user_rows(rank), layout.item_rows(rank)
+        (u_cnt, u_cols, u_val), (i_cnt, i_cols, i_val) = self._share_arrays(layout, rank)
         nu_l, ni_l = uhi - ulo, ihi - ilo
-        counts = torch.cat([self.deg_u[ulo:uhi], self.deg_i[ilo:ihi]])
         rowptr = torch.zeros(nu_l + ni_l + 1, dtype=torch.int64, device=self.device)
-        torch.cumsum(counts, 0, out=rowptr[1:])
+        torch.cumsum(torch.cat([u_cnt, i_cnt]), 0, out=rowptr[1:])
         col = torch.cat([u_cols, i_cols]).to(torch.int32)
+        val = torch.cat([u_val, i_val])
+        del u_cols, i_cols, u_val, i_val
         grow = torch.cat([torch.arange(ulo, uhi, device=self.device), self.n_users + torch.arange(ilo, ihi, device=self.device)])
-        row_of = torch.cat([u_rows, nu_l + i_rows])
-        val = (dinv[grow][row_of] * 1.0) * dinv[col.long()]              # fl(fl(d_r * 1) * d_c), the reference's order
-        del row_of, u_rows, i_rows, u_cols, i_cols
-        csr = CsrMatrix.from_device(rowptr, col, val, (nu_l + ni_l, n), order_blocks=[0, nu_l, nu_l + ni_l], xcd_plan=xcd_plan)
+        csr = CsrMatrix.from_device(rowptr, col, val, (nu_l + ni_l, self.n), order_blocks=[0, nu_l, nu_l + ni_l], xcd_plan=xcd_plan)
         return csr, grow
+
+    def rank_blocks(self, layout, rank, csr_factory=None):
+        """What dist.RowShardedPropagator(local_blocks=...) takes, built in HBM from the pair list — never a CSR of the
+        whole graph, on the host or anywhere: the rank's user block [bu, n_pad] and item block [bi, n_pad] (rows padded to
+        the layout's block sizes, column ids in the PADDED replicated layout), or, for a 'fused' layout, the one matrix
+        [bu + bi, n_pad] of both.  csr_factory(rowptr, col int32, val, shape, order_blocks): default CsrMatrix.from_device."""
+        (ulo, uhi), (ilo, ihi) = layout.user_rows(rank), layout.item_rows(rank)
+        (u_cnt, u_cols, u_val), (i_cnt, i_cols, i_val) = self._share_arrays(layout, rank)
+        if csr_factory is None:
+            csr_factory = lambda rp, c, v, shape, blocks: CsrMatrix.from_device(rp, c, v, shape, order_blocks=blocks)
+
+        def padded_rowptr(cnt, rows):
+            rp = torch.zeros(rows + 1, dtype=torch.int64, device=self.device)
+            torch.cumsum(cnt, 0, out=rp[1:cnt.shape[0] + 1])
+            rp[cnt.shape[0] + 1:] = rp[cnt.shape[0]]                    # padding rows are empty
+            return rp
+        u_cols = layout.pad_index_torch(u_cols).to(torch.int32)
+        i_cols = layout.pad_index_torch(i_cols).to(torch.int32)
+        if layout.fused:
+            cnt = torch.zeros(layout.block, dtype=torch.int64, device=self.device)
+            cnt[:uhi - ulo] = u_cnt
+            cnt[layout.bu:layout.bu + ihi - ilo] = i_cnt
+            rp = torch.zeros(layout.block + 1, dtype=torch.int64, device=self.device)
+            torch.cumsum(cnt, 0, out=rp[1:])
+            return (csr_factory(rp, torch.cat([u_cols, i_cols]), torch.cat([u_val, i_val]), (layout.block, layout.n_pad),
+                                [0, layout.bu, layout.block]),)
+        return (csr_factory(padded_rowptr(u_cnt, layout.bu), u_cols, u_val, (layout.bu, layout.n_pad), [0, layout.bu]),
+                csr_factory(padded_rowptr(i_cnt, layout.bi), i_cols, i_val, (layout.bi, layout.n_pad), [0, layout.bi]))
 
 
 def check_rows_f64(csr, x, y, rows):

@@ -14,7 +14,7 @@ i=0
 for P in "$P1" "$P2" "$P3"; do
   i=$((i+1))
   timeout -k 10 200 rocprofv3 --pmc $P --output-format csv -d $OUT/topk_p$i -- python3 $REPO/scripts/dev_topk_once.py > $OUT/topk_p$i.log 2>&1 || { tail -5 $OUT/topk_p$i.log; exit 1; }
-  timeout -k 10 200 rocprofv3 --pmc $P --output-format csv -d $OUT/spmm_p$i -- python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-hbm-leg > $OUT/spmm_p$i.log 2>&1 || { tail -5 $OUT/spmm_p$i.log; exit 1; }
+  timeout -k 10 200 rocprofv3 --pmc $P --output-format csv -d $OUT/spmm_p$i -- python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-hbm-leg --no-config5 > $OUT/spmm_p$i.log 2>&1 || { tail -5 $OUT/spmm_p$i.log; exit 1; }
 done
 python3 - <<PY
 import csv, glob, collections

@@ -22,7 +22,7 @@ def main():
     src = os.path.join('gpurun_out', 'prof_' + tag)
     os.makedirs('profiles', exist_ok=True)
     lines = []
-    for sub, cmd, top in (('kt', 'bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras --no-hbm-leg  (the headline workload alone: '
+    for sub, cmd, top in (('kt', 'bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras --no-hbm-leg --no-config5  (the headline workload alone: '
                                  'the SpMM average below is that of the timed launches)', 8),
                           ('kt_full', 'bench.py --steps 100 --warmup 10 --no-cpu-baseline  (with eval, train step, HBM-bound leg, '
                                       'Gowalla-size step: the SpMM kernel name now also covers masked and small-graph launches)', 24)):

@@ -266,3 +266,74 @@ def test_column_sharded_training_step_equals_unsharded(golden):
         losses, full = ret[r]
         np.testing.assert_allclose(losses, ref_losses, rtol=1e-5)
         np.testing.assert_allclose(full, e.detach().numpy(), rtol=1e-4, atol=1e-6)
+
+
+# ---- local blocks built from the pair list (BASELINE config 5's constructor path) ------------------------------
+class TorchCsr:
+    """What the injected factory hands to cpu_spmm when the blocks arrive as torch tensors (synth.rank_blocks)."""
+    def __init__(self, rowptr, col, val, shape, blocks=None):
+        self.rowptr, self.col, self.val, self.shape = rowptr.numpy(), col.numpy(), val.numpy(), tuple(shape)
+        self.nnz = int(col.shape[0])
+
+
+def _blocks_worker(rank, world, port, sizes, seed, emb, n_layers, exchange, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from igcn_cf_amd.dist import RowShardedPropagator, ShardLayout
+        from igcn_cf_amd.synth import BipartiteGraphDevice
+        g = BipartiteGraphDevice(*sizes, 'cpu', seed=seed)          # every rank draws the same graph (same seed) ...
+        L = ShardLayout.balanced(g.rowptr_host(), g.n_users, g.n_items, world, fused=exchange == 'fused')
+        blocks = g.rank_blocks(L, rank, csr_factory=TorchCsr)       # ... and builds ONLY its own rows of A_hat
+        prop = RowShardedPropagator(None, g.n_users, g.n_items, n_layers, rank, world, 'cpu', spmm_fn=cpu_spmm, exchange=exchange,
+                                    layout=L, local_blocks=blocks, global_nnz=g.nnz)
+        (ulo, uhi), (ilo, ihi) = L.user_rows(rank), L.item_rows(rank)
+        nu = g.n_users
+        prop.load_local_embedding(torch.from_numpy(emb[ulo:uhi]), torch.from_numpy(emb[nu + ilo:nu + ihi]))
+        ru, ri = prop.propagate()
+        ret[rank] = (ru[:uhi - ulo].numpy().copy(), ri[:ihi - ilo].numpy().copy(), prop.local_nnz, prop.global_nnz, (ulo, uhi, ilo, ihi))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('exchange,n_layers', [('halves', 3), ('halves', 2), ('fused', 3)])
+def test_row_sharded_propagation_from_device_built_local_blocks(exchange, n_layers):
+    """RowShardedPropagator(layout=, local_blocks=): every rank builds its own blocks from the generator's pair list
+    (padded rows, padded column ids computed with torch ops) — no CSR of the whole graph anywhere — and the sharded
+    K-layer pass (alternating half order, layer-mean epilogue) equals the unsharded oracle on the same graph."""
+    from igcn_cf_amd.synth import BipartiteGraphDevice
+    sizes, seed, world = (260, 90, 3000), 5, 2
+    g = BipartiteGraphDevice(*sizes, 'cpu', seed=seed)
+    nu, ni = g.n_users, g.n_items
+    ta = np.stack([g.users.numpy(), g.items.numpy()], axis=1)
+    rng = np.random.default_rng(0)
+    emb = (rng.standard_normal((nu + ni, 16)) * 0.1).astype(np.float32)
+    ref = O.lightgcn_get_rep(O.lightgcn_norm_adj(ta, nu, ni), emb, n_layers)
+    ret = mp.Manager().dict()
+    mp.spawn(_blocks_worker, args=(world, _free_port(), sizes, seed, emb, n_layers, exchange, ret), nprocs=world, join=True)
+    nnz = users_seen = items_seen = 0
+    for r in range(world):
+        ru, ri, lnnz, gnnz, (ulo, uhi, ilo, ihi) = ret[r]
+        np.testing.assert_allclose(ru, ref[ulo:uhi], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(ri, ref[nu + ilo:nu + ihi], rtol=1e-5, atol=1e-7)
+        nnz += lnnz
+        users_seen += uhi - ulo
+        items_seen += ihi - ilo
+    assert nnz == gnnz == 2 * g.n_edges and users_seen == nu and items_seen == ni
+
+
+def test_local_blocks_are_checked_against_their_layout():
+    from igcn_cf_amd.dist import RowShardedPropagator, ShardLayout
+    from igcn_cf_amd.synth import BipartiteGraphDevice
+    g = BipartiteGraphDevice(60, 30, 400, 'cpu', seed=1)
+    L = ShardLayout.balanced(g.rowptr_host(), g.n_users, g.n_items, 2)
+    blocks = g.rank_blocks(L, 0, csr_factory=TorchCsr)
+    with pytest.raises(ValueError):                                  # blocks without the layout they were cut with
+        RowShardedPropagator(None, 60, 30, 2, 0, 2, 'cpu', spmm_fn=cpu_spmm, exchange='halves', local_blocks=blocks)
+    with pytest.raises(ValueError):                                  # a 'halves' layout under the 'fused' exchange
+        RowShardedPropagator(None, 60, 30, 2, 0, 2, 'cpu', spmm_fn=cpu_spmm, exchange='fused', layout=L, local_blocks=blocks)
+    with pytest.raises(ValueError):                                  # another rank count's blocks
+        L3 = ShardLayout.balanced(g.rowptr_host(), g.n_users, g.n_items, 3)
+        RowShardedPropagator(None, 60, 30, 2, 0, 2, 'cpu', spmm_fn=cpu_spmm, exchange='halves', layout=L3, local_blocks=blocks)
+    with pytest.raises(ValueError):                                  # users and items swapped
+        RowShardedPropagator(None, 60, 30, 2, 0, 2, 'cpu', spmm_fn=cpu_spmm, exchange='halves', layout=L, local_blocks=blocks[::-1])

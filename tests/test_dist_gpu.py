@@ -207,3 +207,99 @@ def test_config4_amazon_size_row_sharded_against_the_unsharded_hip_path(world):
     assert users_seen == nu and nnz_seen == model.norm_adj.nnz
     nnzs = [ret[r]['local_nnz'] for r in range(world)]
     assert max(nnzs) / (sum(nnzs) / world) < 1.02                                 # nnz-balanced blocks
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE config 5's N-rank path: every rank builds ITS OWN blocks of A_hat in HBM from the generator's pair list
+# (synth.rank_blocks -> RowShardedPropagator(layout=, local_blocks=)), K = 3 layers at d = 128 under the 'halves'
+# exchange, on a reduced bipartite graph (1 M x 200 k x ~50 M edges), two ranks sharing the GPU over gloo, against
+# the UNSHARDED HIP pass over the same graph.  Covers the alternating half order, the all-gathers in flight under the
+# other half's SpMM and the layer-mean epilogue at a size where blocks have long rows and unequal row counts.
+# ------------------------------------------------------------------------------------------------------------------
+C5_SIZES, C5_SEED, C5_D, C5_K = (1_000_000, 200_000, 50_000_000), 2021, 128, 3
+
+
+def _c5_embedding(n, dev):
+    g = torch.Generator(device=dev).manual_seed(11)
+    return torch.randn(n, C5_D, device=dev, generator=g) * 0.1
+
+
+def _config5_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from igcn_cf_amd.dist import RowShardedPropagator, ShardLayout
+        from igcn_cf_amd.synth import BipartiteGraphDevice
+        dev = torch.device('cuda', 0)
+        g = BipartiteGraphDevice(*C5_SIZES, dev, seed=C5_SEED)
+        L = ShardLayout.balanced(g.rowptr_host(), g.n_users, g.n_items, world)
+        blocks = g.rank_blocks(L, rank)
+        prop = RowShardedPropagator(None, g.n_users, g.n_items, C5_K, rank, world, dev, exchange='halves', layout=L,
+                                    local_blocks=blocks, global_nnz=g.nnz)
+        (ulo, uhi), (ilo, ihi) = L.user_rows(rank), L.item_rows(rank)
+        x0 = _c5_embedding(g.n, dev)
+        prop.load_local_embedding(x0[ulo:uhi], x0[g.n_users + ilo:g.n_users + ihi])
+        ru, ri = prop.propagate()
+        torch.cuda.synchronize()
+        ret[rank] = dict(bounds=(ulo, uhi, ilo, ihi), ru=ru[:uhi - ulo:997].cpu().numpy().copy(), ri=ri[:ihi - ilo:211].cpu().numpy().copy(),
+                         local_nnz=prop.local_nnz, n_long=(blocks[0].n_long, blocks[1].n_long), bu=L.bu, bi=L.bi)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config5_rank_local_blocks_across_two_ranks_against_the_unsharded_hip_pass():
+    from igcn_cf_amd import ops
+    from igcn_cf_amd.dist import ShardLayout
+    from igcn_cf_amd.synth import BipartiteGraphDevice
+    dev = torch.device('cuda', 0)
+    g = BipartiteGraphDevice(*C5_SIZES, dev, seed=C5_SEED)
+    whole, _ = g.rank_share(ShardLayout(g.n_users, g.n_items, 1), 0)               # all rows, global column ids
+    assert whole.nnz == g.nnz
+    rep = ops.propagate_mean(whole, _c5_embedding(g.n, dev), C5_K)
+    scale = float(rep.abs().max())
+    nu, nnz = g.n_users, g.nnz
+    del whole, g
+    torch.cuda.empty_cache()
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_config5_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    seen = 0
+    for r in range(world):
+        out = ret[r]
+        ulo, uhi, ilo, ihi = out['bounds']
+        assert np.abs(out['ru'] - rep[ulo:uhi:997].cpu().numpy()).max() <= 1e-5 * scale
+        assert np.abs(out['ri'] - rep[nu + ilo:nu + ihi:211].cpu().numpy()).max() <= 1e-5 * scale
+        assert out['n_long'][1] > 0                                               # popular items: long-row segments in the item block
+        seen += out['local_nnz']
+    assert seen == nnz
+    a, b = ret[0]['local_nnz'], ret[1]['local_nnz']
+    assert max(a, b) / ((a + b) / 2) < 1.02                                       # nnz-balanced
+    assert (ret[0]['bounds'][3] - ret[0]['bounds'][2]) != (ret[1]['bounds'][3] - ret[1]['bounds'][2])   # unequal item row counts
+
+
+def test_bench_starts_its_own_ranks_and_rehearses_both_multi_gpu_legs():
+    """`IGCN_BENCH_ONE_GPU=1 python bench.py --gpus 2` from the plain command (no launcher): the parent spawns the ranks as
+    fresh processes before any GPU call and relays ONE JSON line holding the config-4 headline and the config-5 leg, both
+    labelled as a rehearsal."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IGCN_BENCH_ONE_GPU='1')
+    env.pop('WORLD_SIZE', None), env.pop('RANK', None), env.pop('LOCAL_RANK', None)
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--no-extras'],
+                       env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['value'] > 0 and 'REHEARSAL' in out['config']['parallelism']
+    assert 'REHEARSAL' in out['config5_label'] and out['config5_world'] == 2
+    assert out['config5_pass_ms'] > 0 and out['config5_edges_per_s'] > 0 and out['config5_sample_rel_err_vs_f64'] < 1e-4
+    assert out['roofline']['config5_pass_ms'] == out['config5_pass_ms']
+    # without the rehearsal switch and without enough GPUs the launcher refuses, with a message, before starting anything
+    env.pop('IGCN_BENCH_ONE_GPU')
+    if torch.cuda.device_count() < 2:
+        p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'], env=env, cwd=root, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=300)
+        assert p.returncode != 0 and b'IGCN_BENCH_ONE_GPU' in p.stderr and not p.stdout.strip()

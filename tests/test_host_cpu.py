@@ -431,6 +431,15 @@ def test_split_lists_invalidate_themselves(golden):
     assert isinstance(ds.test_data[:3], list) and ds.test_data[:3] == [list(x) for x in ds.test_data[:3]]
     import copy
     assert type(copy.deepcopy(ds.test_data)) is list
+    # a dataset that went through pickle / deepcopy (mp.spawn arguments) keeps tracking its own lists — not the original's
+    import pickle
+    for clone in (copy.deepcopy(ds), pickle.loads(pickle.dumps(ds))):
+        v_clone, v_orig = clone.version('test'), ds.version('test')
+        rp_c, _ = clone.csr('test')
+        w = int(np.flatnonzero(np.diff(rp_c) > 0)[0])
+        clone.test_data[w] = []
+        assert clone.version('test') == v_clone + 1 and ds.version('test') == v_orig
+        assert clone.csr('test')[0][w + 1] == clone.csr('test')[0][w] and len(ds.test_data[w]) > 0
 
 
 @pytest.mark.parametrize('threshold', [3, 8, 1000])
@@ -542,7 +551,9 @@ def test_xcd_plan_with_fewer_lists(golden):
     n = nu + ni
     rowptr, col, _ = normalized_adjacency_host(golden['train_array'], nu, ni)
     lr, sg, order, off, load = xcd_plan(torch.from_numpy(rowptr), torch.from_numpy(col), [0, nu, n], 3, 4, n_lists=4)
-    assert off.shape[0] == 5 and load.shape[0] == 4 and int(off[-1]) == order.shape[0]
+    # the kernels always walk 8 lists (xcd_off[(blockIdx.x & 7) + 1]): the four missing ones are there, and empty
+    assert off.shape[0] == 9 and load.shape[0] == 4 and int(off[-1]) == int(off[4]) == order.shape[0]
+    assert off[4:].tolist() == [order.shape[0]] * 5
     lens = np.diff(rowptr)
     order = order.numpy()
     assert sorted(order[order < n].tolist()) == np.flatnonzero(lens <= 3).tolist()

@@ -609,6 +609,65 @@ def test_two_stage_stragglers_hand_their_users_to_the_fp32_sweep(d):
         _lib.set_tuning('topk_fast_narrow', None)
 
 
+def test_bounded_sweep_with_a_bound_that_is_too_high_falls_back_to_the_plain_sweep():
+    """igcn_score_topk_bounded_f32 only looks at items that reach the caller's bound.  A bound above the true k-th best
+    score (by an ulp, or plainly invalid) must cost time, not correctness: ops.score_topk redoes the users whose lists came
+    out short with the plain fp32 sweep.  Exact bounds, bounds an ulp high, +inf, and valid ones, mixed in one batch."""
+    from igcn_cf_amd.ops import score_topk
+    rng = np.random.default_rng(31)
+    n_users, n_items, d, k = 200, 5000, 64, 20
+    U, I = _dev((rng.standard_normal((n_users, d)) * 0.1).astype(np.float32)), _dev((rng.standard_normal((n_items, d)) * 0.1).astype(np.float32))
+    ex = [np.sort(rng.choice(n_items, size=int(rng.integers(0, 40)), replace=False)) for _ in range(n_users)]
+    rowptr = np.zeros(n_users + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in ex], out=rowptr[1:])
+    kw = dict(excl_rowptr=_dev(rowptr), excl_col=_dev(np.concatenate(ex).astype(np.int32)))
+    ref_idx, ref_val = score_topk(U, I, k, mode='exact', **kw)
+    kth = ref_val[:, k - 1].clone()
+    bound = kth.clone()                                                        # exact: the k-th best itself (>= keeps it)
+    bound[0::4] = torch.nextafter(kth[0::4], torch.full_like(kth[0::4], float('inf')))      # an ulp too high
+    bound[1::4] = float('inf')                                                               # nothing reaches it
+    bound[2::4] = kth[2::4] - 0.01                                                           # valid, loose
+    got_idx, got_val = score_topk(U, I, k, mode='exact', lower_bound=bound.contiguous(), **kw)
+    assert torch.equal(got_idx, ref_idx) and torch.equal(got_val, ref_val)
+    assert int((got_idx < 0).sum()) == 0
+
+
+def test_two_stage_second_whole_sweep_of_a_wave_counts_its_own_leavers():
+    """Several whole sweeps per wave (more 64-user groups than wave slots: above 131 072 users per call on the MI355X; here
+    the slots are tuned down): the give-up rule compares the waves that have left THIS job with three quarters of the grid.
+    Counted per call instead (round 3), the leavers of job 0 pushed every wave of job 1 that was alive at the first check
+    to hand its users over.  On a trained-like table (log-normal row scales: most waves leave within a few checks) the users
+    handed to the fp32 sweep must stay a few stragglers whatever the number of jobs; the lists are the fp32 sweep's."""
+    from igcn_cf_amd import _lib
+    from igcn_cf_amd.ops import score_topk
+    rng = np.random.default_rng(29)
+    d, n_users, n_items, k = 64, 64 * 96, 40000, 20
+    pop = rng.standard_normal(d).astype(np.float32)
+    pop /= np.linalg.norm(pop)
+    scale = np.exp(1.0 * rng.standard_normal((n_items, 1))).astype(np.float32)
+    I = (0.05 * rng.standard_normal((n_items, d)) + 0.3 * scale * pop[None, :]).astype(np.float32)
+    U = (0.05 * rng.standard_normal((n_users, d)) + 1.0 * pop[None, :]).astype(np.float32)
+    odd = rng.choice(n_users, size=12, replace=False)
+    U[odd] = (0.3 * rng.standard_normal((12, d))).astype(np.float32)                       # the stragglers: no taste for the popular rows
+    Ud, Id = _dev(U), _dev(I)
+    ref = score_topk(Ud, Id, k, mode='exact')
+    flagged = {}
+    try:
+        _lib.set_tuning('topk_fast_narrow', 0)                                              # 64-user wave-groups: 96 of them
+        for slots in (96, 48, 32, 40):          # 1, 2, 3 whole sweeps per wave; 40: two whole sweeps + a rest cut into pieces
+            _lib.set_tuning('topk_slots', slots)
+            got = score_topk(Ud, Id, k, mode='fast')
+            flagged[slots] = score_topk.last_flagged
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), slots
+    finally:
+        _lib.set_tuning('topk_slots', None)
+        _lib.set_tuning('topk_fast_narrow', None)
+    # a handed-over wave carries up to 64 users; 12 stragglers in at most 12 waves.  With the per-call count every wave of the
+    # later jobs that was alive at tile 48 handed over its 64 users: thousands.
+    assert all(v <= 12 * 64 + 64 for v in flagged.values()), flagged
+    assert flagged[48] <= flagged[96] + 6 * 64 and flagged[32] <= flagged[96] + 6 * 64, flagged
+
+
 def test_two_stage_exclusion_lists_of_every_length_class():
     """The candidate sweep walks each user's exclusion list in SWEEP positions, sorted row by row on the device (a segmented
     radix sort): empty lists, short ones, lists of thousands of entries and one that leaves exactly k items.  The lists are
