@@ -128,3 +128,24 @@ extern "C" int igcn_roof_stream_f32(const void *src, void *dst, int64_t n4, int3
 #undef IGCN_STREAM
     return (int)hipGetLastError();
 }
+// idx [n_idx] int32 in [0, n_x_rows), val [n_idx], x [n_x_rows, d] (ldx), y [n_out, d] (ldy); d in {16, 32, 64, 128, 256}.
+// blocks: workgroups of 256 threads to launch.  Returns 0 or a hipError_t / -1 on a bad argument.
+extern "C" int igcn_roof_gather_f32(const int32_t *idx, const float *val, int64_t n_idx, const float *x, int64_t ldx,
+                                    float *y, int64_t ldy, int64_t n_out, int32_t d, int64_t blocks, void *stream)
+{
+    if (!idx || !val || !x || !y || n_idx < 1 || n_out < 1 || blocks < 1 || blocks >= ((int64_t)1 << 31)) return -1;
+    if (ldx < d || ldy < d || ldx % 4 || ldy % 4) return -1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)blocks), block(kBlock);
+    const double rpi = (double)n_out / (double)n_idx;
+    switch (d) {
+    case 16: hipLaunchKernelGGL(gather_roof_kernel<4>, grid, block, 0, st, idx, val, n_idx, x, ldx, y, ldy, n_out, rpi); break;
+    case 32: hipLaunchKernelGGL(gather_roof_kernel<8>, grid, block, 0, st, idx, val, n_idx, x, ldx, y, ldy, n_out, rpi); break;
+    case 64: hipLaunchKernelGGL(gather_roof_kernel<16>, grid, block, 0, st, idx, val, n_idx, x, ldx, y, ldy, n_out, rpi); break;
+    case 128: hipLaunchKernelGGL(gather_roof_kernel<32>, grid, block, 0, st, idx, val, n_idx, x, ldx, y, ldy, n_out, rpi); break;
+    case 256: hipLaunchKernelGGL(gather_roof_kernel<64>, grid, block, 0, st, idx, val, n_idx, x, ldx, y, ldy, n_out, rpi); break;
+    default: return -1;
+    }
+    return (int)hipGetLastError();
+}
+

@@ -29,6 +29,19 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().igcn_error_string(-1).decode().startswith('a required pointer')
 
 
+def test_measurement_library_exports_its_probes():
+    """libigcn_roof.so (bench.py's in-run probes: the rowless gather and the stream kernels; never loaded by the product):
+    both entry points resolve with the signatures bench.py binds, and bad arguments come back as -1 without a launch."""
+    import ctypes as C
+    import bench
+    lib = bench.roof_lib()
+    assert lib.igcn_roof_gather_f32(None, None, 0, None, 0, None, 0, 0, 64, 1, None) == -1
+    assert lib.igcn_roof_stream_f32(None, None, 0, 0, 0, 1, None) == -1
+    buf = (C.c_float * 8)()
+    assert lib.igcn_roof_stream_f32(C.addressof(buf), C.addressof(buf), 1, 2, 0, 1, None) == -1       # mode out of range
+    assert lib.igcn_roof_stream_f32(C.addressof(buf), C.addressof(buf), 1, 0, 4, 1, None) == -1       # variant out of range
+
+
 def test_spmm_plan_host_functions():
     from igcn_cf_amd import _lib
     L = _lib.lib()
