@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_PKG, 'libigcn_hip.so')
 MAX_ADDS = 8
 MAX_TOPK = 256
 MAX_METRIC_CUTS = 8
+FAST_FALLBACK_MAX = 256          # IGCN_FAST_FALLBACK_MAX: flagged users igcn_score_topk_fast_f32 finishes by itself
 
 c_i64_p = C.POINTER(C.c_int64)
 vp = C.c_void_p

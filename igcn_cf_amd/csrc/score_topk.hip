@@ -347,6 +347,10 @@ struct TopkArgs {
     // early exit bookkeeping (MODE 2 / 3, NULL: none): waves that left early; users a wave gave up on (see the sweep loop)
     unsigned int *exit_count; uint8_t *unfinished;
     unsigned int *shared_thr;   // NULL, or per batch position the best k-th-best any piece of the user's sweep has published (see flush())
+    // BOUNDED only (the two-stage path's fall-back, planned on the device): the batch is a LIST in device memory — count_dev[0]
+    // users (at most `batch`: the plan's size), user b of it sits at batch position rows[b] of the caller's arrays (user_ids,
+    // out_idx / out_val); init_thr stays indexed by b.  NULL: the batch is positions 0 .. batch - 1.
+    const int32_t *rows; const int32_t *count_dev;
 };
 
 // FULL: d == D, no k-slice of a row is padding.  NG: 32-user groups of a wave.  MODE 0: fp32 MFMA, the exact fmaf
@@ -389,6 +393,10 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
     const bool owner = NG == 2 || h == 0;
     const int64_t units = gridDim.x;
     const int64_t n_full = A.n_whole * units;
+    int64_t batch_n = A.batch;                                   // users of the batch; BOUNDED with a device list: as many as it holds
+    if constexpr (BOUNDED) {
+        if (A.count_dev) { const int64_t c = *A.count_dev; batch_n = c < A.batch ? c : A.batch; }
+    }
     int64_t rx = (int64_t)blockIdx.x * A.run;                    // cursor in the rest groups' tile space
     const int64_t rx_end = rx + A.run < A.rest_tiles ? rx + A.run : A.rest_tiles;
 
@@ -412,6 +420,9 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
             direct = A.p_max == 1;
             rx += tin1 - tin0;
         }
+        if constexpr (BOUNDED) {
+            if (group * UPW >= batch_n) break;                   // planned for more users than the list holds: groups ascend, nothing follows
+        }
         const int item_lo = tin0 * 32;
         const int item_hi = (int64_t)tin1 * 32 < n_items ? tin1 * 32 : (int)n_items;
 
@@ -424,8 +435,10 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int64_t b = group * UPW + g * 32 + j;
-            user_ok[g] = b < A.batch;
-            uid[g] = user_ok[g] ? (A.user_ids ? A.user_ids[b] : b) : 0;
+            user_ok[g] = b < batch_n;
+            int64_t brow = b;                                     // position in the caller's arrays
+            if constexpr (BOUNDED) { if (A.rows && user_ok[g]) brow = A.rows[b]; }
+            uid[g] = user_ok[g] ? (A.user_ids ? A.user_ids[brow] : brow) : 0;
             if constexpr (MODE == 0) {
 #pragma unroll
                 for (int q = 0; q < D / 8; ++q) {
@@ -914,7 +927,12 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
 #pragma unroll
             for (int g = 0; g < NG; ++g)
                 ureach[g] = A.tile_bound && user_ok[g] ? sqrtf(A.unorm2[group * UPW + g * 32 + j]) * ldexpf(1.f, -scale_exp(__uint_as_float(A.stats[2]))) : 0.f;
-            for (int tile = tin0; tile < tin1; tile += 3) {
+#ifdef IGCN_X_TURN6
+            constexpr int kTurn = 6;
+#else
+            constexpr int kTurn = 3;
+#endif
+            for (int tile = tin0; tile < tin1; tile += kTurn) {
                 if (A.tile_bound && tile > tin0 && (tile - tin0) % 24 == 0) {
                     // Cauchy-Schwarz exit (every 24 tiles): the items come by descending norm, so if no user of this wave
                     // can still be reached by a row as long as this tile's longest, none of the remaining tiles matters
@@ -973,8 +991,26 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                 if (tile + 2 < tin1) {
                     if constexpr (kRing12) tile_step(acc_a, acc_b, a, a3, tile + 2, a2);
                     else tile_step(acc_a, acc_b, a, a3, tile + 2, a);
+#ifndef IGCN_X_TURN6
+                    // a turn of three steps ends with the accumulator pair in swapped roles: 32 moves
 #pragma unroll
                     for (int g = 0; g < NG; ++g) acc_a[g] = acc_b[g];
+#else
+                    // Developer A/B (round 4, rejected): the second half of a SIX-step turn — the same three buffer roles with
+                    // the accumulator pair swapped, so that the turn ends where it began and no accumulator is ever copied.
+                    // 244 -> 238 VGPRs, scratch of the d = 128 variant 44 -> 12 bytes, and the same time within the run-to-run
+                    // spread (d = 64: 2.93-3.47 vs 3.26-3.40 ms without masks, 3.47-3.58 vs 3.47-3.49 with; d = 128 4.3-4.7 vs
+                    // 4.4-4.6: profiles/r04c_*): the moves are not on the wave's critical path, and the library took twice as long to compile.
+                    if constexpr (kRing12) {
+                        if (tile + 3 < tin1) tile_step(acc_b, acc_a, a3, a2, tile + 3, a);
+                        if (tile + 4 < tin1) tile_step(acc_a, acc_b, a2, a, tile + 4, a3);
+                        if (tile + 5 < tin1) tile_step(acc_b, acc_a, a, a3, tile + 5, a2);
+                    } else {
+                        if (tile + 3 < tin1) tile_step(acc_b, acc_a, a2, a, tile + 3, a);
+                        if (tile + 4 < tin1) tile_step(acc_a, acc_b, a3, a2, tile + 4, a);
+                        if (tile + 5 < tin1) tile_step(acc_b, acc_a, a, a3, tile + 5, a);
+                    }
+#endif
                 }
             }
         } else {
@@ -999,12 +1035,14 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
             heap_replace_root(heap, n, last);
         }
         const int64_t b_own = group * UPW + lane;                // owner lane l keeps user l of the wave-group
-        if (owner && b_own < A.batch) {
+        if (owner && b_own < batch_n) {
             if (direct) {
+                int64_t orow = b_own;
+                if constexpr (BOUNDED) { if (A.rows) orow = A.rows[b_own]; }
                 for (int r = 0; r < k; ++r) {
                     const unsigned long long key = heap[r * kWave];
-                    A.out_idx[b_own * k + r] = key ? key_item(key) : -1;
-                    A.out_val[b_own * k + r] = key ? key_score(key) : -INFINITY;
+                    A.out_idx[orow * k + r] = key ? key_item(key) : -1;
+                    A.out_val[orow * k + r] = key ? key_score(key) : -INFINITY;
                 }
             } else {
                 const int64_t slot = ((b_own - n_full * UPW) * A.p_max + pidx) * k;
@@ -1044,12 +1082,15 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
 __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restrict__ ws_val, const int32_t *__restrict__ ws_idx,
                                                             int64_t first_user, int64_t batch, int n_tiles, int64_t run,
                                                             int p_max, int k, int upw,
-                                                            int64_t *__restrict__ out_idx, float *__restrict__ out_val)
+                                                            int64_t *__restrict__ out_idx, float *__restrict__ out_val,
+                                                            const int32_t *__restrict__ rows, const int32_t *__restrict__ count_dev)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t rb = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-    const int64_t b = first_user + rb;
+    int64_t b = first_user + rb;
+    if (count_dev && *count_dev < batch) batch = *count_dev;      // the batch is a device list (TopkArgs::rows / count_dev)
     if (b >= batch) return;
+    if (rows) b = rows[b];
     const int64_t rg = rb / upw;
     const int n_lists = (int)((((rg + 1) * n_tiles - 1) / run) - (rg * n_tiles) / run + 1);
     const bool live = lane < n_lists;
@@ -1083,11 +1124,14 @@ template <int P>
 __global__ __launch_bounds__(kBlock) void topk_merge_lanes_kernel(const float *__restrict__ ws_val, const int32_t *__restrict__ ws_idx,
                                                                   int64_t first_user, int64_t batch, int n_tiles, int64_t run,
                                                                   int p_max, int k, int upw,
-                                                                  int64_t *__restrict__ out_idx, float *__restrict__ out_val)
+                                                                  int64_t *__restrict__ out_idx, float *__restrict__ out_val,
+                                                                  const int32_t *__restrict__ rows, const int32_t *__restrict__ count_dev)
 {
     const int64_t rb = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    const int64_t b = first_user + rb;
+    int64_t b = first_user + rb;
+    if (count_dev && *count_dev < batch) batch = *count_dev;
     if (b >= batch) return;
+    if (rows) b = rows[b];
     const int64_t rg = rb / upw;
     const int n_lists = (int)((((rg + 1) * n_tiles - 1) / run) - (rg * n_tiles) / run + 1);
     const float *v = ws_val + rb * p_max * k;
@@ -1463,8 +1507,10 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
                     int32_t k, int64_t *out_idx, float *out_val, void *workspace, const float4 *packed,
                     const unsigned int *stats, hipStream_t st, const int32_t *perm = nullptr, const float *init_thr = nullptr,
                     const float *tile_bound = nullptr, const float *unorm2 = nullptr, unsigned int *exit_count = nullptr,
-                    uint8_t *unfinished = nullptr, unsigned int *shared_thr = nullptr)
+                    uint8_t *unfinished = nullptr, unsigned int *shared_thr = nullptr,
+                    const int32_t *rows = nullptr, const int32_t *count_dev = nullptr)
 {
+    if ((rows || count_dev) && !(mode == 0 && init_thr && (d == 64 || d == 128))) return IGCN_E_SHAPE;   // the bounded variants only
     if (!user_rows || !item_rows || !out_idx || !out_val) return IGCN_E_NULL;
     if ((excl_rowptr == nullptr) != (excl_col == nullptr)) return IGCN_E_NULL;
     TopkPlan p;
@@ -1501,6 +1547,7 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
     a.tile_bound = tile_bound; a.unorm2 = unorm2;
     a.exit_count = exit_count; a.unfinished = unfinished;
     a.shared_thr = p.p_max > 1 ? shared_thr : nullptr;          // (only pieces have anything to share)
+    a.rows = rows; a.count_dev = count_dev;
 
     if (mode != 0) {
         if ((d != 64 && !(mode >= 2 && d == 128)) || !packed || (mode >= 2 && !stats)) return IGCN_E_SHAPE;
@@ -1528,13 +1575,13 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
         const int64_t first = p.n_whole * p.units * 32 * p.ng;
         if (p.p_max <= 4)
             hipLaunchKernelGGL(topk_merge_lanes_kernel<4>, dim3((unsigned)((rest_users + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                               ws_val, ws_idx, first, batch, p.n_tiles, p.run, p.p_max, (int)k, 32 * p.ng, out_idx, out_val);
+                               ws_val, ws_idx, first, batch, p.n_tiles, p.run, p.p_max, (int)k, 32 * p.ng, out_idx, out_val, rows, count_dev);
         else if (p.p_max <= 8)
             hipLaunchKernelGGL(topk_merge_lanes_kernel<8>, dim3((unsigned)((rest_users + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
-                               ws_val, ws_idx, first, batch, p.n_tiles, p.run, p.p_max, (int)k, 32 * p.ng, out_idx, out_val);
+                               ws_val, ws_idx, first, batch, p.n_tiles, p.run, p.p_max, (int)k, 32 * p.ng, out_idx, out_val, rows, count_dev);
         else
             hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)((rest_users + 3) / 4)), dim3(kBlock), 0, st, ws_val, ws_idx,
-                               first, batch, p.n_tiles, p.run, p.p_max, (int)k, 32 * p.ng, out_idx, out_val);
+                               first, batch, p.n_tiles, p.run, p.p_max, (int)k, 32 * p.ng, out_idx, out_val, rows, count_dev);
         rc = launch_status();
     }
     return rc;
@@ -1563,7 +1610,12 @@ extern "C" int igcn_score_topk_bounded_f32(const float *user_rows, int64_t ldu, 
 // ---- the two-stage evaluation: bf16 candidate sweep + exact fp32 re-scoring (d = 64, k <= 60) --------------------
 // workspace: [sweep workspace for k + 4][item planes][candidate ids][candidate scores][max |item|^2], each 256-aligned
 static inline int64_t align256(int64_t n) { return (n + 255) / 256 * 256; }
-struct FastLayout { int64_t sweep, packed, cand_idx, cand_val, norm, tile_bound, unorm2, exit_state, order, total; int kc; TopkOrderLayout ord; };
+// Users the two-stage call finishes by itself: the first kFastFallbackMax flagged ones go through the bounded fp32 sweep inside
+// igcn_score_topk_fast_f32, planned for that many and run for as many as the device-side count says (ABI v7).  256 = 8 narrow
+// groups x 58 pieces fill a quarter of the wave slots — the plan a host that knew the count (43 at random init, 20-40 on
+// trained tables) would make for anything up to 256 users; beyond it the caller re-does the rest.
+constexpr int64_t kFastFallbackMax = IGCN_FAST_FALLBACK_MAX;
+struct FastLayout { int64_t sweep, packed, cand_idx, cand_val, norm, tile_bound, unorm2, exit_state, order, fallback, total; int kc; TopkOrderLayout ord; };
 static int topk_fast_layout(int64_t batch, int64_t n_items, int32_t d, int32_t k, int64_t excl_rows, int64_t excl_nnz, FastLayout *L) {
     if ((d != 64 && d != 128) || k < 1 || k + kFastExtra > kWave) return IGCN_E_RANGE;
     L->kc = k + topk_fast_extra(k, topk_fast_mode(d));
@@ -1583,7 +1635,10 @@ static int topk_fast_layout(int64_t batch, int64_t n_items, int32_t d, int32_t k
     L->unorm2 = L->tile_bound + align256((int64_t)p.n_tiles * 4);
     L->exit_state = L->unorm2 + align256(batch * 4);                  // [256 B: waves that left early][batch B: users given up on]
     L->order = L->exit_state + 256 + align256(batch) + align256(batch * 4);   // (+ the thresholds the pieces of a sweep share)
-    L->total = L->order + L->ord.total;
+    L->fallback = align256(L->order + L->ord.total);
+    const int64_t fb = igcn_score_topk_workspace_bytes(batch < kFastFallbackMax ? batch : kFastFallbackMax, n_items, d, k);
+    if (fb < 0) return IGCN_E_RANGE;
+    L->total = L->fallback + align256(fb);
     return IGCN_OK;
 }
 
@@ -1686,7 +1741,16 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
         hipLaunchKernelGGL(topk_rescore_kernel<64>, dim3((unsigned)((batch + 3) / 4)), dim3(kBlock), 0, st, user_rows, ldu, user_ids, batch,
                            item_rows, ldi, cand_idx, cand_val, L.kc, (int)k, (int)d, norm_bits, mode, perm, out_idx, out_val, flagged,
                            flagged_lower_bound, give_up ? (const uint8_t *)unfinished : (const uint8_t *)nullptr);
-    return launch_status();
+    rc = launch_status();
+    if (rc != IGCN_OK || !flagged_lower_bound || tuning_get(IGCN_TUNE_TOPK_FAST_FALLBACK) == 0) return rc;
+    // The flagged users' fp32 sweep, planned HERE for up to kFastFallbackMax of them and run for as many as flagged[0] says when
+    // the kernel starts — no host read between the stages (round 3 read the count back first: ~0.11 ms of an idle GPU and five
+    // small torch launches per call).  Each starts from the k-th exact score of its candidates.  In id space: the caller's
+    // exclusion lists and banned items as they came.
+    const int64_t fb_users = batch < kFastFallbackMax ? batch : kFastFallbackMax;
+    return topk_run(0, user_rows, ldu, user_ids, fb_users, item_rows, ldi, n_items, d, excl_rowptr, excl_col, banned, k, out_idx, out_val,
+                    ws + L.fallback, nullptr, nullptr, st, nullptr, flagged_lower_bound, nullptr, nullptr, nullptr, nullptr, nullptr,
+                    flagged + 1, flagged);
 }
 
 #ifdef IGCN_TOPK_STATS

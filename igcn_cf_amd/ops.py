@@ -550,7 +550,9 @@ def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_co
     if banned is not None and (banned.dtype != torch.uint8 or banned.numel() != n_items or not banned.is_cuda):
         raise _lib.IgcnError('banned must be uint8 [n_items] on the GPU')
     L = _lib.lib()
-    fast_ok = d in (64, 128) and k + 4 <= 64 and k <= n_items and B > 0
+    # the re-scoring wave has 64 lanes, one per candidate: k + 6 candidates while k <= 58, 64 - k of them at k = 59, 60 (the library's
+    # own rule, topk_fast_extra), nothing above — igcn_score_topk_fast_workspace_bytes refuses k > 60
+    fast_ok = d in (64, 128) and k <= 60 and k <= n_items and B > 0
     if lower_bound is not None and mode != 'exact':
         raise _lib.IgcnError("lower_bound goes with mode='exact'")
     if mode == 'fast' and not fast_ok:
@@ -592,6 +594,15 @@ def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_co
     return out_idx, out_val
 
 
+_fast_fallback_inside = [True]      # tests: set_fast_fallback(False) = the ABI v6 split (every flagged user re-done from here)
+
+
+def set_fast_fallback(inside):
+    """Developer / test switch: whether igcn_score_topk_fast_f32 finishes its first FAST_FALLBACK_MAX flagged users itself."""
+    _fast_fallback_inside[0] = bool(inside)
+    _lib.set_tuning('topk_fast_fallback', None if inside else 0)
+
+
 def _score_topk_fast(L, user_rows, item_rows, k, user_ids, excl_rowptr, excl_col, banned, B, n_items, d):
     dev = item_rows.device
     excl_rows = excl_rowptr.numel() - 1 if excl_rowptr is not None else 0
@@ -605,20 +616,25 @@ def _score_topk_fast(L, user_rows, item_rows, k, user_ids, excl_rowptr, excl_col
     out_val = torch.empty((B, k), dtype=torch.float32, device=dev)
     flagged = torch.empty(B + 1, dtype=torch.int32, device=dev)
     bounds = torch.empty(B, dtype=torch.float32, device=dev)
+    fallback_inside = _fast_fallback_inside[0]
     _lib.check(L.igcn_score_topk_fast_f32(
         user_rows.data_ptr(), user_rows.stride(0), _lib.ptr(user_ids), B,
         item_rows.data_ptr(), item_rows.stride(0), n_items, d,
         _lib.ptr(excl_rowptr), _lib.ptr(excl_col), excl_rows, excl_nnz, _lib.ptr(banned), k,
         out_idx.data_ptr(), out_val.data_ptr(), flagged.data_ptr(), bounds.data_ptr(), ws_ptr, _lib.current_stream()),
         'igcn_score_topk_fast_f32')
-    n_flagged = int(flagged[0].item())                      # the one host read of the path
-    if n_flagged:
-        # the users whose candidate set could not be proven complete: the fp32 sweep, started from the k-th exact score
-        # of their candidates (a valid lower bound) instead of from an empty list
-        pos = flagged[1:1 + n_flagged].long()
+    # The call has already re-done its first FAST_FALLBACK_MAX flagged users with the bounded fp32 sweep, planned on the device
+    # (ABI v7).  The one host read of the path comes AFTER everything is queued — the GPU is never idle waiting for it — and only
+    # tells whether more users than that were flagged (exact-arithmetic tables with ties in droves; a few dozen is the norm).
+    n_flagged = int(flagged[0].item())
+    done = _lib.FAST_FALLBACK_MAX if fallback_inside else 0
+    if n_flagged > done:
+        # the rest: the fp32 sweep, started from the k-th exact score of their candidates (a valid lower bound) instead of
+        # from an empty list
+        pos = flagged[1 + done:1 + n_flagged].long()
         ids = user_ids[pos] if user_ids is not None else pos
         idx_f, val_f = score_topk(user_rows, item_rows, k, user_ids=ids.contiguous(), excl_rowptr=excl_rowptr, excl_col=excl_col,
-                                  banned=banned, mode='exact', lower_bound=bounds[:n_flagged].contiguous())
+                                  banned=banned, mode='exact', lower_bound=bounds[done:n_flagged].contiguous())
         out_idx[pos] = idx_f
         out_val[pos] = val_f
     score_topk.last_flagged = n_flagged                     # developer statistic

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IGCN_ABI_VERSION 6
+#define IGCN_ABI_VERSION 7
 
 #define IGCN_OK            0
 #define IGCN_E_NULL       -1   /* a required pointer is NULL               */
@@ -34,6 +34,7 @@ extern "C" {
 
 #define IGCN_MAX_ADDS      8   /* epilogue addends of igcn_spmm_csr_f32     */
 #define IGCN_MAX_TOPK    256   /* k of igcn_score_topk_f32                  */
+#define IGCN_FAST_FALLBACK_MAX 256   /* flagged users igcn_score_topk_fast_f32 finishes by itself (ABI v7) */
 
 int         igcn_abi_version(void);
 const char *igcn_error_string(int code);
@@ -42,7 +43,8 @@ const char *igcn_error_string(int code);
  * "spmm_multirow", "topk_slots", "topk_waves_per_cu", "topk_cap", "topk_stagger", "topk_fast_order", "topk_fast_exit",
  * "topk_fast_wide", "topk_fast_extra" (candidates kept beyond k), "topk_fast_give_up" (0: no wave hands users over),
  * "topk_fast_narrow" (0: small batches keep 64-user wave-groups), "topk_fast_share" (0: the pieces of a cut sweep
- * keep their thresholds to themselves), "topk_fast_mode" (candidate sweep of
+ * keep their thresholds to themselves), "topk_fast_fallback" (0: igcn_score_topk_fast_f32 leaves every flagged user to the
+ * caller), "topk_fast_mode" (candidate sweep of
  * igcn_score_topk_fast_f32: 3 = one fp16 plane each side, the default; 2 = two fp16 user planes; 1 = two bf16 planes each side,
  * d = 64 only); value < 0 restores the library
  * default.  Results never depend on them (tests/test_spmm_gpu.py::test_launch_shape_does_not_change_results).
@@ -264,8 +266,13 @@ int igcn_score_topk_bounded_f32(const float *user_rows, int64_t ldu, const int64
  * whom an item dropped by stage 1 could still reach the k-th exact score (its bound does not stay below it: near-ties
  * at the k-th place) is reported instead of trusted: flagged[0] = how many, flagged[1..] = their positions in the
  * batch (int32 [batch + 1]), flagged_lower_bound[0..] (float [batch] or NULL) = for each of them, in the same order,
- * the k-th exact score among its candidates — a valid lower bound for igcn_score_topk_bounded_f32, which the caller
- * runs for those users.  No host synchronisation inside.
+ * the k-th exact score among its candidates — a valid lower bound for igcn_score_topk_bounded_f32.
+ * ABI v7: when flagged_lower_bound is given, the call FINISHES the first IGCN_FAST_FALLBACK_MAX flagged users itself: the
+ * bounded fp32 sweep is launched behind stage 2, planned for that many users and run for as many as flagged[0] holds when
+ * it starts (the batch of that sweep is the device-side list flagged[1..]) — no host read between the stages.  The caller
+ * reads flagged[0] afterwards and re-does only positions flagged[1 + IGCN_FAST_FALLBACK_MAX ..] with
+ * igcn_score_topk_bounded_f32 (bounds flagged_lower_bound[IGCN_FAST_FALLBACK_MAX ..]); with flagged_lower_bound NULL
+ * every flagged user is the caller's.  No host synchronisation inside.
  * ABI v5: stage 1 meets the items by DESCENDING squared norm (likely winners first: the running thresholds are near
  * their final values early and most later items fail the cheap selection test; -16 % on the Amazon-like evaluation),
  * not by id: a permutation, its inverse and the exclusion lists in sweep positions are built per call in the

@@ -13,7 +13,7 @@ VDIR = os.path.join(ROOT, 'igcn_cf_amd', '_variants')
 VARIANTS = {'base': [], 'nohits': ['-DIGCN_X_NOHITS'], 'noselect': ['-DIGCN_X_NOSELECT', '-DIGCN_X_NOHITS'],
             'noloada': ['-DIGCN_X_NOLOADA'], 'bare': ['-DIGCN_X_NOSELECT', '-DIGCN_X_NOHITS', '-DIGCN_X_NOLOADA'],
             'stats': ['-DIGCN_TOPK_STATS'], 'sametile': ['-DIGCN_X_SAMETILE'],
-            'bare_sametile': ['-DIGCN_X_NOSELECT', '-DIGCN_X_NOHITS', '-DIGCN_X_SAMETILE'], 'todoonly': ['-DIGCN_X_TODOONLY'], 'noflush': ['-DIGCN_X_NOFLUSH']}
+            'turn6': ['-DIGCN_X_TURN6'], 'bare_sametile': ['-DIGCN_X_NOSELECT', '-DIGCN_X_NOHITS', '-DIGCN_X_SAMETILE'], 'todoonly': ['-DIGCN_X_TODOONLY'], 'noflush': ['-DIGCN_X_NOFLUSH']}
 
 
 def build(only=None):

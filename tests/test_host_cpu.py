@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert getattr(_lib.lib(), name) is not None
-    assert _lib.lib().igcn_abi_version() == 6
+    assert _lib.lib().igcn_abi_version() == 7
     assert _lib.lib().igcn_error_string(-1).decode().startswith('a required pointer')
 
 

@@ -53,7 +53,9 @@ def _check_topk(scores, idx, val, ex_lists, banned, k):
                                                   (50, 100, 3000, 20), (6, 40, 200, 7),
                                                   (64, 130, 2000, 100), (32, 70, 1500, 200), (128, 40, 900, 64),
                                                   (64, 65, 700, 25), (16, 129, 333, 256), (64, 2500, 9000, 60),
-                                                  (64, 200, 40, 20), (256, 70, 1500, 20), (192, 33, 800, 30)])
+                                                  (64, 200, 40, 20), (256, 70, 1500, 20), (192, 33, 800, 30),
+                                                  # the two-stage path's upper end: k + 6 candidates up to k = 58, then 64 - k
+                                                  (64, 400, 5000, 58), (64, 400, 5000, 59), (128, 130, 3000, 60), (64, 90, 4000, 61)])
 def test_score_topk_matches_dense_oracle(d, n_users, n_items, k):
     from igcn_cf_amd.ops import score_topk
     rng = np.random.default_rng(d + n_items)
@@ -607,6 +609,72 @@ def test_two_stage_stragglers_hand_their_users_to_the_fp32_sweep(d):
     finally:
         _lib.set_tuning('topk_fast_give_up', None)
         _lib.set_tuning('topk_fast_narrow', None)
+
+
+@pytest.mark.parametrize('d', [64, 128])
+def test_two_stage_fall_back_planned_on_the_device(d):
+    """ABI v7: igcn_score_topk_fast_f32 finishes its first 256 flagged users itself — the bounded fp32 sweep is launched behind the
+    re-scoring kernel, planned for 256 users and run for as many as the device-side count holds (its batch is the flagged list);
+    the caller re-does only what lies beyond.  No flagged user, a few, exactly around 256 and thousands (integer tables tie in
+    droves), with masks, banned items and a permuted user subset: the lists are the fp32 sweep's, and the same as with the
+    whole fall-back done from the host (the ABI v6 split)."""
+    from igcn_cf_amd import ops
+    from igcn_cf_amd.ops import score_topk
+    rng = np.random.default_rng(43)
+    n_users, n_items, k = 3000, 9000, 20
+    ex = [np.sort(rng.choice(n_items, size=int(rng.integers(0, 30)), replace=False)) for _ in range(n_users)]
+    rowptr = np.zeros(n_users + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in ex], out=rowptr[1:])
+    bmask = np.zeros(n_items, dtype=np.uint8)
+    bmask[rng.choice(n_items, size=n_items // 9, replace=False)] = 1
+    kw = dict(excl_rowptr=_dev(rowptr), excl_col=_dev(np.concatenate(ex).astype(np.int32)), banned=_dev(bmask))
+    sub = _dev(rng.permutation(n_users)[:1700].astype(np.int64))
+    gauss_u, gauss_i = (rng.standard_normal((n_users, d)) * 0.1).astype(np.float32), (rng.standard_normal((n_items, d)) * 0.1).astype(np.float32)
+    ties_u = gauss_u.copy()
+    ties_u[:260] = rng.integers(-2, 3, size=(260, d)).astype(np.float32)          # ~260 users whose scores tie: flagged
+    ties_i = gauss_i.copy()
+    ties_i[:3000] = rng.integers(-2, 3, size=(3000, d)).astype(np.float32)
+    cases = {'gaussian (a handful flagged)': (gauss_u, gauss_i),
+             'integer rows for 260 users (around the 256 the call finishes itself)': (ties_u, ties_i),
+             'all integer (thousands flagged)': (rng.integers(-3, 4, size=(n_users, d)).astype(np.float32),
+                                                 rng.integers(-3, 4, size=(n_items, d)).astype(np.float32))}
+    seen = []
+    try:
+        for name, (U, I) in cases.items():
+            Ud, Id = _dev(U), _dev(I)
+            for users in (None, sub):
+                ref = score_topk(Ud, Id, k, user_ids=users, mode='exact', **kw)
+                for inside in (True, False):
+                    ops.set_fast_fallback(inside)
+                    got = score_topk(Ud, Id, k, user_ids=users, mode='fast', **kw)
+                    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (name, inside)
+                seen.append(score_topk.last_flagged)
+    finally:
+        ops.set_fast_fallback(True)
+    assert min(seen) <= 64 and max(seen) > 1000 and any(200 < n < 400 for n in seen), seen       # below, around and far above 256
+
+
+@pytest.mark.parametrize('d', [64, 128])
+def test_two_stage_candidate_count_at_the_upper_end_of_k(d):
+    """k = 57 ... 60 on Gaussian tables: the candidate sweep keeps k + 6 candidates while they fit the 64 lanes of the
+    re-scoring wave (k <= 58) and 64 - k beyond (5 at k = 59, 4 at k = 60 — more users then fail the completeness check and
+    take the fp32 sweep); k = 61 is refused by the two-stage path and taken by the fp32 sweep under mode='auto'.  The lists
+    are the fp32 sweep's at every k."""
+    from igcn_cf_amd import _lib
+    from igcn_cf_amd.ops import score_topk
+    rng = np.random.default_rng(41)
+    n_users, n_items = 700, 12000
+    U, I = _dev((rng.standard_normal((n_users, d)) * 0.1).astype(np.float32)), _dev((rng.standard_normal((n_items, d)) * 0.1).astype(np.float32))
+    flagged = {}
+    for k in (57, 58, 59, 60):
+        a, b = score_topk(U, I, k, mode='fast'), score_topk(U, I, k, mode='exact')
+        flagged[k] = score_topk.last_flagged
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), k
+    assert flagged[58] <= n_users // 4, flagged                    # six spare candidates: few users fail the check
+    with pytest.raises(_lib.IgcnError):
+        score_topk(U, I, 61, mode='fast')
+    a, b = score_topk(U, I, 61, mode='auto'), score_topk(U, I, 61, mode='exact')
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
 def test_bounded_sweep_with_a_bound_that_is_too_high_falls_back_to_the_plain_sweep():
