@@ -630,14 +630,19 @@ def test_two_stage_fall_back_planned_on_the_device(d):
     kw = dict(excl_rowptr=_dev(rowptr), excl_col=_dev(np.concatenate(ex).astype(np.int32)), banned=_dev(bmask))
     sub = _dev(rng.permutation(n_users)[:1700].astype(np.int64))
     gauss_u, gauss_i = (rng.standard_normal((n_users, d)) * 0.1).astype(np.float32), (rng.standard_normal((n_items, d)) * 0.1).astype(np.float32)
-    ties_u = gauss_u.copy()
-    ties_u[:260] = rng.integers(-2, 3, size=(260, d)).astype(np.float32)          # ~260 users whose scores tie: flagged
-    ties_i = gauss_i.copy()
-    ties_i[:3000] = rng.integers(-2, 3, size=(3000, d)).astype(np.float32)
+    # rows in {-1, 0, 1} on eight columns, zero elsewhere: scores are small integers and tie in droves — such a user's candidate
+    # list ends inside a run of equal scores and cannot be proven complete
+    def coarse(n):
+        t = np.zeros((n, d), dtype=np.float32)
+        t[:, :8] = rng.integers(-1, 2, size=(n, 8))
+        return t
+    coarse_i = coarse(n_items)
+    mixed_u = gauss_u.copy()
+    mixed_u[:, 8:] = 0                                                       # Gaussian on the items' eight live columns: no ties ...
+    mixed_u[:270] = coarse(270)                                              # ... except for these 270 users
     cases = {'gaussian (a handful flagged)': (gauss_u, gauss_i),
-             'integer rows for 260 users (around the 256 the call finishes itself)': (ties_u, ties_i),
-             'all integer (thousands flagged)': (rng.integers(-3, 4, size=(n_users, d)).astype(np.float32),
-                                                 rng.integers(-3, 4, size=(n_items, d)).astype(np.float32))}
+             'coarse items, 270 coarse users (around the 256 the call finishes itself)': (mixed_u, coarse_i),
+             'all coarse (every user flagged)': (coarse(n_users), coarse_i)}
     seen = []
     try:
         for name, (U, I) in cases.items():
@@ -651,7 +656,7 @@ def test_two_stage_fall_back_planned_on_the_device(d):
                 seen.append(score_topk.last_flagged)
     finally:
         ops.set_fast_fallback(True)
-    assert min(seen) <= 64 and max(seen) > 1000 and any(200 < n < 400 for n in seen), seen       # below, around and far above 256
+    assert min(seen) <= 64 and max(seen) > 1000 and any(150 < n < 400 for n in seen), seen       # below, around and far above 256
 
 
 @pytest.mark.parametrize('d', [64, 128])
