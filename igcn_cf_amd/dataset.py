@@ -355,7 +355,14 @@ class SyntheticDataset(CsrBackedDataset):
     LogNormal), items drawn from a Zipf-Mandelbrot popularity over a random
     permutation (zipf_q = 0 gives the pure Zipf stress case, zipf_a = 0 the
     uniform one), de-duplicated per user, split 70/10/20 per user in draw order
-    as dataset.py:94-114 does."""
+    as dataset.py:94-114 does.
+
+    communities = C > 1 (round 4, measurement only — the headline stays on the graph above): PLANTED user / item communities of
+    equal size and the same degree laws.  The item at popularity rank r belongs to community r mod C (every community gets
+    the same popularity profile), a user to a uniformly drawn one; a draw of rank r goes, with probability community_share,
+    to the item of (nearly) the same rank in the user's OWN community instead.  Item ids stay a random permutation of the
+    ranks, user ids carry no information: the structure is in the graph, not in the labels.  The planted labels are kept
+    as user_community / item_community (int64) for the experiments that need the ground truth."""
 
     PRESETS = {
         'gowalla': dict(n_users=29858, n_items=40988, n_inter=1027464),
@@ -394,7 +401,17 @@ class SyntheticDataset(CsrBackedDataset):
         perm = rng.permutation(self.n_items)
 
         users = np.repeat(np.arange(self.n_users, dtype=np.int64), cnt)
-        items = perm[np.minimum(np.searchsorted(cdf, rng.random(users.size)), self.n_items - 1)]
+        ranks = np.minimum(np.searchsorted(cdf, rng.random(users.size)), self.n_items - 1)
+        n_comm = int(dataset_config.get('communities', 0) or 0)
+        if n_comm > 1:
+            crng = np.random.default_rng([seed, 77])                   # a stream of its own: communities = 0 draws as before
+            self.user_community = crng.integers(0, n_comm, self.n_users)
+            own = crng.random(users.size) < float(dataset_config.get('community_share', 0.8))
+            in_own = (ranks // n_comm) * n_comm + self.user_community[users]
+            ranks = np.where(own & (in_own < self.n_items), in_own, ranks)
+            self.item_community = np.empty(self.n_items, dtype=np.int64)
+            self.item_community[perm] = np.arange(self.n_items) % n_comm
+        items = perm[ranks]
         # de-duplicate per user, keeping draw order (first occurrence)
         key = users * np.int64(self.n_items) + items
         _, first = np.unique(key, return_index=True)

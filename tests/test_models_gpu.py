@@ -856,24 +856,19 @@ def _dropout_keep_mask(nnz, seed, keep_prob, device):
     return h < keep_below
 
 
-@pytest.mark.parametrize('dropout', [0., 0.3])
-def test_yelp_size_inmo_training_recall_parity_with_a_float64_restatement(dropout):
-    """BASELINE config 3 at full size, TRAINED — with the config's edge dropout 0.3 (the float64 side applies the SAME mask:
-    the product's keep decision is a hash of (seed, edge position), restated above with torch integer ops; semantics of
-    NGCF.dropout_sp_mat, model.py:263-275: kept values / (1 - p)) and without: one epoch (646 steps) of IGCN 3-layer d = 64 on the Yelp-like
-    split through the product path — ONE autograd node and one captured HIP graph per step, the template layer, the
-    auxiliary loss with w, the anneal at the epoch's end — against the reference algorithm restated in float64 torch on
-    the same batches: model.py:374-377, :423-446 (F's values row_sum^((alpha-1)/2 - 1/2), X0 = F T, propagation, mean),
-    :293-299 (L2 on the propagated rows), trainer.py:300-318 (BPR + l2_reg * mean + aux_reg * auxiliary BPR weighted by w
-    on raw template rows, items offset by len(user_map); Adam over T and w; feat_mat_anneal).  Gate: Recall@20 / NDCG@20 /
-    Precision@20 of the two trained models within 0.001, parameters and loss curves close."""
+def _inmo_training_parity(dropout, model_overrides=None, max_steps=None):
+    """IGCN on the Yelp-like split through the product path against the reference algorithm restated in float64 torch on the
+    same batches (see the tests below); model_overrides: model-config keys to change (feature_ratio, ranking_metric);
+    max_steps: stop the epoch early.  Returns (model, dataset, the float64 get_rep, the float64 template table, alpha)."""
+    model_overrides = model_overrides or {}
+
     from igcn_cf_amd import config as cfg
     from igcn_cf_amd.dataset import get_dataset
     from igcn_cf_amd.model import get_model
     from igcn_cf_amd.trainer import DeviceSampler, get_trainer
     dev = torch.device('cuda')
     ds_cfg, m_cfg, t_cfg = cfg.get_synthetic_config(dev, 'yelp')[2]
-    m_cfg = dict(m_cfg, dropout=dropout)
+    m_cfg = dict(m_cfg, dropout=dropout, **model_overrides)
     ds = get_dataset(ds_cfg)
     nu, ni = ds.n_users, ds.n_items
     torch.manual_seed(2021)
@@ -906,7 +901,9 @@ def test_yelp_size_inmo_training_recall_parity_with_a_float64_restatement(dropou
     model.train()
     sampler, aux_sampler = DeviceSampler(ds, dev, seed=5), DeviceSampler(trainer.aux_dataset, dev, seed=6)
     loss_a, loss_b = [], []
-    for nodes, aux in zip(sampler.epoch_node_batches(B, nu), aux_sampler.epoch_batches(B)):
+    for step, (nodes, aux) in enumerate(zip(sampler.epoch_node_batches(B, nu), aux_sampler.epoch_batches(B))):
+        if max_steps is not None and step >= max_steps:
+            break
         loss_a.append(trainer.igcn_node_step(nodes, aux))
         b = nodes.numel() // 3
         u, p, n = nodes[:b], nodes[b:2 * b], nodes[2 * b:]
@@ -920,7 +917,7 @@ def test_yelp_size_inmo_training_recall_parity_with_a_float64_restatement(dropou
         opt64.zero_grad(); loss.backward(); opt64.step()
         loss_b.append(loss.detach())
     model.feat_mat_anneal(); alpha *= model.delta                            # trainer.py:318
-    assert len(loss_b) == (len(ds) + B - 1) // B and trainer._graph is not None and abs(model.alpha - alpha) < 1e-15
+    assert len(loss_b) == (max_steps if max_steps is not None else (len(ds) + B - 1) // B) and trainer._graph is not None and abs(model.alpha - alpha) < 1e-15
     loss_a = torch.stack([x.double() for x in loss_a]).cpu().numpy(); loss_b = torch.stack(loss_b).cpu().numpy()
     assert np.abs(loss_a - loss_b).max() < 2e-5, np.abs(loss_a - loss_b).max()
     d_t = float((model.embedding.weight.detach().double() - t64.detach()).abs().max())
@@ -944,9 +941,65 @@ def test_yelp_size_inmo_training_recall_parity_with_a_float64_restatement(dropou
     m_ref = O.calculate_metrics(ds.test_data, rec64, [20])
     for name in ('Recall', 'NDCG', 'Precision'):
         assert abs(float(m_prod[name][20]) - float(m_ref[name][20])) < 1e-3, (name, m_prod[name][20], m_ref[name][20])
-    print('INMO recall parity (dropout %.1f, %d steps): product %r float64 %r; max |d T| %.2e, |d w| %.2e, loss curve max diff %.1e'
-          % (dropout, len(loss_b), {k: round(float(v[20]), 5) for k, v in m_prod.items()}, {k: round(float(v[20]), 5) for k, v in m_ref.items()},
+    print('INMO recall parity (%s dropout %.1f, %d steps): product %r float64 %r; max |d T| %.2e, |d w| %.2e, loss curve max diff %.1e'
+          % (model_overrides or '', dropout, len(loss_b), {k: round(float(v[20]), 5) for k, v in m_prod.items()}, {k: round(float(v[20]), 5) for k, v in m_ref.items()},
              d_t, d_w, float(np.abs(loss_a - loss_b).max())))
+    return model, ds, rep64, t64, alpha
+
+
+@pytest.mark.parametrize('dropout', [0., 0.3])
+def test_yelp_size_inmo_training_recall_parity_with_a_float64_restatement(dropout):
+    """BASELINE config 3 at full size, TRAINED — with the config's edge dropout 0.3 (the float64 side applies the SAME mask:
+    the product's keep decision is a hash of (seed, edge position), restated above with torch integer ops; semantics of
+    NGCF.dropout_sp_mat, model.py:263-275: kept values / (1 - p)) and without: one epoch (646 steps) of IGCN 3-layer d = 64 on the Yelp-like
+    split through the product path — ONE autograd node and one captured HIP graph per step, the template layer, the
+    auxiliary loss with w, the anneal at the epoch's end — against the reference algorithm restated in float64 torch on
+    the same batches: model.py:374-377, :423-446 (F's values row_sum^((alpha-1)/2 - 1/2), X0 = F T, propagation, mean),
+    :293-299 (L2 on the propagated rows), trainer.py:300-318 (BPR + l2_reg * mean + aux_reg * auxiliary BPR weighted by w
+    on raw template rows, items offset by len(user_map); Adam over T and w; feat_mat_anneal).  Gate: Recall@20 / NDCG@20 /
+    Precision@20 of the two trained models within 0.001, parameters and loss curves close."""
+    _inmo_training_parity(dropout)
+
+
+def test_yelp_size_inmo_with_half_the_nodes_as_templates():
+    """feature_ratio < 1 beyond the toy splits (model.py:386-421 with :388-391, utils.py:94-113; the paper's template-ratio
+    sweep, run/plot.py:102-109): IGCN on the Yelp-like split with HALF of the users and items as templates, ranked by 'sort'
+    (column sums of the row-L1-normalised adjacency).
+      * template selection on the host (graph.graph_rank_nodes: numpy's argsort decides the ties, as in the reference) —
+        timed here; it stays on the host unless it costs more than ~50 ms;
+      * the feature matrix built in HBM (feature_matrix_device) equals the host builder (feature_matrix_host) on the same
+        maps bit for bit: row pointers, column ids, row sums; user_map / item_map in the reference's insertion order;
+      * get_rep against the float64 chain <= 1e-4;
+      * 100 training steps (edge dropout 0.3, auxiliary loss, captured HIP graph) against the float64 restatement on the
+        same batches: losses, parameters, Recall / NDCG / Precision @20 within 0.001."""
+    import time
+    from igcn_cf_amd import config as cfg
+    from igcn_cf_amd.dataset import get_dataset
+    from igcn_cf_amd.graph import feature_matrix_host, graph_rank_nodes
+    overrides = {'feature_ratio': 0.5, 'ranking_metric': 'sort'}
+    model, ds, rep64, t64, alpha = _inmo_training_parity(0.3, overrides, max_steps=100)
+    nu, ni = ds.n_users, ds.n_items
+    t0 = time.perf_counter()
+    ranked_users, ranked_items = graph_rank_nodes(ds, 'sort')
+    rank_s = time.perf_counter() - t0
+    tu, ti = int(nu * 0.5), int(ni * 0.5)
+    assert list(model.user_map.keys()) == ranked_users[:tu].tolist() and list(model.user_map.values()) == list(range(tu))
+    assert list(model.item_map.keys()) == ranked_items[:ti].tolist() and list(model.item_map.values()) == list(range(ti))
+    assert model.embedding.weight.shape[0] == tu + ti + 2
+    rowptr, col, row_sum, shape = feature_matrix_host(ds.train_array, nu, ni, model.user_map, model.item_map)
+    f = model.feat_mat
+    assert tuple(f.shape) == tuple(shape) == (nu + ni, tu + ti + 2)
+    assert np.array_equal(f.rowptr.cpu().numpy(), rowptr) and np.array_equal(f.col.cpu().numpy(), col)
+    assert np.array_equal(model.row_sum.cpu().numpy(), row_sum)
+    # a node that is not a template keeps only its neighbours' templates + the global column: rows differ in length from ratio 1
+    assert f.nnz < 2 * len(ds.train_array) + nu + ni and int((f.rowptr[1:] - f.rowptr[:-1]).min()) >= 1
+    model.eval()
+    with torch.no_grad():
+        got = model.get_rep()
+        ref = rep64(model.embedding.weight.detach().double(), model.alpha)
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) <= 1e-4
+    print('template ranking (sort) on the host: %.1f ms for %d + %d nodes' % (rank_s * 1e3, nu, ni))
+    assert rank_s < 2.0                                                       # measured ~0.1 s; the builder runs once per model
 
 
 def test_gowalla_size_mf_training_recall_parity_with_a_float64_restatement():
