@@ -135,6 +135,23 @@ def test_rank_nodes_matches_reference(golden):
         graph_rank_nodes(DS(), 'page_rank')
 
 
+def test_rank_metric_equals_the_adjacency_form(golden):
+    """graph_rank_nodes forms its metric from the (user, item)-sorted pair list; the long way round — the coalesced 2 T-entry
+    adjacency matrix of utils.py:94-123 — gives the same float32 values and therefore the same argsort order, ties included:
+    the golden toys (duplicate pairs, empty lists) and a mid-size synthetic split with many equal degrees."""
+    from igcn_cf_amd.dataset import SyntheticDataset, get_dataset
+    from igcn_cf_amd.graph import graph_rank_nodes, graph_rank_nodes_from_adjacency
+    mid = SyntheticDataset({'name': 'SyntheticDataset', 'n_users': 4000, 'n_items': 2500, 'n_inter': 90000, 'device': 'cpu', 'min_inter': 3})
+    toy = get_dataset({'name': 'ProcessedDataset', 'path': golden['path'], 'device': 'cpu'})
+    for ds in (toy, mid):
+        for metric in ('degree', 'sort'):
+            a, b = graph_rank_nodes(ds, metric), graph_rank_nodes_from_adjacency(ds, metric)
+            np.testing.assert_array_equal(a[0], b[0])
+            np.testing.assert_array_equal(a[1], b[1])
+    with pytest.raises(ValueError):
+        graph_rank_nodes(toy, 'page_rank')
+
+
 def test_processed_dataset_matches_reference(golden, tmp_path):
     from igcn_cf_amd.dataset import AuxiliaryDataset, get_dataset
     ds = get_dataset({'name': 'ProcessedDataset', 'path': golden['path'], 'device': 'cpu'})
@@ -157,6 +174,27 @@ def test_processed_dataset_matches_reference(golden, tmp_path):
     s = ds.sample_batch_host(2000, np.random.default_rng(0))
     for u, p, n in s:
         assert ds.train_data[u] and p in ds.train_data[u] and n not in ds.train_data[u]
+
+
+def test_synthetic_dataset_with_planted_communities():
+    """communities = C: the same sizes and the same kind of degree laws, most of a user's items inside the user's own community,
+    labels that carry nothing (item ids are a random permutation of the popularity ranks), and communities = 0 draws exactly
+    what the generator drew before the option existed."""
+    from igcn_cf_amd.dataset import SyntheticDataset
+    base = dict(name='SyntheticDataset', n_users=3000, n_items=2000, n_inter=60000, device='cpu')
+    a, b = SyntheticDataset(base), SyntheticDataset(dict(base, communities=0))
+    np.testing.assert_array_equal(a.train_array, b.train_array)
+    c = SyntheticDataset(dict(base, communities=16, community_share=0.8))
+    ta = c.train_array
+    assert (c.n_users, c.n_items) == (3000, 2000) and abs(len(ta) / len(a.train_array) - 1) < 0.2
+    inside = (c.user_community[ta[:, 0]] == c.item_community[ta[:, 1]]).mean()
+    assert 0.7 < inside < 0.9
+    assert np.bincount(c.item_community, minlength=16).min() == 125 and np.bincount(c.user_community, minlength=16).min() > 120
+    deg_a, deg_c = np.sort(np.bincount(a.train_array[:, 1], minlength=2000))[::-1], np.sort(np.bincount(ta[:, 1], minlength=2000))[::-1]
+    assert 0.6 < deg_c[:20].sum() / deg_a[:20].sum() < 1.2 and abs(int(deg_c[1000]) - int(deg_a[1000])) <= 3      # a head and a tail, as before
+    # nothing in the labels: the correlation between an item's id and its community is that of a random assignment
+    assert abs(np.corrcoef(np.arange(2000), c.item_community)[0, 1]) < 0.1
+    assert len(np.unique(ta[:, 0] * 2000 + ta[:, 1])) == len(ta)
 
 
 def test_synthetic_dataset_properties():

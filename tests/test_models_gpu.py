@@ -999,7 +999,7 @@ def test_yelp_size_inmo_with_half_the_nodes_as_templates():
         ref = rep64(model.embedding.weight.detach().double(), model.alpha)
     assert float((got.double() - ref).abs().max() / ref.abs().max()) <= 1e-4
     print('template ranking (sort) on the host: %.1f ms for %d + %d nodes' % (rank_s * 1e3, nu, ni))
-    assert rank_s < 2.0                                                       # measured ~0.1 s; the builder runs once per model
+    assert rank_s < 0.5                                                       # ~10-30 ms from the sorted pair list (0.15 s through the adjacency matrix)
 
 
 def test_gowalla_size_mf_training_recall_parity_with_a_float64_restatement():
