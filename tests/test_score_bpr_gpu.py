@@ -741,6 +741,43 @@ def test_two_stage_second_whole_sweep_of_a_wave_counts_its_own_leavers():
     assert flagged[48] <= flagged[96] + 6 * 64 and flagged[32] <= flagged[96] + 6 * 64, flagged
 
 
+def test_two_stage_exclusion_lists_sorted_on_the_device_hold_every_users_best_items():
+    """The exclusion lists reach the candidate sweep as sweep POSITIONS, sorted row by row on the device (csrc/topk_order.hip:
+    half-wave rank sorts up to 32 entries, wave rank sorts up to 256, a workgroup's bitonic network in LDS up to 8 192 and in
+    place in HBM beyond; which kernel takes a row is decided on the device, no host read).  Here user u excludes exactly its
+    OWN L best items, L at and around every class boundary: one entry that is lost, duplicated or out of order puts an
+    excluded item into the list or drops a rightful one.  Lists equal to the fp32 sweep's and to the float64 ranking."""
+    from igcn_cf_amd.ops import score_topk
+    rng = np.random.default_rng(47)
+    n_items, d, k = 45000, 64, 20
+    lengths = [0, 1, 2, 31, 32, 33, 63, 64, 65, 255, 256, 257, 1000, 4095, 8191, 8192, 8193, 20000, n_items - k]
+    lengths = lengths + [int(x) for x in rng.integers(1, 300, size=45)]
+    n_users = len(lengths)
+    U = (rng.standard_normal((n_users, d)) * 0.1).astype(np.float32)
+    I = (rng.standard_normal((n_items, d)) * 0.1 * np.exp(0.3 * rng.standard_normal((n_items, 1)))).astype(np.float32)
+    s64 = U.astype(np.float64) @ I.astype(np.float64).T
+    order = np.argsort(-s64, axis=1, kind='stable')
+    ex = [np.sort(order[u, :L]) for u, L in enumerate(lengths)]                  # ascending ids, as the API wants them
+    rowptr = np.zeros(n_users + 1, dtype=np.int64)
+    np.cumsum(lengths, out=rowptr[1:])
+    kw = dict(excl_rowptr=_dev(rowptr), excl_col=_dev(np.concatenate(ex).astype(np.int32)))
+    # a permuted user subset as well: rows are looked up by user id, not by batch position
+    for users in (None, _dev(rng.permutation(n_users).astype(np.int64))):
+        a = score_topk(_dev(U), _dev(I), k, user_ids=users, mode='fast', **kw)
+        b = score_topk(_dev(U), _dev(I), k, user_ids=users, mode='exact', **kw)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        got = a[0].cpu().numpy()
+        ids = np.arange(n_users) if users is None else users.cpu().numpy()
+        for row, u in enumerate(ids):
+            L = lengths[u]
+            want = order[u, L:L + k]
+            gap = np.abs(np.diff(s64[u, order[u, L:L + k + 1]])).min()           # a float64 near-tie may swap neighbours in fp32
+            if gap > 1e-6:
+                np.testing.assert_array_equal(got[row], want, err_msg='user %d, %d exclusions' % (u, L))
+            else:
+                assert set(got[row]) <= set(order[u, L:L + k + 2].tolist())
+
+
 def test_two_stage_exclusion_lists_of_every_length_class():
     """The candidate sweep walks each user's exclusion list in SWEEP positions, sorted row by row on the device (a segmented
     radix sort): empty lists, short ones, lists of thousands of entries and one that leaves exactly k items.  The lists are
