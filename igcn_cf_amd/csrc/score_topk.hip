@@ -1688,7 +1688,9 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     const int n_tiles = (int)((n_items + 31) / 32);
     const int64_t pack_threads = (int64_t)n_tiles * ks * kWave;
     int64_t stat_blocks = ((n_items << lg) + kBlock - 1) / kBlock;
-    if (stat_blocks > 8 * (int64_t)cu_count()) stat_blocks = 8 * (int64_t)cu_count();
+    // (measured, round 4: eight workgroups per CU took 47 us against 23 for one here — two contended words and the norm table to
+    // write; the users' pass below, one word and no table, takes 16 against 33 with eight)
+    if (stat_blocks > (int64_t)cu_count()) stat_blocks = (int64_t)cu_count();
     hipLaunchKernelGGL(topk_row_stats_kernel, dim3((unsigned)stat_blocks), dim3(kBlock), 0, st, item_rows, ldi, n_items,
                        (const int64_t *)nullptr, 0, lg, norm_bits, by_norm ? reinterpret_cast<float *>(ows + L.ord.norm2) : (float *)nullptr);
     const int32_t *perm = nullptr, *excl_pos = nullptr;

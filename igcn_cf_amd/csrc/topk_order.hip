@@ -14,13 +14,11 @@
 //   perm[pos] = item id at sweep position pos   (stable descending radix sort of the norms: ties keep ascending id)
 //   inv[item] = pos
 //   excl_pos  = the exclusion CSR's entries as sweep positions, ascending inside every row (the sweep walks each
-//               user's list with a cursor): inv[col], sorted row by row by three kernels of this file (round 4) —
-//               rows of <= 32 entries by a half-wave each (rank counting: an entry's place is the number of smaller ones,
-//               32 shuffles), rows of 33 .. 256 by a wave each (the same with four entries per lane), longer rows by a
-//               workgroup each (a bitonic network in its all-ascending form, in LDS up to 8 192 entries, in place in HBM
-//               beyond).  Which class a row falls into is decided on the device: the first kernel appends the rows it does
-//               not take to two lists, the other two run over fixed grids and read the lists' lengths there — NO host
-//               read.  Rounds 2-3 used rocprim::segmented_radix_sort_keys, which partitions its segments by size and copies
+//               user's list with a cursor): inv[col], sorted row by row by two kernels of this file (round 4) —
+//               rows of <= 32 entries by a half-wave each and rows of 33 .. 256 by a wave each, in registers (bitonic
+//               networks of xor-shuffles, sixteen rows' networks interleaved), longer rows by a workgroup each (the same
+//               network in LDS up to 8 192 entries, in place in HBM beyond).  Which class a row falls into is decided
+//               where it is sorted — NO host read.  Rounds 2-3 used rocprim::segmented_radix_sort_keys, which partitions its segments by size and copies
 //               the partition sizes to the HOST before it can launch its sort kernels: a stream synchronisation inside an
 //               entry point whose contract says there is none (it could not be captured into a HIP graph), 115 us of kernels
 //               and 15-140 us of an idle GPU behind the read (profiles/r03ae_*, r04d_*).  A global sort of
@@ -43,133 +41,172 @@ __global__ __launch_bounds__(kBlock) void order_keys_kernel(const float *__restr
     iota[i] = (int32_t)i;
 }
 
-__global__ __launch_bounds__(kBlock) void invert_perm_kernel(const int32_t *__restrict__ perm, int64_t n, int32_t *__restrict__ inv,
-                                                             unsigned int *__restrict__ list_counts)
+__global__ __launch_bounds__(kBlock) void invert_perm_kernel(const int32_t *__restrict__ perm, int64_t n, int32_t *__restrict__ inv)
 {
     const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (p < n) inv[perm[p]] = (int32_t)p;
-    if (p == 0 && list_counts) { list_counts[0] = 0u; list_counts[1] = 0u; }      // lengths of the two row lists of the kernels below
 }
 
 // ---- the exclusion lists as sweep positions, ascending inside every row ------------------------------------------------
-constexpr int kExclShort = 32, kExclMid = 256, kExclLds = 8192;
+// No lists of rows, no counters, no atomics: a wave looks at kExclScan consecutive rows, sorts the ones of its classes and
+// skips the rest; the workgroups of the second kernel look at 256 rows each for the (rare) huge ones.  (A first version
+// appended the rows it did not take to two lists with one atomic each: 27 k atomics on two words — 240 us.)
+constexpr int kExclShort = 32, kExclMid = 256, kExclLds = 8192, kExclScan = 8, kHugeScan = 64;
 constexpr uint32_t kPosNone = 0xFFFFFFFFu;
 
-// Rows of <= kExclShort entries: one HALF-WAVE per row.  Longer rows go to mid_list (<= kExclMid) / long_list.
-__global__ __launch_bounds__(kBlock) void excl_sort_short_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                                 int64_t n_rows, const int32_t *__restrict__ inv, uint32_t *__restrict__ pos,
-                                                                 int32_t *__restrict__ mid_list, int32_t *__restrict__ long_list,
-                                                                 unsigned int *__restrict__ list_counts)
+// One stage-by-stage bitonic network in the form whose compare-exchanges all point the same way (stage k first pairs i with
+// i ^ (k - 1), then with i + j for j = k / 4 ... 1): an index past the end of the row stands for +infinity and its exchanges
+// are simply skipped, so a row needs no padding to a power of two and can be sorted where it lies.  `sync`: what separates two
+// steps (nothing for a single wave on LDS — its LDS instructions execute in order —, a barrier for a workgroup).
+template <int THREADS, typename Buf, typename Sync>
+__device__ __forceinline__ void bitonic_ascending(Buf buf, int len, int tid, Sync sync)
 {
-    const int l32 = threadIdx.x & 31;
-    const int64_t hw = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 5;
-    const int64_t n_hw = ((int64_t)gridDim.x * kBlock) >> 5;
-    for (int64_t r = hw; r < n_rows; r += n_hw) {
-        const int64_t s = rowptr[r];
-        const int len = (int)(rowptr[r + 1] - s);
-        if (len <= 0) continue;
-        if (len > kExclShort) {
-            if (l32 == 0) {
-                const int which = len > kExclMid ? 1 : 0;
-                const unsigned int slot = atomicAdd(list_counts + which, 1u);
-                (which ? long_list : mid_list)[slot] = (int32_t)r;
+    int top = 1;
+    while (top < len) top <<= 1;
+    for (int k = 2; k <= top; k <<= 1) {
+        for (int j = k - 1; j > 0;) {
+            for (int t = tid; t < top / 2; t += THREADS) {
+                int lo, hi;
+                if (j == k - 1) {                                         // the flip: (i, i ^ (k - 1)) inside blocks of k
+                    const int blk = t / (k >> 1), off = t % (k >> 1);
+                    lo = blk * k + off;
+                    hi = blk * k + (k - 1 - off);
+                } else {                                                  // (i, i + j) with bit j of i clear
+                    lo = (t / j) * 2 * j + (t % j);
+                    hi = lo + j;
+                }
+                if (hi < len) {
+                    const uint32_t a = buf[lo], b = buf[hi];
+                    if (b < a) { buf[lo] = b; buf[hi] = a; }
+                }
             }
-            continue;
+            sync();
+            j = (j == k - 1) ? (k >> 2) : (j >> 1);                       // k - 1, then k / 4, k / 8, ..., 1 (k = 2: the flip is all)
         }
-        uint32_t key = kPosNone;
-        if (l32 < len) key = (uint32_t)inv[col[s + l32]];
-        int rank = 0;
-        for (int c = 0; c < len; ++c) {                          // (len is uniform inside the half-wave; the shuffle stays inside it)
-            const uint32_t other = (uint32_t)__shfl((int)key, c, 32);
-            rank += (other < key || (other == key && c < l32)) ? 1 : 0;
-        }
-        if (l32 < len) pos[s + rank] = key;
     }
 }
 
-// Rows of kExclShort + 1 .. kExclMid entries: one WAVE per row of mid_list, up to four entries per lane.
-__global__ __launch_bounds__(kBlock) void excl_sort_mid_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                               const int32_t *__restrict__ inv, uint32_t *__restrict__ pos,
-                                                               const int32_t *__restrict__ mid_list, const unsigned int *__restrict__ list_counts)
+// Rows of up to kExclMid entries, sorted in REGISTERS by bitonic networks whose exchanges are xor-shuffles (padding = kPosNone,
+// which sorts last).  A wave looks at kExclScan consecutive rows:
+//   * their first 32 entries are loaded for all of them at once (two independent loads in flight per row: the column id, then
+//     the position it maps to) into kExclScan / 2 register slots — slot i holds row 2 i in the lower half-wave and row 2 i + 1 in
+//     the upper — and all slots go through the 32-key network TOGETHER: 15 steps of independent shuffles, so the
+//     latency of a shuffle is paid 15 times per turn, not per row (rank counting with one shuffle, or one LDS read, per
+//     key paid it per key: 240 and 170 us for the Amazon-like lists); the rows of <= 32 entries are then stored;
+//   * the rows of 33 .. 256 entries follow one at a time: four keys per lane (entry e = 64 q + lane), 36 steps of which the
+//     distances >= 64 are exchanges between a lane's own registers.
+__device__ __forceinline__ uint32_t bitonic_pick(uint32_t mine, uint32_t other, bool keep_min)
 {
-    constexpr int Q = kExclMid / kWave;
-    const int lane = threadIdx.x & (kWave - 1);
+    const uint32_t lo = mine < other ? mine : other, hi = mine < other ? other : mine;
+    return keep_min ? lo : hi;
+}
+
+__global__ __launch_bounds__(kBlock) void excl_sort_rows_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                                int64_t n_rows, const int32_t *__restrict__ inv, uint32_t *__restrict__ pos)
+{
+    const int lane = threadIdx.x & (kWave - 1), l32 = lane & 31, hw = lane >> 5;
     const int64_t w0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int64_t n_w = ((int64_t)gridDim.x * kBlock) >> 6;
-    const int64_t n = list_counts[0];
-    for (int64_t i = w0; i < n; i += n_w) {
-        const int64_t r = mid_list[i];
-        const int64_t s = rowptr[r];
-        const int len = (int)(rowptr[r + 1] - s);
-        uint32_t key[Q];
-        int rank[Q];
+    constexpr int S = kExclScan / 2;
+    for (int64_t base = w0 * kExclScan; base < n_rows; base += n_w * kExclScan) {
+        long long s_l = 0;
+        int len_l = 0;
+        if (lane < kExclScan && base + lane < n_rows) {
+            s_l = rowptr[base + lane];
+            len_l = (int)(rowptr[base + lane + 1] - s_l);
+        }
+        if (!__any(len_l > 0)) continue;
+        long long s[S];
+        int len[S];
+        uint32_t key[S];
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const int e = q * kWave + lane;
-            key[q] = e < len ? (uint32_t)inv[col[s + e]] : kPosNone;
-            rank[q] = 0;
+        for (int i = 0; i < S; ++i) {
+            s[i] = __shfl(s_l, 2 * i + hw);
+            len[i] = __shfl(len_l, 2 * i + hw);
         }
 #pragma unroll
-        for (int q2 = 0; q2 < Q; ++q2) {
-            const int lim = len - q2 * kWave < kWave ? len - q2 * kWave : kWave;      // entries held in register q2 (wave-uniform)
-            for (int c = 0; c < lim; ++c) {
-                const uint32_t other = (uint32_t)__shfl((int)key[q2], c);
-                const int oc = q2 * kWave + c;
+        for (int i = 0; i < S; ++i) key[i] = l32 < len[i] ? (uint32_t)col[s[i] + l32] : kPosNone;
 #pragma unroll
-                for (int q = 0; q < Q; ++q)
-                    rank[q] += (other < key[q] || (other == key[q] && oc < q * kWave + lane)) ? 1 : 0;
+        for (int i = 0; i < S; ++i) key[i] = l32 < len[i] ? (uint32_t)inv[key[i]] : kPosNone;
+        for (int k = 2; k <= kExclShort; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const bool keep_min = ((l32 & j) == 0) == ((l32 & k) == 0);
+#pragma unroll
+                for (int i = 0; i < S; ++i) key[i] = bitonic_pick(key[i], (uint32_t)__shfl_xor((int)key[i], j), keep_min);
             }
-        }
 #pragma unroll
-        for (int q = 0; q < Q; ++q)
-            if (q * kWave + lane < len) pos[s + rank[q]] = key[q];
+        for (int i = 0; i < S; ++i)
+            if (len[i] <= kExclShort && l32 < len[i]) pos[s[i] + l32] = key[i];
+        // rows of 33 .. 256 entries, one at a time
+        unsigned long long todo = __ballot(len_l > kExclShort && len_l <= kExclMid);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const long long sr = __shfl(s_l, src);
+            const int lr = __shfl(len_l, src);
+            constexpr int Q = kExclMid / kWave;
+            uint32_t kq[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) kq[q] = q * kWave + lane < lr ? (uint32_t)col[sr + q * kWave + lane] : kPosNone;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) kq[q] = q * kWave + lane < lr ? (uint32_t)inv[kq[q]] : kPosNone;
+            for (int k = 2; k <= kExclMid; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    if (j >= kWave) {                                     // partners are registers of the same lane
+                        const int dq = j / kWave;
+#pragma unroll
+                        for (int q = 0; q < Q; ++q)
+                            if ((q & dq) == 0 && (q | dq) < Q) {
+                                const bool asc = (((q * kWave) & k) == 0);
+                                const uint32_t a = kq[q], b = kq[q | dq];
+                                const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+                                kq[q] = asc ? lo : hi;
+                                kq[q | dq] = asc ? hi : lo;
+                            }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) {
+                            const int e = q * kWave + lane;
+                            const bool keep_min = ((e & j) == 0) == ((e & k) == 0);
+                            kq[q] = bitonic_pick(kq[q], (uint32_t)__shfl_xor((int)kq[q], j), keep_min);
+                        }
+                    }
+                }
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                if (q * kWave + lane < lr) pos[sr + q * kWave + lane] = kq[q];
+        }
     }
 }
 
-// Longer rows: one WORKGROUP per row of long_list.  Bitonic network in the form whose compare-exchanges all point the same way
-// (stage k first pairs i with i ^ (k - 1), then with i ^ j for j = k / 4 ... 1): an index past the end of the row stands for
-// +infinity and its exchanges are simply skipped, so a row needs no padding to a power of two and is sorted where it lies —
-// in LDS up to kExclLds entries, in its own place in HBM beyond (a user who excludes a twelfth of a 96 k-item table and more).
-__global__ __launch_bounds__(kBlock) void excl_sort_long_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                                const int32_t *__restrict__ inv, uint32_t *__restrict__ pos,
-                                                                const int32_t *__restrict__ long_list, const unsigned int *__restrict__ list_counts)
+// Rows of more than kExclMid entries: a workgroup looks at kHugeScan rows and sorts each long one among them by the bitonic network
+// above — in LDS up to kExclLds entries, in place in HBM beyond (a user who excludes a twelfth of a 96 k-item table and more).
+__global__ __launch_bounds__(kBlock) void excl_sort_huge_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                                int64_t n_rows, const int32_t *__restrict__ inv, uint32_t *__restrict__ pos)
 {
     __shared__ uint32_t lds[kExclLds];
-    const int64_t n = list_counts[1];
-    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
-        const int64_t r = long_list[i];
-        const int64_t s = rowptr[r];
-        const int len = (int)(rowptr[r + 1] - s);
-        uint32_t *buf = len <= kExclLds ? lds : pos + s;
-        for (int e = threadIdx.x; e < len; e += kBlock) buf[e] = (uint32_t)inv[col[s + e]];
-        __syncthreads();
-        int top = 1;
-        while (top < len) top <<= 1;
-        for (int k = 2; k <= top; k <<= 1) {
-            for (int j = k - 1; j > 0; j = (j == k - 1) ? (k >> 2) : (j >> 1)) {     // k - 1 (the flip), then k / 4, k / 8, ..., 1
-                for (int t = threadIdx.x; t < top / 2; t += kBlock) {
-                    int lo, hi;
-                    if (j == k - 1) {                                     // pairs (i, i ^ (k - 1)) inside blocks of k
-                        const int blk = t / (k >> 1), off = t % (k >> 1);
-                        lo = blk * k + off;
-                        hi = blk * k + (k - 1 - off);
-                    } else {                                              // pairs (i, i + j) with bit j of i clear
-                        lo = ((t / j) * 2 * j) + (t % j);
-                        hi = lo + j;
-                    }
-                    if (hi < len) {
-                        const uint32_t a = buf[lo], b = buf[hi];
-                        if (b < a) { buf[lo] = b; buf[hi] = a; }
-                    }
-                }
-                __syncthreads();
-                if (j == 1) break;
-                if (j == k - 1 && (k >> 2) == 0) break;                  // k = 2: the flip was the whole stage
-            }
+    __shared__ int lens[kHugeScan];
+    __shared__ long long starts[kHugeScan];
+    for (int64_t base = (int64_t)blockIdx.x * kHugeScan; base < n_rows; base += (int64_t)gridDim.x * kHugeScan) {
+        const int64_t r = base + threadIdx.x;
+        long long s = 0;
+        int len = 0;
+        if (threadIdx.x < kHugeScan && r < n_rows) { s = rowptr[r]; len = (int)(rowptr[r + 1] - s); }
+        __syncthreads();                                                  // (the arrays below are still read by the previous turn)
+        if (threadIdx.x < kHugeScan) { lens[threadIdx.x] = len; starts[threadIdx.x] = s; }
+        if (!__syncthreads_or(len > kExclMid)) continue;
+        for (int i = 0; i < kHugeScan; ++i) {
+            const int li = lens[i];
+            if (li <= kExclMid) continue;                                 // (uniform over the workgroup)
+            const long long si = starts[i];
+            uint32_t *buf = li <= kExclLds ? lds : pos + si;
+            for (int e = threadIdx.x; e < li; e += kBlock) buf[e] = (uint32_t)inv[col[si + e]];
+            __syncthreads();
+            bitonic_ascending<kBlock>(buf, li, (int)threadIdx.x, [] { __syncthreads(); });
+            if (li <= kExclLds)
+                for (int e = threadIdx.x; e < li; e += kBlock) pos[si + e] = lds[e];
+            __syncthreads();                                              // the next row re-uses the buffer
         }
-        if (len <= kExclLds)
-            for (int e = threadIdx.x; e < len; e += kBlock) pos[s + e] = lds[e];
-        __syncthreads();                                                  // the next row re-uses the buffer
     }
 }
 
@@ -191,7 +228,7 @@ int topk_order_layout(int64_t n_items, int64_t excl_rows, int64_t excl_nnz, Topk
     L->iota = off; off += al256(n_items * 4);
     L->perm = off; off += al256(n_items * 4);
     L->inv = off; off += al256(n_items * 4);
-    L->ekeys = off; off += excl_nnz > 0 ? al256(excl_rows * 4) * 2 + 256 : 0;     // [mid_list][long_list][two counters]
+    L->ekeys = off;
     L->ekeys_sorted = 0;
     L->excl_pos = off; off += al256(excl_nnz * 4);
     L->tmp = off; off += al256((int64_t)L->tmp_bytes);
@@ -212,25 +249,22 @@ int topk_order_build(const TopkOrderLayout &L, char *ws, int64_t n_items, const 
     hipError_t e = rocprim::radix_sort_pairs_desc(ws + L.tmp, tmp_bytes, (const uint32_t *)keys, keys_sorted, (const int32_t *)iota, perm,
                                                   (size_t)n_items, kNormBeginBit, 31, st);
     if (e != hipSuccess) return (int)e;
-    int32_t *mid_list = reinterpret_cast<int32_t *>(ws + L.ekeys), *long_list = reinterpret_cast<int32_t *>(ws + L.ekeys + al256(excl_rows * 4));
-    unsigned int *list_counts = reinterpret_cast<unsigned int *>(ws + L.ekeys + 2 * al256(excl_rows * 4));
-    hipLaunchKernelGGL(invert_perm_kernel, dim3(ib), dim3(kBlock), 0, st, (const int32_t *)perm, n_items, inv,
-                       excl_nnz > 0 ? list_counts : (unsigned int *)nullptr);
+    hipLaunchKernelGGL(invert_perm_kernel, dim3(ib), dim3(kBlock), 0, st, (const int32_t *)perm, n_items, inv);
     *perm_out = perm;
     *excl_pos_out = nullptr;
     if (excl_nnz > 0) {
         if (excl_rows >= ((int64_t)1 << 31)) return IGCN_E_SHAPE;
         uint32_t *pos = reinterpret_cast<uint32_t *>(ws + L.excl_pos);
         const int64_t cus = cu_count();
-        int64_t sb = (excl_rows * 32 + kBlock - 1) / kBlock;                    // a half-wave per row, at most 16 workgroups per CU
-        if (sb > 16 * cus) sb = 16 * cus;
-        hipLaunchKernelGGL(excl_sort_short_kernel, dim3((unsigned)sb), dim3(kBlock), 0, st, excl_rowptr, excl_col, excl_rows,
-                           (const int32_t *)inv, pos, mid_list, long_list, list_counts);
-        // the lists' lengths are only known on the device: fixed grids, every wave / workgroup walks its share of a list
-        hipLaunchKernelGGL(excl_sort_mid_kernel, dim3((unsigned)(8 * cus)), dim3(kBlock), 0, st, excl_rowptr, excl_col,
-                           (const int32_t *)inv, pos, (const int32_t *)mid_list, (const unsigned int *)list_counts);
-        hipLaunchKernelGGL(excl_sort_long_kernel, dim3((unsigned)(4 * cus)), dim3(kBlock), 0, st, excl_rowptr, excl_col,
-                           (const int32_t *)inv, pos, (const int32_t *)long_list, (const unsigned int *)list_counts);
+        const int64_t turns = (excl_rows + kExclScan - 1) / kExclScan;          // a wave per kExclScan rows
+        int64_t rb = (turns + kBlock / kWave - 1) / (kBlock / kWave);
+        if (rb > 8 * cus) rb = 8 * cus;
+        hipLaunchKernelGGL(excl_sort_rows_kernel, dim3((unsigned)rb), dim3(kBlock), 0, st, excl_rowptr, excl_col, excl_rows,
+                           (const int32_t *)inv, pos);
+        int64_t hb = (excl_rows + kHugeScan - 1) / kHugeScan;                   // 32 KiB of LDS each: five per CU
+        if (hb > 5 * cus) hb = 5 * cus;
+        hipLaunchKernelGGL(excl_sort_huge_kernel, dim3((unsigned)hb), dim3(kBlock), 0, st, excl_rowptr, excl_col, excl_rows,
+                           (const int32_t *)inv, pos);
         *excl_pos_out = reinterpret_cast<const int32_t *>(pos);
     }
     return launch_status();
