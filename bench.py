@@ -1,7 +1,9 @@
 """Benchmark of the propagation + scoring path (driver contract: one JSON line).
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...     (the driver's N > 1 command)
+A plain `python bench.py --gpus N` (N > 1, no launcher) starts its own N ranks as fresh child processes before any GPU call
+(spawn_ranks) and relays rank 0's line; IGCN_BENCH_ONE_GPU=1 rehearses N > 1 on a one-GPU box (gloo; timings are not measurements).
 
 Workload (BASELINE.json: "propagation edges/sec + eval users/sec, Amazon-book dim=64"; configs[3]):
 LightGCN, 3 layers, d = 64, fp32, on the seeded Amazon-book-like synthetic split (109 730 users x
@@ -15,21 +17,26 @@ A STEP is one K-layer propagation pass over the whole graph (LightGCN.get_rep, m
 N = 1 three SpMM launches with the layer mean fused in the last; at N > 1 the X_0 exchange, K local
 SpMMs and K - 1 all-gathers.  Inputs are resident in HBM before the timed region.
 value = edges/s = steps * n_layers * nnz(A_hat) / time (whole job, max over ranks).
-Also reported (outside `value`): full-evaluation users/s (propagate once + fused score/mask/top-20 over
-every user) and the full training step (sample + forward + BPR + backward + Adam).
+Also reported (outside `value`, flat keys + copies inside `roofline`, whose values the driver keeps): full-evaluation users/s
+(propagate once + fused score/mask/top-20 over every user; the fp32 sweep's MFMA fraction beside it), the full training step, and
 
-roofline: the dominant kernel is spmm_csr_multirow_kernel<16,2,false>; `achieved` = algorithmic bytes
-per launch (nnz*(8+4d) + N*(4d+4)) / average launch duration measured with HIP events
-over the timed region.  The 52.8 MB operand of this workload lives in the 256 MiB Infinity Cache, so the
-8 TB/s HBM roof does not bind it; `peak` is therefore the roof that does, MEASURED IN THIS RUN: a
-row-structure-free gather + FMA + store kernel over the same index stream
-(igcn_cf_amd/csrc/roof_probe.hip), expressed in the same algorithmic bytes/s, and `frac` =
-achieved / peak <= 1.  The figure against the HBM spec is kept as `frac_of_hbm_spec` (not a bound).
-The HBM-bound leg — one GPU's 1/8 row share of BASELINE config 5 (125 M nonzeros against a 12 M x 128
-operand = 6.1 GB, kernel spmm_csr_rows_kernel<32,false>) — is timed in the same run:
-extras.roofline_hbm_bound, against the 8 TB/s HBM peak.
-cpu_baseline (rank 0, N = 1): the C restatement of the path (oracle/oracle_c.c, kind "port") on all
-host cores, on the same graph, bounded to ~10-30 s.
+roofline: the dominant kernel is spmm_csr_multirow_kernel<16,2,false>; `achieved` = algorithmic bytes per launch
+(nnz*(8+4d) + N*(4d+4)) / average launch duration measured with HIP events over the timed region; `peak` = the
+8 TB/s HBM spec and `frac` = achieved / peak.  The 52.8 MB operand of this workload lives in the 256 MiB Infinity Cache, so that
+fraction EXCEEDS 1 and bounds nothing here: `bound` says "mall-gather", and next to it the line carries the rate of gathered rows
+against the guide's 8.6 TB/s for Infinity-Cache gathers, the counter-measured bytes beyond L2 of a committed rocprofv3 pass
+(`traffic`, profiles/pmc_traffic.json), the L2 hit rate, and an in-run rowless gather over the same index stream
+(igcn_cf_amd/csrc/roof_probe.hip; a sibling kernel, not a roof).
+The HBM-bound leg — one GPU's 1/8 row share of BASELINE config 5 (125 M nonzeros against a 12 M x 128 operand = 6.1 GB, kernel
+spmm_csr_rows_kernel<32,false>), its user block and its item block as launches of their own — is timed in the same run
+(extras.roofline_hbm_bound, flat hbm_bound_*): counter bytes (2*FETCH_SIZE + WRITE_SIZE of the committed pass of these very
+launches, profiles/pmc_traffic_config5.json) / this run's time against the 8 TB/s spec and against what this box streams
+(hbm_stream_read_GBps / hbm_stream_copy_GBps: roof_probe.hip's stream kernels, 2 GiB buffers); the algorithmic figure is kept
+under its own name (hbm_bound_algorithmic_*).
+BASELINE config 5 across the ranks of the job (extras.config5_sharded, flat config5_*): K = 3, d = 128, 'halves' exchange, every
+rank building only its own blocks in HBM; at N = 1 the whole 1 G-nonzero graph on the one GPU.
+cpu_baseline (rank 0, N = 1): the best host path on the same graph — the C restatement of the path (oracle/oracle_c.c, kind
+"port") at its best thread count, torch's sparse matmuls, scipy — bounded to ~10-30 s.
 """
 import argparse
 import json
