@@ -1697,7 +1697,7 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     float *tile_bound = reinterpret_cast<float *>(ws + L.tile_bound), *unorm2 = reinterpret_cast<float *>(ws + L.unorm2);
     bool early_exit = false;
     if (by_norm) {
-        rc = topk_order_build(L.ord, ows, n_items, excl_rowptr, excl_col, excl_rows, excl_nnz, st, &perm, &excl_pos);
+        rc = topk_order_build(L.ord, ows, n_items, excl_rowptr, excl_col, excl_rows, excl_nnz, user_ids, batch, st, &perm, &excl_pos);
         if (rc != IGCN_OK) return rc;
     }
     if (mode >= 2) {

@@ -13,8 +13,10 @@ struct TopkOrderLayout {
 int topk_order_layout(int64_t n_items, int64_t excl_rows, int64_t excl_nnz, TopkOrderLayout *L);
 
 // perm (position -> item id, descending |row|^2, ties by ascending id), its inverse, and — when an exclusion CSR is given
-// — that CSR's entries as sweep positions, ascending inside every row.  Everything lives in `ws`.
+// — that CSR's entries as sweep positions, ascending inside every row, for the rows the call's users own (user_ids[0..batch), or
+// rows 0..batch-1 when user_ids is NULL).  Everything lives in `ws`.
 int topk_order_build(const TopkOrderLayout &L, char *ws, int64_t n_items, const int64_t *excl_rowptr, const int32_t *excl_col,
-                     int64_t excl_rows, int64_t excl_nnz, hipStream_t st, const int32_t **perm_out, const int32_t **excl_pos_out);
+                     int64_t excl_rows, int64_t excl_nnz, const int64_t *user_ids, int64_t batch, hipStream_t st,
+                     const int32_t **perm_out, const int32_t **excl_pos_out);
 
 }  // namespace igcn

@@ -47,6 +47,17 @@ __global__ __launch_bounds__(kBlock) void invert_perm_kernel(const int32_t *__re
     if (p < n) inv[perm[p]] = (int32_t)p;
 }
 
+// needed[row] = 1 for the exclusion rows the users of this call own (idempotent writes: a user id may repeat in a batch).  Every
+// flagged row is then sorted exactly once, by whichever wave / workgroup scans it — the in-place sort of a huge row must not run twice.
+__global__ __launch_bounds__(kBlock) void excl_mark_rows_kernel(const int64_t *__restrict__ user_ids, int64_t batch, int64_t n_rows,
+                                                                uint8_t *__restrict__ needed)
+{
+    const int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (b >= batch) return;
+    const int64_t r = user_ids ? user_ids[b] : b;
+    if (r >= 0 && r < n_rows) needed[r] = 1;
+}
+
 // ---- the exclusion lists as sweep positions, ascending inside every row ------------------------------------------------
 // No lists of rows, no counters, no atomics: a wave looks at kExclScan consecutive rows, sorts the ones of its classes and
 // skips the rest; the workgroups of the second kernel look at 256 rows each for the (rare) huge ones.  (A first version
@@ -102,7 +113,8 @@ __device__ __forceinline__ uint32_t bitonic_pick(uint32_t mine, uint32_t other, 
 }
 
 __global__ __launch_bounds__(kBlock) void excl_sort_rows_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                                int64_t n_rows, const int32_t *__restrict__ inv, uint32_t *__restrict__ pos)
+                                                                int64_t n_rows, const int32_t *__restrict__ inv, uint32_t *__restrict__ pos,
+                                                                const uint8_t *__restrict__ needed)
 {
     const int lane = threadIdx.x & (kWave - 1), l32 = lane & 31, hw = lane >> 5;
     const int64_t w0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
@@ -111,7 +123,7 @@ __global__ __launch_bounds__(kBlock) void excl_sort_rows_kernel(const int64_t *_
     for (int64_t base = w0 * kExclScan; base < n_rows; base += n_w * kExclScan) {
         long long s_l = 0;
         int len_l = 0;
-        if (lane < kExclScan && base + lane < n_rows) {
+        if (lane < kExclScan && base + lane < n_rows && (!needed || needed[base + lane])) {    // (a row no user of the batch owns: skipped)
             s_l = rowptr[base + lane];
             len_l = (int)(rowptr[base + lane + 1] - s_l);
         }
@@ -182,7 +194,8 @@ __global__ __launch_bounds__(kBlock) void excl_sort_rows_kernel(const int64_t *_
 // Rows of more than kExclMid entries: a workgroup looks at kHugeScan rows and sorts each long one among them by the bitonic network
 // above — in LDS up to kExclLds entries, in place in HBM beyond (a user who excludes a twelfth of a 96 k-item table and more).
 __global__ __launch_bounds__(kBlock) void excl_sort_huge_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                                int64_t n_rows, const int32_t *__restrict__ inv, uint32_t *__restrict__ pos)
+                                                                int64_t n_rows, const int32_t *__restrict__ inv, uint32_t *__restrict__ pos,
+                                                                const uint8_t *__restrict__ needed)
 {
     __shared__ uint32_t lds[kExclLds];
     __shared__ int lens[kHugeScan];
@@ -191,7 +204,7 @@ __global__ __launch_bounds__(kBlock) void excl_sort_huge_kernel(const int64_t *_
         const int64_t r = base + threadIdx.x;
         long long s = 0;
         int len = 0;
-        if (threadIdx.x < kHugeScan && r < n_rows) { s = rowptr[r]; len = (int)(rowptr[r + 1] - s); }
+        if (threadIdx.x < kHugeScan && r < n_rows && (!needed || needed[r])) { s = rowptr[r]; len = (int)(rowptr[r + 1] - s); }
         __syncthreads();                                                  // (the arrays below are still read by the previous turn)
         if (threadIdx.x < kHugeScan) { lens[threadIdx.x] = len; starts[threadIdx.x] = s; }
         if (!__syncthreads_or(len > kExclMid)) continue;
@@ -228,7 +241,7 @@ int topk_order_layout(int64_t n_items, int64_t excl_rows, int64_t excl_nnz, Topk
     L->iota = off; off += al256(n_items * 4);
     L->perm = off; off += al256(n_items * 4);
     L->inv = off; off += al256(n_items * 4);
-    L->ekeys = off;
+    L->ekeys = off; off += excl_nnz > 0 ? al256(excl_rows) : 0;                 // needed[row]: the rows this call's users own
     L->ekeys_sorted = 0;
     L->excl_pos = off; off += al256(excl_nnz * 4);
     L->tmp = off; off += al256((int64_t)L->tmp_bytes);
@@ -237,7 +250,8 @@ int topk_order_layout(int64_t n_items, int64_t excl_rows, int64_t excl_nnz, Topk
 }
 
 int topk_order_build(const TopkOrderLayout &L, char *ws, int64_t n_items, const int64_t *excl_rowptr, const int32_t *excl_col,
-                     int64_t excl_rows, int64_t excl_nnz, hipStream_t st, const int32_t **perm_out, const int32_t **excl_pos_out)
+                     int64_t excl_rows, int64_t excl_nnz, const int64_t *user_ids, int64_t batch, hipStream_t st,
+                     const int32_t **perm_out, const int32_t **excl_pos_out)
 {
     const float *norm2 = reinterpret_cast<const float *>(ws + L.norm2);
     uint32_t *keys = reinterpret_cast<uint32_t *>(ws + L.keys), *keys_sorted = reinterpret_cast<uint32_t *>(ws + L.keys_sorted);
@@ -256,15 +270,26 @@ int topk_order_build(const TopkOrderLayout &L, char *ws, int64_t n_items, const 
         if (excl_rows >= ((int64_t)1 << 31)) return IGCN_E_SHAPE;
         uint32_t *pos = reinterpret_cast<uint32_t *>(ws + L.excl_pos);
         const int64_t cus = cu_count();
+        // Only the rows of this call's users are sorted (a 512-user call against a 110 k-user CSR used to sort all of it: ADVICE r3):
+        // unless the batch IS the CSR's rows in order, a kernel over the batch flags them first.
+        const uint8_t *needed = nullptr;
+        if (user_ids || batch < excl_rows) {
+            uint8_t *flags = reinterpret_cast<uint8_t *>(ws + L.ekeys);
+            hipError_t me = hipMemsetAsync(flags, 0, (size_t)excl_rows, st);
+            if (me != hipSuccess) return (int)me;
+            hipLaunchKernelGGL(excl_mark_rows_kernel, dim3((unsigned)((batch + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, user_ids, batch,
+                               excl_rows, flags);
+            needed = flags;
+        }
         const int64_t turns = (excl_rows + kExclScan - 1) / kExclScan;          // a wave per kExclScan rows
         int64_t rb = (turns + kBlock / kWave - 1) / (kBlock / kWave);
         if (rb > 8 * cus) rb = 8 * cus;
         hipLaunchKernelGGL(excl_sort_rows_kernel, dim3((unsigned)rb), dim3(kBlock), 0, st, excl_rowptr, excl_col, excl_rows,
-                           (const int32_t *)inv, pos);
+                           (const int32_t *)inv, pos, needed);
         int64_t hb = (excl_rows + kHugeScan - 1) / kHugeScan;                   // 32 KiB of LDS each: five per CU
         if (hb > 5 * cus) hb = 5 * cus;
         hipLaunchKernelGGL(excl_sort_huge_kernel, dim3((unsigned)hb), dim3(kBlock), 0, st, excl_rowptr, excl_col, excl_rows,
-                           (const int32_t *)inv, pos);
+                           (const int32_t *)inv, pos, needed);
         *excl_pos_out = reinterpret_cast<const int32_t *>(pos);
     }
     return launch_status();

@@ -762,7 +762,10 @@ def test_two_stage_exclusion_lists_sorted_on_the_device_hold_every_users_best_it
     np.cumsum(lengths, out=rowptr[1:])
     kw = dict(excl_rowptr=_dev(rowptr), excl_col=_dev(np.concatenate(ex).astype(np.int32)))
     # a permuted user subset as well: rows are looked up by user id, not by batch position
-    for users in (None, _dev(rng.permutation(n_users).astype(np.int64))):
+    # ... and a subset with repeats: only the rows of the call's users are sorted (flagged by a kernel over the batch), each once
+    part = rng.choice(n_users, size=n_users // 2, replace=False)
+    part = np.concatenate([part, part[:7], [17, 17, 18]]).astype(np.int64)          # (17, 18: the 20 000-entry and the all-but-k rows)
+    for users in (None, _dev(rng.permutation(n_users).astype(np.int64)), _dev(part)):
         a = score_topk(_dev(U), _dev(I), k, user_ids=users, mode='fast', **kw)
         b = score_topk(_dev(U), _dev(I), k, user_ids=users, mode='exact', **kw)
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
