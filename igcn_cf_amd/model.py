@@ -87,9 +87,13 @@ class BasicModel(nn.Module):
 
     def recommend(self, users, k, excl_rowptr=None, excl_col=None, banned=None, mode='auto'):
         """Top-k item ids per user (best first), masked by the exclusion CSR and the
-        banned mask: predict -> mask -> topk of trainer.py:147-163, fused.  mode: ops.score_topk's ('exact' = the
-        fp32 sweep alone; the lists are the same either way)."""
+        banned mask: predict -> mask -> topk of trainer.py:147-163, fused.  users: int64 ids on the GPU, or None = all users in
+        order.  mode: ops.score_topk's ('exact' = the fp32 sweep alone; the lists are the same either way)."""
         user_rows, item_rows = self.score_tables()
+        if users is None:                  # every user, in order: no id list to follow, no exclusion rows to pick out
+            idx, _ = ops.score_topk(user_rows, item_rows, k, batch=self.n_users, excl_rowptr=excl_rowptr, excl_col=excl_col,
+                                    banned=banned, mode=mode)
+            return idx
         idx, _ = ops.score_topk(user_rows, item_rows, k, user_ids=users.contiguous(), excl_rowptr=excl_rowptr,
                                 excl_col=excl_col, banned=banned, mode=mode)
         return idx

@@ -484,8 +484,8 @@ class BasicTrainer:
         out = []
         with torch.no_grad():
             for start in range(0, self.dataset.n_users, self.eval_chunk):
-                users = torch.arange(start, min(start + self.eval_chunk, self.dataset.n_users), dtype=torch.int64,
-                                     device=self.device)
+                users = None if self.eval_chunk >= self.dataset.n_users else \
+                    torch.arange(start, min(start + self.eval_chunk, self.dataset.n_users), dtype=torch.int64, device=self.device)
                 out.append(self.model.recommend(users, k, excl_rowptr, excl_col, banned, **({} if mode == 'auto' else {'mode': mode})))
         return torch.cat(out, dim=0) if len(out) > 1 else out[0]
 

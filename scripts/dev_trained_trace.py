@@ -1,4 +1,5 @@
-"""Developer: LightGCN on the Amazon-like split, 2 epochs, then three scoring calls (two-stage, no masks) for a kernel trace."""
+"""Developer: LightGCN on the Amazon-like split, 2 epochs, then three scoring calls (two-stage, no masks; MASKS=1: three full
+evaluations with the train + val lists masked) for a kernel trace."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -22,5 +23,9 @@ U, I = rep[:ds.n_users], rep[ds.n_users:]
 users = torch.arange(ds.n_users, device=dev)
 torch.cuda.synchronize()
 for _ in range(3):
-    score_topk(U, I, 20, user_ids=users, mode='fast')
+    if os.environ.get('MASKS') == '1':                      # the evaluation as the trainer runs it: propagation + train/val lists masked
+        model._rep_cache = None
+        trainer.recommend_all('test')
+    else:
+        score_topk(U, I, 20, user_ids=users, mode='fast')
     torch.cuda.synchronize()
