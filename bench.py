@@ -324,6 +324,10 @@ def main():
         roof['traffic'] = t['bytes'] if t else None
         roof['traffic_source'] = t['source'] if t else 'no PMC pass on file for this kernel/workload'
         if t:
+            # what the fabric behind L2 (Infinity Cache for this operand) delivered per second, against the guide's rate for
+            # Infinity-Cache gathers: the one ratio on this line that is a measured quantity over a measured ceiling
+            roof['traffic_GBps'] = t['bytes'] / ms_launch / 1e6
+            roof['traffic_frac_of_mall_gather_peak'] = roof['traffic_GBps'] / MALL_GATHER_PEAK_GBPS
             roof['traffic_over_compulsory'] = t['bytes'] / b_min
             roof['traffic_over_algorithmic'] = t['bytes'] / b_alg
             roof['l2_hit_rate'] = t.get('l2_hit_rate')
