@@ -546,13 +546,16 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                 // ... that reaches the caller's lower bound (the list fills from the items above it: there are >= k)
                 if constexpr (BOUNDED) { if (user_ok[g]) thr[g] = fmaxf(thr[g], A.init_thr[group * UPW + g * 32 + j]); }
             }
-            if constexpr (MODE == 3 && D == 64) if (A.shared_thr) {      // (compiled into the default candidate sweep only: registers)
+            // (compiled into the default candidate sweep and into the narrow bounded sweep — the two-stage path's fall-back, whose
+            // few users are always cut into ~58 pieces: without sharing each piece warms a list of its own, k ln(1 700 / k) ~ 110
+            // candidates per user and piece instead of a handful; the other variants have no registers to spare)
+            if constexpr ((MODE == 3 && D == 64) || (BOUNDED && NG == 1)) if (A.shared_thr) {
                 // The pieces a user's sweep is cut into run at the same time, each with a list of its own: they share their
                 // thresholds.  A piece's k-th best is a lower bound of the user's k-th best over the whole table, so every
                 // piece may use the largest one any of them has reached — the pieces over the short rows then stop staging
                 // almost at once instead of warming up a list nobody will look at.  (Sortable score bits, atomicMax; 0 = none.)
                 const int64_t b_own = group * UPW + lane;
-                if (owner && root && b_own < A.batch) atomicMax(A.shared_thr + b_own, (unsigned int)(root >> 32));
+                if (owner && root && b_own < batch_n) atomicMax(A.shared_thr + b_own, (unsigned int)(root >> 32));
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     const unsigned int sh = user_ok[g] ? A.shared_thr[group * UPW + g * 32 + j] : 0u;
@@ -1639,8 +1642,9 @@ static int topk_fast_layout(int64_t batch, int64_t n_items, int32_t d, int32_t k
     L->norm = L->cand_val + align256(batch * L->kc * 4);
     L->tile_bound = L->norm + 256;
     L->unorm2 = L->tile_bound + align256((int64_t)p.n_tiles * 4);
-    L->exit_state = L->unorm2 + align256(batch * 4);                  // [256 B: waves that left early][batch B: users given up on]
-    L->order = L->exit_state + 256 + align256(batch) + align256(batch * 4);   // (+ the thresholds the pieces of a sweep share)
+    L->exit_state = L->unorm2 + align256(batch * 4);
+    // [256 B: early leavers per job][the fall-back's shared thresholds][batch B: users given up on][batch x 4 B: the sweep's shared thresholds]
+    L->order = L->exit_state + 256 + kFastFallbackMax * 4 + align256(batch) + align256(batch * 4);
     L->fallback = align256(L->order + L->ord.total);
     const int64_t fb = igcn_score_topk_workspace_bytes(batch < kFastFallbackMax ? batch : kFastFallbackMax, n_items, d, k);
     if (fb < 0) return IGCN_E_RANGE;
@@ -1727,13 +1731,12 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     // (whole sweeps only — `n_whole` of them per wave, counted job by job; the pieces of a rest never give up)
     const bool give_up = early_exit && sweep_plan.n_whole >= 1 && tuning_get(IGCN_TUNE_TOPK_FAST_GIVE_UP) != 0;
     unsigned int *exit_count = reinterpret_cast<unsigned int *>(ws + L.exit_state);
-    uint8_t *unfinished = reinterpret_cast<uint8_t *>(ws + L.exit_state + 256);
-    unsigned int *shared_thr = reinterpret_cast<unsigned int *>(ws + L.exit_state + 256 + align256(batch));
+    unsigned int *fb_shared_thr = reinterpret_cast<unsigned int *>(ws + L.exit_state + 256);
+    uint8_t *unfinished = reinterpret_cast<uint8_t *>(ws + L.exit_state + 256 + kFastFallbackMax * 4);
+    unsigned int *shared_thr = reinterpret_cast<unsigned int *>(ws + L.exit_state + 256 + kFastFallbackMax * 4 + align256(batch));
     const bool share = sweep_plan.p_max > 1 && mode == 3 && d == 64 && tuning_get(IGCN_TUNE_TOPK_FAST_SHARE) != 0;
-    if (give_up || share) {
-        e = hipMemsetAsync(ws + L.exit_state, 0, (size_t)(256 + align256(batch) + (share ? batch * 4 : 0)), st);
-        if (e != hipSuccess) return (int)e;
-    }
+    e = hipMemsetAsync(ws + L.exit_state, 0, (size_t)(256 + kFastFallbackMax * 4 + (give_up || share ? align256(batch) + (share ? batch * 4 : 0) : 0)), st);
+    if (e != hipSuccess) return (int)e;
     // the sweep runs in position space: its exclusion lists and banned bits are those of the positions, and the
     // candidate ids it returns are positions (mapped back by the re-scoring kernel)
     rc = topk_run(mode, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, d, excl_rowptr, by_norm && excl_rowptr ? excl_pos : excl_col,
@@ -1757,8 +1760,8 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     // exclusion lists and banned items as they came.
     const int64_t fb_users = batch < kFastFallbackMax ? batch : kFastFallbackMax;
     return topk_run(0, user_rows, ldu, user_ids, fb_users, item_rows, ldi, n_items, d, excl_rowptr, excl_col, banned, k, out_idx, out_val,
-                    ws + L.fallback, nullptr, nullptr, st, nullptr, flagged_lower_bound, nullptr, nullptr, nullptr, nullptr, nullptr,
-                    flagged + 1, flagged);
+                    ws + L.fallback, nullptr, nullptr, st, nullptr, flagged_lower_bound, nullptr, nullptr, nullptr, nullptr,
+                    tuning_get(IGCN_TUNE_TOPK_FAST_SHARE) != 0 ? fb_shared_thr : nullptr, flagged + 1, flagged);
 }
 
 #ifdef IGCN_TOPK_STATS

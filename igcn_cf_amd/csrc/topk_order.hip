@@ -223,7 +223,6 @@ __global__ __launch_bounds__(kBlock) void excl_sort_huge_kernel(const int64_t *_
     }
 }
 
-static int bits_for(int64_t n) { int b = 1; while (b < 31 && ((int64_t)1 << b) < n) ++b; return b; }
 constexpr int kNormBeginBit = 15;                    // float bits [15, 31): exponent + 8 significant bits (the sign is 0)
 
 int topk_order_layout(int64_t n_items, int64_t excl_rows, int64_t excl_nnz, TopkOrderLayout *L)
@@ -241,8 +240,7 @@ int topk_order_layout(int64_t n_items, int64_t excl_rows, int64_t excl_nnz, Topk
     L->iota = off; off += al256(n_items * 4);
     L->perm = off; off += al256(n_items * 4);
     L->inv = off; off += al256(n_items * 4);
-    L->ekeys = off; off += excl_nnz > 0 ? al256(excl_rows) : 0;                 // needed[row]: the rows this call's users own
-    L->ekeys_sorted = 0;
+    L->needed = off; off += excl_nnz > 0 ? al256(excl_rows) : 0;                // needed[row]: the rows this call's users own
     L->excl_pos = off; off += al256(excl_nnz * 4);
     L->tmp = off; off += al256((int64_t)L->tmp_bytes);
     L->total = off;
@@ -274,7 +272,7 @@ int topk_order_build(const TopkOrderLayout &L, char *ws, int64_t n_items, const 
         // unless the batch IS the CSR's rows in order, a kernel over the batch flags them first.
         const uint8_t *needed = nullptr;
         if (user_ids || batch < excl_rows) {
-            uint8_t *flags = reinterpret_cast<uint8_t *>(ws + L.ekeys);
+            uint8_t *flags = reinterpret_cast<uint8_t *>(ws + L.needed);
             hipError_t me = hipMemsetAsync(flags, 0, (size_t)excl_rows, st);
             if (me != hipSuccess) return (int)me;
             hipLaunchKernelGGL(excl_mark_rows_kernel, dim3((unsigned)((batch + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, user_ids, batch,
