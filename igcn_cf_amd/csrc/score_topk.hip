@@ -139,6 +139,7 @@ constexpr int kMinCap = 8, kMaxCap = 16, kQuad = 4;
 // and crawl at ~6 us a tile; scoring 1.3-1.45 ms with 48 (the same with 24), 1.5-1.7 with 96, 1.8-2.0 with 192, 3.4-3.8
 // when nobody gives up; after the first epoch (every wave leaves within ~50 tiles) nobody is handed over (0.41 ms).
 constexpr int kGiveUpAfterTiles = 48;
+constexpr int kEarlyCheckEvery = 6;      // exit checks every so many tiles up to tile 48 (a multiple of 3: the sweep's turn), give-up from twice that; 0: off
 constexpr int kExitSlots = 64;       // counters of early leavers, one per whole sweep of a wave (256 B of the call's workspace)
 __device__ __forceinline__ int exit_slot(int64_t job) { return job < kExitSlots ? (int)job : kExitSlots - 1; }
 constexpr int kMinCapSweep = 6;      // candidate sweeps: a shallower staging list (more drains) rather than half the resident waves (k + extra = 25..28)
@@ -351,6 +352,7 @@ struct TopkArgs {
     // users (at most `batch`: the plan's size), user b of it sits at batch position rows[b] of the caller's arrays (user_ids,
     // out_idx / out_val); init_thr stays indexed by b.  NULL: the batch is positions 0 .. batch - 1.
     const int32_t *rows; const int32_t *count_dev;
+    int early_checks;          // candidate sweep: exit checks every so many tiles up to tile 48, give-up from twice that (0: every 24 tiles / from tile 48)
 };
 
 // FULL: d == D, no k-slice of a row is padding.  NG: 32-user groups of a wave.  MODE 0: fp32 MFMA, the exact fmaf
@@ -936,7 +938,12 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
             constexpr int kTurn = 3;
 #endif
             for (int tile = tin0; tile < tin1; tile += kTurn) {
-                if (A.tile_bound && tile > tin0 && (tile - tin0) % 24 == 0) {
+                // Exit check every 24 tiles — and every 6 up to tile 48 (round 4): on trained tables 99 % of the users are out of reach after
+                // 8 tiles, yet the median wave swept 24 (154 us) because that was its first check, and the few crawling waves (2.5 drains
+                // a tile, 15 us a tile) reached their first give-up opportunity at tile 48 after 720 us — the kernel's whole tail
+                // (profiles/r04s_*).  At random init nobody leaves and the eight extra checks cost nothing measurable.
+                const int rel = tile - tin0;
+                if (A.tile_bound && rel > 0 && (rel % 24 == 0 || (A.early_checks && rel < 48 && rel % A.early_checks == 0))) {
                     // Cauchy-Schwarz exit (every 24 tiles): the items come by descending norm, so if no user of this wave
                     // can still be reached by a row as long as this tile's longest, none of the remaining tiles matters
                     // (a user whose list is not full yet has thr = -inf and keeps the sweep alive)
@@ -951,7 +958,9 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                     for (int g = 0; g < NG; ++g) {
                         alive[g] = user_ok[g] && ureach[g] * reach >= thr[g];
                         any_alive |= alive[g];
-                        // far from done: the rows would have to get another third shorter (norms fall slowly in the tail)
+                        // far from done: the rows would have to get another third shorter (norms fall slowly in the tail).  (Round 4 also
+                        // tried "still reachable N tiles further on" from the table of tile bounds, N = 24 ... 384: the same users within a
+                        // few, the same time — profiles/r04q_*.)
                         far |= alive[g] && ureach[g] * reach >= 1.5f * thr[g];
                     }
                     if (!__any(any_alive)) {
@@ -974,7 +983,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                     const unsigned gone = gone_next;
                     const bool counting = A.exit_count && job < A.n_whole;
                     if (counting) gone_next = __hip_atomic_load(A.exit_count + exit_slot(job), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (counting && tile - tin0 >= kGiveUpAfterTiles) {
+                    if (counting && rel >= (A.early_checks ? 2 * A.early_checks : kGiveUpAfterTiles)) {
                         if ((uint64_t)gone * 4 >= (uint64_t)gridDim.x * 3 && __any(far)) {   // (a wave about to leave by itself stays)
                             if (lane == 0) atomicAdd(A.exit_count + exit_slot(job), 1u);
 #pragma unroll
@@ -1073,7 +1082,8 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
             if (blockIdx.x < 4096) {
                 g_topk_wave_times[3 * blockIdx.x] = st_rt_begin;
                 g_topk_wave_times[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-                g_topk_wave_times[3 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+                g_topk_wave_times[3 * blockIdx.x + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) |
+                                                        ((st_0 & 0xFFFFull) << 32) | ((st_3 & 0xFFFFull) << 48);   // + tiles swept, flushes
             }
         }
     }
@@ -1557,6 +1567,7 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
     a.exit_count = exit_count; a.unfinished = unfinished;
     a.shared_thr = p.p_max > 1 ? shared_thr : nullptr;          // (only pieces have anything to share)
     a.rows = rows; a.count_dev = count_dev;
+    { const int ec = tuning_get(IGCN_TUNE_TOPK_FAST_EARLY_CHECKS); a.early_checks = ec < 0 ? kEarlyCheckEvery : ec / 3 * 3; }
 
     if (mode != 0) {
         if ((d != 64 && !(mode >= 2 && d == 128)) || !packed || (mode >= 2 && !stats)) return IGCN_E_SHAPE;

@@ -44,7 +44,7 @@ const char *igcn_error_string(int code);
  * "topk_fast_wide", "topk_fast_extra" (candidates kept beyond k), "topk_fast_give_up" (0: no wave hands users over),
  * "topk_fast_narrow" (0: small batches keep 64-user wave-groups), "topk_fast_share" (0: the pieces of a cut sweep
  * keep their thresholds to themselves), "topk_fast_fallback" (0: igcn_score_topk_fast_f32 leaves every flagged user to the
- * caller), "topk_fast_mode" (candidate sweep of
+ * caller), "topk_fast_early_checks" (0: exit checks every 24 tiles only, give-up from tile 48), "topk_fast_mode" (candidate sweep of
  * igcn_score_topk_fast_f32: 3 = one fp16 plane each side, the default; 2 = two fp16 user planes; 1 = two bf16 planes each side,
  * d = 64 only); value < 0 restores the library
  * default.  Results never depend on them (tests/test_spmm_gpu.py::test_launch_shape_does_not_change_results).
