@@ -323,7 +323,7 @@ __device__ __forceinline__ float vmax2(float a, float b) {
 // Developer build only (scripts/dev_topk_variants.py): event counts summed over waves.
 // [0] tiles  [1] tiles with a hit quad  [2] hit quads  [3] flushes  [4] flush iterations  [5] staged candidates  [6] waves
 // [7] shader cycles inside flush()  [8] inside stage_hits()  [9] whole wave  [10] inside build_masks()
-__device__ unsigned long long g_topk_stats[12];
+__device__ unsigned long long g_topk_stats[16];   // ... [12] cycles before the first tile of a job (operands, cursors, heaps)  [13] cycles after the last (heapsort, emit)
 __device__ unsigned long long g_topk_wave_times[3 * 4096];   // begin, end (100 MHz ticks), HW_ID per workgroup
 #define IGCN_CLOCK() __builtin_amdgcn_s_memtime()
 #define IGCN_STAT(i, v) (st_##i += (v))
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
     const bool prio_boost = (A.stagger & 2) != 0;
     set_base_priority(prio_slot);
 #ifdef IGCN_TOPK_STATS
-    unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0, st_5 = 0, st_7 = 0, st_8 = 0, st_10 = 0;
+    unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0, st_5 = 0, st_7 = 0, st_8 = 0, st_10 = 0, st_12 = 0, st_13 = 0, st_job = 0;
     const unsigned long long st_begin = IGCN_CLOCK();
     const unsigned long long st_rt_begin = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -404,6 +404,9 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
 
     for (int64_t job = 0;; ++job) {
         // ---- next piece: users of wave-group `group`, item tiles [tin0, tin1) -------------------
+#ifdef IGCN_TOPK_STATS
+        st_job = IGCN_CLOCK();
+#endif
         int64_t group;
         int tin0, tin1, pidx = 0;
         bool direct = true;
@@ -911,6 +914,9 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
             stage_hits(cur, tile_base);
         };
 
+#ifdef IGCN_TOPK_STATS
+        st_12 += IGCN_CLOCK() - st_job;
+#endif
         // prologue: scores of the first tile, A operand of the second
         f32x16 acc_a[NG], acc_b[NG];
         if constexpr (kRing12) { load_half(a, tin0, 0); load_half(a2, tin0, 1); } else load_a(tin0);
@@ -1038,6 +1044,9 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
         }
         }
         flush();
+#ifdef IGCN_TOPK_STATS
+        st_job = IGCN_CLOCK();
+#endif
 
         // ---- emit: every owner lane heapsorts its user's list in place (best first) and writes it to the
         // output, or to the workspace when the user's sweep was cut into pieces ----------------------
@@ -1046,26 +1055,58 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
             heap[n * kWave] = heap[0];                           // current minimum goes to the end
             heap_replace_root(heap, n, last);
         }
-        const int64_t b_own = group * UPW + lane;                // owner lane l keeps user l of the wave-group
-        if (owner && b_own < batch_n) {
-            if (direct) {
-                int64_t orow = b_own;
-                if constexpr (BOUNDED) { if (A.rows) orow = A.rows[b_own]; }
-                for (int r = 0; r < k; ++r) {
-                    const unsigned long long key = heap[r * kWave];
-                    A.out_idx[orow * k + r] = key ? key_item(key) : -1;
-                    A.out_val[orow * k + r] = key ? key_score(key) : -INFINITY;
+        // The lists leave through the WAVE, not through their owner lanes: user l of the wave-group sits in column l of the heap
+        // array ([slot][lane]), the wave's users are consecutive batch positions, so [users here][k] is one contiguous block of the
+        // output (a run per user in the pieces' workspace) and lane e mod 64 writes its element e — 512 contiguous bytes per store
+        // instruction instead of 64 scattered 8-byte pieces.  (Round 4: on trained tables every wave finishes within the same
+        // ~100 us and the owner lanes' scattered stores took 178 k cycles per wave — half of the wave's life; profiles/r04y_*.)
+        const int64_t b0 = group * UPW;
+        const int n_here = batch_n - b0 < UPW ? (int)(batch_n - b0) : UPW;
+        bool by_rows = false;
+        if constexpr (BOUNDED) by_rows = A.rows != nullptr;
+        asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (!by_rows) {
+            const int total = n_here * k;
+            for (int e = lane; e < total; e += kWave) {
+                const int u = e / k, r = e - u * k;
+                const unsigned long long key = heap_base[r * kWave + u];
+                if (direct) {
+                    A.out_idx[b0 * k + e] = key ? key_item(key) : -1;
+                    A.out_val[b0 * k + e] = key ? key_score(key) : -INFINITY;
+                } else {
+                    const int64_t slot = ((b0 + u - n_full * UPW) * A.p_max + pidx) * k + r;
+                    A.ws_val[slot] = key ? key_score(key) : -INFINITY;
+                    A.ws_idx[slot] = key ? key_item(key) : kIdxNone;
                 }
-            } else {
-                const int64_t slot = ((b_own - n_full * UPW) * A.p_max + pidx) * k;
-                for (int r = 0; r < k; ++r) {
-                    const unsigned long long key = heap[r * kWave];
-                    A.ws_val[slot + r] = key ? key_score(key) : -INFINITY;
-                    A.ws_idx[slot + r] = key ? key_item(key) : kIdxNone;
+            }
+        } else {
+            // (the two-stage path's fall-back: a handful of users whose output rows are scattered over the batch)
+            const int64_t b_own = b0 + lane;
+            if (owner && b_own < batch_n) {
+                if (direct) {
+                    int64_t orow = b_own;
+                    if constexpr (BOUNDED) orow = A.rows[b_own];
+                    for (int r = 0; r < k; ++r) {
+                        const unsigned long long key = heap[r * kWave];
+                        A.out_idx[orow * k + r] = key ? key_item(key) : -1;
+                        A.out_val[orow * k + r] = key ? key_score(key) : -INFINITY;
+                    }
+                } else {
+                    const int64_t slot = ((b_own - n_full * UPW) * A.p_max + pidx) * k;
+                    for (int r = 0; r < k; ++r) {
+                        const unsigned long long key = heap[r * kWave];
+                        A.ws_val[slot + r] = key ? key_score(key) : -INFINITY;
+                        A.ws_idx[slot + r] = key ? key_item(key) : kIdxNone;
+                    }
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();
+#ifdef IGCN_TOPK_STATS
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : : : "memory");
+        st_13 += IGCN_CLOCK() - st_job;
+#endif
     }
 #ifdef IGCN_TOPK_STATS
     {
@@ -1079,6 +1120,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
             atomicAdd(&g_topk_stats[7], st_7); atomicAdd(&g_topk_stats[8], st_8);
             atomicAdd(&g_topk_stats[9], IGCN_CLOCK() - st_begin); atomicAdd(&g_topk_stats[10], st_10);
             atomicAdd(&g_topk_stats[11], __builtin_amdgcn_s_memrealtime() - st_rt_begin);   // 100 MHz ticks
+            atomicAdd(&g_topk_stats[12], st_12); atomicAdd(&g_topk_stats[13], st_13);
             if (blockIdx.x < 4096) {
                 g_topk_wave_times[3 * blockIdx.x] = st_rt_begin;
                 g_topk_wave_times[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
@@ -1785,10 +1827,10 @@ extern "C" int igcn_debug_topk_wave_times(unsigned long long *host, int n_waves)
 extern "C" int igcn_debug_topk_stats(unsigned long long *host8, int reset)
 {
     hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess && host8) e = hipMemcpyFromSymbol(host8, HIP_SYMBOL(igcn::g_topk_stats), 96);
+    if (e == hipSuccess && host8) e = hipMemcpyFromSymbol(host8, HIP_SYMBOL(igcn::g_topk_stats), 128);
     if (e == hipSuccess && reset) {
-        const unsigned long long z[12] = {0};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(igcn::g_topk_stats), z, 96);
+        const unsigned long long z[16] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(igcn::g_topk_stats), z, 128);
     }
     return (int)e;
 }

@@ -53,7 +53,7 @@ def run():
     for name in names:
         _lib._handle, _lib._bound = C.CDLL(os.path.join(VDIR, 'lib_%s.so' % name)), {}
         if name == 'stats':
-            buf = (C.c_ulonglong * 12)()
+            buf = (C.c_ulonglong * 16)()
             for k in (1, 20):
                 score_topk(U, I, k, user_ids=users, excl_rowptr=rp, excl_col=cl)
                 _lib._handle.igcn_debug_topk_stats(buf, 1)

@@ -18,7 +18,7 @@ trainer = get_trainer({'name': 'BPRTrainer', 'optimizer': 'Adam', 'lr': 1e-3, 'l
 users = torch.arange(ds.n_users, device=dev)
 main_handle, main_bound = _lib.lib(), None
 stats = C.CDLL(os.path.join(ROOT, 'igcn_cf_amd', '_variants', 'lib_stats.so'))
-buf = (C.c_ulonglong * 12)()
+buf = (C.c_ulonglong * 16)()
 for epoch in range(4):
     model.eval()
     with torch.no_grad():
@@ -60,6 +60,7 @@ for epoch in range(4):
                           staged_per_wave=round(t[5] / max(t[6], 1), 1), wave_life_us_quantiles_10_50_75_90_99_max=[round(float(np.percentile(life, q)), 1) for q in (10, 50, 75, 90, 99, 100)],
                           wave_start_us_max=round(float(start.max()), 1), waves_alive_after_us={str(t_): int((life > t_).sum()) for t_ in (200, 300, 400, 500, 600, 700)},
                           flagged=n_flagged, longest_waves_us_tiles_flushes=[[round(float(life[i]), 1), int(tiles_w[i]), int(flushes_w[i])] for i in np.argsort(-life)[:6]],
-                          median_wave_us_tiles_flushes=[round(float(np.median(life)), 1), int(np.median(tiles_w)), int(np.median(flushes_w))])), flush=True)
+                          cycles_per_wave=dict(flush=t[7] // max(t[6], 1), stage_hits_incl_flush=t[8] // max(t[6], 1), wave=t[9] // max(t[6], 1), build_masks=t[10] // max(t[6], 1), before_first_tile=t[12] // max(t[6], 1), after_last_tile=t[13] // max(t[6], 1)),
+                          clock_GHz=round(t[9] / max(t[11], 1) / 10, 3), median_wave_us_tiles_flushes=[round(float(np.median(life)), 1), int(np.median(tiles_w)), int(np.median(flushes_w))])), flush=True)
     model.train()
     trainer.train_one_epoch()
