@@ -598,8 +598,10 @@ def test_two_stage_stragglers_hand_their_users_to_the_fp32_sweep(d):
     Ud, Id = _dev(U), _dev(I)
     ref = score_topk(Ud, Id, k, mode='exact', **kw)
     try:
-        for give_up, narrow in ((None, None), (0, None), (None, 0)):
+        # (early: exit checks every 6 tiles up to tile 48 and give-up from tile 12, the default; 0: every 24 tiles / from tile 48; 3: every 3)
+        for give_up, narrow, early in ((None, None, None), (0, None, None), (None, 0, None), (None, 0, 0), (None, 0, 3), (None, None, 0)):
             _lib.set_tuning('topk_fast_give_up', give_up)
+            _lib.set_tuning('topk_fast_early_checks', early)
             _lib.set_tuning('topk_fast_narrow', narrow)            # 0: 64-user wave-groups although the batch is small
             got = score_topk(Ud, Id, k, mode='fast', **kw)
             flagged = score_topk.last_flagged
@@ -609,6 +611,7 @@ def test_two_stage_stragglers_hand_their_users_to_the_fp32_sweep(d):
     finally:
         _lib.set_tuning('topk_fast_give_up', None)
         _lib.set_tuning('topk_fast_narrow', None)
+        _lib.set_tuning('topk_fast_early_checks', None)
 
 
 @pytest.mark.parametrize('d', [64, 128])
