@@ -281,7 +281,9 @@ int igcn_score_topk_bounded_f32(const float *user_rows, int64_t ldu, const int64
  * returned do not depend on the order.  igcn_set_tuning("topk_fast_order", 0) sweeps in id order.
  * In that order a wave leaves the sweep once no row still to come can reach any of its users (|score| <= |u| |i|), and a
  * wave that outlasts three quarters of the others hands the users it could not finish to the flagged list as well
- * (ABI v6; which users take that way depends on timing, the lists do not).
+ * (ABI v6; which users take that way depends on timing, the lists do not).  Round 4: a wave checks whether it may leave every 6
+ * tiles up to tile 48 and every 24 after that, and may hand its users over from tile 12 on ("topk_fast_early_checks": the
+ * cadence, 0 = every 24 tiles / from tile 48) — on trained tables most users are out of reach after 8 tiles.
  * workspace: igcn_score_topk_fast_workspace_bytes(...) bytes, 256-byte aligned. */
 int64_t igcn_score_topk_fast_workspace_bytes(int64_t batch, int64_t n_items, int32_t d, int32_t k,
                                              int64_t excl_rows, int64_t excl_nnz);
