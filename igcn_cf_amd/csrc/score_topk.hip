@@ -140,6 +140,12 @@ constexpr int kMinCap = 8, kMaxCap = 16, kQuad = 4;
 // when nobody gives up; after the first epoch (every wave leaves within ~50 tiles) nobody is handed over (0.41 ms).
 constexpr int kGiveUpAfterTiles = 48;
 constexpr int kEarlyCheckEvery = 6;      // exit checks every so many tiles up to tile 48 (a multiple of 3: the sweep's turn), give-up from twice that; 0: off
+// A user that keeps filling its staging list while the rest of its wave has gone quiet makes the wave crawl (a drain is paid by all 64
+// lanes: 2.5 drains and 15 us a tile against ~1 us).  Such users are handed to the fp32 sweep by THEIR OWN wave as soon as they show:
+// drains a lane pair triggered between tiles 3 and 6 of the sweep (after the lists' warm-up), checked at tile 6 — at most kMaxEvict
+// users of a wave, and only when at least half of the wave's users are already out of reach (at random init everybody is still
+// reachable and nobody is handed over).  A local, deterministic rule: no counter of other waves is read.
+constexpr int kHotDrains = 3, kMaxEvict = 4;
 constexpr int kExitSlots = 64;       // counters of early leavers, one per whole sweep of a wave (256 B of the call's workspace)
 __device__ __forceinline__ int exit_slot(int64_t job) { return job < kExitSlots ? (int)job : kExitSlots - 1; }
 constexpr int kMinCapSweep = 6;      // candidate sweeps: a shallower staging list (more drains) rather than half the resident waves (k + extra = 25..28)
@@ -509,6 +515,10 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
             stage_addr[g] = (unsigned)(uintptr_t)(stage_all + (g * cap) * kWave + lane);
         }
 
+        constexpr bool kHotTrack = MODE == 3 && D == 64;         // (the default candidate sweep; the others have no registers to spare)
+        int hot[kHotTrack ? NG : 1];                             // drains this lane's staging list has triggered (see kHotDrains)
+#pragma unroll
+        for (int g = 0; g < (kHotTrack ? NG : 1); ++g) hot[g] = 0;
         unsigned exm[NG];                                        // mask bits of the current tile (see build_masks)
 #pragma unroll
         for (int g = 0; g < NG; ++g) exm[g] = 0u;
@@ -770,7 +780,10 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
 #ifdef IGCN_X_NOFLUSH
                             cnt[g] = cnt[g] > cap - 4 ? cap - 4 : cnt[g];        // developer ablation: wrong results, no drain
 #else
-                            if (__any(cnt[g] > cap - 4)) flush();
+                            if (__any(cnt[g] > cap - 4)) {
+                                if constexpr (kHotTrack) hot[g] += cnt[g] > cap - 4 ? 1 : 0;
+                                flush();
+                            }
 #endif
                             stage_quad(cur[g], g, q4, item_h, masks);
                         }
@@ -949,6 +962,12 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                 // a tile, 15 us a tile) reached their first give-up opportunity at tile 48 after 720 us — the kernel's whole tail
                 // (profiles/r04s_*).  At random init nobody leaves and the eight extra checks cost nothing measurable.
                 const int rel = tile - tin0;
+                if constexpr (kHotTrack) {
+                    if (rel == 3) {                                       // the lists' warm-up (every first item is a candidate) is over
+#pragma unroll
+                        for (int g = 0; g < NG; ++g) hot[g] = 0;
+                    }
+                }
                 if (A.tile_bound && rel > 0 && (rel % 24 == 0 || (A.early_checks && rel < 48 && rel % A.early_checks == 0))) {
                     // Cauchy-Schwarz exit (every 24 tiles): the items come by descending norm, so if no user of this wave
                     // can still be reached by a row as long as this tile's longest, none of the remaining tiles matters
@@ -968,6 +987,33 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                         // tried "still reachable N tiles further on" from the table of tile bounds, N = 24 ... 384: the same users within a
                         // few, the same time — profiles/r04q_*.)
                         far |= alive[g] && ureach[g] * reach >= 1.5f * thr[g];
+                    }
+                    if constexpr (kHotTrack) {
+                        if (A.unfinished && job < A.n_whole && rel == 6 && A.early_checks) {
+                            bool evict[NG];
+                            unsigned long long ev = 0ull, al = 0ull;
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) {
+                                const int other = __shfl_xor(hot[g], 32);
+                                const int hu = hot[g] > other ? hot[g] : other;          // the user's two lanes stage different rows
+                                evict[g] = alive[g] && ureach[g] * reach >= 1.5f * thr[g] && hu >= kHotDrains;
+                                ev |= __ballot(evict[g] && h == 0) << (g ? 32 : 0);
+                                al |= __ballot(alive[g] && h == 0) << (g ? 32 : 0);
+                            }
+                            const int n_evict = __popcll(ev), n_alive = __popcll(al);
+                            if (n_evict > 0 && n_evict <= kMaxEvict && 2 * n_alive <= UPW) {
+                                any_alive = false; far = false;
+#pragma unroll
+                                for (int g = 0; g < NG; ++g) {
+                                    if (evict[g]) {
+                                        if (h == 0) A.unfinished[group * UPW + g * 32 + j] = 1;
+                                        user_ok[g] = false; thr[g] = INFINITY; alive[g] = false;
+                                    }
+                                    any_alive |= alive[g];
+                                    far |= alive[g] && ureach[g] * reach >= 1.5f * thr[g];
+                                }
+                            }
+                        }
                     }
                     if (!__any(any_alive)) {
                         if (A.exit_count && job < A.n_whole && lane == 0) atomicAdd(A.exit_count + exit_slot(job), 1u);
