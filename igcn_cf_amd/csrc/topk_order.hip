@@ -15,8 +15,8 @@
 //   inv[item] = pos
 //   excl_pos  = the exclusion CSR's entries as sweep positions, ascending inside every row (the sweep walks each
 //               user's list with a cursor): inv[col], sorted row by row by two kernels of this file (round 4) —
-//               rows of <= 32 entries by a half-wave each and rows of 33 .. 256 by a wave each, in registers (bitonic
-//               networks of xor-shuffles, sixteen rows' networks interleaved), longer rows by a workgroup each (the same
+//               rows of <= 32 entries by a half-wave each and rows of 33 .. 1 024 by a wave each, in registers (bitonic
+//               networks of xor-shuffles, a turn's short rows interleaved), longer rows by a workgroup each (the same
 //               network in LDS up to 8 192 entries, in place in HBM beyond).  Which class a row falls into is decided
 //               where it is sorted — NO host read.  Rounds 2-3 used rocprim::segmented_radix_sort_keys, which partitions its segments by size and copies
 //               the partition sizes to the HOST before it can launch its sort kernels: a stream synchronisation inside an
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kBlock) void excl_mark_rows_kernel(const int64_t *_
 // No lists of rows, no counters, no atomics: a wave looks at kExclScan consecutive rows, sorts the ones of its classes and
 // skips the rest; the workgroups of the second kernel look at 256 rows each for the (rare) huge ones.  (A first version
 // appended the rows it did not take to two lists with one atomic each: 27 k atomics on two words — 240 us.)
-constexpr int kExclShort = 32, kExclMid = 256, kExclLds = 8192, kExclScan = 8, kHugeScan = 64;
+constexpr int kExclShort = 32, kExclMid = 256, kExclBig = 1024, kExclLds = 8192, kExclScan = 8, kHugeScan = 64;
 constexpr uint32_t kPosNone = 0xFFFFFFFFu;
 
 // One stage-by-stage bitonic network in the form whose compare-exchanges all point the same way (stage k first pairs i with
@@ -97,7 +97,7 @@ __device__ __forceinline__ void bitonic_ascending(Buf buf, int len, int tid, Syn
     }
 }
 
-// Rows of up to kExclMid entries, sorted in REGISTERS by bitonic networks whose exchanges are xor-shuffles (padding = kPosNone,
+// Rows of up to kExclBig entries, sorted in REGISTERS by bitonic networks whose exchanges are xor-shuffles (padding = kPosNone,
 // which sorts last).  A wave looks at kExclScan consecutive rows:
 //   * their first 32 entries are loaded for all of them at once (two independent loads in flight per row: the column id, then
 //     the position it maps to) into kExclScan / 2 register slots — slot i holds row 2 i in the lower half-wave and row 2 i + 1 in
@@ -105,11 +105,61 @@ __device__ __forceinline__ void bitonic_ascending(Buf buf, int len, int tid, Syn
 //     latency of a shuffle is paid 15 times per turn, not per row (rank counting with one shuffle, or one LDS read, per
 //     key paid it per key: 240 and 170 us for the Amazon-like lists); the rows of <= 32 entries are then stored;
 //   * the rows of 33 .. 256 entries follow one at a time: four keys per lane (entry e = 64 q + lane), 36 steps of which the
-//     distances >= 64 are exchanges between a lane's own registers.
+//     distances >= 64 are exchanges between a lane's own registers; then the rows of 257 .. 1 024 with sixteen keys per lane
+//     (the workgroup kernel below took 54 us for the ~300 such rows of the Amazon-like lists: a barrier per step).
 __device__ __forceinline__ uint32_t bitonic_pick(uint32_t mine, uint32_t other, bool keep_min)
 {
     const uint32_t lo = mine < other ? mine : other, hi = mine < other ? other : mine;
     return keep_min ? lo : hi;
+}
+
+// One row of up to 64 Q entries sorted by the whole wave: Q keys per lane (entry e = 64 q + lane), the bitonic network's distances
+// below 64 as xor-shuffles, the ones from 64 up as exchanges between a lane's own registers (the loops unroll: every register index
+// is a compile-time constant).
+template <int Q, typename Load, typename Store>
+__device__ __forceinline__ void sort_in_registers(int len, int lane, Load load, Store store)
+{
+    uint32_t kq[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) kq[q] = load(q * kWave + lane, q * kWave + lane < len);
+#pragma unroll
+    for (int k = 2; k <= Q * kWave; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= kWave) {                                             // partners are registers of the same lane
+                const int dq = j / kWave;
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+                    if ((q & dq) == 0 && (q | dq) < Q) {
+                        const bool asc = (((q * kWave) & k) == 0);
+                        const uint32_t a = kq[q], b = kq[q | dq];
+                        const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+                        kq[q] = asc ? lo : hi;
+                        kq[q | dq] = asc ? hi : lo;
+                    }
+            } else {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const int e = q * kWave + lane;
+                    const bool keep_min = ((e & j) == 0) == ((e & k) == 0);
+                    kq[q] = bitonic_pick(kq[q], (uint32_t)__shfl_xor((int)kq[q], j), keep_min);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+        if (q * kWave + lane < len) store(q * kWave + lane, kq[q]);
+}
+
+// ... a row of the exclusion CSR: column ids -> positions on the way in (two dependent loads per key, all Q of a lane in flight)
+template <int Q>
+__device__ __forceinline__ void sort_row_in_registers(const int32_t *__restrict__ col, const int32_t *__restrict__ inv,
+                                                      uint32_t *__restrict__ pos, long long sr, int lr, int lane)
+{
+    sort_in_registers<Q>(lr, lane,
+                         [&](int e, bool in) { return in ? (uint32_t)inv[col[sr + e]] : kPosNone; },
+                         [&](int e, uint32_t key) { pos[sr + e] = key; });
 }
 
 __global__ __launch_bounds__(kBlock) void excl_sort_rows_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
@@ -149,50 +199,25 @@ __global__ __launch_bounds__(kBlock) void excl_sort_rows_kernel(const int64_t *_
 #pragma unroll
         for (int i = 0; i < S; ++i)
             if (len[i] <= kExclShort && l32 < len[i]) pos[s[i] + l32] = key[i];
-        // rows of 33 .. 256 entries, one at a time
+        // rows of 33 .. 256 entries (four keys per lane), then of 257 .. 1 024 (sixteen), one at a time
         unsigned long long todo = __ballot(len_l > kExclShort && len_l <= kExclMid);
         while (todo) {
             const int src = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
-            const long long sr = __shfl(s_l, src);
-            const int lr = __shfl(len_l, src);
-            constexpr int Q = kExclMid / kWave;
-            uint32_t kq[Q];
-#pragma unroll
-            for (int q = 0; q < Q; ++q) kq[q] = q * kWave + lane < lr ? (uint32_t)col[sr + q * kWave + lane] : kPosNone;
-#pragma unroll
-            for (int q = 0; q < Q; ++q) kq[q] = q * kWave + lane < lr ? (uint32_t)inv[kq[q]] : kPosNone;
-            for (int k = 2; k <= kExclMid; k <<= 1)
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    if (j >= kWave) {                                     // partners are registers of the same lane
-                        const int dq = j / kWave;
-#pragma unroll
-                        for (int q = 0; q < Q; ++q)
-                            if ((q & dq) == 0 && (q | dq) < Q) {
-                                const bool asc = (((q * kWave) & k) == 0);
-                                const uint32_t a = kq[q], b = kq[q | dq];
-                                const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
-                                kq[q] = asc ? lo : hi;
-                                kq[q | dq] = asc ? hi : lo;
-                            }
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < Q; ++q) {
-                            const int e = q * kWave + lane;
-                            const bool keep_min = ((e & j) == 0) == ((e & k) == 0);
-                            kq[q] = bitonic_pick(kq[q], (uint32_t)__shfl_xor((int)kq[q], j), keep_min);
-                        }
-                    }
-                }
-#pragma unroll
-            for (int q = 0; q < Q; ++q)
-                if (q * kWave + lane < lr) pos[sr + q * kWave + lane] = kq[q];
+            sort_row_in_registers<kExclMid / kWave>(col, inv, pos, __shfl(s_l, src), __shfl(len_l, src), lane);
+        }
+        todo = __ballot(len_l > kExclMid && len_l <= kExclBig);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            sort_row_in_registers<kExclBig / kWave>(col, inv, pos, __shfl(s_l, src), __shfl(len_l, src), lane);
         }
     }
 }
 
-// Rows of more than kExclMid entries: a workgroup looks at kHugeScan rows and sorts each long one among them by the bitonic network
-// above — in LDS up to kExclLds entries, in place in HBM beyond (a user who excludes a twelfth of a 96 k-item table and more).
+// Rows of more than kExclBig entries: a workgroup looks at kHugeScan rows and sorts each long one among them — up to kExclLds entries as
+// register-sorted chunks merged through LDS, beyond that by the bitonic network above in place in HBM (a user who excludes a twelfth of
+// a 96 k-item table and more).
 __global__ __launch_bounds__(kBlock) void excl_sort_huge_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                                 int64_t n_rows, const int32_t *__restrict__ inv, uint32_t *__restrict__ pos,
                                                                 const uint8_t *__restrict__ needed)
@@ -207,17 +232,48 @@ __global__ __launch_bounds__(kBlock) void excl_sort_huge_kernel(const int64_t *_
         if (threadIdx.x < kHugeScan && r < n_rows && (!needed || needed[r])) { s = rowptr[r]; len = (int)(rowptr[r + 1] - s); }
         __syncthreads();                                                  // (the arrays below are still read by the previous turn)
         if (threadIdx.x < kHugeScan) { lens[threadIdx.x] = len; starts[threadIdx.x] = s; }
-        if (!__syncthreads_or(len > kExclMid)) continue;
+        if (!__syncthreads_or(len > kExclBig)) continue;
         for (int i = 0; i < kHugeScan; ++i) {
             const int li = lens[i];
-            if (li <= kExclMid) continue;                                 // (uniform over the workgroup)
+            if (li <= kExclBig) continue;                                 // (uniform over the workgroup)
             const long long si = starts[i];
-            uint32_t *buf = li <= kExclLds ? lds : pos + si;
-            for (int e = threadIdx.x; e < li; e += kBlock) buf[e] = (uint32_t)inv[col[si + e]];
-            __syncthreads();
-            bitonic_ascending<kBlock>(buf, li, (int)threadIdx.x, [] { __syncthreads(); });
-            if (li <= kExclLds)
-                for (int e = threadIdx.x; e < li; e += kBlock) pos[si + e] = lds[e];
+            if (li <= kExclLds) {
+                // chunks of kExclBig entries sorted in registers, a wave each (column id -> position on the way in), left in LDS;
+                // then every entry's place = its place in its own chunk + the entries of the other chunks that sort before it
+                // (binary searches in LDS; an equal key of an earlier chunk goes first).  (A barrier-per-step bitonic network over
+                // the whole row took 50 us for one row of 1 100 entries.)
+                const int n_chunks = (li + kExclBig - 1) / kExclBig;
+                const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+                for (int c = wave; c < n_chunks; c += kBlock / kWave) {
+                    const int c0 = c * kExclBig, cl = li - c0 < kExclBig ? li - c0 : kExclBig;
+                    sort_in_registers<kExclBig / kWave>(cl, lane,
+                                                        [&](int e, bool in) { return in ? (uint32_t)inv[col[si + c0 + e]] : kPosNone; },
+                                                        [&](int e, uint32_t key) { lds[c0 + e] = key; });
+                }
+                __syncthreads();
+                for (int e = threadIdx.x; e < li; e += kBlock) {
+                    const uint32_t key = lds[e];
+                    const int c = e / kExclBig;
+                    int rank = e - c * kExclBig;
+                    for (int c2 = 0; c2 < n_chunks; ++c2) {
+                        if (c2 == c) continue;
+                        const int c0 = c2 * kExclBig, cl = li - c0 < kExclBig ? li - c0 : kExclBig;
+                        int lo = 0, hi = cl;                              // entries of chunk c2 before `key`: < key, or <= key if c2 < c
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            const uint32_t v = lds[c0 + mid];
+                            if (v < key || (v == key && c2 < c)) lo = mid + 1; else hi = mid;
+                        }
+                        rank += lo;
+                    }
+                    pos[si + rank] = key;
+                }
+            } else {
+                uint32_t *buf = pos + si;
+                for (int e = threadIdx.x; e < li; e += kBlock) buf[e] = (uint32_t)inv[col[si + e]];
+                __syncthreads();
+                bitonic_ascending<kBlock>(buf, li, (int)threadIdx.x, [] { __syncthreads(); });
+            }
             __syncthreads();                                              // the next row re-uses the buffer
         }
     }

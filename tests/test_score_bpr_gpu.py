@@ -753,7 +753,7 @@ def test_two_stage_exclusion_lists_sorted_on_the_device_hold_every_users_best_it
     from igcn_cf_amd.ops import score_topk
     rng = np.random.default_rng(47)
     n_items, d, k = 45000, 64, 20
-    lengths = [0, 1, 2, 31, 32, 33, 63, 64, 65, 255, 256, 257, 1000, 4095, 8191, 8192, 8193, 20000, n_items - k]
+    lengths = [0, 1, 2, 31, 32, 33, 63, 64, 65, 255, 256, 257, 1000, 4095, 8191, 8192, 8193, 20000, n_items - k, 1023, 1024, 1025, 500, 700]
     lengths = lengths + [int(x) for x in rng.integers(1, 300, size=45)]
     n_users = len(lengths)
     U = (rng.standard_normal((n_users, d)) * 0.1).astype(np.float32)
