@@ -15,8 +15,8 @@
 //   inv[item] = pos
 //   excl_pos  = the exclusion CSR's entries as sweep positions, ascending inside every row (the sweep walks each
 //               user's list with a cursor): inv[col], sorted row by row by two kernels of this file (round 4) —
-//               rows of <= 32 entries by a half-wave each and rows of 33 .. 1 024 by a wave each, in registers (bitonic
-//               networks of xor-shuffles, a turn's short rows interleaved), longer rows by a workgroup each (the same
+//               rows of up to 1 024 entries by a wave each, in registers (bitonic networks of xor-shuffles, the <= 64-entry
+//               rows of a turn interleaved), longer rows by a workgroup each (the same
 //               network in LDS up to 8 192 entries, in place in HBM beyond).  Which class a row falls into is decided
 //               where it is sorted — NO host read.  Rounds 2-3 used rocprim::segmented_radix_sort_keys, which partitions its segments by size and copies
 //               the partition sizes to the HOST before it can launch its sort kernels: a stream synchronisation inside an
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kBlock) void excl_mark_rows_kernel(const int64_t *_
 // No lists of rows, no counters, no atomics: a wave looks at kExclScan consecutive rows, sorts the ones of its classes and
 // skips the rest; the workgroups of the second kernel look at 256 rows each for the (rare) huge ones.  (A first version
 // appended the rows it did not take to two lists with one atomic each: 27 k atomics on two words — 240 us.)
-constexpr int kExclShort = 32, kExclMid = 256, kExclBig = 1024, kExclLds = 8192, kExclScan = 8, kHugeScan = 64;
+constexpr int kExclShort = 64, kExclMid = 256, kExclBig = 1024, kExclLds = 8192, kExclScan = 8, kHugeScan = 64;
 constexpr uint32_t kPosNone = 0xFFFFFFFFu;
 
 // One stage-by-stage bitonic network in the form whose compare-exchanges all point the same way (stage k first pairs i with
@@ -99,12 +99,13 @@ __device__ __forceinline__ void bitonic_ascending(Buf buf, int len, int tid, Syn
 
 // Rows of up to kExclBig entries, sorted in REGISTERS by bitonic networks whose exchanges are xor-shuffles (padding = kPosNone,
 // which sorts last).  A wave looks at kExclScan consecutive rows:
-//   * their first 32 entries are loaded for all of them at once (two independent loads in flight per row: the column id, then
-//     the position it maps to) into kExclScan / 2 register slots — slot i holds row 2 i in the lower half-wave and row 2 i + 1 in
-//     the upper — and all slots go through the 32-key network TOGETHER: 15 steps of independent shuffles, so the
-//     latency of a shuffle is paid 15 times per turn, not per row (rank counting with one shuffle, or one LDS read, per
-//     key paid it per key: 240 and 170 us for the Amazon-like lists); the rows of <= 32 entries are then stored;
-//   * the rows of 33 .. 256 entries follow one at a time: four keys per lane (entry e = 64 q + lane), 36 steps of which the
+//   * their first 64 entries are loaded for all of them at once (two independent loads in flight per row: the column id, then
+//     the position it maps to), one register slot per row, and all slots go through the 64-key network TOGETHER: 21 steps of
+//     kExclScan independent shuffles, so the latency of a shuffle — and of the two dependent loads — is paid once per turn, not per
+//     row (rank counting with one shuffle, or one LDS read, per key paid it per key: 240 and 170 us for the Amazon-like lists;
+//     half-waves for rows of <= 32 entries with the 33 .. 64 ones taken one at a time: 74 us); the rows of <= 64 entries — 95 %
+//     of them — are then stored;
+//   * the rows of 65 .. 256 entries follow one at a time: four keys per lane (entry e = 64 q + lane), 36 steps of which the
 //     distances >= 64 are exchanges between a lane's own registers; then the rows of 257 .. 1 024 with sixteen keys per lane
 //     (the workgroup kernel below took 54 us for the ~300 such rows of the Amazon-like lists: a barrier per step).
 __device__ __forceinline__ uint32_t bitonic_pick(uint32_t mine, uint32_t other, bool keep_min)
@@ -166,10 +167,10 @@ __global__ __launch_bounds__(kBlock) void excl_sort_rows_kernel(const int64_t *_
                                                                 int64_t n_rows, const int32_t *__restrict__ inv, uint32_t *__restrict__ pos,
                                                                 const uint8_t *__restrict__ needed)
 {
-    const int lane = threadIdx.x & (kWave - 1), l32 = lane & 31, hw = lane >> 5;
+    const int lane = threadIdx.x & (kWave - 1);
     const int64_t w0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int64_t n_w = ((int64_t)gridDim.x * kBlock) >> 6;
-    constexpr int S = kExclScan / 2;
+    constexpr int S = kExclScan;
     for (int64_t base = w0 * kExclScan; base < n_rows; base += n_w * kExclScan) {
         long long s_l = 0;
         int len_l = 0;
@@ -183,23 +184,25 @@ __global__ __launch_bounds__(kBlock) void excl_sort_rows_kernel(const int64_t *_
         uint32_t key[S];
 #pragma unroll
         for (int i = 0; i < S; ++i) {
-            s[i] = __shfl(s_l, 2 * i + hw);
-            len[i] = __shfl(len_l, 2 * i + hw);
+            s[i] = __shfl(s_l, i);
+            len[i] = __shfl(len_l, i);
         }
 #pragma unroll
-        for (int i = 0; i < S; ++i) key[i] = l32 < len[i] ? (uint32_t)col[s[i] + l32] : kPosNone;
+        for (int i = 0; i < S; ++i) key[i] = lane < len[i] ? (uint32_t)col[s[i] + lane] : kPosNone;
 #pragma unroll
-        for (int i = 0; i < S; ++i) key[i] = l32 < len[i] ? (uint32_t)inv[key[i]] : kPosNone;
+        for (int i = 0; i < S; ++i) key[i] = lane < len[i] ? (uint32_t)inv[key[i]] : kPosNone;
+#pragma unroll
         for (int k = 2; k <= kExclShort; k <<= 1)
+#pragma unroll
             for (int j = k >> 1; j > 0; j >>= 1) {
-                const bool keep_min = ((l32 & j) == 0) == ((l32 & k) == 0);
+                const bool keep_min = ((lane & j) == 0) == ((lane & k) == 0);
 #pragma unroll
                 for (int i = 0; i < S; ++i) key[i] = bitonic_pick(key[i], (uint32_t)__shfl_xor((int)key[i], j), keep_min);
             }
 #pragma unroll
         for (int i = 0; i < S; ++i)
-            if (len[i] <= kExclShort && l32 < len[i]) pos[s[i] + l32] = key[i];
-        // rows of 33 .. 256 entries (four keys per lane), then of 257 .. 1 024 (sixteen), one at a time
+            if (len[i] <= kExclShort && lane < len[i]) pos[s[i] + lane] = key[i];
+        // rows of 65 .. 256 entries (four keys per lane), then of 257 .. 1 024 (sixteen), one at a time
         unsigned long long todo = __ballot(len_l > kExclShort && len_l <= kExclMid);
         while (todo) {
             const int src = __ffsll((long long)todo) - 1;
