@@ -30,8 +30,11 @@ def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
     headers.append(os.path.join(ROOT, 'include', 'igcn_hip.h'))
+    srcs = [os.path.join(CSRC, name) for name in SOURCES]
+    # The shipped library is current (the GPU box gets the .so but not the objects: *.o is in .gpurunignore): nothing to do there
+    main_current = not force and not _newer(srcs + headers, LIB)
     objs = []
-    for name in SOURCES:
+    for name in ([] if main_current else SOURCES):
         src = os.path.join(CSRC, name)
         if not os.path.exists(src):
             raise FileNotFoundError(src)
@@ -42,7 +45,7 @@ def build(force=False, verbose=True):
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd)
         objs.append(obj)
-    if force or _newer(objs, LIB):
+    if not main_current and (force or _newer(objs, LIB)):
         cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         if verbose:
             print(' '.join(cmd), flush=True)

@@ -87,6 +87,11 @@ def handle():
     """The loaded shared library; raises if it is missing (no fallback)."""
     global _handle
     if _handle is None:
+        # torch first: its wheel bundles a HIP runtime of its own (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's, which
+        # this library is linked against).  Whichever is loaded first serves the whole process; loaded the other way round
+        # the process ends up with two runtimes and this library's first launch fails with "no ROCm-capable device"
+        # (seen when __graft_entry__.build() and smoke() ran in one process on the GPU box).
+        import torch                                            # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise IgcnError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                             '(hipcc --offload-arch=gfx950); there is no CPU fallback' % LIB_PATH)
