@@ -3,6 +3,7 @@ logic (graph builders, datasets, configs, metric reductions) matches the oracle 
 reference's golden vectors, and the ops fail loudly without a GPU."""
 import ctypes as C
 import os
+import sys
 import re
 
 import numpy as np
@@ -27,6 +28,18 @@ def test_library_exports_every_declared_symbol():
         assert getattr(_lib.lib(), name) is not None
     assert _lib.lib().igcn_abi_version() == 7
     assert _lib.lib().igcn_error_string(-1).decode().startswith('a required pointer')
+
+
+def test_library_is_loaded_behind_torch_in_a_fresh_process():
+    """torch's wheel bundles a HIP runtime with the SONAME of the one the library is linked against: whichever is loaded first
+    serves the process.  Loaded before torch, the library ended up on a second runtime and its first launch on the GPU box failed
+    with "no ROCm-capable device" (build() + smoke() in one process).  _lib.handle() therefore imports torch first."""
+    import subprocess
+    code = ("import sys; from igcn_cf_amd import _lib; assert 'torch' not in sys.modules; v = _lib.lib().igcn_abi_version(); "
+            "assert 'torch' in sys.modules; print(v)")
+    p = subprocess.run([sys.executable, '-c', code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-1000:]
+    assert p.stdout.decode().strip() == '7'
 
 
 def test_measurement_library_exports_its_probes():
