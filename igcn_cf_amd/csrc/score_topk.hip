@@ -358,6 +358,10 @@ struct TopkArgs {
     // users (at most `batch`: the plan's size), user b of it sits at batch position rows[b] of the caller's arrays (user_ids,
     // out_idx / out_val); init_thr stays indexed by b.  NULL: the batch is positions 0 .. batch - 1.
     const int32_t *rows; const int32_t *count_dev;
+    // BOUNDED, NG = 1, pieces (the two-stage path's fall-back): per user k slots of sortable score bits, slot s = the best score any
+    // of the pieces s P / k .. (s + 1) P / k - 1 has met — k slots certify k DIFFERENT items, so their minimum is a lower bound of the
+    // user's k-th best (see flush()).  NULL: off.
+    unsigned int *piece_best;
     int early_checks;          // candidate sweep: exit checks every so many tiles up to tile 48, give-up from twice that (0: every 24 tiles / from tile 48)
 };
 
@@ -503,6 +507,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
         // (-inf) ones included.
         for (int s = 0; s < k; ++s) heap[s * kWave] = 0ull;
         unsigned long long root = 0ull;
+        unsigned long long best = 0ull;                          // (BOUNDED, NG = 1: the best key this piece has met, see A.piece_best)
         float thr[NG];                                           // k-th best score of user (g, j): the same in both lanes of a user
         int cnt[NG];                                             // staged candidates of this lane, per group
         unsigned stage_addr[NG];                                 // LDS byte address of this lane's first staging slot
@@ -551,6 +556,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                     const unsigned long long raw = i < n0 ? l0[i * kWave] : l0[(i - n0) * kWave + 32];
                     const unsigned long long cand = make_key(__uint_as_float((unsigned int)raw), (int)(raw >> 32));
                     if (cand > root) root = heap_replace_root(heap, k, cand);
+                    if constexpr (BOUNDED && NG == 1) { if (cand > best && (unsigned int)raw != 0xff800000u) best = cand; }   // (-inf: a masked fill-in)
                 }
             }
 #pragma unroll
@@ -575,6 +581,26 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                 for (int g = 0; g < NG; ++g) {
                     const unsigned int sh = user_ok[g] ? A.shared_thr[group * UPW + g * 32 + j] : 0u;
                     if (sh) thr[g] = fmaxf(thr[g], key_score((unsigned long long)sh << 32));
+                }
+            }
+            if constexpr (BOUNDED && NG == 1) if (A.piece_best && !direct) {
+                // A piece's own k-th best is a poor bound for a user whose sweep is cut into ~58 pieces of 1 700 items: rank ~1 000 of
+                // the table at the piece's end, ~10 000 at its start — every piece stages ~100 candidates where one sweep would
+                // stage 170 in all.  The pieces' BEST scores combine to much more: k slots, slot s collecting the maximum over
+                // a k-th of the pieces (disjoint item ranges: k different items), and the minimum over the slots — valid as soon
+                // as every slot is set — is the k-th largest of k sample maxima: rank ~1 000 after a few tiles, below 100 at the end.
+                const int64_t rg = group - n_full;
+                const int n_lists = (int)((((rg + 1) * n_tiles - 1) / A.run) - (rg * n_tiles) / A.run + 1);
+                const int64_t b_own = group * UPW + lane;
+                if (n_lists >= k) {
+                    if (owner && best && b_own < batch_n)
+                        atomicMax(A.piece_best + b_own * k + (int)((int64_t)pidx * k / n_lists), (unsigned int)(best >> 32));
+                    if (user_ok[0]) {
+                        const unsigned int *slots = A.piece_best + (group * UPW + j) * k;
+                        unsigned int m = ~0u;
+                        for (int sl = 0; sl < k; ++sl) { const unsigned int v = slots[sl]; m = v < m ? v : m; }
+                        if (m) thr[0] = fmaxf(thr[0], key_score((unsigned long long)m << 32));
+                    }
                 }
             }
 #ifdef IGCN_TOPK_STATS
@@ -1615,7 +1641,7 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
                     const unsigned int *stats, hipStream_t st, const int32_t *perm = nullptr, const float *init_thr = nullptr,
                     const float *tile_bound = nullptr, const float *unorm2 = nullptr, unsigned int *exit_count = nullptr,
                     uint8_t *unfinished = nullptr, unsigned int *shared_thr = nullptr,
-                    const int32_t *rows = nullptr, const int32_t *count_dev = nullptr)
+                    const int32_t *rows = nullptr, const int32_t *count_dev = nullptr, unsigned int *piece_best = nullptr)
 {
     if ((rows || count_dev) && !(mode == 0 && init_thr && (d == 64 || d == 128))) return IGCN_E_SHAPE;   // the bounded variants only
     if (!user_rows || !item_rows || !out_idx || !out_val) return IGCN_E_NULL;
@@ -1654,7 +1680,7 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
     a.tile_bound = tile_bound; a.unorm2 = unorm2;
     a.exit_count = exit_count; a.unfinished = unfinished;
     a.shared_thr = p.p_max > 1 ? shared_thr : nullptr;          // (only pieces have anything to share)
-    a.rows = rows; a.count_dev = count_dev;
+    a.rows = rows; a.count_dev = count_dev; a.piece_best = p.p_max > 1 && p.ng == 1 ? piece_best : nullptr;
     { const int ec = tuning_get(IGCN_TUNE_TOPK_FAST_EARLY_CHECKS); a.early_checks = ec < 0 ? kEarlyCheckEvery : ec / 3 * 3; }
 
     if (mode != 0) {
@@ -1743,7 +1769,7 @@ static int topk_fast_layout(int64_t batch, int64_t n_items, int32_t d, int32_t k
     L->unorm2 = L->tile_bound + align256((int64_t)p.n_tiles * 4);
     L->exit_state = L->unorm2 + align256(batch * 4);
     // [256 B: early leavers per job][the fall-back's shared thresholds][batch B: users given up on][batch x 4 B: the sweep's shared thresholds]
-    L->order = L->exit_state + 256 + kFastFallbackMax * 4 + align256(batch) + align256(batch * 4);
+    L->order = L->exit_state + 256 + kFastFallbackMax * 4 + kFastFallbackMax * kWave * 4 + align256(batch) + align256(batch * 4);   // (+ the fall-back's piece_best: k <= 64 slots per user)
     L->fallback = align256(L->order + L->ord.total);
     const int64_t fb = igcn_score_topk_workspace_bytes(batch < kFastFallbackMax ? batch : kFastFallbackMax, n_items, d, k);
     if (fb < 0) return IGCN_E_RANGE;
@@ -1831,10 +1857,12 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     const bool give_up = early_exit && sweep_plan.n_whole >= 1 && tuning_get(IGCN_TUNE_TOPK_FAST_GIVE_UP) != 0;
     unsigned int *exit_count = reinterpret_cast<unsigned int *>(ws + L.exit_state);
     unsigned int *fb_shared_thr = reinterpret_cast<unsigned int *>(ws + L.exit_state + 256);
-    uint8_t *unfinished = reinterpret_cast<uint8_t *>(ws + L.exit_state + 256 + kFastFallbackMax * 4);
-    unsigned int *shared_thr = reinterpret_cast<unsigned int *>(ws + L.exit_state + 256 + kFastFallbackMax * 4 + align256(batch));
+    unsigned int *fb_piece_best = reinterpret_cast<unsigned int *>(ws + L.exit_state + 256 + kFastFallbackMax * 4);
+    const int64_t fb_state = 256 + kFastFallbackMax * 4 + kFastFallbackMax * kWave * 4;
+    uint8_t *unfinished = reinterpret_cast<uint8_t *>(ws + L.exit_state + fb_state);
+    unsigned int *shared_thr = reinterpret_cast<unsigned int *>(ws + L.exit_state + fb_state + align256(batch));
     const bool share = sweep_plan.p_max > 1 && mode == 3 && d == 64 && tuning_get(IGCN_TUNE_TOPK_FAST_SHARE) != 0;
-    e = hipMemsetAsync(ws + L.exit_state, 0, (size_t)(256 + kFastFallbackMax * 4 + (give_up || share ? align256(batch) + (share ? batch * 4 : 0) : 0)), st);
+    e = hipMemsetAsync(ws + L.exit_state, 0, (size_t)(fb_state + (give_up || share ? align256(batch) + (share ? batch * 4 : 0) : 0)), st);
     if (e != hipSuccess) return (int)e;
     // the sweep runs in position space: its exclusion lists and banned bits are those of the positions, and the
     // candidate ids it returns are positions (mapped back by the re-scoring kernel)
@@ -1860,7 +1888,8 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     const int64_t fb_users = batch < kFastFallbackMax ? batch : kFastFallbackMax;
     return topk_run(0, user_rows, ldu, user_ids, fb_users, item_rows, ldi, n_items, d, excl_rowptr, excl_col, banned, k, out_idx, out_val,
                     ws + L.fallback, nullptr, nullptr, st, nullptr, flagged_lower_bound, nullptr, nullptr, nullptr, nullptr,
-                    tuning_get(IGCN_TUNE_TOPK_FAST_SHARE) != 0 ? fb_shared_thr : nullptr, flagged + 1, flagged);
+                    tuning_get(IGCN_TUNE_TOPK_FAST_SHARE) != 0 ? fb_shared_thr : nullptr, flagged + 1, flagged,
+                    tuning_get(IGCN_TUNE_TOPK_FAST_SHARE) != 0 ? fb_piece_best : nullptr);
 }
 
 #ifdef IGCN_TOPK_STATS
