@@ -62,5 +62,26 @@ for epoch in range(4):
                           flagged=n_flagged, longest_waves_us_tiles_flushes=[[round(float(life[i]), 1), int(tiles_w[i]), int(flushes_w[i])] for i in np.argsort(-life)[:6]],
                           cycles_per_wave=dict(flush=t[7] // max(t[6], 1), stage_hits_incl_flush=t[8] // max(t[6], 1), wave=t[9] // max(t[6], 1), build_masks=t[10] // max(t[6], 1), before_first_tile=t[12] // max(t[6], 1), after_last_tile=t[13] // max(t[6], 1)),
                           clock_GHz=round(t[9] / max(t[11], 1) / 10, 3), median_wave_us_tiles_flushes=[round(float(np.median(life)), 1), int(np.median(tiles_w)), int(np.median(flushes_w))])), flush=True)
+    if n_flagged and epoch >= 2:
+        # the bounded fp32 sweep of the handed-over users alone (host-side call: no threshold pooling), same stats build
+        pos = flagged[1:1 + n_flagged].long()
+        stats.igcn_debug_topk_stats(buf, 1)
+        saved2 = (_lib._handle, _lib._bound)
+        _lib._handle, _lib._bound = stats, {}
+        score_topk(U, I, 20, user_ids=users[pos].contiguous(), mode='exact', lower_bound=bounds[:n_flagged].contiguous())
+        torch.cuda.synchronize()
+        stats.igcn_debug_topk_stats(buf, 1)
+        _lib._handle, _lib._bound = saved2
+        t = list(buf)
+        wt = (C.c_ulonglong * (3 * 2048))()
+        stats.igcn_debug_topk_wave_times(wt, 2048)
+        nw = int(t[6])
+        w = np.array(list(wt), dtype=np.uint64).reshape(2048, 3)[:nw]
+        life = (w[:, 1] - w[:, 0]).astype(np.float64) / 100
+        print(json.dumps(dict(bounded_sweep_of_handed_over_users=n_flagged, waves=nw, tiles_per_wave=round(t[0] / max(nw, 1), 1), hit_quads_per_wave=round(t[2] / max(nw, 1), 1),
+                              flushes_per_wave=round(t[3] / max(nw, 1), 1), drained_per_wave=round(t[5] / max(nw, 1), 1),
+                              cycles_per_wave=dict(flush=t[7] // max(nw, 1), stage_hits_incl_flush=t[8] // max(nw, 1), wave=t[9] // max(nw, 1), build_masks=t[10] // max(nw, 1),
+                                                   before_first_tile=t[12] // max(nw, 1), after_last_tile=t[13] // max(nw, 1)),
+                              wave_life_us_quantiles_10_50_90_max=[round(float(np.percentile(life, q)), 1) for q in (10, 50, 90, 100)])), flush=True)
     model.train()
     trainer.train_one_epoch()
