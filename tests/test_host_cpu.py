@@ -42,6 +42,44 @@ def test_library_is_loaded_behind_torch_in_a_fresh_process():
     assert p.stdout.decode().strip() == '7'
 
 
+def test_bench_launcher_refuses_without_enough_gpus_before_starting_anything():
+    """`python bench.py --gpus N` (N > 1, no launcher) becomes the launcher of its own ranks — but with fewer than N visible GPUs
+    and no rehearsal switch it must say so and stop: rc != 0, nothing on stdout (the driver parses stdout as ONE JSON line), no
+    child started.  This container has no GPU at all."""
+    import subprocess
+    env = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'IGCN_BENCH_ONE_GPU'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    if p.returncode == 0:
+        pytest.skip('two GPUs are visible here: the launcher went ahead')
+    assert not p.stdout.strip() and b'IGCN_BENCH_ONE_GPU' in p.stderr and b'torch.distributed.run' not in p.stderr
+
+
+def test_a_rank_share_splits_into_the_two_blocks_the_halves_exchange_launches():
+    """bench.split_share: the user block and the item block of a rank share as matrices of their own (views of the same col / val) —
+    the launches whose counters profiles/pmc_traffic_config5.json holds.  Rows, columns and values of the blocks are the share's."""
+    import bench
+    from igcn_cf_amd.dist import ShardLayout
+    from igcn_cf_amd.synth import BipartiteGraphDevice
+    g = BipartiteGraphDevice(900, 300, 12000, 'cpu', seed=3)
+    layout = ShardLayout.balanced(g.rowptr_host(), g.n_users, g.n_items, 4)
+    for rank in (0, 3):
+        csr, _ = g.rank_share(layout, rank)
+        (ulo, uhi) = layout.user_rows(rank)
+        cu, ci = bench.split_share(csr, uhi - ulo)
+        assert cu.shape == (uhi - ulo, g.n) and ci.shape == (csr.shape[0] - (uhi - ulo), g.n) and cu.nnz + ci.nnz == csr.nnz
+        rp = csr.rowptr.numpy()
+        np.testing.assert_array_equal(cu.rowptr.numpy(), rp[:uhi - ulo + 1])
+        np.testing.assert_array_equal(ci.rowptr.numpy(), rp[uhi - ulo:] - rp[uhi - ulo])
+        np.testing.assert_array_equal(np.concatenate([cu.col.numpy(), ci.col.numpy()]), csr.col.numpy())
+        np.testing.assert_array_equal(np.concatenate([cu.val.numpy(), ci.val.numpy()]), csr.val.numpy())
+        assert int(cu.col.min()) >= g.n_users and int(ci.col.max()) < g.n_users          # user rows gather items, item rows gather users
+    t = bench.stored_config5_traffic(-1, 128)
+    assert t is None                                                                      # counters of another share are never quoted
+
+
 def test_measurement_library_exports_its_probes():
     """libigcn_roof.so (bench.py's in-run probes: the rowless gather and the stream kernels; never loaded by the product):
     both entry points resolve with the signatures bench.py binds, and bad arguments come back as -1 without a launch."""
