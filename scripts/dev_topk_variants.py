@@ -78,7 +78,7 @@ def run():
                                       ms=round(ms, 2), wave_us=t[11] / t[6] / 100, clock_GHz=round(t[9] / max(t[11], 1) / 10, 3),
                                       cycles_per_wave=dict(flush=t[7] // t[6], stage_hits=t[8] // t[6], wave=t[9] // t[6], build_masks=t[10] // t[6]))), flush=True)
             continue
-        for tune in ({},):
+        for tune in [dict((kv.split('=')[0], int(kv.split('=')[1])) for kv in t.split(',') if kv) for t in os.environ.get('TUNES', '').split(';')]:   # e.g. TUNES=';topk_cap=8': defaults, then one knob
             for key, v in tune.items():
                 _lib.set_tuning(key, v)
             rec = dict(variant=name, tune=tune)
