@@ -148,6 +148,8 @@ constexpr int kEarlyCheckEvery = 6;      // exit checks every so many tiles up t
 constexpr int kHotDrains = 3, kMaxEvict = 4;
 constexpr int kExitSlots = 64;       // counters of early leavers, one per whole sweep of a wave (256 B of the call's workspace)
 __device__ __forceinline__ int exit_slot(int64_t job) { return job < kExitSlots ? (int)job : kExitSlots - 1; }
+constexpr int kWarmTiles = 128;     // tiles of the candidate sweep's warm-up pass ("topk_fast_warm"; see the kernel)
+constexpr float kWarmFlat = 0.5f;   // ... taken only if the rows at its end are still this long relative to the first
 constexpr int kMinCapSweep = 6;      // candidate sweeps: a shallower staging list (more drains) rather than half the resident waves (k + extra = 25..28)
 
 // (the fp16 candidate sweep at d = 128 runs ONE wave per SIMD with 512 registers: both user groups stay)
@@ -329,7 +331,7 @@ __device__ __forceinline__ float vmax2(float a, float b) {
 // Developer build only (scripts/dev_topk_variants.py): event counts summed over waves.
 // [0] tiles  [1] tiles with a hit quad  [2] hit quads  [3] flushes  [4] flush iterations  [5] staged candidates  [6] waves
 // [7] shader cycles inside flush()  [8] inside stage_hits()  [9] whole wave  [10] inside build_masks()
-__device__ unsigned long long g_topk_stats[16];   // ... [12] cycles before the first tile of a job (operands, cursors, heaps)  [13] cycles after the last (heapsort, emit)
+__device__ unsigned long long g_topk_stats[16];   // ... [12] cycles before the first tile of a job (operands, cursors, heaps)  [13] cycles after the last (heapsort, emit)  [14] / [15] cycles from the first tile to tile 63 / 255
 __device__ unsigned long long g_topk_wave_times[3 * 4096];   // begin, end (100 MHz ticks), HW_ID per workgroup
 #define IGCN_CLOCK() __builtin_amdgcn_s_memtime()
 #define IGCN_STAT(i, v) (st_##i += (v))
@@ -362,6 +364,10 @@ struct TopkArgs {
     // of the pieces s P / k .. (s + 1) P / k - 1 has met — k slots certify k DIFFERENT items, so their minimum is a lower bound of the
     // user's k-th best (see flush()).  NULL: off.
     unsigned int *piece_best;
+    // Whole candidate sweeps (MODE 3, d = 64): a warm-up pass over the first warm_tiles tiles keeps, per user, the best score of each
+    // of the 32 accumulator slots (32 different items); the kc-th largest of them is a lower bound of the user's kc-th best, kept in
+    // warm_thr[batch position] — the sweep proper then starts with that threshold instead of -inf (see the kernel).  0 / NULL: off.
+    int warm_tiles; float *warm_thr;
     int early_checks;          // candidate sweep: exit checks every so many tiles up to tile 48, give-up from twice that (0: every 24 tiles / from tile 48)
 };
 
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
     const bool prio_boost = (A.stagger & 2) != 0;
     set_base_priority(prio_slot);
 #ifdef IGCN_TOPK_STATS
-    unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0, st_5 = 0, st_7 = 0, st_8 = 0, st_10 = 0, st_12 = 0, st_13 = 0, st_job = 0;
+    unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0, st_5 = 0, st_7 = 0, st_8 = 0, st_10 = 0, st_12 = 0, st_13 = 0, st_14 = 0, st_15 = 0, st_job = 0, st_first = 0;
     const unsigned long long st_begin = IGCN_CLOCK();
     const unsigned long long st_rt_begin = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -520,6 +526,8 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
             stage_addr[g] = (unsigned)(uintptr_t)(stage_all + (g * cap) * kWave + lane);
         }
 
+        constexpr bool kWarm = MODE == 3 && D == 64;             // warm-up pass before a whole sweep (see below)
+        bool warm = false;
         constexpr bool kHotTrack = MODE == 3 && D == 64;         // (the default candidate sweep; the others have no registers to spare)
         int hot[kHotTrack ? NG : 1];                             // drains this lane's staging list has triggered (see kHotDrains)
 #pragma unroll
@@ -564,6 +572,10 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                 cnt[g] = 0;
                 const unsigned long long r = heap_base[g * 32 + j];     // root of user (g, j), kept by lane g * 32 + j
                 thr[g] = !user_ok[g] ? INFINITY : r ? key_score(r) : -INFINITY;   // list not full yet: everything may enter
+                if constexpr (kWarm) {                                  // ... that reaches the warm-up pass's bound (>= kc items do)
+                    if (warm && !r && user_ok[g])
+                        thr[g] = __hip_atomic_load(A.warm_thr + group * UPW + g * 32 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 // ... that reaches the caller's lower bound (the list fills from the items above it: there are >= k)
                 if constexpr (BOUNDED) { if (user_ok[g]) thr[g] = fmaxf(thr[g], A.init_thr[group * UPW + g * 32 + j]); }
             }
@@ -956,6 +968,103 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
 #ifdef IGCN_TOPK_STATS
         st_12 += IGCN_CLOCK() - st_job;
 #endif
+        if constexpr (kWarm) {
+            // ---- warm-up pass (round 4, late) ---------------------------------------------------------------------------------------
+            // A sweep that starts from empty lists stages k (1 + ln(n / k)) ~ 240 candidates per user (k + extra = 26, 96 k items), half
+            // of them in its first 2 % — where every quad holds candidates and a drain follows every other quad: the first 63 tiles took
+            // 16 % of a wave's life, the first 255 29 % (profiles/r04zw_*).  So the first P tiles are multiplied TWICE: once here with no
+            // selection at all — each of the lane's 16 accumulator registers keeps the best unmasked score it has held, 32 slots per user
+            // over its two lanes, 32 different items — and the kc-th largest of the 32 slot maxima is a lower bound tau of the user's kc-th
+            // best that >= kc items of these tiles reach.  The sweep proper then starts at tile 0 with thr = tau: ~45 candidates in
+            // the first P tiles instead of ~140 (P = 64), and the same stream as before after them (simulated: 240 -> 143 per user at
+            // P = 64, 108 at P = 256).  The scores are the sweep's own, bit for bit (same operands, same MFMA order), so tau is exact.
+            // A list that is not full keeps tau as its threshold (flush()), and keeps its wave in the sweep (the exit check below).
+            const int P = A.warm_tiles;
+            warm = A.warm_thr != nullptr && P > 0 && job < A.n_whole && k <= 32 && tin1 - tin0 > P;
+            // Only where nobody can leave during those tiles anyway: a wave leaves once |u| x (longest row still to come) < thr for
+            // all its users, and on a trained table (rows at tile 128 a quarter as long as the first: 0.23-0.26 after 1-3 epochs,
+            // 0.78 at random init) most waves have left after 6-12 tiles — the pass then costs more tiles than the sweep
+            // (measured: 0.58 -> 0.72 ms after one epoch at P = 128, no gain at any P; profiles/r04zy_*).
+            if (warm && A.tile_bound) {
+                const float b0 = ((const_f32_ptr)(uintptr_t)A.tile_bound)[tin0], bp = ((const_f32_ptr)(uintptr_t)A.tile_bound)[tin0 + P];
+                warm = bp >= kWarmFlat * b0;
+            }
+            if (warm) {
+                int sv_pos[NG], sv_next[NG], sv_after[NG];
+                float slot[NG][16];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    sv_pos[g] = ex_pos[g]; sv_next[g] = ex_next[g]; sv_after[g] = ex_after[g];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) slot[g][r] = -INFINITY;
+                }
+                auto warm_step = [&](float4 (&buf)[D / 8], int t) {
+                    build_masks(t, t * 32);
+                    f32x16 sc[NG];
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sc[g][r] = 0.f;
+#pragma unroll
+                    for (int st = 0; st < KS; ++st)
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+                            sc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(buf[st]), as_half8(ub[g][0][st]), sc[g], 0, 0, 0);
+                    if (mflag) {
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                slot[g][r] = fmaxf(slot[g][r], ((exm[g] >> (8 * (r >> 2) + (r & 3))) & 1u) ? -INFINITY : sc[g][r]);
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < NG; ++g)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) slot[g][r] = fmaxf(slot[g][r], sc[g][r]);
+                    }
+                };
+                const int t_end = tin0 + P;
+                auto clamp_t = [&](int t) { return t < tin1 ? t : tin1 - 1; };
+                load_into(a, tin0); load_into(a2, clamp_t(tin0 + 1)); load_into(a3, clamp_t(tin0 + 2));
+                for (int t = tin0; t < t_end; t += 3) {
+                    warm_step(a, t);
+                    load_into(a, clamp_t(t + 3));
+                    if (t + 1 < t_end) { warm_step(a2, t + 1); load_into(a2, clamp_t(t + 4)); }
+                    if (t + 2 < t_end) { warm_step(a3, t + 2); load_into(a3, clamp_t(t + 5)); }
+                }
+                // the kc-th largest of a user's 32 slot maxima: drop the 32 - kc smallest (one per round, from whichever of the
+                // user's two lanes holds it), the smallest left is tau.  Fewer than kc unmasked slots: tau = -inf, nothing changes.
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    for (int it = 0; it < 32 - k; ++it) {
+                        float m = slot[g][0];
+#pragma unroll
+                        for (int r = 1; r < 16; ++r) m = fminf(m, slot[g][r]);
+                        const float o = __shfl_xor(m, 32);
+                        bool done = !(m < o || (m == o && h == 0));
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const bool hit = !done && slot[g][r] == m;
+                            slot[g][r] = hit ? INFINITY : slot[g][r];
+                            done = done || hit;
+                        }
+                    }
+                    float m = slot[g][0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) m = fminf(m, slot[g][r]);
+                    const float tau = fminf(m, __shfl_xor(m, 32));
+                    if (user_ok[g]) {
+                        thr[g] = tau;
+                        if (h == 0) A.warm_thr[group * UPW + g * 32 + j] = tau;
+                    }
+                    // the sweep proper starts over at the piece's first tile
+                    ex_pos[g] = sv_pos[g]; ex_next[g] = sv_next[g]; ex_after[g] = sv_after[g];
+                    exm[g] = 0u;
+                }
+                mflag = false;
+                asm volatile("s_waitcnt vmcnt(0)" : : : "memory");     // (flush() reads the bound back, either lane of the user)
+            }
+        }
         // prologue: scores of the first tile, A operand of the second
         f32x16 acc_a[NG], acc_b[NG];
         if constexpr (kRing12) { load_half(a, tin0, 0); load_half(a2, tin0, 1); } else load_a(tin0);
@@ -988,6 +1097,11 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                 // a tile, 15 us a tile) reached their first give-up opportunity at tile 48 after 720 us — the kernel's whole tail
                 // (profiles/r04s_*).  At random init nobody leaves and the eight extra checks cost nothing measurable.
                 const int rel = tile - tin0;
+#ifdef IGCN_TOPK_STATS
+                if (rel == 0) st_first = IGCN_CLOCK();
+                if (rel == 63) st_14 += IGCN_CLOCK() - st_first;       // the lists' warm-up: 2 % of the table, half of the candidates
+                if (rel == 255) st_15 += IGCN_CLOCK() - st_first;
+#endif
                 if constexpr (kHotTrack) {
                     if (rel == 3) {                                       // the lists' warm-up (every first item is a candidate) is over
 #pragma unroll
@@ -1008,6 +1122,8 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
                         alive[g] = user_ok[g] && ureach[g] * reach >= thr[g];
+                        // (a list the warm-up bound has not filled yet: its items are among the first warm_tiles tiles)
+                        if constexpr (kWarm) { if (warm) alive[g] = alive[g] || (user_ok[g] && heap_base[g * 32 + j] == 0ull); }
                         any_alive |= alive[g];
                         // far from done: the rows would have to get another third shorter (norms fall slowly in the tail).  (Round 4 also
                         // tried "still reachable N tiles further on" from the table of tile bounds, N = 24 ... 384: the same users within a
@@ -1193,6 +1309,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
             atomicAdd(&g_topk_stats[9], IGCN_CLOCK() - st_begin); atomicAdd(&g_topk_stats[10], st_10);
             atomicAdd(&g_topk_stats[11], __builtin_amdgcn_s_memrealtime() - st_rt_begin);   // 100 MHz ticks
             atomicAdd(&g_topk_stats[12], st_12); atomicAdd(&g_topk_stats[13], st_13);
+            atomicAdd(&g_topk_stats[14], st_14); atomicAdd(&g_topk_stats[15], st_15);
             if (blockIdx.x < 4096) {
                 g_topk_wave_times[3 * blockIdx.x] = st_rt_begin;
                 g_topk_wave_times[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
@@ -1641,7 +1758,8 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
                     const unsigned int *stats, hipStream_t st, const int32_t *perm = nullptr, const float *init_thr = nullptr,
                     const float *tile_bound = nullptr, const float *unorm2 = nullptr, unsigned int *exit_count = nullptr,
                     uint8_t *unfinished = nullptr, unsigned int *shared_thr = nullptr,
-                    const int32_t *rows = nullptr, const int32_t *count_dev = nullptr, unsigned int *piece_best = nullptr)
+                    const int32_t *rows = nullptr, const int32_t *count_dev = nullptr, unsigned int *piece_best = nullptr,
+                    float *warm_thr = nullptr)
 {
     if ((rows || count_dev) && !(mode == 0 && init_thr && (d == 64 || d == 128))) return IGCN_E_SHAPE;   // the bounded variants only
     if (!user_rows || !item_rows || !out_idx || !out_val) return IGCN_E_NULL;
@@ -1681,6 +1799,7 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
     a.exit_count = exit_count; a.unfinished = unfinished;
     a.shared_thr = p.p_max > 1 ? shared_thr : nullptr;          // (only pieces have anything to share)
     a.rows = rows; a.count_dev = count_dev; a.piece_best = p.p_max > 1 && p.ng == 1 ? piece_best : nullptr;
+    { const int wt = tuning_get(IGCN_TUNE_TOPK_FAST_WARM); a.warm_tiles = warm_thr ? (wt < 0 ? kWarmTiles : wt) : 0; a.warm_thr = a.warm_tiles > 0 ? warm_thr : nullptr; }
     { const int ec = tuning_get(IGCN_TUNE_TOPK_FAST_EARLY_CHECKS); a.early_checks = ec < 0 ? kEarlyCheckEvery : ec / 3 * 3; }
 
     if (mode != 0) {
@@ -1749,7 +1868,7 @@ static inline int64_t align256(int64_t n) { return (n + 255) / 256 * 256; }
 // groups x 58 pieces fill a quarter of the wave slots — the plan a host that knew the count (43 at random init, 20-40 on
 // trained tables) would make for anything up to 256 users; beyond it the caller re-does the rest.
 constexpr int64_t kFastFallbackMax = IGCN_FAST_FALLBACK_MAX;
-struct FastLayout { int64_t sweep, packed, cand_idx, cand_val, norm, tile_bound, unorm2, exit_state, order, fallback, total; int kc; TopkOrderLayout ord; };
+struct FastLayout { int64_t sweep, packed, cand_idx, cand_val, norm, tile_bound, unorm2, warm, exit_state, order, fallback, total; int kc; TopkOrderLayout ord; };
 static int topk_fast_layout(int64_t batch, int64_t n_items, int32_t d, int32_t k, int64_t excl_rows, int64_t excl_nnz, FastLayout *L) {
     if ((d != 64 && d != 128) || k < 1 || k + kFastExtra > kWave) return IGCN_E_RANGE;
     L->kc = k + topk_fast_extra(k, topk_fast_mode(d));
@@ -1767,7 +1886,8 @@ static int topk_fast_layout(int64_t batch, int64_t n_items, int32_t d, int32_t k
     L->norm = L->cand_val + align256(batch * L->kc * 4);
     L->tile_bound = L->norm + 256;
     L->unorm2 = L->tile_bound + align256((int64_t)p.n_tiles * 4);
-    L->exit_state = L->unorm2 + align256(batch * 4);
+    L->warm = L->unorm2 + align256(batch * 4);                  // the warm-up pass's bounds, one float per user
+    L->exit_state = L->warm + align256(batch * 4);
     // [256 B: early leavers per job][the fall-back's shared thresholds][batch B: users given up on][batch x 4 B: the sweep's shared thresholds]
     L->order = L->exit_state + 256 + kFastFallbackMax * 4 + kFastFallbackMax * kWave * 4 + align256(batch) + align256(batch * 4);   // (+ the fall-back's piece_best: k <= 64 slots per user)
     L->fallback = align256(L->order + L->ord.total);
@@ -1869,7 +1989,8 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     rc = topk_run(mode, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, d, excl_rowptr, by_norm && excl_rowptr ? excl_pos : excl_col,
                   banned, L.kc, cand_idx, cand_val, ws + L.sweep, packed, norm_bits, st, perm, nullptr,
                   early_exit ? tile_bound : nullptr, early_exit ? unorm2 : nullptr, give_up ? exit_count : nullptr,
-                  give_up ? unfinished : nullptr, share ? shared_thr : nullptr);
+                  give_up ? unfinished : nullptr, share ? shared_thr : nullptr, nullptr, nullptr, nullptr,
+                  mode == 3 && d == 64 ? reinterpret_cast<float *>(ws + L.warm) : nullptr);
     if (rc != IGCN_OK) return rc;
     if (L.kc <= 32)
         hipLaunchKernelGGL(topk_rescore_kernel<32>, dim3((unsigned)((batch + 7) / 8)), dim3(kBlock), 0, st, user_rows, ldu, user_ids, batch,

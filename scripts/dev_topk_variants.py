@@ -73,10 +73,11 @@ def run():
                                                   life_us_percentiles=[round(float(np.percentile(end - beg, q)), 1) for q in (0, 25, 50, 75, 100)],
                                                   end_us_max=round(float(end.max()), 1),
                                                   simd_of_first_16=[int((x >> 4) & 3) for x in hw[:16]], cu_of_first_16=[int((x >> 8) & 15) for x in hw[:16]]))), flush=True)
+                print(json.dumps(dict(raw=t)), flush=True)
                 print(json.dumps(dict(variant=name, k=k, tiles=t[0], tiles_with_hits=t[1], hit_quads=t[2], flushes=t[3],
                                       flush_iterations=t[4], staged_drained=t[5], waves=t[6],
                                       ms=round(ms, 2), wave_us=t[11] / t[6] / 100, clock_GHz=round(t[9] / max(t[11], 1) / 10, 3),
-                                      cycles_per_wave=dict(flush=t[7] // t[6], stage_hits=t[8] // t[6], wave=t[9] // t[6], build_masks=t[10] // t[6]))), flush=True)
+                                      cycles_per_wave=dict(flush=t[7] // t[6], stage_hits=t[8] // t[6], wave=t[9] // t[6], build_masks=t[10] // t[6], first_63_tiles=t[14] // t[6], first_255_tiles=t[15] // t[6]))), flush=True)
             continue
         for tune in [dict((kv.split('=')[0], int(kv.split('=')[1])) for kv in t.split(',') if kv) for t in os.environ.get('TUNES', '').split(';')]:   # e.g. TUNES=';topk_cap=8': defaults, then one knob
             for key, v in tune.items():

@@ -744,6 +744,62 @@ def test_two_stage_second_whole_sweep_of_a_wave_counts_its_own_leavers():
     assert flagged[48] <= flagged[96] + 6 * 64 and flagged[32] <= flagged[96] + 6 * 64, flagged
 
 
+def test_two_stage_warm_up_pass_bounds_do_not_change_the_lists():
+    """Whole candidate sweeps start with a warm-up pass ("topk_fast_warm" tiles): the kc-th largest of a user's 32 slot maxima over
+    those tiles becomes the threshold the sweep proper starts from.  The bound must hold with exclusion lists that take away the
+    user's best items of exactly those tiles, with banned items, with users that have fewer unmasked items than slots (bound = -inf),
+    with scores that tie in droves, on Gaussian and trained-like tables (where waves leave early: a list the bound has not filled
+    keeps its wave in the sweep), for one and several whole sweeps per wave and every warm-up length from 1 tile to all but one:
+    the lists are the fp32 sweep's, bit for bit."""
+    from igcn_cf_amd import _lib
+    from igcn_cf_amd.ops import score_topk
+    rng = np.random.default_rng(53)
+    d, n_users, n_items = 64, 64 * 24, 6000
+    pop = rng.standard_normal(d).astype(np.float32)
+    pop /= np.linalg.norm(pop)
+    scale = np.exp(1.0 * rng.standard_normal((n_items, 1))).astype(np.float32)
+    tables = {'gaussian': ((rng.standard_normal((n_users, d)) * 0.1).astype(np.float32), (rng.standard_normal((n_items, d)) * 0.1).astype(np.float32)),
+              'trained-like': ((0.05 * rng.standard_normal((n_users, d)) + 1.0 * pop[None, :]).astype(np.float32),
+                               (0.05 * rng.standard_normal((n_items, d)) + 0.3 * scale * pop[None, :]).astype(np.float32))}
+    # (the pass is taken only where the rows at its end are still half as long as the first: not on the table above, but on this one —
+    # whose waves still leave before the end of the table)
+    mild = np.exp(0.12 * rng.standard_normal((n_items, 1))).astype(np.float32)
+    tables['mildly trained-like'] = ((0.02 * rng.standard_normal((n_users, d)) + 1.0 * pop[None, :]).astype(np.float32),
+                                     (0.02 * rng.standard_normal((n_items, d)) + 0.3 * mild * pop[None, :]).astype(np.float32))
+    coarse_u, coarse_i = np.zeros((n_users, d), dtype=np.float32), np.zeros((n_items, d), dtype=np.float32)
+    coarse_u[:, :8] = rng.integers(-1, 2, size=(n_users, 8))
+    coarse_i[:, :8] = rng.integers(-1, 2, size=(n_items, 8))
+    coarse_i *= (1.0 + 0.001 * rng.random((n_items, 1))).astype(np.float32)        # (distinct norms: the sweep order is not the id order)
+    tables['small integers (ties)'] = (coarse_u, coarse_i)
+    bmask = np.zeros(n_items, dtype=np.uint8)
+    bmask[rng.choice(n_items, size=n_items // 7, replace=False)] = 1
+    try:
+        _lib.set_tuning('topk_fast_narrow', 0)
+        for name, (U, I) in tables.items():
+            Ud, Id = _dev(U), _dev(I)
+            # every user's exclusion list: its 0 ... 40 best items (so the warm-up tiles' best scores are masked ones), some random
+            # ones; a few users keep fewer than k items at all
+            best = np.argsort(-(U[:, :] @ I.T), axis=1)[:, :40]
+            ex = [np.unique(np.concatenate([best[u, :int(rng.integers(0, 41))], rng.choice(n_items, size=int(rng.integers(0, 20)), replace=False)])) for u in range(n_users)]
+            for u in rng.choice(n_users, size=6, replace=False):
+                ex[u] = np.setdiff1d(np.arange(n_items), rng.choice(n_items, size=int(rng.integers(3, 30)), replace=False))
+            rowptr = np.zeros(n_users + 1, dtype=np.int64)
+            np.cumsum([len(x) for x in ex], out=rowptr[1:])
+            masks = dict(excl_rowptr=_dev(rowptr), excl_col=_dev(np.concatenate(ex).astype(np.int32)), banned=_dev(bmask))
+            for kw in ({}, masks):
+                for k in (20, 1, 26):                                                   # k + extra = 26, 7, 32 (the most the pass takes)
+                    ref = score_topk(Ud, Id, k, mode='exact', **kw)
+                    for slots, warm in ((24, 0), (24, 1), (24, 2), (24, 63), (24, 128), (24, 186), (12, 64), (8, 30), (16, 64)):
+                        _lib.set_tuning('topk_slots', slots)                            # 24 groups: 1, 2, 3 whole sweeps per wave; 16: one + pieces
+                        _lib.set_tuning('topk_fast_warm', warm)
+                        got = score_topk(Ud, Id, k, mode='fast', **kw)
+                        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (name, bool(kw), k, slots, warm)
+    finally:
+        _lib.set_tuning('topk_slots', None)
+        _lib.set_tuning('topk_fast_warm', None)
+        _lib.set_tuning('topk_fast_narrow', None)
+
+
 def test_two_stage_exclusion_lists_sorted_on_the_device_hold_every_users_best_items():
     """The exclusion lists reach the candidate sweep as sweep POSITIONS, sorted row by row on the device (csrc/topk_order.hip:
     half-wave rank sorts up to 32 entries, wave rank sorts up to 256, a workgroup's bitonic network in LDS up to 8 192 and in
