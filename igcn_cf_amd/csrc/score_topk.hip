@@ -321,6 +321,9 @@ __device__ __forceinline__ float vmax3(float a, float b, float c) {
     asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
     return m;
 }
+__device__ __forceinline__ void vmax_into(float &m, float x) {      // m = max(m, x) in m's own register
+    asm volatile("v_max_f32 %0, %0, %1" : "+v"(m) : "v"(x));
+}
 __device__ __forceinline__ float vmax2(float a, float b) {
     float m;
     asm volatile("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
@@ -1017,10 +1020,16 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                             for (int r = 0; r < 16; ++r)
                                 slot[g][r] = fmaxf(slot[g][r], ((exm[g] >> (8 * (r >> 2) + (r & 3))) & 1u) ? -INFINITY : sc[g][r]);
                     } else {
+                        // (fmaxf would canonicalise both operands first — three v_max_f32 per slot, 93 + 8 MFMAs per step; written by
+                        // hand the compiler does not see the operands as MFMA results: the wait is spelled out, as before the last tile's
+                        // selection)
+                        __builtin_amdgcn_sched_barrier(0);
+                        asm volatile("s_nop 15\n\ts_nop 15" : : : "memory");
 #pragma unroll
                         for (int g = 0; g < NG; ++g)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) slot[g][r] = fmaxf(slot[g][r], sc[g][r]);
+                            for (int r = 0; r < 16; ++r) vmax_into(slot[g][r], sc[g][r]);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 };
                 const int t_end = tin0 + P;

@@ -44,7 +44,8 @@ const char *igcn_error_string(int code);
  * "topk_fast_wide", "topk_fast_extra" (candidates kept beyond k), "topk_fast_give_up" (0: no wave hands users over),
  * "topk_fast_narrow" (0: small batches keep 64-user wave-groups), "topk_fast_share" (0: the pieces of a cut sweep
  * keep their thresholds to themselves), "topk_fast_fallback" (0: igcn_score_topk_fast_f32 leaves every flagged user to the
- * caller), "topk_fast_early_checks" (0: exit checks every 24 tiles only, give-up from tile 48), "topk_fast_mode" (candidate sweep of
+ * caller), "topk_fast_early_checks" (0: exit checks every 24 tiles only, give-up from tile 48), "topk_fast_warm" (tiles of the
+ * candidate sweep's warm-up pass, 0: none; default 128, taken where the item rows at its end are still half as long as the first), "topk_fast_mode" (candidate sweep of
  * igcn_score_topk_fast_f32: 3 = one fp16 plane each side, the default; 2 = two fp16 user planes; 1 = two bf16 planes each side,
  * d = 64 only); value < 0 restores the library
  * default.  Results never depend on them (tests/test_spmm_gpu.py::test_launch_shape_does_not_change_results).
@@ -284,6 +285,10 @@ int igcn_score_topk_bounded_f32(const float *user_rows, int64_t ldu, const int64
  * (ABI v6; which users take that way depends on timing, the lists do not).  Round 4: a wave checks whether it may leave every 6
  * tiles up to tile 48 and every 24 after that, and may hand its users over from tile 12 on ("topk_fast_early_checks": the
  * cadence, 0 = every 24 tiles / from tile 48) — on trained tables most users are out of reach after 8 tiles.
+ * Where nobody can leave that early (item rows at tile 128 still half as long as the first: untrained or normalised tables), a
+ * whole sweep at d = 64, k + extra <= 32 begins with a warm-up pass over its first 128 tiles that only keeps the best score of each
+ * accumulator slot; the (k + extra)-th largest of a user's 32 slot maxima bounds its (k + extra)-th best score from below, and the
+ * sweep proper starts from that threshold instead of from an empty list ("topk_fast_warm": the tiles, 0 = none).
  * workspace: igcn_score_topk_fast_workspace_bytes(...) bytes, 256-byte aligned. */
 int64_t igcn_score_topk_fast_workspace_bytes(int64_t batch, int64_t n_items, int32_t d, int32_t k,
                                              int64_t excl_rows, int64_t excl_nnz);
