@@ -1547,14 +1547,15 @@ __global__ __launch_bounds__(kBlock) void topk_pack_items_kernel(const float *__
 // fixed grid walks the table; the maxima are reduced inside the workgroup and ONE lane per workgroup issues the atomics
 // (one atomic per wave from 2 048 waves on the same two words took 43 us).
 // With ids: the rows ids[0..n) of the table, and only the element maximum, into stats[2] (the users of a call).
-__global__ __launch_bounds__(kBlock) void topk_row_stats_kernel(const float *__restrict__ rows, int64_t ld, int64_t n,
-                                                                const int64_t *__restrict__ ids, int of_users, int lg,
-                                                                unsigned int *__restrict__ stats, float *__restrict__ norm2_out)
+__device__ __forceinline__ void row_stats_body(const float *__restrict__ rows, int64_t ld, int64_t n,
+                                               const int64_t *__restrict__ ids, int of_users, int lg,
+                                               unsigned int *__restrict__ stats, float *__restrict__ norm2_out,
+                                               unsigned block, unsigned blocks)
 {
     const int lpr = 1 << lg;
     __shared__ float sh[2][kBlock / kWave];
-    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t0 = (int64_t)block * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)blocks * blockDim.x;
     float best_n2 = 0.f, best_el = 0.f;
     for (int64_t t = t0; (t >> lg) < n + 3; t += stride) {                // (+3: the groups of a wave stay together)
         const int64_t r = t >> lg;
@@ -1590,6 +1591,19 @@ __global__ __launch_bounds__(kBlock) void topk_row_stats_kernel(const float *__r
             raise(stats + 1, best_el);
         }
     }
+}
+// The two tables of igcn_score_topk_fast_f32 in ONE launch (late round 4: the users' pass used to wait behind the order build for
+// no reason, 20 us of a mostly idle GPU): workgroups [0, item_blocks) walk the items, the others the batch's users.  Thread 0 also
+// clears the caller's flagged count (one memset launch less; the re-scoring kernel that counts into it is queued behind).
+__global__ __launch_bounds__(kBlock) void topk_row_stats_both_kernel(const float *__restrict__ item_rows, int64_t ldi, int64_t n_items,
+                                                                     float *__restrict__ item_norm2, unsigned item_blocks,
+                                                                     const float *__restrict__ user_rows, int64_t ldu, int64_t batch,
+                                                                     const int64_t *__restrict__ user_ids, float *__restrict__ user_norm2,
+                                                                     int lg, unsigned int *__restrict__ stats, int32_t *__restrict__ flagged)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0 && flagged) flagged[0] = 0;
+    if (blockIdx.x < item_blocks) row_stats_body(item_rows, ldi, n_items, nullptr, 0, lg, stats, item_norm2, blockIdx.x, item_blocks);
+    else row_stats_body(user_rows, ldu, batch, user_ids, 1, lg, stats, user_norm2, blockIdx.x - item_blocks, gridDim.x - item_blocks);
 }
 
 // Item table -> one MFMA-ready fp16 plane for MODE 2: [tile][k-step 0..ks-1][lane 0..63] x 16 B (ks = d / 16), scaled by
@@ -1892,11 +1906,11 @@ static int topk_fast_layout(int64_t batch, int64_t n_items, int32_t d, int32_t k
     L->packed = align256(topk_merge_bytes(p, batch, L->kc) + (int64_t)p.n_tiles * 4);
     L->cand_idx = L->packed + (int64_t)p.n_tiles * 8 * kWave * 16;
     L->cand_val = L->cand_idx + align256(batch * L->kc * 8);
-    L->norm = L->cand_val + align256(batch * L->kc * 4);
-    L->tile_bound = L->norm + 256;
+    L->tile_bound = L->cand_val + align256(batch * L->kc * 4);
     L->unorm2 = L->tile_bound + align256((int64_t)p.n_tiles * 4);
     L->warm = L->unorm2 + align256(batch * 4);                  // the warm-up pass's bounds, one float per user
-    L->exit_state = L->warm + align256(batch * 4);
+    L->norm = L->warm + align256(batch * 4);                    // (the table maxima sit right before the exit state: one memset clears both)
+    L->exit_state = L->norm + 256;
     // [256 B: early leavers per job][the fall-back's shared thresholds][batch B: users given up on][batch x 4 B: the sweep's shared thresholds]
     L->order = L->exit_state + 256 + kFastFallbackMax * 4 + kFastFallbackMax * kWave * 4 + align256(batch) + align256(batch * 4);   // (+ the fall-back's piece_best: k <= 64 slots per user)
     L->fallback = align256(L->order + L->ord.total);
@@ -1940,8 +1954,10 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     const int mode = topk_fast_mode(d);
     const int ks = d / 16, lg = d == 128 ? 5 : 4;
     const bool by_norm = tuning_get(IGCN_TUNE_TOPK_FAST_ORDER) != 0;       // developer knob: 0 = sweep in id order
-    hipError_t e = hipMemsetAsync(norm_bits, 0, 16, st);
-    if (e == hipSuccess) e = hipMemsetAsync(flagged, 0, 4, st);
+    // one memset: the table maxima, and behind them the exit counters, the fall-back's shared state, the give-up marks and the
+    // sweep's shared thresholds (the last two are used by some plans only; clearing 0.6 MB costs what clearing 16 bytes costs)
+    const int64_t fb_state = 256 + kFastFallbackMax * 4 + kFastFallbackMax * kWave * 4;
+    hipError_t e = hipMemsetAsync(norm_bits, 0, (size_t)(256 + fb_state + align256(batch) + align256(batch * 4)), st);   // (a whole number of 256-byte pieces: ONE fill kernel)
     if (e != hipSuccess) return (int)e;
     const int n_tiles = (int)((n_items + 31) / 32);
     const int64_t pack_threads = (int64_t)n_tiles * ks * kWave;
@@ -1949,22 +1965,23 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     // (measured, round 4: eight workgroups per CU took 47 us against 23 for one here — two contended words and the norm table to
     // write; the users' pass below, one word and no table, takes 16 against 33 with eight)
     if (stat_blocks > (int64_t)cu_count()) stat_blocks = (int64_t)cu_count();
-    hipLaunchKernelGGL(topk_row_stats_kernel, dim3((unsigned)stat_blocks), dim3(kBlock), 0, st, item_rows, ldi, n_items,
-                       (const int64_t *)nullptr, 0, lg, norm_bits, by_norm ? reinterpret_cast<float *>(ows + L.ord.norm2) : (float *)nullptr);
     const int32_t *perm = nullptr, *excl_pos = nullptr;
     float *tile_bound = reinterpret_cast<float *>(ws + L.tile_bound), *unorm2 = reinterpret_cast<float *>(ws + L.unorm2);
-    bool early_exit = false;
+    const bool early_exit = mode >= 2 && by_norm && tuning_get(IGCN_TUNE_TOPK_FAST_EXIT) != 0;     // developer knob: 0 = always sweep to the end
+    int64_t ub = 0;
+    if (mode >= 2) {
+        if (!user_rows || ldu < d || ldu % 4 || reinterpret_cast<uintptr_t>(user_rows) % 16) return IGCN_E_SHAPE;
+        ub = ((batch << lg) + kBlock - 1) / kBlock;
+        if (ub > 8 * (int64_t)cu_count()) ub = 8 * (int64_t)cu_count();
+    }
+    hipLaunchKernelGGL(topk_row_stats_both_kernel, dim3((unsigned)(stat_blocks + ub)), dim3(kBlock), 0, st, item_rows, ldi, n_items,
+                       by_norm ? reinterpret_cast<float *>(ows + L.ord.norm2) : (float *)nullptr, (unsigned)stat_blocks,
+                       user_rows, ldu, batch, user_ids, early_exit ? unorm2 : (float *)nullptr, lg, norm_bits, flagged);
     if (by_norm) {
         rc = topk_order_build(L.ord, ows, n_items, excl_rowptr, excl_col, excl_rows, excl_nnz, user_ids, batch, st, &perm, &excl_pos);
         if (rc != IGCN_OK) return rc;
     }
     if (mode >= 2) {
-        if (!user_rows || ldu < d || ldu % 4 || reinterpret_cast<uintptr_t>(user_rows) % 16) return IGCN_E_SHAPE;
-        int64_t ub = ((batch << lg) + kBlock - 1) / kBlock;
-        if (ub > 8 * (int64_t)cu_count()) ub = 8 * (int64_t)cu_count();
-        early_exit = by_norm && tuning_get(IGCN_TUNE_TOPK_FAST_EXIT) != 0;     // developer knob: 0 = always sweep to the end
-        hipLaunchKernelGGL(topk_row_stats_kernel, dim3((unsigned)ub), dim3(kBlock), 0, st, user_rows, ldu, batch, user_ids, 1, lg, norm_bits,
-                           early_exit ? unorm2 : (float *)nullptr);
         hipLaunchKernelGGL(topk_pack_items_f16_kernel, dim3((unsigned)((pack_threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                            item_rows, ldi, n_items, n_tiles, ks, norm_bits, perm, packed,
                            early_exit ? reinterpret_cast<const float *>(ows + L.ord.norm2) : (const float *)nullptr,
@@ -1987,12 +2004,9 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     unsigned int *exit_count = reinterpret_cast<unsigned int *>(ws + L.exit_state);
     unsigned int *fb_shared_thr = reinterpret_cast<unsigned int *>(ws + L.exit_state + 256);
     unsigned int *fb_piece_best = reinterpret_cast<unsigned int *>(ws + L.exit_state + 256 + kFastFallbackMax * 4);
-    const int64_t fb_state = 256 + kFastFallbackMax * 4 + kFastFallbackMax * kWave * 4;
     uint8_t *unfinished = reinterpret_cast<uint8_t *>(ws + L.exit_state + fb_state);
     unsigned int *shared_thr = reinterpret_cast<unsigned int *>(ws + L.exit_state + fb_state + align256(batch));
     const bool share = sweep_plan.p_max > 1 && mode == 3 && d == 64 && tuning_get(IGCN_TUNE_TOPK_FAST_SHARE) != 0;
-    e = hipMemsetAsync(ws + L.exit_state, 0, (size_t)(fb_state + (give_up || share ? align256(batch) + (share ? batch * 4 : 0) : 0)), st);
-    if (e != hipSuccess) return (int)e;
     // the sweep runs in position space: its exclusion lists and banned bits are those of the positions, and the
     // candidate ids it returns are positions (mapped back by the re-scoring kernel)
     rc = topk_run(mode, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, d, excl_rowptr, by_norm && excl_rowptr ? excl_pos : excl_col,

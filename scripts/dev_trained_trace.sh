@@ -7,8 +7,8 @@ python3 - <<PY
 import csv, glob
 f = glob.glob('$O/t/**/*kernel_trace.csv', recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'topk_row_stats_kernel' in r['Kernel_Name']]
-i0 = idx[-2]                                   # the last call: item stats, (user stats later)
+idx = [i for i, r in enumerate(rows) if 'topk_row_stats' in r['Kernel_Name']]
+i0 = idx[-1]                                   # the last call: from the two tables' statistics on
 t0 = int(rows[i0]['Start_Timestamp']); prev = t0
 for r in rows[i0:]:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
