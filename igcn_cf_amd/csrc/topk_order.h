@@ -6,7 +6,7 @@ namespace igcn {
 
 // byte offsets into the order workspace (each 256-aligned); norm2 is filled by topk_row_stats_kernel
 struct TopkOrderLayout {
-    int64_t norm2, keys, keys_sorted, iota, perm, inv, needed, excl_pos, tmp, total;
+    int64_t norm2, keys, keys_sorted, iota, perm, inv, needed, huge, excl_pos, tmp, total;     // huge: [count][row ids] of the rows the wave kernel leaves to the workgroup kernel
     size_t tmp_bytes;
 };
 

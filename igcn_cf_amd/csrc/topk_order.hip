@@ -33,9 +33,10 @@ namespace igcn {
 static inline int64_t al256(int64_t n) { return (n + 255) / 256 * 256; }
 
 __global__ __launch_bounds__(kBlock) void order_keys_kernel(const float *__restrict__ norm2, int64_t n, uint32_t *__restrict__ keys,
-                                                            int32_t *__restrict__ iota)
+                                                            int32_t *__restrict__ iota, int32_t *__restrict__ huge_count)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i == 0 && huge_count) *huge_count = 0;       // (the list of long exclusion rows, filled by excl_sort_rows_kernel further down the stream)
     if (i >= n) return;
     keys[i] = __float_as_uint(norm2[i]);             // non-negative floats: the bit patterns order like the values
     iota[i] = (int32_t)i;
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(kBlock) void excl_mark_rows_kernel(const int64_t *_
 // No lists of rows, no counters, no atomics: a wave looks at kExclScan consecutive rows, sorts the ones of its classes and
 // skips the rest; the workgroups of the second kernel look at 256 rows each for the (rare) huge ones.  (A first version
 // appended the rows it did not take to two lists with one atomic each: 27 k atomics on two words — 240 us.)
-constexpr int kExclShort = 64, kExclMid = 256, kExclBig = 1024, kExclLds = 8192, kExclScan = 8, kHugeScan = 64;
+constexpr int kExclShort = 64, kExclMid = 256, kExclBig = 1024, kExclLds = 8192, kExclScan = 8;
 constexpr uint32_t kPosNone = 0xFFFFFFFFu;
 
 // One stage-by-stage bitonic network in the form whose compare-exchanges all point the same way (stage k first pairs i with
@@ -165,7 +166,7 @@ __device__ __forceinline__ void sort_row_in_registers(const int32_t *__restrict_
 
 __global__ __launch_bounds__(kBlock) void excl_sort_rows_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                                 int64_t n_rows, const int32_t *__restrict__ inv, uint32_t *__restrict__ pos,
-                                                                const uint8_t *__restrict__ needed)
+                                                                const uint8_t *__restrict__ needed, int32_t *__restrict__ huge)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t w0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6;
@@ -179,6 +180,9 @@ __global__ __launch_bounds__(kBlock) void excl_sort_rows_kernel(const int64_t *_
             len_l = (int)(rowptr[base + lane + 1] - s_l);
         }
         if (!__any(len_l > 0)) continue;
+        // rows beyond this kernel's classes go on a list for excl_sort_huge_kernel (which used to scan every row length again: 27 us
+        // for a handful of rows)
+        if (len_l > kExclBig) huge[1 + atomicAdd(huge, 1)] = (int32_t)(base + lane);
         long long s[S];
         int len[S];
         uint32_t key[S];
@@ -218,67 +222,57 @@ __global__ __launch_bounds__(kBlock) void excl_sort_rows_kernel(const int64_t *_
     }
 }
 
-// Rows of more than kExclBig entries: a workgroup looks at kHugeScan rows and sorts each long one among them — up to kExclLds entries as
-// register-sorted chunks merged through LDS, beyond that by the bitonic network above in place in HBM (a user who excludes a twelfth of
-// a 96 k-item table and more).
+// Rows of more than kExclBig entries, from the list excl_sort_rows_kernel left (huge[0] of them, ids behind it): a workgroup per row —
+// up to kExclLds entries as register-sorted chunks merged through LDS, beyond that by the bitonic network above in place in HBM (a user
+// who excludes a twelfth of a 96 k-item table and more).
 __global__ __launch_bounds__(kBlock) void excl_sort_huge_kernel(const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                                int64_t n_rows, const int32_t *__restrict__ inv, uint32_t *__restrict__ pos,
-                                                                const uint8_t *__restrict__ needed)
+                                                                const int32_t *__restrict__ inv, uint32_t *__restrict__ pos,
+                                                                const int32_t *__restrict__ huge)
 {
     __shared__ uint32_t lds[kExclLds];
-    __shared__ int lens[kHugeScan];
-    __shared__ long long starts[kHugeScan];
-    for (int64_t base = (int64_t)blockIdx.x * kHugeScan; base < n_rows; base += (int64_t)gridDim.x * kHugeScan) {
-        const int64_t r = base + threadIdx.x;
-        long long s = 0;
-        int len = 0;
-        if (threadIdx.x < kHugeScan && r < n_rows && (!needed || needed[r])) { s = rowptr[r]; len = (int)(rowptr[r + 1] - s); }
-        __syncthreads();                                                  // (the arrays below are still read by the previous turn)
-        if (threadIdx.x < kHugeScan) { lens[threadIdx.x] = len; starts[threadIdx.x] = s; }
-        if (!__syncthreads_or(len > kExclBig)) continue;
-        for (int i = 0; i < kHugeScan; ++i) {
-            const int li = lens[i];
-            if (li <= kExclBig) continue;                                 // (uniform over the workgroup)
-            const long long si = starts[i];
-            if (li <= kExclLds) {
-                // chunks of kExclBig entries sorted in registers, a wave each (column id -> position on the way in), left in LDS;
-                // then every entry's place = its place in its own chunk + the entries of the other chunks that sort before it
-                // (binary searches in LDS; an equal key of an earlier chunk goes first).  (A barrier-per-step bitonic network over
-                // the whole row took 50 us for one row of 1 100 entries.)
-                const int n_chunks = (li + kExclBig - 1) / kExclBig;
-                const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
-                for (int c = wave; c < n_chunks; c += kBlock / kWave) {
-                    const int c0 = c * kExclBig, cl = li - c0 < kExclBig ? li - c0 : kExclBig;
-                    sort_in_registers<kExclBig / kWave>(cl, lane,
-                                                        [&](int e, bool in) { return in ? (uint32_t)inv[col[si + c0 + e]] : kPosNone; },
-                                                        [&](int e, uint32_t key) { lds[c0 + e] = key; });
-                }
-                __syncthreads();
-                for (int e = threadIdx.x; e < li; e += kBlock) {
-                    const uint32_t key = lds[e];
-                    const int c = e / kExclBig;
-                    int rank = e - c * kExclBig;
-                    for (int c2 = 0; c2 < n_chunks; ++c2) {
-                        if (c2 == c) continue;
-                        const int c0 = c2 * kExclBig, cl = li - c0 < kExclBig ? li - c0 : kExclBig;
-                        int lo = 0, hi = cl;                              // entries of chunk c2 before `key`: < key, or <= key if c2 < c
-                        while (lo < hi) {
-                            const int mid = (lo + hi) >> 1;
-                            const uint32_t v = lds[c0 + mid];
-                            if (v < key || (v == key && c2 < c)) lo = mid + 1; else hi = mid;
-                        }
-                        rank += lo;
-                    }
-                    pos[si + rank] = key;
-                }
-            } else {
-                uint32_t *buf = pos + si;
-                for (int e = threadIdx.x; e < li; e += kBlock) buf[e] = (uint32_t)inv[col[si + e]];
-                __syncthreads();
-                bitonic_ascending<kBlock>(buf, li, (int)threadIdx.x, [] { __syncthreads(); });
+    const int n_huge = huge[0];                                            // (written by the kernel before this one in the stream)
+    for (int idx = blockIdx.x; idx < n_huge; idx += gridDim.x) {
+        const int64_t r = huge[1 + idx];
+        const long long si = rowptr[r];
+        const int li = (int)(rowptr[r + 1] - si);
+        if (li <= kExclLds) {
+            // chunks of kExclBig entries sorted in registers, a wave each (column id -> position on the way in), left in LDS;
+            // then every entry's place = its place in its own chunk + the entries of the other chunks that sort before it
+            // (binary searches in LDS; an equal key of an earlier chunk goes first).  (A barrier-per-step bitonic network over
+            // the whole row took 50 us for one row of 1 100 entries.)
+            const int n_chunks = (li + kExclBig - 1) / kExclBig;
+            const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+            for (int c = wave; c < n_chunks; c += kBlock / kWave) {
+                const int c0 = c * kExclBig, cl = li - c0 < kExclBig ? li - c0 : kExclBig;
+                sort_in_registers<kExclBig / kWave>(cl, lane,
+                                                    [&](int e, bool in) { return in ? (uint32_t)inv[col[si + c0 + e]] : kPosNone; },
+                                                    [&](int e, uint32_t key) { lds[c0 + e] = key; });
             }
-            __syncthreads();                                              // the next row re-uses the buffer
+            __syncthreads();
+            for (int e = threadIdx.x; e < li; e += kBlock) {
+                const uint32_t key = lds[e];
+                const int c = e / kExclBig;
+                int rank = e - c * kExclBig;
+                for (int c2 = 0; c2 < n_chunks; ++c2) {
+                    if (c2 == c) continue;
+                    const int c0 = c2 * kExclBig, cl = li - c0 < kExclBig ? li - c0 : kExclBig;
+                    int lo = 0, hi = cl;                              // entries of chunk c2 before `key`: < key, or <= key if c2 < c
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        const uint32_t v = lds[c0 + mid];
+                        if (v < key || (v == key && c2 < c)) lo = mid + 1; else hi = mid;
+                    }
+                    rank += lo;
+                }
+                pos[si + rank] = key;
+            }
+        } else {
+            uint32_t *buf = pos + si;
+            for (int e = threadIdx.x; e < li; e += kBlock) buf[e] = (uint32_t)inv[col[si + e]];
+            __syncthreads();
+            bitonic_ascending<kBlock>(buf, li, (int)threadIdx.x, [] { __syncthreads(); });
         }
+        __syncthreads();                                              // the next row re-uses the buffer
     }
 }
 
@@ -300,6 +294,7 @@ int topk_order_layout(int64_t n_items, int64_t excl_rows, int64_t excl_nnz, Topk
     L->perm = off; off += al256(n_items * 4);
     L->inv = off; off += al256(n_items * 4);
     L->needed = off; off += excl_nnz > 0 ? al256(excl_rows) : 0;                // needed[row]: the rows this call's users own
+    L->huge = off; off += excl_nnz > 0 ? al256((excl_rows + 1) * 4) : 0;        // [count][ids of rows longer than kExclBig]
     L->excl_pos = off; off += al256(excl_nnz * 4);
     L->tmp = off; off += al256((int64_t)L->tmp_bytes);
     L->total = off;
@@ -315,7 +310,8 @@ int topk_order_build(const TopkOrderLayout &L, char *ws, int64_t n_items, const 
     int32_t *iota = reinterpret_cast<int32_t *>(ws + L.iota), *perm = reinterpret_cast<int32_t *>(ws + L.perm);
     int32_t *inv = reinterpret_cast<int32_t *>(ws + L.inv);
     const unsigned ib = (unsigned)((n_items + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(order_keys_kernel, dim3(ib), dim3(kBlock), 0, st, norm2, n_items, keys, iota);
+    int32_t *huge = excl_nnz > 0 ? reinterpret_cast<int32_t *>(ws + L.huge) : nullptr;
+    hipLaunchKernelGGL(order_keys_kernel, dim3(ib), dim3(kBlock), 0, st, norm2, n_items, keys, iota, huge);
     size_t tmp_bytes = L.tmp_bytes;
     hipError_t e = rocprim::radix_sort_pairs_desc(ws + L.tmp, tmp_bytes, (const uint32_t *)keys, keys_sorted, (const int32_t *)iota, perm,
                                                   (size_t)n_items, kNormBeginBit, 31, st);
@@ -342,11 +338,10 @@ int topk_order_build(const TopkOrderLayout &L, char *ws, int64_t n_items, const 
         int64_t rb = (turns + kBlock / kWave - 1) / (kBlock / kWave);
         if (rb > 8 * cus) rb = 8 * cus;
         hipLaunchKernelGGL(excl_sort_rows_kernel, dim3((unsigned)rb), dim3(kBlock), 0, st, excl_rowptr, excl_col, excl_rows,
-                           (const int32_t *)inv, pos, needed);
-        int64_t hb = (excl_rows + kHugeScan - 1) / kHugeScan;                   // 32 KiB of LDS each: five per CU
-        if (hb > 5 * cus) hb = 5 * cus;
-        hipLaunchKernelGGL(excl_sort_huge_kernel, dim3((unsigned)hb), dim3(kBlock), 0, st, excl_rowptr, excl_col, excl_rows,
-                           (const int32_t *)inv, pos, needed);
+                           (const int32_t *)inv, pos, needed, huge);
+        int64_t hb = excl_rows < 5 * cus ? excl_rows : 5 * cus;                 // a workgroup per listed row (32 KiB of LDS each: five per CU); most leave at once
+        hipLaunchKernelGGL(excl_sort_huge_kernel, dim3((unsigned)hb), dim3(kBlock), 0, st, excl_rowptr, excl_col,
+                           (const int32_t *)inv, pos, (const int32_t *)huge);
         *excl_pos_out = reinterpret_cast<const int32_t *>(pos);
     }
     return launch_status();
