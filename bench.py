@@ -892,20 +892,26 @@ def side_measurements(ds, device, d, K):
     # evaluation: propagate once + fused score/mask/top-20 for every user (device part of trainer.eval)
     model.eval()
 
-    def eval_ms(mode, reps=7):
+    samples = {}
+
+    def eval_ms(mode, reps=7, warm=2):
         """median wall time of one full evaluation (propagation recomputed + scoring), each call timed on its own"""
         ts, rec = [], None
-        for i in range(reps + 2):
+        for i in range(reps + warm):
             model._rep_cache = None
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             rec = trainer.recommend_all('test', mode=mode)
             torch.cuda.synchronize()
-            if i >= 2:                                         # two warm calls (kernel attributes, allocator, device lists)
+            if i >= warm:                                      # warm calls: kernel attributes, allocator, device lists, clocks
                 ts.append((time.perf_counter() - t0) * 1e3)
+        samples[mode] = [round(t, 3) for t in ts]
         ts.sort()
         return ts[len(ts) // 2], ts[0], rec
-    med, best, rec = eval_ms('auto')
+    # (the legs before this one leave the GPU idle for tens of ms at a time — host-side graph builds — and the first calls after that
+    # ran 0.1-0.2 ms slower than the rest on some boxes: four warm calls, 15 timed ones, every sample kept in extras)
+    med, best, rec = eval_ms('auto', reps=15, warm=4)
+    res['eval_ms_samples'] = samples['auto']
     res['eval_users_per_s'] = ds.n_users / (med / 1e3)
     res['eval_ms'] = med
     res['eval_ms_min'] = best

@@ -1957,7 +1957,10 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     // one memset: the table maxima, and behind them the exit counters, the fall-back's shared state, the give-up marks and the
     // sweep's shared thresholds (the last two are used by some plans only; clearing 0.6 MB costs what clearing 16 bytes costs)
     const int64_t fb_state = 256 + kFastFallbackMax * 4 + kFastFallbackMax * kWave * 4;
-    hipError_t e = hipMemsetAsync(norm_bits, 0, (size_t)(256 + fb_state + align256(batch) + align256(batch * 4)), st);   // (a whole number of 256-byte pieces: ONE fill kernel)
+    // ... and, right behind them, the counters of the order build (the first kOrderBinsBytes of its workspace)
+    static_assert(kOrderBinsBytes % 256 == 0, "");
+    if (L.order != L.exit_state + fb_state + align256(batch) + align256(batch * 4) || L.ord.bins != 0) return IGCN_E_RANGE;   // (the layout this memset relies on)
+    hipError_t e = hipMemsetAsync(norm_bits, 0, (size_t)(256 + fb_state + align256(batch) + align256(batch * 4) + (by_norm ? kOrderBinsBytes : 0)), st);   // (a whole number of 256-byte pieces: ONE fill kernel)
     if (e != hipSuccess) return (int)e;
     const int n_tiles = (int)((n_items + 31) / 32);
     const int64_t pack_threads = (int64_t)n_tiles * ks * kWave;

@@ -11,7 +11,8 @@
 // do not depend on the order (they come from the exact re-scoring stage, ranked by score, then lower item id).
 //
 // Built per call, in HBM (the embeddings change between evaluations):
-//   perm[pos] = item id at sweep position pos   (stable descending radix sort of the norms: ties keep ascending id)
+//   perm[pos] = item id at sweep position pos   (counting sort of the norms' upper 16 bits, descending — late round 4; rounds 2-4 ran
+//               rocPRIM's radix sort: ten launches, 56 us for 96 k keys)
 //   inv[item] = pos
 //   excl_pos  = the exclusion CSR's entries as sweep positions, ascending inside every row (the sweep walks each
 //               user's list with a cursor): inv[col], sorted row by row by two kernels of this file (round 4) —
@@ -23,33 +24,105 @@
 //               entry point whose contract says there is none (it could not be captured into a HIP graph), 115 us of kernels
 //               and 15-140 us of an idle GPU behind the read (profiles/r03ae_*, r04d_*).  A global sort of
 //               (row << 32 | position) keys took 6 passes x 29 us on the Amazon-like lists.
-// The norms are sorted on their upper 16 bits (exponent + 8 significant bits: two radix passes): any order is valid, a finer one buys
-// nothing, and the sort is two passes shorter.
-#include <rocprim/device/device_radix_sort.hpp>
+// The norms are sorted on their upper 16 bits (exponent + 8 significant bits): any order is valid and a finer one buys nothing.  That
+// makes it ONE counting pass over 65 536 bins: a kernel counts (the bins arrive zeroed), one workgroup turns the counts into start
+// positions, a kernel hands out positions — and writes the inverse permutation in the same breath.  The lanes of a wave that hold
+// the same key go to the bin together (one atomic per distinct key and wave: a table whose rows all have the same norm — normalised
+// embeddings, an all-zero table — would otherwise queue 96 k atomics on one word).  Equal keys end up in no particular order (the
+// lists do not depend on it; which users the completeness check hands to the fp32 sweep may, by a handful).
 #include "topk_order.h"
 
 namespace igcn {
 
 static inline int64_t al256(int64_t n) { return (n + 255) / 256 * 256; }
 
-__global__ __launch_bounds__(kBlock) void order_keys_kernel(const float *__restrict__ norm2, int64_t n, uint32_t *__restrict__ keys,
-                                                            int32_t *__restrict__ iota, int32_t *__restrict__ huge_count)
+constexpr int kOrderBins = 1 << 16;
+constexpr int kNormBeginBit = 15;                    // float bits [15, 31): exponent + 8 significant bits (the sign is 0)
+
+// bin of a squared norm, 0 = the longest rows (descending order = ascending bins)
+__device__ __forceinline__ uint32_t order_bin(float n2) { return (kOrderBins - 1) - ((__float_as_uint(n2) >> kNormBeginBit) & (kOrderBins - 1)); }
+// Where a bin's counter lives: neighbouring bins 256 bytes apart.  The norms of a table crowd into a few hundred neighbouring bins
+// (random init: ~500), which in bin order are 16 cache lines — and device-scope atomics on one line queue up behind each other
+// (~5 ns each: 34 us for 96 k items, measured); spread out, every hot bin has a line of its own.
+__device__ __forceinline__ uint32_t order_slot(uint32_t bin) { return ((bin & 1023u) << 6) | (bin >> 10); }
+
+// The lanes of the wave that hold the same bin as this one: `peers`; the lowest of them is the group's leader.
+__device__ __forceinline__ unsigned long long same_bin_lanes(uint32_t bin, bool active) {
+    unsigned long long todo = __ballot(active), mine = 0ull;
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        const uint32_t b0 = (uint32_t)__shfl((int)bin, src);
+        const unsigned long long m = __ballot(active && bin == b0);
+        if (active && bin == b0) mine = m;
+        todo &= ~m;
+    }
+    return mine;
+}
+
+__global__ __launch_bounds__(kBlock) void order_count_kernel(const float *__restrict__ norm2, int64_t n, uint32_t *__restrict__ keys,
+                                                             uint32_t *__restrict__ bins, int32_t *__restrict__ huge_count)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i == 0 && huge_count) *huge_count = 0;       // (the list of long exclusion rows, filled by excl_sort_rows_kernel further down the stream)
-    if (i >= n) return;
-    keys[i] = __float_as_uint(norm2[i]);             // non-negative floats: the bit patterns order like the values
-    iota[i] = (int32_t)i;
+    const bool active = i < n;
+    const uint32_t bin = active ? order_bin(norm2[i]) : 0u;
+    if (active) keys[i] = bin;
+    const unsigned long long peers = same_bin_lanes(bin, active);
+    const int lane = threadIdx.x & (kWave - 1);
+    if (active && (peers & ((1ull << lane) - 1)) == 0) atomicAdd(bins + order_slot(bin), (uint32_t)__popcll(peers));
 }
 
-__global__ __launch_bounds__(kBlock) void invert_perm_kernel(const int32_t *__restrict__ perm, int64_t n, int32_t *__restrict__ inv)
+// counts -> start positions, in place, in two levels: workgroup q of 64 scans the 1 024 bins q << 10 ... (their counters are 64 slots
+// apart: order_slot) and leaves their total in totals[q]; the 64 totals are scanned by whoever needs a position (order_place_kernel).
+// (One workgroup scanning all 65 536 counters — 64 per thread, 384 shuffles each — took 45 us.)
+__global__ __launch_bounds__(1024) void order_scan_kernel(uint32_t *__restrict__ bins, uint32_t *__restrict__ totals)
 {
-    const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (p < n) inv[perm[p]] = (int32_t)p;
+    __shared__ uint32_t wave_tot[1024 / kWave];
+    const uint32_t slot = ((uint32_t)threadIdx.x << 6) | blockIdx.x;
+    const uint32_t v = bins[slot];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += t; }
+    if (lane == kWave - 1) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (int w = 0; w < 1024 / kWave; ++w) { const uint32_t t = wave_tot[w]; before += w < wave ? t : 0u; all += t; }
+    bins[slot] = before + incl - v;
+    if (threadIdx.x == 0) totals[blockIdx.x] = all;
 }
 
-// needed[row] = 1 for the exclusion rows the users of this call own (idempotent writes: a user id may repeat in a batch).  Every
-// flagged row is then sorted exactly once, by whichever wave / workgroup scans it — the in-place sort of a huge row must not run twice.
+// positions: a wave's lanes of one bin take consecutive positions (ascending id among themselves); perm and its inverse
+__global__ __launch_bounds__(kBlock) void order_place_kernel(const uint32_t *__restrict__ keys, int64_t n, uint32_t *__restrict__ bins,
+                                                             const uint32_t *__restrict__ totals, int32_t *__restrict__ perm,
+                                                             int32_t *__restrict__ inv)
+{
+    __shared__ uint32_t group_base[kOrderBins / 1024];   // items in the bins before group q of 1 024 bins
+    if (threadIdx.x < kWave) {
+        const uint32_t t = totals[threadIdx.x];
+        uint32_t incl = t;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)incl, o); if ((int)threadIdx.x >= o) incl += u; }
+        group_base[threadIdx.x] = incl - t;
+    }
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool active = i < n;
+    const uint32_t bin = active ? keys[i] : 0u;
+    const unsigned long long peers = same_bin_lanes(bin, active);
+    const int lane = threadIdx.x & (kWave - 1);
+    const unsigned long long below = peers & ((1ull << lane) - 1);
+    uint32_t start = 0;
+    if (active && below == 0) start = atomicAdd(bins + order_slot(bin), (uint32_t)__popcll(peers));
+    const int leader = peers ? __ffsll((long long)peers) - 1 : lane;
+    start = (uint32_t)__shfl((int)start, leader);
+    if (active) {
+        const uint32_t pos = group_base[bin >> 10] + start + (uint32_t)__popcll(below);
+        perm[pos] = (int32_t)i;
+        inv[i] = (int32_t)pos;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void excl_mark_rows_kernel(const int64_t *__restrict__ user_ids, int64_t batch, int64_t n_rows,
                                                                 uint8_t *__restrict__ needed)
 {
@@ -276,27 +349,19 @@ __global__ __launch_bounds__(kBlock) void excl_sort_huge_kernel(const int64_t *_
     }
 }
 
-constexpr int kNormBeginBit = 15;                    // float bits [15, 31): exponent + 8 significant bits (the sign is 0)
-
 int topk_order_layout(int64_t n_items, int64_t excl_rows, int64_t excl_nnz, TopkOrderLayout *L)
 {
     if (n_items < 1 || n_items >= ((int64_t)1 << 31) || excl_rows < 0 || excl_nnz < 0 || excl_nnz >= ((int64_t)1 << 31)) return IGCN_E_SHAPE;
-    size_t t1 = 0;
-    hipError_t e = rocprim::radix_sort_pairs_desc(nullptr, t1, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const int32_t *)nullptr,
-                                                  (int32_t *)nullptr, (size_t)n_items, kNormBeginBit, 31, (hipStream_t)0);
-    if (e != hipSuccess) return (int)e;
-    L->tmp_bytes = t1;
     int64_t off = 0;
+    L->bins = off; off += kOrderBinsBytes;                                       // (first: see topk_order.h)
+    L->totals = off; off += 256;                                                 // items per group of 1 024 bins
     L->norm2 = off; off += al256(n_items * 4);
     L->keys = off; off += al256(n_items * 4);
-    L->keys_sorted = off; off += al256(n_items * 4);
-    L->iota = off; off += al256(n_items * 4);
     L->perm = off; off += al256(n_items * 4);
     L->inv = off; off += al256(n_items * 4);
     L->needed = off; off += excl_nnz > 0 ? al256(excl_rows) : 0;                // needed[row]: the rows this call's users own
     L->huge = off; off += excl_nnz > 0 ? al256((excl_rows + 1) * 4) : 0;        // [count][ids of rows longer than kExclBig]
     L->excl_pos = off; off += al256(excl_nnz * 4);
-    L->tmp = off; off += al256((int64_t)L->tmp_bytes);
     L->total = off;
     return IGCN_OK;
 }
@@ -306,17 +371,14 @@ int topk_order_build(const TopkOrderLayout &L, char *ws, int64_t n_items, const 
                      const int32_t **perm_out, const int32_t **excl_pos_out)
 {
     const float *norm2 = reinterpret_cast<const float *>(ws + L.norm2);
-    uint32_t *keys = reinterpret_cast<uint32_t *>(ws + L.keys), *keys_sorted = reinterpret_cast<uint32_t *>(ws + L.keys_sorted);
-    int32_t *iota = reinterpret_cast<int32_t *>(ws + L.iota), *perm = reinterpret_cast<int32_t *>(ws + L.perm);
-    int32_t *inv = reinterpret_cast<int32_t *>(ws + L.inv);
+    uint32_t *keys = reinterpret_cast<uint32_t *>(ws + L.keys), *bins = reinterpret_cast<uint32_t *>(ws + L.bins);
+    int32_t *perm = reinterpret_cast<int32_t *>(ws + L.perm), *inv = reinterpret_cast<int32_t *>(ws + L.inv);
     const unsigned ib = (unsigned)((n_items + kBlock - 1) / kBlock);
     int32_t *huge = excl_nnz > 0 ? reinterpret_cast<int32_t *>(ws + L.huge) : nullptr;
-    hipLaunchKernelGGL(order_keys_kernel, dim3(ib), dim3(kBlock), 0, st, norm2, n_items, keys, iota, huge);
-    size_t tmp_bytes = L.tmp_bytes;
-    hipError_t e = rocprim::radix_sort_pairs_desc(ws + L.tmp, tmp_bytes, (const uint32_t *)keys, keys_sorted, (const int32_t *)iota, perm,
-                                                  (size_t)n_items, kNormBeginBit, 31, st);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(invert_perm_kernel, dim3(ib), dim3(kBlock), 0, st, (const int32_t *)perm, n_items, inv);
+    hipLaunchKernelGGL(order_count_kernel, dim3(ib), dim3(kBlock), 0, st, norm2, n_items, keys, bins, huge);
+    uint32_t *totals = reinterpret_cast<uint32_t *>(ws + L.totals);
+    hipLaunchKernelGGL(order_scan_kernel, dim3(kOrderBins / 1024), dim3(1024), 0, st, bins, totals);
+    hipLaunchKernelGGL(order_place_kernel, dim3(ib), dim3(kBlock), 0, st, (const uint32_t *)keys, n_items, bins, (const uint32_t *)totals, perm, inv);
     *perm_out = perm;
     *excl_pos_out = nullptr;
     if (excl_nnz > 0) {

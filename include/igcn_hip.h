@@ -277,7 +277,7 @@ int igcn_score_topk_bounded_f32(const float *user_rows, int64_t ldu, const int64
  * ABI v5: stage 1 meets the items by DESCENDING squared norm (likely winners first: the running thresholds are near
  * their final values early and most later items fail the cheap selection test; -16 % on the Amazon-like evaluation),
  * not by id: a permutation, its inverse and the exclusion lists in sweep positions are built per call in the
- * workspace (rocPRIM radix sorts), which is why the exclusion CSR's size is passed: excl_rows = rows of excl_rowptr
+ * workspace (a counting sort of the norms' upper 16 bits and per-row sorts of the library's own), which is why the exclusion CSR's size is passed: excl_rows = rows of excl_rowptr
  * (every user id of the batch < excl_rows), excl_nnz = its entries; both 0 when excl_rowptr is NULL.  The lists
  * returned do not depend on the order.  igcn_set_tuning("topk_fast_order", 0) sweeps in id order.
  * In that order a wave leaves the sweep once no row still to come can reach any of its users (|score| <= |u| |i|), and a

@@ -15,6 +15,9 @@ torch.manual_seed(2021)
 model = get_model({'name': 'LightGCN', 'embedding_size': 64, 'n_layers': 3, 'device': dev}, ds)
 trainer = get_trainer({'name': 'BPRTrainer', 'optimizer': 'Adam', 'lr': 1e-3, 'l2_reg': 1e-5, 'device': dev, 'n_epochs': 1,
                        'batch_size': 2048, 'dataloader_num_workers': 0, 'test_batch_size': 512, 'topks': [20]}, ds, model)
+if os.environ.get('TRAIN_STEPS'):                      # bench.py evaluates after its training-step measurement (35 steps)
+    import bench
+    bench.train_step_ms(trainer, int(os.environ['TRAIN_STEPS']), 0)
 model.eval()
 ts = {v: [] for v in values}
 for rnd in range(11):
@@ -28,4 +31,5 @@ for rnd in range(11):
         if rnd >= 2:
             ts[v].append((time.perf_counter() - t0) * 1e3)
 _lib.set_tuning(knob, None)
+print(json.dumps({'all_ms': {str(v): [round(x, 3) for x in t] for v, t in ts.items()}}))
 print(json.dumps({'knob': knob, 'full_eval_ms_median_min': {str(v): [round(sorted(t)[len(t) // 2], 3), round(min(t), 3)] for v, t in ts.items()}}))

@@ -744,6 +744,37 @@ def test_two_stage_second_whole_sweep_of_a_wave_counts_its_own_leavers():
     assert flagged[48] <= flagged[96] + 6 * 64 and flagged[32] <= flagged[96] + 6 * 64, flagged
 
 
+def test_two_stage_order_build_on_degenerate_norm_distributions():
+    """The sweep order is a counting sort of the item norms on 65 536 bins (csrc/topk_order.hip).  Tables whose norms fall into ONE
+    bin (unit-length rows: every lane of every wave goes to the same counter), into two, into every binade from 2^-60 to 2^60, an
+    all-zero table, and tables smaller than a wave / a tile: the lists are the fp32 sweep's, with exclusion lists and a user subset."""
+    from igcn_cf_amd.ops import score_topk
+    rng = np.random.default_rng(61)
+    d, n_users, k = 64, 900, 10
+
+    def unit(n):
+        x = rng.standard_normal((n, d)).astype(np.float32)
+        return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+    U = _dev((rng.standard_normal((n_users, d)) * 0.1).astype(np.float32))
+    two = unit(30000)
+    two[::3] *= 2.0
+    wide = unit(30000) * np.exp2(rng.integers(-60, 61, size=(30000, 1))).astype(np.float32)
+    tables = {'one bin': unit(30000), 'two bins': two, 'every binade': wide, 'all zero': np.zeros((5000, d), dtype=np.float32),
+              '40 items': unit(40), '11 items': unit(11) * 3.0, '33 items, equal rows': np.tile(unit(1), (33, 1))}
+    for name, I in tables.items():
+        n_items = I.shape[0]
+        ex = [np.sort(rng.choice(n_items, size=int(rng.integers(0, min(20, n_items - k))), replace=False)) for _ in range(n_users)]
+        rowptr = np.zeros(n_users + 1, dtype=np.int64)
+        np.cumsum([len(x) for x in ex], out=rowptr[1:])
+        masks = dict(excl_rowptr=_dev(rowptr), excl_col=_dev(np.concatenate(ex).astype(np.int32)))
+        sub = _dev(rng.permutation(n_users)[:500].astype(np.int64))
+        Id = _dev(I)
+        for kw in ({}, masks, dict(user_ids=sub, **masks)):
+            ref = score_topk(U, Id, k, mode='exact', **kw)
+            got = score_topk(U, Id, k, mode='fast', **kw)
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (name, sorted(kw))
+
+
 def test_two_stage_warm_up_pass_bounds_do_not_change_the_lists():
     """Whole candidate sweeps start with a warm-up pass ("topk_fast_warm" tiles): the kc-th largest of a user's 32 slot maxima over
     those tiles becomes the threshold the sweep proper starts from.  The bound must hold with exclusion lists that take away the
