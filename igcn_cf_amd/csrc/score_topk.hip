@@ -148,6 +148,7 @@ constexpr int kEarlyCheckEvery = 6;      // exit checks every so many tiles up t
 constexpr int kHotDrains = 3, kMaxEvict = 4;
 constexpr int kExitSlots = 64;       // counters of early leavers, one per whole sweep of a wave (256 B of the call's workspace)
 __device__ __forceinline__ int exit_slot(int64_t job) { return job < kExitSlots ? (int)job : kExitSlots - 1; }
+constexpr int kFastFallbackMaxInt = IGCN_FAST_FALLBACK_MAX;
 constexpr int kWarmTiles = 128;     // tiles of the candidate sweep's warm-up pass ("topk_fast_warm"; see the kernel)
 constexpr float kWarmFlat = 0.5f;   // ... taken only if the rows at its end are still this long relative to the first
 constexpr int kMinCapSweep = 6;      // candidate sweeps: a shallower staging list (more drains) rather than half the resident waves (k + extra = 25..28)
@@ -1651,7 +1652,7 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(const float *__res
                                                               const int32_t *__restrict__ perm,
                                                               int64_t *__restrict__ out_idx, float *__restrict__ out_val,
                                                               int32_t *__restrict__ flagged, float *__restrict__ flagged_thr,
-                                                              const uint8_t *__restrict__ unfinished)
+                                                              const uint8_t *__restrict__ unfinished, uint8_t *__restrict__ flagged_weak)
 {
     constexpr int UPW = kWave / LANES;                            // users per wave
     const int lane = threadIdx.x & (LANES - 1);
@@ -1730,6 +1731,139 @@ __global__ __launch_bounds__(kBlock) void topk_rescore_kernel(const float *__res
             const int slot = atomicAdd(flagged, 1);
             flagged[1 + slot] = (int32_t)b;
             if (flagged_thr) flagged_thr[slot] = e_k;
+            // (a user its wave gave up on has seen a few tiles only: its bound admits thousands of items — not a case for the streaming filter)
+            if (flagged_weak && slot < (int)kFastFallbackMaxInt) flagged_weak[slot] = unfinished && unfinished[b] ? 1 : 0;
+        }
+    }
+}
+
+// ---- the flagged users of the two-stage path, as a streaming filter (late round 4) ------------------------------------------------
+// A flagged user comes with a lower bound of its k-th best score that is nearly always that score itself (the k-th exact score among
+// its candidates).  The bounded fp32 sweep needs ~85 us (random init, ~55 users) to ~190 us (trained tables) for them plus a merge of
+// 58 partial lists per user — a handful of users cut into pieces of 52 tiles, each piece a latency chain of 32 fp32 MFMAs per tile.
+// With bounds that tight the job is a filter: score every (flagged user, item) pair once — plain fmaf chains in the order the fp32
+// sweep adds its products (the re-scoring kernel's: bit-identical values), 55 x 96 k x 64 = 0.3 G — and keep the pairs that reach the
+// user's bound and are neither banned nor excluded: k of them, a few more on ties.  topk_filter_kernel appends those to a list per
+// user (as sortable keys), topk_filter_select_kernel ranks each list and writes the best k.  A user whose list overflows kFilterCap
+// entries (a weak bound: fewer than k real candidates, or a user its wave gave up on early) or holds fewer than k goes on to the
+// bounded sweep as before — through a second device-side list, usually empty.
+constexpr int kFilterCap = 256;        // entries per user: 4 per lane of the selecting wave
+constexpr int kFilterUsers = 32;       // users staged in LDS at a time
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void topk_filter_kernel(const float *__restrict__ user_rows, int64_t ldu, const int64_t *__restrict__ user_ids,
+                                                             const float *__restrict__ item_rows, int64_t ldi, int64_t n_items,
+                                                             const int64_t *__restrict__ excl_rowptr, const int32_t *__restrict__ excl_col,
+                                                             const uint8_t *__restrict__ banned, const int32_t *__restrict__ flagged,
+                                                             const float *__restrict__ bound, const uint8_t *__restrict__ weak, int max_users,
+                                                             int32_t *__restrict__ cnt, unsigned long long *__restrict__ lists)
+{
+    __shared__ float4 urow[kFilterUsers][D / 4];
+    __shared__ int64_t uid_s[kFilterUsers];
+    __shared__ float bound_s[kFilterUsers];
+    const int n_f = flagged[0] < max_users ? flagged[0] : max_users;
+    if ((int)blockIdx.y * kFilterUsers >= n_f) return;            // (planned for max_users: blockIdx.y = a chunk of kFilterUsers of them)
+    const int64_t item = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = item < n_items;
+    {
+        const int u0 = (int)blockIdx.y * kFilterUsers;
+        const int nu = n_f - u0 < kFilterUsers ? n_f - u0 : kFilterUsers;
+        bool any_user = false;
+        if ((int)threadIdx.x < nu) {
+            const int64_t b = flagged[1 + u0 + threadIdx.x];
+            uid_s[threadIdx.x] = user_ids ? user_ids[b] : b;
+            // (no bound to speak of — fewer than k real candidates, or a user given up on early —: every item would queue up at this
+            // user's counter; and a list that has overflowed by now takes no more: these users go to the bounded sweep)
+            const float bd = bound[u0 + threadIdx.x];
+            any_user = bd > -INFINITY && !weak[u0 + threadIdx.x] && cnt[u0 + threadIdx.x] <= kFilterCap;
+            bound_s[threadIdx.x] = any_user ? bd : __builtin_nanf("");   // (nothing reaches a NaN)
+        }
+        if (!__syncthreads_or(any_user)) return;                   // (trained tables: every flagged user of the chunk is one its wave gave up on)
+        float4 it[D / 4];
+#pragma unroll
+        for (int q = 0; q < D / 4; ++q) it[q] = live ? *reinterpret_cast<const float4 *>(item_rows + item * ldi + 4 * q) : f4_zero();
+        const bool is_banned = live && banned && banned[item];
+        for (int e = threadIdx.x; e < nu * (D / 4); e += kBlock) {
+            const int uu = e / (D / 4), q = e - uu * (D / 4);
+            urow[uu][q] = *reinterpret_cast<const float4 *>(user_rows + uid_s[uu] * ldu + 4 * q);
+        }
+        __syncthreads();
+        for (int uu = 0; uu < nu; ++uu) {
+            if (!(bound_s[uu] == bound_s[uu])) continue;           // (NaN: not a user for the filter; uniform over the workgroup)
+            float acc = 0.f;                                       // the chain of topk_rescore_kernel: k = 8 q + c, 8 q + 4 + c
+#pragma unroll
+            for (int q = 0; q < D / 8; ++q) {
+                const float4 ua = urow[uu][2 * q], ub = urow[uu][2 * q + 1];
+                const float4 ia = it[2 * q], ib = it[2 * q + 1];
+                acc = fmaf(ia.x, ua.x, acc); acc = fmaf(ib.x, ub.x, acc);
+                acc = fmaf(ia.y, ua.y, acc); acc = fmaf(ib.y, ub.y, acc);
+                acc = fmaf(ia.z, ua.z, acc); acc = fmaf(ib.z, ub.z, acc);
+                acc = fmaf(ia.w, ua.w, acc); acc = fmaf(ib.w, ub.w, acc);
+            }
+            if (live && !is_banned && acc >= bound_s[uu]) {
+                bool ok = true;
+                if (excl_rowptr) {
+                    const int64_t r0 = excl_rowptr[uid_s[uu]], r1 = excl_rowptr[uid_s[uu] + 1];
+                    int64_t lo = r0, hi = r1;
+                    while (lo < hi) {
+                        const int64_t mid = (lo + hi) >> 1;
+                        if (excl_col[mid] < (int32_t)item) lo = mid + 1; else hi = mid;
+                    }
+                    ok = !(lo < r1 && excl_col[lo] == (int32_t)item);
+                }
+                if (ok) {
+                    const int slot = atomicAdd(cnt + u0 + uu, 1);
+                    if (slot < kFilterCap) lists[(int64_t)(u0 + uu) * kFilterCap + slot] = make_key(acc, (int)item);
+                }
+            }
+        }
+    }
+}
+
+// one wave per flagged user: the best k of its list -> the caller's rows; overflowed / short lists -> the slow list
+__global__ __launch_bounds__(kBlock) void topk_filter_select_kernel(const int32_t *__restrict__ flagged, const float *__restrict__ bound, int max_users,
+                                                                    const int32_t *__restrict__ cnt, const unsigned long long *__restrict__ lists, int k,
+                                                                    int64_t *__restrict__ out_idx, float *__restrict__ out_val,
+                                                                    int32_t *__restrict__ slow_count, int32_t *__restrict__ slow_rows,
+                                                                    float *__restrict__ slow_bound)
+{
+    __shared__ unsigned long long keys[kBlock / kWave][kFilterCap];
+    const int n_f = flagged[0] < max_users ? flagged[0] : max_users;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    const int f = blockIdx.x * (kBlock / kWave) + wave;
+    if (f >= n_f) return;                                          // (a whole wave leaves; no block-wide barrier below)
+    const int n = cnt[f];
+    const int64_t row = flagged[1 + f];
+    if (n > kFilterCap || n < k) {
+        if (lane == 0) {
+            const int s = atomicAdd(slow_count, 1);
+            slow_rows[s] = (int32_t)row;
+            slow_bound[s] = bound[f];
+        }
+        return;
+    }
+    unsigned long long mine[kFilterCap / kWave];
+#pragma unroll
+    for (int j = 0; j < kFilterCap / kWave; ++j) {
+        const int e = lane + j * kWave;
+        mine[j] = e < n ? lists[(int64_t)f * kFilterCap + e] : 0ull;
+        keys[wave][e] = mine[j];
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+    int rank[kFilterCap / kWave];
+#pragma unroll
+    for (int j = 0; j < kFilterCap / kWave; ++j) rank[j] = 0;
+    for (int e = 0; e < n; ++e) {
+        const unsigned long long other = keys[wave][e];            // (an LDS broadcast; keys are distinct: the item id is part of them)
+#pragma unroll
+        for (int j = 0; j < kFilterCap / kWave; ++j) rank[j] += other > mine[j] ? 1 : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < kFilterCap / kWave; ++j) {
+        if (lane + j * kWave < n && rank[j] < k) {
+            out_idx[row * k + rank[j]] = key_item(mine[j]);
+            out_val[row * k + rank[j]] = key_score(mine[j]);
         }
     }
 }
@@ -1891,7 +2025,8 @@ static inline int64_t align256(int64_t n) { return (n + 255) / 256 * 256; }
 // groups x 58 pieces fill a quarter of the wave slots — the plan a host that knew the count (43 at random init, 20-40 on
 // trained tables) would make for anything up to 256 users; beyond it the caller re-does the rest.
 constexpr int64_t kFastFallbackMax = IGCN_FAST_FALLBACK_MAX;
-struct FastLayout { int64_t sweep, packed, cand_idx, cand_val, norm, tile_bound, unorm2, warm, exit_state, order, fallback, total; int kc; TopkOrderLayout ord; };
+struct FastLayout { int64_t sweep, packed, cand_idx, cand_val, norm, filter, filter_lists, tile_bound, unorm2, warm, exit_state, order, fallback, total; int kc; TopkOrderLayout ord; };
+constexpr int64_t kFilterState = kFastFallbackMax * 4 + 128 + 128 + kFastFallbackMax;     // [entries per flagged user][users left to the bounded sweep][weak-bound marks]: zero on entry
 static int topk_fast_layout(int64_t batch, int64_t n_items, int32_t d, int32_t k, int64_t excl_rows, int64_t excl_nnz, FastLayout *L) {
     if ((d != 64 && d != 128) || k < 1 || k + kFastExtra > kWave) return IGCN_E_RANGE;
     L->kc = k + topk_fast_extra(k, topk_fast_mode(d));
@@ -1906,11 +2041,14 @@ static int topk_fast_layout(int64_t batch, int64_t n_items, int32_t d, int32_t k
     L->packed = align256(topk_merge_bytes(p, batch, L->kc) + (int64_t)p.n_tiles * 4);
     L->cand_idx = L->packed + (int64_t)p.n_tiles * 8 * kWave * 16;
     L->cand_val = L->cand_idx + align256(batch * L->kc * 8);
-    L->tile_bound = L->cand_val + align256(batch * L->kc * 4);
+    // the filter's lists (kFilterCap sortable keys per flagged user), then the rows and bounds of the users it leaves to the bounded sweep
+    L->filter_lists = L->cand_val + align256(batch * L->kc * 4);
+    L->tile_bound = L->filter_lists + kFastFallbackMax * kFilterCap * 8 + 2 * align256(kFastFallbackMax * 4);
     L->unorm2 = L->tile_bound + align256((int64_t)p.n_tiles * 4);
     L->warm = L->unorm2 + align256(batch * 4);                  // the warm-up pass's bounds, one float per user
     L->norm = L->warm + align256(batch * 4);                    // (the table maxima sit right before the exit state: one memset clears both)
-    L->exit_state = L->norm + 256;
+    L->filter = L->norm + 256;                                  // (cleared with them)
+    L->exit_state = L->filter + kFilterState;
     // [256 B: early leavers per job][the fall-back's shared thresholds][batch B: users given up on][batch x 4 B: the sweep's shared thresholds]
     L->order = L->exit_state + 256 + kFastFallbackMax * 4 + kFastFallbackMax * kWave * 4 + align256(batch) + align256(batch * 4);   // (+ the fall-back's piece_best: k <= 64 slots per user)
     L->fallback = align256(L->order + L->ord.total);
@@ -1960,7 +2098,7 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     // ... and, right behind them, the counters of the order build (the first kOrderBinsBytes of its workspace)
     static_assert(kOrderBinsBytes % 256 == 0, "");
     if (L.order != L.exit_state + fb_state + align256(batch) + align256(batch * 4) || L.ord.bins != 0) return IGCN_E_RANGE;   // (the layout this memset relies on)
-    hipError_t e = hipMemsetAsync(norm_bits, 0, (size_t)(256 + fb_state + align256(batch) + align256(batch * 4) + (by_norm ? kOrderBinsBytes : 0)), st);   // (a whole number of 256-byte pieces: ONE fill kernel)
+    hipError_t e = hipMemsetAsync(norm_bits, 0, (size_t)(256 + kFilterState + fb_state + align256(batch) + align256(batch * 4) + (by_norm ? kOrderBinsBytes : 0)), st);   // (a whole number of 256-byte pieces: ONE fill kernel)
     if (e != hipSuccess) return (int)e;
     const int n_tiles = (int)((n_items + 31) / 32);
     const int64_t pack_threads = (int64_t)n_tiles * ks * kWave;
@@ -2012,6 +2150,7 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     const bool share = sweep_plan.p_max > 1 && mode == 3 && d == 64 && tuning_get(IGCN_TUNE_TOPK_FAST_SHARE) != 0;
     // the sweep runs in position space: its exclusion lists and banned bits are those of the positions, and the
     // candidate ids it returns are positions (mapped back by the re-scoring kernel)
+    uint8_t *flagged_weak = reinterpret_cast<uint8_t *>(ws + L.filter + kFastFallbackMax * 4 + 128);   // (in the cleared filter state, behind the count of users left over)
     rc = topk_run(mode, user_rows, ldu, user_ids, batch, item_rows, ldi, n_items, d, excl_rowptr, by_norm && excl_rowptr ? excl_pos : excl_col,
                   banned, L.kc, cand_idx, cand_val, ws + L.sweep, packed, norm_bits, st, perm, nullptr,
                   early_exit ? tile_bound : nullptr, early_exit ? unorm2 : nullptr, give_up ? exit_count : nullptr,
@@ -2021,11 +2160,11 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     if (L.kc <= 32)
         hipLaunchKernelGGL(topk_rescore_kernel<32>, dim3((unsigned)((batch + 7) / 8)), dim3(kBlock), 0, st, user_rows, ldu, user_ids, batch,
                            item_rows, ldi, cand_idx, cand_val, L.kc, (int)k, (int)d, norm_bits, mode, perm, out_idx, out_val, flagged,
-                           flagged_lower_bound, give_up ? (const uint8_t *)unfinished : (const uint8_t *)nullptr);
+                           flagged_lower_bound, give_up ? (const uint8_t *)unfinished : (const uint8_t *)nullptr, flagged_weak);
     else
         hipLaunchKernelGGL(topk_rescore_kernel<64>, dim3((unsigned)((batch + 3) / 4)), dim3(kBlock), 0, st, user_rows, ldu, user_ids, batch,
                            item_rows, ldi, cand_idx, cand_val, L.kc, (int)k, (int)d, norm_bits, mode, perm, out_idx, out_val, flagged,
-                           flagged_lower_bound, give_up ? (const uint8_t *)unfinished : (const uint8_t *)nullptr);
+                           flagged_lower_bound, give_up ? (const uint8_t *)unfinished : (const uint8_t *)nullptr, flagged_weak);
     rc = launch_status();
     if (rc != IGCN_OK || !flagged_lower_bound || tuning_get(IGCN_TUNE_TOPK_FAST_FALLBACK) == 0) return rc;
     // The flagged users' fp32 sweep, planned HERE for up to kFastFallbackMax of them and run for as many as flagged[0] says when
@@ -2033,9 +2172,31 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     // small torch launches per call).  Each starts from the k-th exact score of its candidates.  In id space: the caller's
     // exclusion lists and banned items as they came.
     const int64_t fb_users = batch < kFastFallbackMax ? batch : kFastFallbackMax;
+    const int32_t *slow_rows = flagged + 1, *slow_count = flagged;
+    const float *slow_bound = flagged_lower_bound;
+    if (tuning_get(IGCN_TUNE_TOPK_FAST_FILTER) != 0) {
+        // the streaming filter first (see topk_filter_kernel); what it cannot finish arrives at the bounded sweep through a list of its own
+        int32_t *cnt = reinterpret_cast<int32_t *>(ws + L.filter), *left = reinterpret_cast<int32_t *>(ws + L.filter + kFastFallbackMax * 4);
+        unsigned long long *lists = reinterpret_cast<unsigned long long *>(ws + L.filter_lists);
+        int32_t *left_rows = reinterpret_cast<int32_t *>(ws + L.filter_lists + kFastFallbackMax * kFilterCap * 8);
+        float *left_bound = reinterpret_cast<float *>(ws + L.filter_lists + kFastFallbackMax * kFilterCap * 8 + align256(kFastFallbackMax * 4));
+        const dim3 fgrid((unsigned)((n_items + kBlock - 1) / kBlock), (unsigned)((fb_users + kFilterUsers - 1) / kFilterUsers));
+        if (d == 64)
+            hipLaunchKernelGGL(topk_filter_kernel<64>, fgrid, dim3(kBlock), 0, st, user_rows, ldu, user_ids, item_rows, ldi, n_items, excl_rowptr,
+                               excl_col, banned, (const int32_t *)flagged, (const float *)flagged_lower_bound, (const uint8_t *)flagged_weak, (int)fb_users, cnt, lists);
+        else
+            hipLaunchKernelGGL(topk_filter_kernel<128>, fgrid, dim3(kBlock), 0, st, user_rows, ldu, user_ids, item_rows, ldi, n_items, excl_rowptr,
+                               excl_col, banned, (const int32_t *)flagged, (const float *)flagged_lower_bound, (const uint8_t *)flagged_weak, (int)fb_users, cnt, lists);
+        hipLaunchKernelGGL(topk_filter_select_kernel, dim3((unsigned)((fb_users + kBlock / kWave - 1) / (kBlock / kWave))), dim3(kBlock), 0, st,
+                           (const int32_t *)flagged, (const float *)flagged_lower_bound, (int)fb_users, (const int32_t *)cnt,
+                           (const unsigned long long *)lists, (int)k, out_idx, out_val, left, left_rows, left_bound);
+        rc = launch_status();
+        if (rc != IGCN_OK) return rc;
+        slow_rows = left_rows; slow_count = left; slow_bound = left_bound;
+    }
     return topk_run(0, user_rows, ldu, user_ids, fb_users, item_rows, ldi, n_items, d, excl_rowptr, excl_col, banned, k, out_idx, out_val,
-                    ws + L.fallback, nullptr, nullptr, st, nullptr, flagged_lower_bound, nullptr, nullptr, nullptr, nullptr,
-                    tuning_get(IGCN_TUNE_TOPK_FAST_SHARE) != 0 ? fb_shared_thr : nullptr, flagged + 1, flagged,
+                    ws + L.fallback, nullptr, nullptr, st, nullptr, slow_bound, nullptr, nullptr, nullptr, nullptr,
+                    tuning_get(IGCN_TUNE_TOPK_FAST_SHARE) != 0 ? fb_shared_thr : nullptr, slow_rows, slow_count,
                     tuning_get(IGCN_TUNE_TOPK_FAST_SHARE) != 0 ? fb_piece_best : nullptr);
 }
 

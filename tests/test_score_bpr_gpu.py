@@ -621,7 +621,7 @@ def test_two_stage_fall_back_planned_on_the_device(d):
     the caller re-does only what lies beyond.  No flagged user, a few, exactly around 256 and thousands (integer tables tie in
     droves), with masks, banned items and a permuted user subset: the lists are the fp32 sweep's, and the same as with the
     whole fall-back done from the host (the ABI v6 split)."""
-    from igcn_cf_amd import ops
+    from igcn_cf_amd import _lib, ops
     from igcn_cf_amd.ops import score_topk
     rng = np.random.default_rng(43)
     n_users, n_items, k = 3000, 9000, 20
@@ -652,13 +652,18 @@ def test_two_stage_fall_back_planned_on_the_device(d):
             Ud, Id = _dev(U), _dev(I)
             for users in (None, sub):
                 ref = score_topk(Ud, Id, k, user_ids=users, mode='exact', **kw)
-                for inside in (True, False):
+                # (inside the call the flagged users first meet the streaming filter — every (user, item) pair scored once, the pairs that
+                # reach the user's bound kept — and only those whose lists overflow it, or whose bound is -inf, the bounded sweep;
+                # "topk_fast_filter" 0: the bounded sweep for all of them, as until late round 4)
+                for inside, filt in ((True, None), (True, 0), (False, None)):
                     ops.set_fast_fallback(inside)
+                    _lib.set_tuning('topk_fast_filter', filt)
                     got = score_topk(Ud, Id, k, user_ids=users, mode='fast', **kw)
-                    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (name, inside)
+                    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (name, inside, filt)
                 seen.append(score_topk.last_flagged)
     finally:
         ops.set_fast_fallback(True)
+        _lib.set_tuning('topk_fast_filter', None)
     assert min(seen) <= 64 and max(seen) > 1000 and any(150 < n < 400 for n in seen), seen       # below, around and far above 256
 
 
