@@ -44,7 +44,8 @@ const char *igcn_error_string(int code);
  * "topk_fast_wide", "topk_fast_extra" (candidates kept beyond k), "topk_fast_give_up" (0: no wave hands users over),
  * "topk_fast_narrow" (0: small batches keep 64-user wave-groups), "topk_fast_share" (0: the pieces of a cut sweep
  * keep their thresholds to themselves), "topk_fast_fallback" (0: igcn_score_topk_fast_f32 leaves every flagged user to the
- * caller), "topk_fast_early_checks" (0: exit checks every 24 tiles only, give-up from tile 48), "topk_fast_warm" (tiles of the
+ * caller), "topk_fast_early_checks" (0: exit checks every 24 tiles only, give-up from tile 48), "topk_fast_filter" (0: every flagged user of igcn_score_topk_fast_f32 takes the bounded fp32 sweep; default: users with a tight
+ * bound take a streaming filter over all items first), "topk_fast_warm" (tiles of the
  * candidate sweep's warm-up pass, 0: none; default 128, taken where the item rows at its end are still half as long as the first), "topk_fast_mode" (candidate sweep of
  * igcn_score_topk_fast_f32: 3 = one fp16 plane each side, the default; 2 = two fp16 user planes; 1 = two bf16 planes each side,
  * d = 64 only); value < 0 restores the library
@@ -273,7 +274,10 @@ int igcn_score_topk_bounded_f32(const float *user_rows, int64_t ldu, const int64
  * it starts (the batch of that sweep is the device-side list flagged[1..]) — no host read between the stages.  The caller
  * reads flagged[0] afterwards and re-does only positions flagged[1 + IGCN_FAST_FALLBACK_MAX ..] with
  * igcn_score_topk_bounded_f32 (bounds flagged_lower_bound[IGCN_FAST_FALLBACK_MAX ..]); with flagged_lower_bound NULL
- * every flagged user is the caller's.  No host synchronisation inside.
+ * every flagged user is the caller's.  No host synchronisation inside.  (Late round 4: of those first users, the ones whose bound is
+ * the k-th exact score of a complete candidate list first take a streaming filter — every (user, item) pair scored once with the
+ * fp32 sweep's arithmetic, the pairs that reach the bound kept and ranked — and the bounded sweep runs for the rest: users whose wave
+ * gave up on them, users without a bound, users whose ties overflow the filter's 256 entries.  Same lists either way.)
  * ABI v5: stage 1 meets the items by DESCENDING squared norm (likely winners first: the running thresholds are near
  * their final values early and most later items fail the cheap selection test; -16 % on the Amazon-like evaluation),
  * not by id: a permutation, its inverse and the exclusion lists in sweep positions are built per call in the
