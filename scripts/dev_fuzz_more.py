@@ -101,11 +101,18 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
         _lib.set_tuning('topk_fast_mode', 2 if case % 4 == 3 else None)
         _lib.set_tuning('topk_fast_narrow', 0 if case % 3 == 2 else None)
         _lib.set_tuning('topk_fast_extra', int(rng.integers(1, 9)) if case % 5 == 4 else None)
+        # (round 4: whole sweeps at these sizes — the plan's wave slots tuned down —, so that the warm-up pass runs; its length at random)
+        _lib.set_tuning('topk_slots', int(rng.integers(2, 40)) if case % 2 == 0 else None)
+        _lib.set_tuning('topk_fast_warm', int(rng.integers(1, 200)) if case % 3 == 0 else None)
+        _lib.set_tuning('topk_fast_filter', 0 if case % 7 == 6 else None)
         a = score_topk(Ut, It, k, user_ids=ids, mode='fast', **kw)
         b = score_topk(Ut, It, k, user_ids=ids, mode='exact', **kw)
         if not (torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])):
             n_bad += 1
             print('TWO-STAGE MISMATCH', seed, case, n_users, n_items, k, su, si, flush=True)
+    for knob in ('topk_fast_mode', 'topk_fast_narrow', 'topk_fast_extra', 'topk_slots', 'topk_fast_warm', 'topk_fast_filter'):
+        _lib.set_tuning(knob, None)
+    print('seed', seed, 'two-stage cases done, mismatches so far:', n_bad, flush=True)
     for case in range(40):
         nu, ni = int(rng.integers(1, 4000)), int(rng.integers(1, 3000))
         d = int(rng.choice([8, 16, 32, 64, 128]))
