@@ -274,7 +274,9 @@ int igcn_score_topk_bounded_f32(const float *user_rows, int64_t ldu, const int64
  * it starts (the batch of that sweep is the device-side list flagged[1..]) — no host read between the stages.  The caller
  * reads flagged[0] afterwards and re-does only positions flagged[1 + IGCN_FAST_FALLBACK_MAX ..] with
  * igcn_score_topk_bounded_f32 (bounds flagged_lower_bound[IGCN_FAST_FALLBACK_MAX ..]); with flagged_lower_bound NULL
- * every flagged user is the caller's.  No host synchronisation inside.  (Late round 4: of those first users, the ones whose bound is
+ * every flagged user is the caller's.  No host synchronisation inside: the call can be captured into a HIP graph — run it once eagerly on
+ * the stream that will replay the graph first (the sweep kernels use scratch; ROCm 7.2 faulted on a replay by a queue that had never run
+ * a scratch-using kernel).  (Late round 4: of those first users, the ones whose bound is
  * the k-th exact score of a complete candidate list first take a streaming filter — every (user, item) pair scored once with the
  * fp32 sweep's arithmetic, the pairs that reach the bound kept and ranked — and the bounded sweep runs for the rest: users whose wave
  * gave up on them, users without a bound, users whose ties overflow the filter's 256 entries.  Same lists either way.)
