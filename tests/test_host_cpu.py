@@ -662,3 +662,19 @@ def test_xcd_plan_with_fewer_lists(golden):
     assert sorted((order[order >= n] - n).tolist()) == list(range(sg.shape[0]))
     assert int(sg[:, 2].sum()) == int(lens[lens > 3].sum())
 
+
+
+def test_every_tuning_knob_the_header_names_is_accepted_and_unknown_ones_are_refused():
+    """include/igcn_hip.h lists the developer knobs of igcn_set_tuning by name; the library must know each of them (a knob the
+    header documents but the name table lacks would silently never apply) and refuse anything else."""
+    import re
+    from igcn_cf_amd import _lib
+    text = open(os.path.join(ROOT, 'include', 'igcn_hip.h')).read()
+    block = text[text.index('Developer / test knobs of the launch heuristics'):text.index('int igcn_set_tuning')]
+    names = sorted(set(re.findall(r'"((?:spmm|topk)_[a-z_]+)"', block)))
+    assert len(names) >= 18 and 'topk_fast_warm' in names and 'topk_fast_filter' in names, names
+    for name in names:
+        _lib.set_tuning(name, 1)
+        _lib.set_tuning(name, None)
+    with pytest.raises(_lib.IgcnError):
+        _lib.set_tuning('topk_no_such_knob', 1)
