@@ -48,6 +48,7 @@ enum {
     IGCN_TUNE_TOPK_FAST_EARLY_CHECKS,   // 0: the candidate sweep checks for its exit every 24 tiles and gives up from tile 48 on (round 3); default: every 6 tiles up to tile 48, gives up from tile 12
     IGCN_TUNE_TOPK_FAST_WARM,           // whole candidate sweeps: tiles of the warm-up pass that bounds every user's k-th best before the sweep stages anything (0: none)
     IGCN_TUNE_TOPK_FAST_FILTER,         // 0: the flagged users of the two-stage path all take the bounded fp32 sweep (default: a streaming filter first, the sweep for what overflows it)
+    IGCN_TUNE_TOPK_FAST_PIECES,         // 0: the narrow bounded sweep is cut into at most 58 pieces per group (default: up to 232, four lists per lane of its merge)
     IGCN_TUNE_COUNT
 };
 extern int g_tuning[IGCN_TUNE_COUNT];   // defined in spmm.hip; holds value + 1, 0 = unset

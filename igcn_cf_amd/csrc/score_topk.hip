@@ -245,6 +245,14 @@ static inline int topk_make_plan(int64_t batch, int64_t n_items, int32_t d, int3
         // not fit the 64 lanes of the merge
         int64_t min_run = L < 32 ? L : 32;
         if ((L + 57) / 58 > min_run) min_run = (L + 57) / 58;
+        // The narrow bounded sweep (the two-stage path's fall-back: a handful of users, one 32-user group per wave, ONE wave per SIMD
+        // at best — each piece is a latency chain of dependent fp32 MFMAs and exposed tile loads, ~3 us per tile where the matrix pipe
+        // alone would need 0.9) takes pieces a quarter as long: four times the waves in flight for the same work, and the lists start
+        // from the caller's bounds, so there is little warm-up to repeat.  Its merge handles four lists per lane (topk_merge_wide_kernel).
+        if (sweep_mode == -1 && p->ng == 1 && tuning_get(IGCN_TUNE_TOPK_FAST_PIECES) != 0) {
+            min_run = L < 12 ? L : 12;
+            if ((L + 229) / 230 > min_run) min_run = (L + 229) / 230;
+        }
         int64_t run = (p->rest_tiles + slots - 1) / slots;
         if (run < min_run) run = min_run;
         p->run = run;
@@ -1371,6 +1379,62 @@ __global__ __launch_bounds__(kBlock) void topk_merge_kernel(const float *__restr
     }
 }
 
+// ... and with up to Q lists per lane, for the narrow bounded sweep's up to 232 pieces: a lane's best head, then the wave's.
+template <int Q>
+__global__ __launch_bounds__(kBlock) void topk_merge_wide_kernel(const float *__restrict__ ws_val, const int32_t *__restrict__ ws_idx,
+                                                                 int64_t first_user, int64_t batch, int n_tiles, int64_t run,
+                                                                 int p_max, int k, int upw,
+                                                                 int64_t *__restrict__ out_idx, float *__restrict__ out_val,
+                                                                 const int32_t *__restrict__ rows, const int32_t *__restrict__ count_dev)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t rb = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    int64_t b = first_user + rb;
+    if (count_dev && *count_dev < batch) batch = *count_dev;
+    if (b >= batch) return;
+    if (rows) b = rows[b];
+    const int64_t rg = rb / upw;
+    const int n_lists = (int)((((rg + 1) * n_tiles - 1) / run) - (rg * n_tiles) / run + 1);
+    const float *v = ws_val + rb * p_max * k;
+    const int32_t *ix = ws_idx + rb * p_max * k;
+    float hv[Q];
+    int hi[Q], cur[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int list = lane * Q + q;
+        const bool live = list < n_lists;
+        hv[q] = live ? v[(int64_t)list * k] : -INFINITY;
+        hi[q] = live ? ix[(int64_t)list * k] : kIdxNone;
+        cur[q] = 0;
+    }
+    for (int r = 0; r < k; ++r) {
+        float mv = hv[0];
+        int mi = hi[0], mq = 0;
+#pragma unroll
+        for (int q = 1; q < Q; ++q)
+            if (ranks_before(hv[q], hi[q], mv, mi)) { mv = hv[q]; mi = hi[q]; mq = q; }
+        float bv = mv;
+        int bi = mi, bl = lane;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off);
+            const int oi = __shfl_xor(bi, off), ol = __shfl_xor(bl, off);
+            if (ranks_before(ov, oi, bv, bi) || (ov == bv && oi == bi && ol < bl)) { bv = ov; bi = oi; bl = ol; }
+        }
+        if (lane == 0) { out_idx[b * k + r] = bi == kIdxNone ? -1 : bi; out_val[b * k + r] = bv; }
+        if (lane == bl) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                if (q == mq && lane * Q + q < n_lists) {
+                    ++cur[q];
+                    const bool more = cur[q] < k;
+                    hv[q] = more ? v[(int64_t)(lane * Q + q) * k + cur[q]] : -INFINITY;
+                    hi[q] = more ? ix[(int64_t)(lane * Q + q) * k + cur[q]] : kIdxNone;
+                }
+        }
+    }
+}
+
 // The same merge with one LANE per user, for plans that cut a group's sweep into at most P pieces (the usual
 // case: 2-3): the lane keeps the heads of its user's lists in registers and emits the best of them k times.  A wave
 // per user spends 18 cross-lane operations per output on 2-3 live lanes; this one spends P compares.
@@ -1989,8 +2053,11 @@ static int topk_run(int mode, const float *user_rows, int64_t ldu, const int64_t
         else if (p.p_max <= 8)
             hipLaunchKernelGGL(topk_merge_lanes_kernel<8>, dim3((unsigned)((rest_users + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                                ws_val, ws_idx, first, batch, p.n_tiles, p.run, p.p_max, (int)k, 32 * p.ng, out_idx, out_val, rows, count_dev);
-        else
+        else if (p.p_max <= kWave)
             hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)((rest_users + 3) / 4)), dim3(kBlock), 0, st, ws_val, ws_idx,
+                               first, batch, p.n_tiles, p.run, p.p_max, (int)k, 32 * p.ng, out_idx, out_val, rows, count_dev);
+        else
+            hipLaunchKernelGGL(topk_merge_wide_kernel<4>, dim3((unsigned)((rest_users + 3) / 4)), dim3(kBlock), 0, st, ws_val, ws_idx,
                                first, batch, p.n_tiles, p.run, p.p_max, (int)k, 32 * p.ng, out_idx, out_val, rows, count_dev);
         rc = launch_status();
     }

@@ -767,7 +767,7 @@ extern "C" int igcn_set_tuning(const char *name, int32_t value)
     static const char *const names[IGCN_TUNE_COUNT] = {"spmm_blocks_per_cu", "spmm_multirow", "topk_slots",
                                                        "topk_waves_per_cu", "topk_cap", "topk_stagger", "topk_fast_mode",
                                                        "topk_fast_order", "topk_fast_exit", "topk_fast_wide", "topk_fast_extra", "topk_fast_give_up", "topk_fast_narrow", "topk_fast_share",
-                                                       "topk_fast_fallback", "topk_fast_early_checks", "topk_fast_warm", "topk_fast_filter"};
+                                                       "topk_fast_fallback", "topk_fast_early_checks", "topk_fast_warm", "topk_fast_filter", "topk_fast_pieces"};
     if (!name) return IGCN_E_NULL;
     for (int i = 0; i < IGCN_TUNE_COUNT; ++i)
         if (strcmp(name, names[i]) == 0) { g_tuning[i] = value < 0 ? 0 : value + 1; return IGCN_OK; }

@@ -44,7 +44,7 @@ const char *igcn_error_string(int code);
  * "topk_fast_wide", "topk_fast_extra" (candidates kept beyond k), "topk_fast_give_up" (0: no wave hands users over),
  * "topk_fast_narrow" (0: small batches keep 64-user wave-groups), "topk_fast_share" (0: the pieces of a cut sweep
  * keep their thresholds to themselves), "topk_fast_fallback" (0: igcn_score_topk_fast_f32 leaves every flagged user to the
- * caller), "topk_fast_early_checks" (0: exit checks every 24 tiles only, give-up from tile 48), "topk_fast_filter" (0: every flagged user of igcn_score_topk_fast_f32 takes the bounded fp32 sweep; default: users with a tight
+ * caller), "topk_fast_early_checks" (0: exit checks every 24 tiles only, give-up from tile 48), "topk_fast_pieces" (0: the narrow bounded sweep in at most 58 pieces per group; default up to 232), "topk_fast_filter" (0: every flagged user of igcn_score_topk_fast_f32 takes the bounded fp32 sweep; default: users with a tight
  * bound take a streaming filter over all items first), "topk_fast_warm" (tiles of the
  * candidate sweep's warm-up pass, 0: none; default 128, taken where the item rows at its end are still half as long as the first), "topk_fast_mode" (candidate sweep of
  * igcn_score_topk_fast_f32: 3 = one fp16 plane each side, the default; 2 = two fp16 user planes; 1 = two bf16 planes each side,
