@@ -16,9 +16,9 @@
 //   inv[item] = pos
 //   excl_pos  = the exclusion CSR's entries as sweep positions, ascending inside every row (the sweep walks each
 //               user's list with a cursor): inv[col], sorted row by row by two kernels of this file (round 4) —
-//               rows of up to 1 024 entries by a wave each, in registers (bitonic networks of xor-shuffles, the <= 64-entry
-//               rows of a turn interleaved), longer rows by a workgroup each (the same
-//               network in LDS up to 8 192 entries, in place in HBM beyond).  Which class a row falls into is decided
+//               rows of up to 256 entries by a wave each, in registers (bitonic networks of xor-shuffles, the <= 64-entry
+//               rows of a turn interleaved), longer rows by a workgroup each (256-entry chunks sorted in registers and merged
+//               through LDS up to 8 192 entries, a bitonic network in place in HBM beyond).  Which class a row falls into is decided
 //               where it is sorted — NO host read.  Rounds 2-3 used rocprim::segmented_radix_sort_keys, which partitions its segments by size and copies
 //               the partition sizes to the HOST before it can launch its sort kernels: a stream synchronisation inside an
 //               entry point whose contract says there is none (it could not be captured into a HIP graph), 115 us of kernels
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void excl_mark_rows_kernel(const int64_t *_
 // No lists of rows, no counters, no atomics: a wave looks at kExclScan consecutive rows, sorts the ones of its classes and
 // skips the rest; the workgroups of the second kernel look at 256 rows each for the (rare) huge ones.  (A first version
 // appended the rows it did not take to two lists with one atomic each: 27 k atomics on two words — 240 us.)
-constexpr int kExclShort = 64, kExclMid = 256, kExclBig = 1024, kExclLds = 8192, kExclScan = 8;
+constexpr int kExclShort = 64, kExclBig = 256, kExclLds = 8192, kExclScan = 8;     // (kExclBig: the longest row a wave sorts by itself)
 constexpr uint32_t kPosNone = 0xFFFFFFFFu;
 
 // One stage-by-stage bitonic network in the form whose compare-exchanges all point the same way (stage k first pairs i with
@@ -180,8 +180,9 @@ __device__ __forceinline__ void bitonic_ascending(Buf buf, int len, int tid, Syn
 //     half-waves for rows of <= 32 entries with the 33 .. 64 ones taken one at a time: 74 us); the rows of <= 64 entries — 95 %
 //     of them — are then stored;
 //   * the rows of 65 .. 256 entries follow one at a time: four keys per lane (entry e = 64 q + lane), 36 steps of which the
-//     distances >= 64 are exchanges between a lane's own registers; then the rows of 257 .. 1 024 with sixteen keys per lane
-//     (the workgroup kernel below took 54 us for the ~300 such rows of the Amazon-like lists: a barrier per step).
+//     distances >= 64 are exchanges between a lane's own registers.  (Until late round 4 the rows of 257 .. 1 024 followed here too,
+//     sixteen keys per lane — ~7 us of the wave each, and the few turns that held two or three of them were the kernel's tail: with
+//     those rows on the workgroup kernel's list, 72 -> 54 us here and no change there.)
 __device__ __forceinline__ uint32_t bitonic_pick(uint32_t mine, uint32_t other, bool keep_min)
 {
     const uint32_t lo = mine < other ? mine : other, hi = mine < other ? other : mine;
@@ -279,14 +280,8 @@ __global__ __launch_bounds__(kBlock) void excl_sort_rows_kernel(const int64_t *_
 #pragma unroll
         for (int i = 0; i < S; ++i)
             if (len[i] <= kExclShort && lane < len[i]) pos[s[i] + lane] = key[i];
-        // rows of 65 .. 256 entries (four keys per lane), then of 257 .. 1 024 (sixteen), one at a time
-        unsigned long long todo = __ballot(len_l > kExclShort && len_l <= kExclMid);
-        while (todo) {
-            const int src = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            sort_row_in_registers<kExclMid / kWave>(col, inv, pos, __shfl(s_l, src), __shfl(len_l, src), lane);
-        }
-        todo = __ballot(len_l > kExclMid && len_l <= kExclBig);
+        // rows of 65 .. 256 entries (four keys per lane), one at a time
+        unsigned long long todo = __ballot(len_l > kExclShort && len_l <= kExclBig);
         while (todo) {
             const int src = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
