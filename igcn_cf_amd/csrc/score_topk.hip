@@ -2172,7 +2172,8 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     int64_t stat_blocks = ((n_items << lg) + kBlock - 1) / kBlock;
     // (measured, round 4: eight workgroups per CU took 47 us against 23 for one here — two contended words and the norm table to
     // write; the users' pass below, one word and no table, takes 16 against 33 with eight)
-    if (stat_blocks > (int64_t)cu_count()) stat_blocks = (int64_t)cu_count();
+    // (in the fused launch, late round 4: two per CU 22 us, one 25-31, four 41)
+    if (stat_blocks > 2 * (int64_t)cu_count()) stat_blocks = 2 * (int64_t)cu_count();
     const int32_t *perm = nullptr, *excl_pos = nullptr;
     float *tile_bound = reinterpret_cast<float *>(ws + L.tile_bound), *unorm2 = reinterpret_cast<float *>(ws + L.unorm2);
     const bool early_exit = mode >= 2 && by_norm && tuning_get(IGCN_TUNE_TOPK_FAST_EXIT) != 0;     // developer knob: 0 = always sweep to the end
