@@ -56,6 +56,21 @@ INFINITY_CACHE_BYTES = 256 << 20
 MFMA_F32_PEAK_TFLOPS = 157.3
 
 
+# The driver's record keeps the VALUES of the first 24 keys of `roofline` (and only the names of other extra keys): these are the
+# ones that grade a round, in this order.  Notes, rank / world and everything else come behind them (or live in `extras`).
+ROOFLINE_HEAD = ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'algorithmic_bytes_per_launch', 'compulsory_bytes_per_launch',
+                 'avg_launch_ms', 'traffic', 'traffic_GBps', 'traffic_over_compulsory', 'l2_hit_rate', 'frac_of_mall_gather', 'frac_of_probe',
+                 'eval_users_per_s', 'eval_ms', 'eval_mfma_frac', 'eval_ms_after_2_epochs', 'train_step_ms', 'hbm_bound_item_block_frac',
+                 'hbm_bound_counter_frac', 'hbm_stream_read_GBps', 'config5_pass_ms')
+
+
+def order_roofline(roof):
+    """The roofline object with ROOFLINE_HEAD as its first 24 keys (None where a leg did not run), the rest in their old order."""
+    head = {k: roof.get(k) for k in ROOFLINE_HEAD}
+    head.update({k: v for k, v in roof.items() if k not in head})
+    return head
+
+
 def lift_flat(out, extras):
     """Driver-visible copies of what `extras` holds: top-level scalars (the driver's parser keeps those, drops nested
     objects) — the second half of BASELINE's metric (eval users/s) with its MFMA fraction, the HBM-bound leg, the steps."""
@@ -119,6 +134,7 @@ def lift_flat(out, extras):
                   'config5_pass_ms', 'config5_edges_per_s', 'config5_exposed_exchange_ms', 'config5_local_spmm_ms'):
             if flat.get(k) is not None:
                 r[k] = flat[k]
+        out['roofline'] = order_roofline(r)
 
 
 def parse():
@@ -153,6 +169,10 @@ def spawn_ranks(args, json_fd):
     sock.bind(('127.0.0.1', 0))
     port = sock.getsockname()[1]
     sock.close()
+    # RCCL shares device buffers between the ranks of a node through IPC handles; this pool's host driver supports only the dmabuf
+    # flavour, and with the legacy mode left on the ranks fail at their first collective with `hipIpcGetMemHandle: invalid argument`.
+    # The image exports the switch already (and so does the driver's own N > 1 command line); set here only if the caller's
+    # environment lost it.  No effect on kernels or timings.
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
@@ -268,6 +288,10 @@ def main():
                        (world, prop.exchange, (K - 1) * (1 if prop.exchange == 'fused' else 2)))
         if rehearsal:
             parallelism += ' — REHEARSAL: all ranks on one GPU, exchange over gloo; timings are not measurements'
+        else:
+            # (rounds 1-5 had one-GPU boxes only: nothing of the N > 1 path has been timed before this very line)
+            parallelism += ('; no scaling curve of this path exists yet (developed on 1-GPU boxes: gloo / shared-GPU tests only); every rank '
+                            'draws the same seeded graph and keeps its own rows')
     out = {
         'metric': 'propagation edges/sec (3-layer LightGCN get_rep, Amazon-book-like, dim=64)',
         'value': value, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -310,7 +334,7 @@ def main():
             'algorithmic_bytes_per_launch': b_alg, 'compulsory_bytes_per_launch': b_min, 'avg_launch_ms': ms_launch,
             'avg_launch_note': launch_note,
             'gathered_row_GBps': gathered, 'mall_gather_peak_GBps': MALL_GATHER_PEAK_GBPS,
-            'frac_of_mall_gather': gathered / MALL_GATHER_PEAK_GBPS,
+            'gathered_rows_frac_of_mall_gather': gathered / MALL_GATHER_PEAK_GBPS,
             'mall_gather_note': 'guide: 8.6 TB/s for uniform random rows of a 38 MB Infinity-Cache table; L2 hits lift a skewed gather',
             'probe_peak_GBps': probe_peak, 'frac_of_probe': ach / probe_peak,
             'probe_note': 'in-run rowless gather+FMA+store on the same col/val stream (roof_probe.hip): sibling kernel, not a roof',
@@ -327,7 +351,7 @@ def main():
             # what the fabric behind L2 (Infinity Cache for this operand) delivered per second, against the guide's rate for
             # Infinity-Cache gathers: the one ratio on this line that is a measured quantity over a measured ceiling
             roof['traffic_GBps'] = t['bytes'] / ms_launch / 1e6
-            roof['traffic_frac_of_mall_gather_peak'] = roof['traffic_GBps'] / MALL_GATHER_PEAK_GBPS
+            roof['frac_of_mall_gather'] = roof['traffic_GBps'] / MALL_GATHER_PEAK_GBPS
             roof['traffic_over_compulsory'] = t['bytes'] / b_min
             roof['traffic_over_algorithmic'] = t['bytes'] / b_alg
             roof['l2_hit_rate'] = t.get('l2_hit_rate')
@@ -942,12 +966,12 @@ def side_measurements(ds, device, d, K):
                             'peak': 157.3, 'unit': 'TFLOP/s', 'frac': tf / 157.3, 'ms': ms_exact,
                             'note': 'fp32 v_mfma_f32_32x32x2_f32; 2*U*I*d flops per evaluation, no masks in this timing'}
     res['eval_two_stage'] = {'ms': ms_fast, 'speedup_over_fp32_sweep': ms_exact / ms_fast, 'users_flagged_for_the_fp32_sweep': ops.score_topk.last_flagged,
-                             'f16_mfma_TFLOPs': 2 * flops / (ms_fast / 1e3) / 1e12, 'f16_mfma_peak_TFLOPs': 2500.0,
-                             'note': 'candidate sweep: v_mfma_f32_32x32x16_f16, items as one fp16 plane, users as two (2x the flops of '
-                                     'the fp32 sweep at ~13x the matrix rate); the time is no longer matrix time: per wave, staging '
-                                     'candidates 60 %, draining them into the heaps 22 %, mask bits 14 % of its cycles, the item-tile '
-                                     'loads behind them (profiles/r02k_topk_two_stage_ablation.jsonl); includes packing, re-scoring, the '
-                                     'host read of the flagged count and the fp32 sweep of the flagged users'}
+                             'f16_mfma_TFLOPs': flops / (ms_fast / 1e3) / 1e12, 'f16_mfma_peak_TFLOPs': 2500.0,
+                             'note': 'candidate sweep (MODE 3): v_mfma_f32_32x32x16_f16, ONE fp16 plane per side (the fp32 sweep\'s flops '
+                                     'at ~13x the matrix rate); the time is not matrix time: per tile step 8 MFMAs against ~104 other vector '
+                                     'instructions — staging candidates, draining them into the heaps, mask bits '
+                                     '(profiles/r04zc_pmc_sq_counters_topk_two_stage.txt); includes statistics, order build, packing, '
+                                     're-scoring, the filter / bounded fp32 sweep of the flagged users and the host read of their count'}
     # the same scoring at d = 128 (BASELINE config 5's width) on random tables of the same sizes: fp32 sweep vs two-stage
     if d != 128:
         gen = torch.Generator(device=device).manual_seed(128)

@@ -26,6 +26,67 @@ def _newer(src_list, out):
     return any(os.path.getmtime(s) > t for s in src_list)
 
 
+def kernel_metadata(lib_path=None):
+    """name -> metadata dict of every gfx950 kernel in a built library (.private_segment_fixed_size, .vgpr_count, .agpr_count,
+    .sgpr_count, .group_segment_fixed_size ...): the code objects are read out of the clang offload bundles inside the .so and
+    their NT_AMDGPU_METADATA notes decoded — no GPU, no external tool."""
+    import struct
+    import msgpack
+    blob = open(lib_path or LIB, 'rb').read()
+    magic = b'__CLANG_OFFLOAD_BUNDLE__'
+    kernels = {}
+    at = blob.find(magic)
+    while at >= 0:
+        n, = struct.unpack_from('<Q', blob, at + 24)
+        o = at + 32
+        for _ in range(n):
+            off, size, tlen = struct.unpack_from('<QQQ', blob, o)
+            o += 24
+            triple = blob[o:o + tlen].decode()
+            o += tlen
+            if size == 0 or 'amdgcn' not in triple:
+                continue
+            elf = blob[at + off: at + off + size]
+            assert elf[:4] == b'\x7fELF' and elf[4] == 2, 'not a 64-bit ELF code object'
+            shoff, = struct.unpack_from('<Q', elf, 0x28)
+            shentsize, shnum = struct.unpack_from('<HH', elf, 0x3A)
+            for i in range(shnum):
+                sh = shoff + i * shentsize
+                sh_type, = struct.unpack_from('<I', elf, sh + 4)
+                if sh_type != 7:                                   # SHT_NOTE
+                    continue
+                s_off, s_size = struct.unpack_from('<QQ', elf, sh + 0x18)
+                q = s_off
+                while q + 12 <= s_off + s_size:
+                    namesz, descsz, ntype = struct.unpack_from('<III', elf, q)
+                    q += 12
+                    name = elf[q:q + namesz].rstrip(b'\0')
+                    q += (namesz + 3) // 4 * 4
+                    desc = elf[q:q + descsz]
+                    q += (descsz + 3) // 4 * 4
+                    if ntype == 32 and name == b'AMDGPU':          # NT_AMDGPU_METADATA (msgpack)
+                        for k in msgpack.unpackb(desc, raw=False, strict_map_key=False).get('amdhsa.kernels', []):
+                            kernels[k['.name']] = k
+        at = blob.find(magic, at + 1)
+    return kernels
+
+
+def scratch_report(lib_path=None):
+    """Kernels of the built library that carry a private segment (scratch): [(demangled name, bytes per lane)].  The library is
+    meant to have none — a kernel with scratch cannot be replayed from a HIP graph on a queue that never ran one (csrc/common.h)."""
+    # (rocPRIM's radix sort kernels — igcn_csr_transpose, a graph-build utility — do carry one; that entry point refuses a capturing
+    # stream, IGCN_E_CAPTURE)
+    bad = [(name, int(k.get('.private_segment_fixed_size', 0))) for name, k in sorted(kernel_metadata(lib_path).items())
+           if (int(k.get('.private_segment_fixed_size', 0)) > 0 or k.get('.uses_dynamic_stack')) and 'rocprim' not in name]
+    if bad:
+        try:
+            dem = subprocess.run(['c++filt'] + [b[0] for b in bad], capture_output=True, text=True).stdout.split('\n')
+            bad = [(dem[i].split('(')[0] or bad[i][0], bad[i][1]) for i in range(len(bad))]
+        except OSError:
+            pass
+    return bad
+
+
 def build(force=False, verbose=True):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
@@ -50,6 +111,9 @@ def build(force=False, verbose=True):
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
+    bad = scratch_report(LIB)
+    if bad:
+        raise RuntimeError('kernels with a private segment in %s (none is allowed: HIP-graph replays fault on them): %s' % (LIB, bad))
     # measurement kernels of bench.py (the in-run gather roof): a library of their own, never loaded by the product
     roof_src = os.path.join(CSRC, 'roof_probe.hip')
     if os.path.exists(roof_src) and (force or _newer([roof_src], ROOF_LIB)):

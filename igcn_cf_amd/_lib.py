@@ -11,6 +11,7 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libigcn_hip.so')
 
+EXPECTED_ABI = 8                 # IGCN_ABI_VERSION of include/igcn_hip.h this binding was written against
 MAX_ADDS = 8
 MAX_TOPK = 256
 MAX_METRIC_CUTS = 8
@@ -53,6 +54,7 @@ SIGNATURES = {
     'igcn_score_topk_bounded_f32': (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32,
                                               vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp]),
     'igcn_score_topk_fast_workspace_bytes': (C.c_int64, [C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, C.c_int64]),
+    'igcn_score_topk_fast_finished_max': (C.c_int64, [C.c_int64, C.c_int32]),
     'igcn_score_topk_fast_f32': (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32,
                                            vp, vp, C.c_int64, C.c_int64, vp, C.c_int32, vp, vp, vp, vp, vp, vp]),
     'igcn_hit_matrix': (C.c_int, [vp, C.c_int64, C.c_int32, vp, vp, vp, vp]),
@@ -95,7 +97,18 @@ def handle():
         if not os.path.exists(LIB_PATH):
             raise IgcnError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                             '(hipcc --offload-arch=gfx950); there is no CPU fallback' % LIB_PATH)
-        _handle = C.CDLL(LIB_PATH)
+        h = C.CDLL(LIB_PATH)
+        # a stale library (the build keeps a .so that is newer than its sources) must not load silently: the wrappers rely on the
+        # current call contracts (who finishes which flagged users, buffer layouts)
+        try:
+            h.igcn_abi_version.restype = C.c_int
+            got = int(h.igcn_abi_version())
+        except AttributeError:
+            got = -1
+        if got != EXPECTED_ABI:
+            raise IgcnError('%s has ABI version %d, this package expects %d: rebuild it (python -c "import __graft_entry__ as g; '
+                            'g.build()", or igcn_cf_amd/_build.py --force)' % (LIB_PATH, got, EXPECTED_ABI))
+        _handle = h
     return _handle
 
 

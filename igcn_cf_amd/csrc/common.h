@@ -14,6 +14,24 @@ inline int launch_status() {
     return e == hipSuccess ? IGCN_OK : static_cast<int>(e);
 }
 
+// A kernel with a private segment (scratch: register spills, dynamic indexing of a local array) cannot be replayed from a HIP graph on
+// a queue that never ran one eagerly: ROCm 7.2 hands the replaying queue no scratch and the GPU faults (round 4,
+// tests/test_score_bpr_gpu.py::test_two_stage_call_replays_from_a_captured_hip_graph).  No kernel of this library has one —
+// tests/test_host_cpu.py reads the private segment sizes out of the built code object — and this is the guard behind that rule: a
+// launch site calls it once per kernel; should a later compiler bring scratch back, the call is REFUSED while the stream is capturing
+// (IGCN_E_CAPTURE) instead of faulting at replay time.  Eager launches are unaffected.
+inline int capture_guard(const void *kernel, hipStream_t st, int *cached_scratch_bytes) {
+    if (*cached_scratch_bytes < 0) {
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, kernel) != hipSuccess) { (void)hipGetLastError(); return IGCN_OK; }
+        *cached_scratch_bytes = (int)fa.localSizeBytes;
+    }
+    if (*cached_scratch_bytes == 0) return IGCN_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return IGCN_OK; }
+    return cs == hipStreamCaptureStatusNone ? IGCN_OK : IGCN_E_CAPTURE;
+}
+
 // Number of CUs of the current device (256 on MI355X); cached.
 inline int cu_count() {
     static int n = 0;

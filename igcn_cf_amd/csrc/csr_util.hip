@@ -85,6 +85,13 @@ extern "C" int igcn_csr_transpose(const int64_t *rowptr, const int32_t *col, int
     if (!rowptr || !t_rowptr) return IGCN_E_NULL;
     if (n_rows < 0 || n_cols < 0 || nnz < 0 || nnz >= ((int64_t)1 << 31)) return IGCN_E_SHAPE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    {
+        // rocPRIM's one-sweep radix sort kernels carry a private segment (80 bytes a lane as built here): the one call of the library
+        // that is refused on a capturing stream (see capture_guard in common.h).  A graph build is not something to replay anyway.
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return IGCN_E_CAPTURE;
+        (void)hipGetLastError();
+    }
     if (nnz == 0) {
         hipError_t e = hipMemsetAsync(t_rowptr, 0, (size_t)(n_cols + 1) * 8, st);
         return e == hipSuccess ? IGCN_OK : (int)e;

@@ -171,7 +171,9 @@ static inline int topk_fast_mode(int d) {
 }
 static inline bool topk_wide_sweep() { return tuning_get(IGCN_TUNE_TOPK_FAST_WIDE) != 0; }
 // sweep_mode: 0 the fp32 sweep, 1 / 2 / 3 the candidate sweeps (MODE of the kernel)
-static inline bool topk_one_wave_per_simd(int d_pad, int sweep_mode) { return sweep_mode == 2 && d_pad == 128 && topk_wide_sweep(); }
+// (d_pad = 256, round 5: a whole item row and user row in registers need ~340; at two waves per SIMD the 90 beyond 256 went to
+// SCRATCH, at one they sit in AGPRs — no kernel of the library carries a private segment, see capture_guard)
+static inline bool topk_one_wave_per_simd(int d_pad, int sweep_mode) { return d_pad == 256 || (sweep_mode == 2 && d_pad == 128 && topk_wide_sweep()); }
 // sweep_mode -1: the bounded fp32 sweep (igcn_score_topk_bounded_f32).  Its batches are the few users the two-stage path hands
 // back: at d = 64 one 32-user group per wave then — a 64-user wave-group cut into the <= 58 pieces the merge takes cannot fill
 // the chip below ~2 000 users, half-size groups give twice the waves for the same work (20-40 users: 243 -> ~130 us).
@@ -323,6 +325,12 @@ __device__ __forceinline__ unsigned long long heap_replace_root(unsigned long lo
     return i == 0 ? cand : first_up;
 }
 
+// An integer the optimiser cannot see through.  Address arithmetic that starts from it stays where it is written: without it the
+// per-lane addresses of the cold paths (bounds read back in flush(), the give-up flags, the emit) are hoisted out of the job loop as
+// loop invariants, stay live across the whole sweep and end up in SCRATCH — and a kernel with a private segment cannot be replayed
+// from a HIP graph on a queue that never ran one (round 4's capture fault).  Costs no instruction.
+__device__ __forceinline__ int cold(int x) { asm volatile("" : "+v"(x)); return x; }
+
 // hand-written vector instructions of the pinned block (the compiler would canonicalise the operands of an fmaxf
 // with v_max_f32 x, x first).
 __device__ __forceinline__ float vmax3(float a, float b, float c) {
@@ -389,7 +397,7 @@ struct TopkArgs {
 // its own so that the plain sweeps carry nothing of it (two more live values cost the fp32 sweep 4 %).
 // MODE 2 at D = 128: one wave per SIMD (512 registers: 128 of user planes, 64 of accumulators, 96 of item-tile ring).
 template <int D, int NG, bool FULL, int MODE = 0, bool BOUNDED = false>
-__global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) void score_topk_kernel(const TopkArgs A)
+__global__ __launch_bounds__(kWave, ((MODE == 2 && D == 128 && NG == 2) || D == 256) ? 1 : 2) void score_topk_kernel(const TopkArgs A)
 {
     static_assert(MODE == 0 || (FULL && ((D == 64 && (NG == 2 || MODE == 3)) || ((MODE == 2 || MODE == 3) && D == 128))), "the candidate sweeps are built for d = 64 (and fp16: d = 128)");
     constexpr int KS = D / 16;                                   // MODE 1 / 2 / 3: k-steps of 16 per row
@@ -425,7 +433,9 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
     const int64_t n_full = A.n_whole * units;
     int64_t batch_n = A.batch;                                   // users of the batch; BOUNDED with a device list: as many as it holds
     if constexpr (BOUNDED) {
-        if (A.count_dev) { const int64_t c = *A.count_dev; batch_n = c < A.batch ? c : A.batch; }
+        // (a SCALAR load: the count was written by an earlier kernel of the stream; a vector load would put the batch size, and every
+        // comparison with it, into vector registers)
+        if (A.count_dev) { const int64_t c = (int32_t)((const_u32_ptr)(uintptr_t)A.count_dev)[0]; batch_n = c < A.batch ? c : A.batch; }
     }
     int64_t rx = (int64_t)blockIdx.x * A.run;                    // cursor in the rest groups' tile space
     const int64_t rx_end = rx + A.run < A.rest_tiles ? rx + A.run : A.rest_tiles;
@@ -476,7 +486,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
 #pragma unroll
                 for (int q = 0; q < D / 8; ++q) {
                     float4 v = f4_zero();
-                    const int e = 8 * q + 4 * h;
+                    const int e = 8 * q + 4 * cold(h);
                     if (user_ok[g] && (FULL || e < A.d)) v = *reinterpret_cast<const float4 *>(A.user_rows + uid[g] * A.ldu + e);
                     bfrag[g][4 * q + 0] = v.x; bfrag[g][4 * q + 1] = v.y; bfrag[g][4 * q + 2] = v.z; bfrag[g][4 * q + 3] = v.w;
                 }
@@ -486,7 +496,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                 for (int st = 0; st < KS; ++st) {
                     float4 lo = f4_zero(), hi = f4_zero();
                     if (user_ok[g]) {
-                        const float *src = A.user_rows + uid[g] * A.ldu + 16 * st + 8 * h;
+                        const float *src = A.user_rows + uid[g] * A.ldu + 16 * st + 8 * cold(h);
                         lo = *reinterpret_cast<const float4 *>(src);
                         hi = *reinterpret_cast<const float4 *>(src + 4);
                     }
@@ -497,45 +507,56 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
             }
         }
 
-        // exclusion cursors: first excluded item >= item_lo of each of this lane's users; the entry after it is
-        // already on its way
-        const int32_t *ex_ptr[NG];
-        int ex_pos[NG], ex_end[NG], ex_next[NG], ex_after[NG];
+        // exclusion cursors: ex_next = first excluded item >= item_lo of each of this lane's users, ex_after = the entry behind it
+        // (already on its way), ex_cur -> that entry's place in the list, ex_left = entries from ex_cur to the list's end (ex_next is
+        // real iff ex_left >= 0, ex_after iff ex_left >= 1).  Five registers per user; a (base, position, end) triple took six.
+        const int32_t *ex_cur[NG];
+        int ex_left[NG], ex_next[NG], ex_after[NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            ex_ptr[g] = A.excl_col;
-            ex_pos[g] = 0; ex_end[g] = 0; ex_next[g] = kIdxNone; ex_after[g] = kIdxNone;
+            ex_cur[g] = A.excl_col;
+            ex_left[g] = -1; ex_next[g] = kIdxNone; ex_after[g] = kIdxNone;
             if (A.excl_rowptr && user_ok[g]) {
                 const int64_t r0 = A.excl_rowptr[uid[g]];
-                ex_ptr[g] = A.excl_col + r0;
-                ex_end[g] = (int)(A.excl_rowptr[uid[g] + 1] - r0);
-                int lo = 0, hi = ex_end[g];
+                const int32_t *ptr = A.excl_col + r0;
+                const int end = (int)(A.excl_rowptr[uid[g] + 1] - r0);
+                int lo = 0, hi = end;
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
-                    if (ex_ptr[g][mid] < item_lo) lo = mid + 1; else hi = mid;
+                    if (ptr[mid] < item_lo) lo = mid + 1; else hi = mid;
                 }
-                ex_pos[g] = lo;
-                if (lo < ex_end[g]) ex_next[g] = ex_ptr[g][lo];
-                if (lo + 1 < ex_end[g]) ex_after[g] = ex_ptr[g][lo + 1];
+                ex_cur[g] = ptr + lo + 1;
+                ex_left[g] = end - (lo + 1);
+                if (lo < end) ex_next[g] = ptr[lo];
+                if (lo + 1 < end) ex_after[g] = ptr[lo + 1];
             }
         }
 
         // running top-k: one min-heap of sortable keys per user in LDS, owned by one lane; its root (= the user's
         // k-th best so far) in the owner's registers.  Key 0 = empty slot: ranks below every real entry, masked
         // (-inf) ones included.
-        for (int s = 0; s < k; ++s) heap[s * kWave] = 0ull;
-        unsigned long long root = 0ull;
+        {
+            // (a zero made HERE: the compiler otherwise keeps one 64-bit zero pair for every job of the kernel — hoisted, carried
+            // across the sweep and, in the variants with the fewest registers to spare, spilled)
+            const unsigned z = (unsigned)cold(0);
+            const unsigned long long zero = ((unsigned long long)z << 32) | z;
+            for (int s = 0; s < k; ++s) heap[s * kWave] = zero;
+        }
+        // (the root is NOT carried in registers across the sweep: flush() reads heap[0] back — two registers the sweep loop needs)
         unsigned long long best = 0ull;                          // (BOUNDED, NG = 1: the best key this piece has met, see A.piece_best)
         float thr[NG];                                           // k-th best score of user (g, j): the same in both lanes of a user
-        int cnt[NG];                                             // staged candidates of this lane, per group
-        unsigned stage_addr[NG];                                 // LDS byte address of this lane's first staging slot
+        // Staging lists: wpos[g] = LDS byte address of this lane's next free slot of group g (slots of a lane are 512 bytes apart).  The
+        // list's first slot is re-derived from the lane id where it is needed (stage_first: one instruction) instead of being carried
+        // beside a counter: two registers less across the sweep, and the store address of a staged row is wpos itself.
+        unsigned wpos[NG];
+        auto stage_first = [&](int g) -> unsigned { return (unsigned)(uintptr_t)(stage_all + (g * cap) * kWave) + ((unsigned)cold(lane) << 3); };
+        auto staged = [&](int g) -> int { return (int)((wpos[g] - stage_first(g)) >> 9); };      // staged candidates of this lane
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             // a lane without a user (past the end of the batch) never has a candidate: its zero embedding would
             // otherwise tie every score with its threshold and flood the staging lists
-            thr[g] = user_ok[g] ? (BOUNDED ? A.init_thr[group * UPW + g * 32 + j] : -INFINITY) : INFINITY;
-            cnt[g] = 0;
-            stage_addr[g] = (unsigned)(uintptr_t)(stage_all + (g * cap) * kWave + lane);
+            thr[g] = user_ok[g] ? (BOUNDED ? A.init_thr[group * UPW + g * 32 + cold(j)] : -INFINITY) : INFINITY;
+            wpos[g] = stage_first(g);
         }
 
         constexpr bool kWarm = MODE == 3 && D == 64;             // warm-up pass before a whole sweep (see below)
@@ -557,17 +578,20 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
             asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");  // the hand-written staging stores
             int n0, n1;
             if constexpr (NG == 2) {
-                const int a0 = __shfl(cnt[0], j), a1 = __shfl(cnt[0], j + 32);
-                const int b0 = __shfl(cnt[1], j), b1 = __shfl(cnt[1], j + 32);
+                const int c0 = staged(0), c1 = staged(1);
+                const int a0 = __shfl(c0, j), a1 = __shfl(c0, j + 32);
+                const int b0 = __shfl(c1, j), b1 = __shfl(c1, j + 32);
                 n0 = h ? b0 : a0;
                 n1 = h ? b1 : a1;
             } else {
-                n0 = __shfl(cnt[0], j);
-                n1 = __shfl(cnt[0], j + 32);
+                const int c0 = staged(0);
+                n0 = __shfl(c0, j);
+                n1 = __shfl(c0, j + 32);
                 if (!owner) n0 = n1 = 0;
             }
             const unsigned long long *l0 = stage_all + (own_g * cap) * kWave + j;
             const int n = n0 + n1;
+            unsigned long long root = heap[0];
             IGCN_STAT(3, 1);
             for (int i = 0; __any(i < n); ++i) {
                 IGCN_STAT(4, 1);
@@ -581,15 +605,15 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
             }
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                cnt[g] = 0;
+                wpos[g] = stage_first(g);
                 const unsigned long long r = heap_base[g * 32 + j];     // root of user (g, j), kept by lane g * 32 + j
                 thr[g] = !user_ok[g] ? INFINITY : r ? key_score(r) : -INFINITY;   // list not full yet: everything may enter
                 if constexpr (kWarm) {                                  // ... that reaches the warm-up pass's bound (>= kc items do)
                     if (warm && !r && user_ok[g])
-                        thr[g] = __hip_atomic_load(A.warm_thr + group * UPW + g * 32 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        thr[g] = __hip_atomic_load(A.warm_thr + group * UPW + g * 32 + cold(j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 // ... that reaches the caller's lower bound (the list fills from the items above it: there are >= k)
-                if constexpr (BOUNDED) { if (user_ok[g]) thr[g] = fmaxf(thr[g], A.init_thr[group * UPW + g * 32 + j]); }
+                if constexpr (BOUNDED) { if (user_ok[g]) thr[g] = fmaxf(thr[g], A.init_thr[group * UPW + g * 32 + cold(j)]); }
             }
             // (compiled into the default candidate sweep and into the narrow bounded sweep — the two-stage path's fall-back, whose
             // few users are always cut into ~58 pieces: without sharing each piece warms a list of its own, k ln(1 700 / k) ~ 110
@@ -599,11 +623,11 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                 // thresholds.  A piece's k-th best is a lower bound of the user's k-th best over the whole table, so every
                 // piece may use the largest one any of them has reached — the pieces over the short rows then stop staging
                 // almost at once instead of warming up a list nobody will look at.  (Sortable score bits, atomicMax; 0 = none.)
-                const int64_t b_own = group * UPW + lane;
+                const int64_t b_own = group * UPW + cold(lane);
                 if (owner && root && b_own < batch_n) atomicMax(A.shared_thr + b_own, (unsigned int)(root >> 32));
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
-                    const unsigned int sh = user_ok[g] ? A.shared_thr[group * UPW + g * 32 + j] : 0u;
+                    const unsigned int sh = user_ok[g] ? A.shared_thr[group * UPW + g * 32 + cold(j)] : 0u;
                     if (sh) thr[g] = fmaxf(thr[g], key_score((unsigned long long)sh << 32));
                 }
             }
@@ -615,12 +639,12 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                 // as every slot is set — is the k-th largest of k sample maxima: rank ~1 000 after a few tiles, below 100 at the end.
                 const int64_t rg = group - n_full;
                 const int n_lists = (int)((((rg + 1) * n_tiles - 1) / A.run) - (rg * n_tiles) / A.run + 1);
-                const int64_t b_own = group * UPW + lane;
+                const int64_t b_own = group * UPW + cold(lane);
                 if (n_lists >= k) {
                     if (owner && best && b_own < batch_n)
                         atomicMax(A.piece_best + b_own * k + (int)((int64_t)pidx * k / n_lists), (unsigned int)(best >> 32));
                     if (user_ok[0]) {
-                        const unsigned int *slots = A.piece_best + (group * UPW + j) * k;
+                        const unsigned int *slots = A.piece_best + (group * UPW + cold(j)) * k;
                         unsigned int m = ~0u;
                         for (int sl = 0; sl < k; ++sl) { const unsigned int v = slots[sl]; m = v < m ? v : m; }
                         if (m) thr[0] = fmaxf(thr[0], key_score((unsigned long long)m << 32));
@@ -756,9 +780,9 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                         do {
                             if (need) {
                                 exm[g] |= (1u << (ex_next[g] - tile_base)) >> (4 * h);
-                                ++ex_pos[g];
                                 ex_next[g] = ex_after[g];
-                                ex_after[g] = ex_pos[g] + 1 < ex_end[g] ? ex_ptr[g][ex_pos[g] + 1] : kIdxNone;
+                                ++ex_cur[g]; --ex_left[g];
+                                ex_after[g] = ex_left[g] >= 1 ? *ex_cur[g] : kIdxNone;
                             }
                             need = ex_next[g] < tile_end;
                         } while (__any(need));
@@ -795,9 +819,8 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                 float sc = cur[4 * q4 + rr];
                 if (masks && ((exm[g] >> (8 * q4 + rr)) & 1u)) sc = -INFINITY;
                 const int item = item_h + 8 * q4 + rr;
-                const unsigned w = stage_addr[g] + ((unsigned)cnt[g] << 9);
-                asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" : : "v"(w), "v"(sc), "v"(item) : "memory");
-                cnt[g] += sc >= thr[g] ? 1 : 0;
+                asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" : : "v"(wpos[g]), "v"(sc), "v"(item) : "memory");
+                wpos[g] += sc >= thr[g] ? 512u : 0u;
             }
         };
         // after a tile's selection: the quads with candidates, in order, each behind a scalar branch on its mask,
@@ -828,10 +851,11 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                         if (qmask[g][q4]) {
                             IGCN_STAT(2, 1);
 #ifdef IGCN_X_NOFLUSH
-                            cnt[g] = cnt[g] > cap - 4 ? cap - 4 : cnt[g];        // developer ablation: wrong results, no drain
+                            { const unsigned lim = stage_first(g) + ((unsigned)(cap - 4) << 9); wpos[g] = wpos[g] > lim ? lim : wpos[g]; }   // developer ablation: wrong results, no drain
 #else
-                            if (__any(cnt[g] > cap - 4)) {
-                                if constexpr (kHotTrack) hot[g] += cnt[g] > cap - 4 ? 1 : 0;
+                            const bool full = wpos[g] > stage_first(g) + ((unsigned)(cap - 4) << 9);     // fewer than 4 free slots
+                            if (__any(full)) {
+                                if constexpr (kHotTrack) hot[g] += full ? 1 : 0;
                                 flush();
                             }
 #endif
@@ -843,7 +867,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
             if (mflag) run(std::true_type{}); else run(std::false_type{});
             if (prio_boost) set_base_priority(prio_slot);
 #ifdef IGCN_TOPK_STATS
-            asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(cnt[0]) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(wpos[0]) : "memory");
             st_8 += IGCN_CLOCK() - t_hits;
 #endif
         };
@@ -1002,11 +1026,11 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                 warm = bp >= kWarmFlat * b0;
             }
             if (warm) {
-                int sv_pos[NG], sv_next[NG], sv_after[NG];
+                int sv_left[NG];                                 // where the cursors stood (the pass walks them, the sweep proper starts over)
                 float slot[NG][16];
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
-                    sv_pos[g] = ex_pos[g]; sv_next[g] = ex_next[g]; sv_after[g] = ex_after[g];
+                    sv_left[g] = ex_left[g];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) slot[g][r] = -INFINITY;
                 }
@@ -1073,10 +1097,13 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                     const float tau = fminf(m, __shfl_xor(m, 32));
                     if (user_ok[g]) {
                         thr[g] = tau;
-                        if (h == 0) A.warm_thr[group * UPW + g * 32 + j] = tau;
+                        if (h == 0) A.warm_thr[group * UPW + g * 32 + cold(j)] = tau;
                     }
                     // the sweep proper starts over at the piece's first tile
-                    ex_pos[g] = sv_pos[g]; ex_next[g] = sv_next[g]; ex_after[g] = sv_after[g];
+                    ex_cur[g] -= sv_left[g] - ex_left[g];
+                    ex_left[g] = sv_left[g];
+                    ex_next[g] = ex_left[g] >= 0 ? ex_cur[g][-1] : kIdxNone;
+                    ex_after[g] = ex_left[g] >= 1 ? ex_cur[g][0] : kIdxNone;
                     exm[g] = 0u;
                 }
                 mflag = false;
@@ -1166,7 +1193,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
 #pragma unroll
                                 for (int g = 0; g < NG; ++g) {
                                     if (evict[g]) {
-                                        if (h == 0) A.unfinished[group * UPW + g * 32 + j] = 1;
+                                        if (h == 0) A.unfinished[group * UPW + g * 32 + cold(j)] = 1;
                                         user_ok[g] = false; thr[g] = INFINITY; alive[g] = false;
                                     }
                                     any_alive |= alive[g];
@@ -1200,7 +1227,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
                             if (lane == 0) atomicAdd(A.exit_count + exit_slot(job), 1u);
 #pragma unroll
                             for (int g = 0; g < NG; ++g)
-                                if (alive[g] && h == 0) A.unfinished[group * UPW + g * 32 + j] = 1;
+                                if (alive[g] && h == 0) A.unfinished[group * UPW + g * 32 + cold(j)] = 1;
                             break;
                         }
                     }
@@ -1274,7 +1301,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
         __builtin_amdgcn_wave_barrier();
         if (!by_rows) {
             const int total = n_here * k;
-            for (int e = lane; e < total; e += kWave) {
+            for (int e = cold(lane); e < total; e += kWave) {
                 const int u = e / k, r = e - u * k;
                 const unsigned long long key = heap_base[r * kWave + u];
                 if (direct) {
@@ -1288,7 +1315,7 @@ __global__ __launch_bounds__(kWave, (MODE == 2 && D == 128 && NG == 2) ? 1 : 2) 
             }
         } else {
             // (the two-stage path's fall-back: a handful of users whose output rows are scattered over the batch)
-            const int64_t b_own = b0 + lane;
+            const int64_t b_own = b0 + cold(lane);
             if (owner && b_own < batch_n) {
                 if (direct) {
                     int64_t orow = b_own;
@@ -1944,6 +1971,9 @@ static int launch_topk(const TopkPlan &p, hipStream_t st, const TopkArgs &args)
         configured = true;
     }
     if (p.units >= ((int64_t)1 << 31)) return IGCN_E_SHAPE;
+    static int scratch_bytes = -1;                             // (per instantiation; see capture_guard)
+    const int cg = capture_guard(reinterpret_cast<const void *>(kern), st, &scratch_bytes);
+    if (cg != IGCN_OK) return cg;
     hipLaunchKernelGGL(kern, dim3((unsigned)p.units), dim3(kWave), p.lds_bytes, st, args);
     return launch_status();
 }
@@ -2130,6 +2160,15 @@ extern "C" int64_t igcn_score_topk_fast_workspace_bytes(int64_t batch, int64_t n
 {
     FastLayout L;
     return topk_fast_layout(batch, n_items, d, k, excl_rows, excl_nnz, &L) == IGCN_OK ? L.total : -1;
+}
+
+// Flagged users the next igcn_score_topk_fast_f32 call of this shape finishes itself (ABI v8): the caller's share of the flagged list
+// starts behind them.  The library is the one place that knows (the limit, and the "topk_fast_fallback" knob that turns it off).
+extern "C" int64_t igcn_score_topk_fast_finished_max(int64_t batch, int32_t with_lower_bound)
+{
+    if (batch < 0) return -1;
+    if (!with_lower_bound || tuning_get(IGCN_TUNE_TOPK_FAST_FALLBACK) == 0) return 0;
+    return batch < kFastFallbackMax ? batch : kFastFallbackMax;
 }
 
 extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,

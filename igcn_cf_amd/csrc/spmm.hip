@@ -783,6 +783,7 @@ extern "C" const char *igcn_error_string(int code)
     case IGCN_E_ALIGN: return "pointer or stride not 16-byte aligned";
     case IGCN_E_RANGE: return "scalar argument out of range";
     case IGCN_E_NO_DEVICE: return "no HIP device";
+    case IGCN_E_CAPTURE: return "stream is capturing and a kernel of this call uses scratch memory (rebuild: the kernels are meant to have none)";
     default: return code > 0 ? hipGetErrorString(static_cast<hipError_t>(code)) : "unknown igcn error";
     }
 }

@@ -594,12 +594,10 @@ def score_topk(user_rows, item_rows, k, user_ids=None, excl_rowptr=None, excl_co
     return out_idx, out_val
 
 
-_fast_fallback_inside = [True]      # tests: set_fast_fallback(False) = the ABI v6 split (every flagged user re-done from here)
-
-
 def set_fast_fallback(inside):
-    """Developer / test switch: whether igcn_score_topk_fast_f32 finishes its first FAST_FALLBACK_MAX flagged users itself."""
-    _fast_fallback_inside[0] = bool(inside)
+    """Developer / test switch: whether igcn_score_topk_fast_f32 finishes its first FAST_FALLBACK_MAX flagged users itself
+    (False = the ABI v6 split: every flagged user re-done from here).  The knob lives in the library and only there:
+    _score_topk_fast asks it how many users a call finishes (igcn_score_topk_fast_finished_max)."""
     _lib.set_tuning('topk_fast_fallback', None if inside else 0)
 
 
@@ -616,7 +614,8 @@ def _score_topk_fast(L, user_rows, item_rows, k, user_ids, excl_rowptr, excl_col
     out_val = torch.empty((B, k), dtype=torch.float32, device=dev)
     flagged = torch.empty(B + 1, dtype=torch.int32, device=dev)
     bounds = torch.empty(B, dtype=torch.float32, device=dev)
-    fallback_inside = _fast_fallback_inside[0]
+    # how many flagged users the call will finish itself: asked of the library, BEFORE the call, under the knobs the call will see
+    done = int(L.igcn_score_topk_fast_finished_max(B, 1))
     _lib.check(L.igcn_score_topk_fast_f32(
         user_rows.data_ptr(), user_rows.stride(0), _lib.ptr(user_ids), B,
         item_rows.data_ptr(), item_rows.stride(0), n_items, d,
@@ -627,7 +626,6 @@ def _score_topk_fast(L, user_rows, item_rows, k, user_ids, excl_rowptr, excl_col
     # (ABI v7).  The one host read of the path comes AFTER everything is queued — the GPU is never idle waiting for it — and only
     # tells whether more users than that were flagged (exact-arithmetic tables with ties in droves; a few dozen is the norm).
     n_flagged = int(flagged[0].item())
-    done = _lib.FAST_FALLBACK_MAX if fallback_inside else 0
     if n_flagged > done:
         # the rest: the fp32 sweep, started from the k-th exact score of their candidates (a valid lower bound) instead of
         # from an empty list

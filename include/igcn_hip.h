@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IGCN_ABI_VERSION 7
+#define IGCN_ABI_VERSION 8
 
 #define IGCN_OK            0
 #define IGCN_E_NULL       -1   /* a required pointer is NULL               */
@@ -31,6 +31,8 @@ extern "C" {
 #define IGCN_E_ALIGN      -3   /* a pointer / stride misses its alignment  */
 #define IGCN_E_RANGE      -4   /* a scalar argument is out of range        */
 #define IGCN_E_NO_DEVICE  -5   /* no HIP device is available               */
+#define IGCN_E_CAPTURE    -6   /* the stream is capturing and a kernel of the call carries scratch (never the case for
+                                  the library as built: its kernels have no private segment; see csrc/common.h) */
 
 #define IGCN_MAX_ADDS      8   /* epilogue addends of igcn_spmm_csr_f32     */
 #define IGCN_MAX_TOPK    256   /* k of igcn_score_topk_f32                  */
@@ -166,7 +168,8 @@ int igcn_pack_mask_bits(const uint8_t *masks, int64_t n, int64_t stride, int32_t
  *  igcn_csr_transpose: CSR of M^T (t_rowptr int64 [n_cols+1], t_col int32 [nnz] = source rows in
  *  ascending order) and edge_id int32 [nnz] = position of each transposed entry in M, so that
  *  igcn_spmm_csr_f32 drops the same edges in both views.  workspace: 256-byte aligned,
- *  igcn_csr_transpose_workspace_bytes(nnz) bytes; nnz < 2^31. */
+ *  igcn_csr_transpose_workspace_bytes(nnz) bytes; nnz < 2^31.  The one call that refuses a CAPTURING stream
+ *  (IGCN_E_CAPTURE): its sort is rocPRIM's, whose kernels carry a private segment (csrc/common.h, capture_guard). */
 int igcn_csr_from_sorted_coo(const int64_t *sorted_row, int64_t nnz, int64_t n_rows, int64_t *rowptr, void *stream);
 int64_t igcn_csr_transpose_workspace_bytes(int64_t nnz);
 int igcn_csr_transpose(const int64_t *rowptr, const int32_t *col, int64_t n_rows, int64_t n_cols, int64_t nnz,
@@ -234,7 +237,7 @@ int igcn_bpr_bwd_f32(const float *u_tab, const float *p_tab, const float *n_tab,
  * user_ids int64 [B] or NULL (then row b of user_rows is user b);
  * excl_rowptr int64 / excl_col int32 may be NULL; banned uint8 [n_items] or NULL.
  * d <= 256, d % 4 == 0 (built for d <= 128: 64 users per wave up to 64, 32 at 128; 129..256 runs the same kernel with a
- * whole item row and user row in registers, which spills — correct, about a third slower per flop); k <= IGCN_MAX_TOPK and k <= n_items (k <= 24 runs 8 waves per CU; the heaps of a
+ * whole item row and user row in registers — ~340 of them, so ONE wave per SIMD: correct, slower per flop); k <= IGCN_MAX_TOPK and k <= n_items (k <= 24 runs 8 waves per CU; the heaps of a
  * larger k take more of the CU's LDS and fewer waves are resident: 4 up to 56, 2 up to 120, 1 above).
  * workspace (8-byte aligned): igcn_score_topk_workspace_bytes(B, n_items, d, k) bytes (partial lists of the
  * item-range splits that fill the chip when B is small + the banned items packed one bit each). */
@@ -274,9 +277,10 @@ int igcn_score_topk_bounded_f32(const float *user_rows, int64_t ldu, const int64
  * it starts (the batch of that sweep is the device-side list flagged[1..]) — no host read between the stages.  The caller
  * reads flagged[0] afterwards and re-does only positions flagged[1 + IGCN_FAST_FALLBACK_MAX ..] with
  * igcn_score_topk_bounded_f32 (bounds flagged_lower_bound[IGCN_FAST_FALLBACK_MAX ..]); with flagged_lower_bound NULL
- * every flagged user is the caller's.  No host synchronisation inside: the call can be captured into a HIP graph — run it once eagerly on
- * the stream that will replay the graph first (the sweep kernels use scratch; ROCm 7.2 faulted on a replay by a queue that had never run
- * a scratch-using kernel).  (Late round 4: of those first users, the ones whose bound is
+ * every flagged user is the caller's (igcn_score_topk_fast_finished_max tells how many the call finishes).  No host synchronisation
+ * inside, and no kernel of the call carries a private segment (round 5; round 4's sweep kernels spilled 32-76 bytes a lane, and ROCm 7.2
+ * faulted when a graph holding them was replayed by a queue that had never run a scratch-using kernel): the call can be captured into a
+ * HIP graph by the standard recipe — warm up on a side stream, capture, replay on any stream.  (Late round 4: of those first users, the ones whose bound is
  * the k-th exact score of a complete candidate list first take a streaming filter — every (user, item) pair scored once with the
  * fp32 sweep's arithmetic, the pairs that reach the bound kept and ranked — and the bounded sweep runs for the rest: users whose wave
  * gave up on them, users without a bound, users whose ties overflow the filter's 256 entries.  Same lists either way.)
@@ -298,6 +302,9 @@ int igcn_score_topk_bounded_f32(const float *user_rows, int64_t ldu, const int64
  * workspace: igcn_score_topk_fast_workspace_bytes(...) bytes, 256-byte aligned. */
 int64_t igcn_score_topk_fast_workspace_bytes(int64_t batch, int64_t n_items, int32_t d, int32_t k,
                                              int64_t excl_rows, int64_t excl_nnz);
+/* How many flagged users a call of that batch size finishes itself under the current knobs (ABI v8): 0 without flagged_lower_bound
+ * or with "topk_fast_fallback" 0, else min(batch, IGCN_FAST_FALLBACK_MAX).  The caller re-does flagged[1 + that ..]. */
+int64_t igcn_score_topk_fast_finished_max(int64_t batch, int32_t with_lower_bound);
 int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, const int64_t *user_ids, int64_t batch,
                              const float *item_rows, int64_t ldi, int64_t n_items, int32_t d,
                              const int64_t *excl_rowptr, const int32_t *excl_col, int64_t excl_rows, int64_t excl_nnz,

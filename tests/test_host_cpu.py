@@ -26,7 +26,8 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert getattr(_lib.lib(), name) is not None
-    assert _lib.lib().igcn_abi_version() == 7
+    assert _lib.lib().igcn_abi_version() == _lib.EXPECTED_ABI == 8
+    assert re.search(r'#define IGCN_ABI_VERSION\s+8\b', header)
     assert _lib.lib().igcn_error_string(-1).decode().startswith('a required pointer')
 
 
@@ -39,7 +40,88 @@ def test_library_is_loaded_behind_torch_in_a_fresh_process():
             "assert 'torch' in sys.modules; print(v)")
     p = subprocess.run([sys.executable, '-c', code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 0, p.stderr.decode()[-1000:]
-    assert p.stdout.decode().strip() == '7'
+    assert p.stdout.decode().strip() == '8'
+
+
+def test_no_kernel_of_the_built_library_carries_a_private_segment():
+    """Read out of the SHIPPED code object (the offload bundles inside libigcn_hip.so, their AMDGPU metadata notes — no compile, no
+    GPU): every kernel of the library has private_segment_fixed_size == 0 and no dynamic stack.  A kernel with scratch cannot be
+    replayed from a HIP graph by a queue that never ran one eagerly (round 4: the candidate sweeps spilled 32-76 bytes a lane and
+    the first replay of a captured igcn_score_topk_fast_f32 faulted the GPU); a later edit that brings spills back fails here —
+    and fails build() — instead of on a caller's GPU.  rocPRIM's radix sort (igcn_csr_transpose, a graph-build utility) is the one
+    exception, and that entry point refuses a capturing stream (IGCN_E_CAPTURE)."""
+    from igcn_cf_amd import _build, _lib
+    meta = _build.kernel_metadata(_lib.LIB_PATH)
+    sweeps = [n for n in meta if 'score_topk_kernel' in n]
+    assert len(sweeps) >= 18, sweeps                                   # every instantiation of the sweep is in the code object
+    ours = {n: k for n, k in meta.items() if 'rocprim' not in n}
+    assert len(ours) >= 60
+    for name, k in ours.items():
+        assert int(k['.private_segment_fixed_size']) == 0 and not k.get('.uses_dynamic_stack'), (name, k['.private_segment_fixed_size'])
+    assert _build.scratch_report(_lib.LIB_PATH) == []
+    # the sweeps keep their residency: 2 waves per SIMD = at most 256 registers (vector + accumulation) — except the two variants that
+    # are planned at one wave per SIMD (d = 256; the two-plane d = 128 candidate sweep)
+    for name in sweeps:
+        k = meta[name]
+        regs = int(k['.vgpr_count'])                                   # (unified file: the count includes the AGPRs)
+        one_wave = 'ILi256E' in name or 'ILi128ELi2ELb1ELi2E' in name
+        assert regs <= (512 if one_wave else 256), (name, regs)
+    assert _lib.lib().igcn_error_string(-6).decode().startswith('stream is capturing')
+
+
+def test_a_library_of_another_abi_version_is_refused_at_load_time():
+    """the build keeps a .so that is newer than its sources, so a stale library could load silently and the wrappers would
+    then mis-read its contract.  _lib.handle() compares igcn_abi_version() with the version it was written against."""
+    import subprocess
+    code = ("from igcn_cf_amd import _lib\n_lib.EXPECTED_ABI = 7\n"
+            "try:\n    _lib.lib().igcn_abi_version()\nexcept _lib.IgcnError as e:\n    print('refused:', e)\n")
+    p = subprocess.run([sys.executable, '-c', code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-1000:]
+    assert 'refused:' in p.stdout.decode() and 'ABI version 8' in p.stdout.decode()
+
+
+def test_the_bench_line_keeps_what_grades_it_inside_the_drivers_24_key_window():
+    """The driver's record keeps the values of the first 24 keys of `roofline` only (BENCH_r03 / r04 both stop at key 24; of other
+    extra keys it keeps the names).  For two rounds `traffic`, `l2_hit_rate` and `eval_users_per_s` — the second half of BASELINE's
+    metric — sat at positions 25+ and were cut.  bench.lift_flat now orders the object: the 24 names below, in this order, whatever
+    the legs that ran."""
+    import bench
+    want = ['bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'algorithmic_bytes_per_launch', 'compulsory_bytes_per_launch',
+            'avg_launch_ms', 'traffic', 'traffic_GBps', 'traffic_over_compulsory', 'l2_hit_rate', 'frac_of_mall_gather', 'frac_of_probe',
+            'eval_users_per_s', 'eval_ms', 'eval_mfma_frac', 'eval_ms_after_2_epochs', 'train_step_ms', 'hbm_bound_item_block_frac',
+            'hbm_bound_counter_frac', 'hbm_stream_read_GBps', 'config5_pass_ms']
+    assert list(bench.ROOFLINE_HEAD) == want and len(want) == 24
+    # a stub of what main() assembles: the SpMM roofline in ITS construction order (notes and rank / world in between), and the extras
+    roof = {'bound': 'mall-gather', 'kernel': 'spmm_csr_multirow_kernel<16,2,false>', 'achieved': 10147.2, 'peak': 8000.0, 'unit': 'GB/s',
+            'frac': 1.27, 'frac_note': 'n' * 100, 'algorithmic_bytes_per_launch': 1204714764, 'compulsory_bytes_per_launch': 141256204,
+            'avg_launch_ms': 0.1187, 'avg_launch_note': 'x', 'gathered_row_GBps': 9401.9, 'mall_gather_peak_GBps': 8600.0,
+            'gathered_rows_frac_of_mall_gather': 1.09, 'mall_gather_note': 'y', 'probe_peak_GBps': 11827.5, 'frac_of_probe': 0.858,
+            'probe_note': 'z', 'frac_of_compulsory': 0.117, 'rank': 0, 'world': 1, 'hbm_stream_read_GBps': 6289.4, 'hbm_stream_copy_GBps': 5100.0,
+            'traffic': 717000000, 'traffic_source': 'profiles/pmc_traffic.json', 'traffic_GBps': 6040.0, 'frac_of_mall_gather': 0.70,
+            'traffic_over_compulsory': 5.08, 'traffic_over_algorithmic': 0.6, 'l2_hit_rate': 0.486}
+    extras = {'eval_users_per_s': 32.9e6, 'eval_ms': 3.34, 'eval_users_per_s_fp32_sweep': 8.9e6, 'train_step_ms': 0.67,
+              'eval_roofline': {'achieved': 117.6, 'frac': 0.75, 'ms': 11.5}, 'eval_two_stage': {'ms': 3.0},
+              'eval_trained': {'eval_ms': 1.03, 'eval_ms_fp32_sweep': 11.2},
+              'roofline_hbm_bound': {'kernel': 'spmm_csr_rows_kernel<32,false>', 'avg_launch_ms': 9.1, 'counter_GBps': 7100.0, 'counter_frac': 0.88,
+                                     'algorithmic_GBps': 7250.0, 'algorithmic_frac': 0.9, 'stream_read_GBps': 6300.0, 'stream_copy_GBps': 5100.0,
+                                     'blocks': {'item_block': {'ms': 4.8, 'counter_GBps': 6800.0, 'counter_frac': 0.85,
+                                                               'counter_frac_of_measured_stream': 1.08, 'algorithmic_GBps': 6780.0},
+                                                'user_block': {'ms': 4.2, 'counter_GBps': 7500.0, 'algorithmic_GBps': 7850.0}}},
+              'config5_sharded': {'pass_ms': 238.7, 'edges_per_s': 12.6e9, 'exposed_exchange_ms': 11.9, 'local_spmm_ms': 226.8, 'label': 'c5'}}
+    out = {'metric': 'm', 'value': 1.0, 'roofline': dict(roof)}
+    bench.lift_flat(out, extras)
+    r = out['roofline']
+    assert list(r)[:24] == want, list(r)[:24]
+    for k in want:
+        assert r[k] is not None, k                                     # every graded value is there when every leg ran
+    assert r['eval_users_per_s'] == 32.9e6 and r['traffic'] == 717000000 and r['l2_hit_rate'] == 0.486 and r['config5_pass_ms'] == 238.7
+    assert set(roof) <= set(r)                                         # nothing is dropped, only moved behind the window
+    # a run without the side legs (--no-extras / N > 1): same positions, None where nothing was measured
+    out2 = {'roofline': {'bound': 'hbm', 'kernel': 'k', 'achieved': 1.0, 'rank': 1, 'world': 2, 'traffic': None}}
+    bench.lift_flat(out2, {})
+    assert list(out2['roofline'])[:24] == want and out2['roofline']['eval_users_per_s'] is None and out2['roofline']['rank'] == 1
+    json_line = __import__('json').dumps(out)
+    assert json_line.index('"traffic"') < json_line.index('"frac_note"')
 
 
 def test_bench_launcher_refuses_without_enough_gpus_before_starting_anything():

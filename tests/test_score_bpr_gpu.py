@@ -750,52 +750,21 @@ def test_two_stage_second_whole_sweep_of_a_wave_counts_its_own_leavers():
 
 
 def test_two_stage_call_replays_from_a_captured_hip_graph():
-    """igcn_score_topk_fast_f32 makes no host read and no allocation (include/igcn_hip.h, ABI v7): the whole evaluation — row statistics,
-    order build, row sorts, candidate sweep, re-scoring, the flagged users' filter and bounded sweep — can be captured into ONE HIP graph
-    and replayed on new table contents.  Captured once on a side stream, replayed three times with the tables overwritten in place: the
-    lists are the fp32 sweep's every time, and so is flagged[0] <= 256 (beyond that the caller would have to re-do users itself)."""
-    from igcn_cf_amd import _lib
-    from igcn_cf_amd.ops import score_topk
-    rng = np.random.default_rng(71)
-    d, n_users, n_items, k = 64, 2500, 20000, 20
-    ex = [np.sort(rng.choice(n_items, size=int(rng.integers(0, 40)), replace=False)) for _ in range(n_users)]
-    rowptr = np.zeros(n_users + 1, dtype=np.int64)
-    np.cumsum([len(x) for x in ex], out=rowptr[1:])
-    rp, cl = _dev(rowptr), _dev(np.concatenate(ex).astype(np.int32))
-    U = torch.empty((n_users, d), dtype=torch.float32, device='cuda')
-    I = torch.empty((n_items, d), dtype=torch.float32, device='cuda')
-    L = _lib.lib()
-    ws_bytes = L.igcn_score_topk_fast_workspace_bytes(n_users, n_items, d, k, n_users, cl.numel())
-    ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device='cuda')
-    ws_ptr = (ws.data_ptr() + 255) // 256 * 256
-    out_idx = torch.empty((n_users, k), dtype=torch.int64, device='cuda')
-    out_val = torch.empty((n_users, k), dtype=torch.float32, device='cuda')
-    flagged = torch.empty(n_users + 1, dtype=torch.int32, device='cuda')
-    bounds = torch.empty(n_users, dtype=torch.float32, device='cuda')
-
-    def call():
-        _lib.check(L.igcn_score_topk_fast_f32(U.data_ptr(), U.stride(0), None, n_users, I.data_ptr(), I.stride(0), n_items, d,
-                                              rp.data_ptr(), cl.data_ptr(), n_users, cl.numel(), None, k, out_idx.data_ptr(), out_val.data_ptr(),
-                                              flagged.data_ptr(), bounds.data_ptr(), ws_ptr, _lib.current_stream()), 'igcn_score_topk_fast_f32')
-
-    def fill(seed, spread):
-        g = torch.Generator(device='cuda').manual_seed(seed)
-        U.copy_(torch.randn(U.shape, device='cuda', generator=g) * 0.1)
-        I.copy_(torch.randn(I.shape, device='cuda', generator=g) * 0.1 * torch.exp(spread * torch.randn((n_items, 1), device='cuda', generator=g)))
-    fill(0, 0.0)
-    call()                       # (kernel attributes are set on first use, and the queue that will replay the graph gets its scratch: not inside a capture)
-    torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        call()
-    for seed, spread in ((1, 0.0), (2, 1.0), (3, 0.3)):                # flat norms (warm-up pass), spread norms (early exits), in between
-        fill(seed, spread)
-        out_idx.fill_(-7)
-        graph.replay()
-        torch.cuda.synchronize()
-        ref = score_topk(U, I, k, excl_rowptr=rp, excl_col=cl, mode='exact')
-        assert int(flagged[0]) <= _lib.FAST_FALLBACK_MAX, int(flagged[0])
-        assert torch.equal(out_idx, ref[0]) and torch.equal(out_val, ref[1]), (seed, spread)
+    """igcn_score_topk_fast_f32 makes no host read and no allocation, and no kernel of it carries a private segment (include/igcn_hip.h,
+    ABI v8): the whole evaluation — row statistics, order build, row sorts, candidate sweep, re-scoring, the flagged users' filter and
+    bounded sweep — can be captured into ONE HIP graph by PyTorch's documented recipe (warm-up on a side stream, capture, replay on the
+    current stream) and replayed on new table contents; so can the fp32 sweep (igcn_score_topk_f32).  Run in a FRESH child process
+    (tests/capture_child.py), where the replaying stream has run nothing eagerly — the sequence that faulted the GPU in round 4, when
+    the sweep kernels still spilled.  d = 64 and 128, three refills each (flat norms: warm-up pass; spread norms: early exits): the lists
+    are the fp32 sweep's every time and flagged[0] stays within what the call finishes itself.  The child also checks that
+    igcn_csr_transpose (rocPRIM's sort, the one kernel family with scratch) REFUSES a capturing stream with IGCN_E_CAPTURE."""
+    import subprocess
+    import sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'capture_child.py')
+    p = subprocess.run([sys.executable, child], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0, (p.returncode, out[-500:], p.stderr.decode()[-2000:])
+    assert 'ok 6' in out and 'ok refused' in out, out
 
 
 def test_two_stage_order_build_on_degenerate_norm_distributions():
