@@ -9,7 +9,9 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'libigcn_hip.so')
+# IGCN_LIB_PATH: developer override (an instrumented host build, an A/B build of another round) — the shipped library is never
+# overwritten for that (scripts/sanitize_host.sh used to copy its ASan build over it)
+LIB_PATH = os.environ.get('IGCN_LIB_PATH') or os.path.join(_PKG, 'libigcn_hip.so')
 
 EXPECTED_ABI = 8                 # IGCN_ABI_VERSION of include/igcn_hip.h this binding was written against
 MAX_ADDS = 8
@@ -20,8 +22,8 @@ FAST_FALLBACK_MAX = 256          # IGCN_FAST_FALLBACK_MAX: flagged users igcn_sc
 c_i64_p = C.POINTER(C.c_int64)
 vp = C.c_void_p
 
-ROW_SEGMENT_DTYPE = np.dtype([('start', '<i8'), ('len', '<i4'), ('slot', '<i4'), ('row', '<i4'), ('reserved', '<i4')])
-LONG_ROW_DTYPE = np.dtype([('row', '<i4'), ('first_slot', '<i4'), ('n_slots', '<i4'), ('reserved', '<i4')])
+ROW_SEGMENT_DTYPE = np.dtype([('start', '<i8'), ('len', '<i4'), ('slot', '<i4'), ('row', '<i4'), ('long_index', '<i4')])
+LONG_ROW_DTYPE = np.dtype([('row', '<i4'), ('first_slot', '<i4'), ('n_slots', '<i4'), ('arrived', '<i4')])
 
 # name -> (restype, argtypes); every symbol of include/igcn_hip.h
 SIGNATURES = {

@@ -14,12 +14,14 @@ inline int launch_status() {
     return e == hipSuccess ? IGCN_OK : static_cast<int>(e);
 }
 
-// A kernel with a private segment (scratch: register spills, dynamic indexing of a local array) cannot be replayed from a HIP graph on
-// a queue that never ran one eagerly: ROCm 7.2 hands the replaying queue no scratch and the GPU faults (round 4,
-// tests/test_score_bpr_gpu.py::test_two_stage_call_replays_from_a_captured_hip_graph).  No kernel of this library has one —
-// tests/test_host_cpu.py reads the private segment sizes out of the built code object — and this is the guard behind that rule: a
-// launch site calls it once per kernel; should a later compiler bring scratch back, the call is REFUSED while the stream is capturing
-// (IGCN_E_CAPTURE) instead of faulting at replay time.  Eager launches are unaffected.
+// No kernel of this library carries a private segment (scratch: register spills, dynamic indexing of a local array) —
+// tests/test_host_cpu.py reads the private segment sizes out of the built code object, and build() fails on a non-zero one.
+// Round 4 blamed a GPU fault at the first replay of a captured igcn_score_topk_fast_f32 on the 32-76 bytes a lane its sweep kernels
+// spilled then (scratch is per-queue state the replaying queue may not have been given).  Round 5 removed the spills and the fault
+// stayed; under rocgdb it turned out to be the call's memset NODE (see zero_async below).  The rule is kept as what it is, a
+// property a drop-in should have (nothing of a call depends on per-queue state), and this is the guard behind it: a launch site
+// calls it once per kernel; should a later compiler bring scratch back, the call is REFUSED while the stream is capturing
+// (IGCN_E_CAPTURE) rather than left to chance at replay time.  Eager launches are unaffected.
 inline int capture_guard(const void *kernel, hipStream_t st, int *cached_scratch_bytes) {
     if (*cached_scratch_bytes < 0) {
         hipFuncAttributes fa;
@@ -30,6 +32,44 @@ inline int capture_guard(const void *kernel, hipStream_t st, int *cached_scratch
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return IGCN_OK; }
     return cs == hipStreamCaptureStatusNone ? IGCN_OK : IGCN_E_CAPTURE;
+}
+
+// Zeroing device memory from inside the library: a KERNEL of its own, never hipMemsetAsync.  Round 5, under rocgdb
+// (profiles/r05b_capture_fault_rocgdb.txt): a captured igcn_score_topk_fast_f32 replayed by PyTorch's standard recipe (warm-up on a
+// side stream, capture, replay on the current stream, fresh process) faulted in order_place_kernel, "write access to a read-only
+// page" — its counting bins, which "arrive zeroed" by the call's hipMemsetAsync, had not: on ROCm 7.2 the memset NODE of a captured
+// graph is not ordered against the kernel nodes behind it the way an eager hipMemsetAsync is ordered against the kernels behind it
+// on its stream (the process has a DMA queue beside its compute queues; the fault round 4 blamed on scratch).  With the zeroing
+// done by a kernel node the same recipe replays cleanly (tests/capture_child.py).  Kernel nodes are ordered against each other —
+// everything else in the library relies on that, and only on that.  p: 4-byte aligned; any byte count.
+static __global__ __launch_bounds__(256) void zero_bytes_kernel(uint32_t *__restrict__ p, int64_t n_words, int64_t n_bytes)
+{
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n_quads = n_words >> 2;
+    uint4 *q = reinterpret_cast<uint4 *>(p);
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0)
+        for (; i < n_quads; i += stride) q[i] = make_uint4(0u, 0u, 0u, 0u);
+    else
+        for (; i < n_quads; i += stride) { p[4 * i] = 0u; p[4 * i + 1] = 0u; p[4 * i + 2] = 0u; p[4 * i + 3] = 0u; }
+    if (blockIdx.x == 0) {
+        for (int64_t w = 4 * n_quads + threadIdx.x; w < n_words; w += 256) p[w] = 0u;
+        uint8_t *b = reinterpret_cast<uint8_t *>(p);
+        for (int64_t k = 4 * n_words + threadIdx.x; k < n_bytes; k += 256) b[k] = 0;
+    }
+}
+inline int zero_async(void *p, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0) return IGCN_OK;
+    if (!p) return IGCN_E_NULL;
+    if (reinterpret_cast<uintptr_t>(p) & 3) return IGCN_E_ALIGN;
+    const int64_t n_words = (int64_t)(bytes / 4);
+    int64_t blocks = (n_words / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(zero_bytes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<uint32_t *>(p), n_words, (int64_t)bytes);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? IGCN_OK : static_cast<int>(e);
 }
 
 // Number of CUs of the current device (256 on MI355X); cached.
@@ -67,6 +107,7 @@ enum {
     IGCN_TUNE_TOPK_FAST_WARM,           // whole candidate sweeps: tiles of the warm-up pass that bounds every user's k-th best before the sweep stages anything (0: none)
     IGCN_TUNE_TOPK_FAST_FILTER,         // 0: the flagged users of the two-stage path all take the bounded fp32 sweep (default: a streaming filter first, the sweep for what overflows it)
     IGCN_TUNE_TOPK_FAST_PIECES,         // 0: the narrow bounded sweep is cut into at most 58 pieces per group (default: up to 232, four lists per lane of its merge)
+    IGCN_TUNE_SPMM_FOLD,                // 0: cut rows are added up by a second kernel (spmm_long_rows_reduce_kernel) instead of inside the launch
     IGCN_TUNE_COUNT
 };
 extern int g_tuning[IGCN_TUNE_COUNT];   // defined in spmm.hip; holds value + 1, 0 = unset
@@ -86,6 +127,13 @@ __host__ __device__ __forceinline__ uint32_t hash_counter(uint64_t counter, uint
     h = mix32(h + (hi ^ s1) * 0x9e3779b9u + 0x85ebca6bu);
     return h;
 }
+
+// An integer the optimiser cannot see through.  Address arithmetic that starts from it stays where it is written: without it the
+// per-lane addresses of a kernel's COLD paths (bounds read back, give-up flags, the emit of the scoring sweeps; the fold of a cut row
+// in the SpMM) are hoisted out of the outer loop as loop invariants and stay live across the hot loop — in the scoring sweeps they
+// ended up in SCRATCH (and a kernel with a private segment is something this library does not ship, see capture_guard), in the SpMM
+// they cost a wave per SIMD.  Costs no instruction.
+__device__ __forceinline__ int cold(int x) { asm volatile("" : "+v"(x)); return x; }
 
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ void f4_fma(float4 &a, float w, const float4 &x) {

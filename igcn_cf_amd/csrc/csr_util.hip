@@ -93,8 +93,7 @@ extern "C" int igcn_csr_transpose(const int64_t *rowptr, const int32_t *col, int
         (void)hipGetLastError();
     }
     if (nnz == 0) {
-        hipError_t e = hipMemsetAsync(t_rowptr, 0, (size_t)(n_cols + 1) * 8, st);
-        return e == hipSuccess ? IGCN_OK : (int)e;
+        return zero_async(t_rowptr, (size_t)(n_cols + 1) * 8, st);
     }
     if (!col || !t_col || !edge_id || !workspace) return IGCN_E_NULL;
     if (reinterpret_cast<uintptr_t>(workspace) % 256) return IGCN_E_ALIGN;

@@ -325,12 +325,6 @@ __device__ __forceinline__ unsigned long long heap_replace_root(unsigned long lo
     return i == 0 ? cand : first_up;
 }
 
-// An integer the optimiser cannot see through.  Address arithmetic that starts from it stays where it is written: without it the
-// per-lane addresses of the cold paths (bounds read back in flush(), the give-up flags, the emit) are hoisted out of the job loop as
-// loop invariants, stay live across the whole sweep and end up in SCRATCH — and a kernel with a private segment cannot be replayed
-// from a HIP graph on a queue that never ran one (round 4's capture fault).  Costs no instruction.
-__device__ __forceinline__ int cold(int x) { asm volatile("" : "+v"(x)); return x; }
-
 // hand-written vector instructions of the pinned block (the compiler would canonicalise the operands of an fmaxf
 // with v_max_f32 x, x first).
 __device__ __forceinline__ float vmax3(float a, float b, float c) {
@@ -2204,8 +2198,10 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     // ... and, right behind them, the counters of the order build (the first kOrderBinsBytes of its workspace)
     static_assert(kOrderBinsBytes % 256 == 0, "");
     if (L.order != L.exit_state + fb_state + align256(batch) + align256(batch * 4) || L.ord.bins != 0) return IGCN_E_RANGE;   // (the layout this memset relies on)
-    hipError_t e = hipMemsetAsync(norm_bits, 0, (size_t)(256 + kFilterState + fb_state + align256(batch) + align256(batch * 4) + (by_norm ? kOrderBinsBytes : 0)), st);   // (a whole number of 256-byte pieces: ONE fill kernel)
-    if (e != hipSuccess) return (int)e;
+    // (the library's own zeroing kernel, not hipMemsetAsync: a memset NODE of a captured graph is not ordered against the kernels behind
+    // it on ROCm 7.2 — see zero_async in common.h)
+    rc = zero_async(norm_bits, (size_t)(256 + kFilterState + fb_state + align256(batch) + align256(batch * 4) + (by_norm ? kOrderBinsBytes : 0)), st);
+    if (rc != IGCN_OK) return rc;
     const int n_tiles = (int)((n_items + 31) / 32);
     const int64_t pack_threads = (int64_t)n_tiles * ks * kWave;
     int64_t stat_blocks = ((n_items << lg) + kBlock - 1) / kBlock;

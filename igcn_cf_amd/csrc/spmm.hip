@@ -31,6 +31,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include "common.h"
+#ifndef IGCN_X_WAVES
+#define IGCN_X_WAVES
+#endif
 
 namespace igcn {
 
@@ -90,6 +93,89 @@ __device__ __forceinline__ DealRange deal_range(const int64_t *__restrict__ xcd_
     return r;
 }
 
+// Epilogue of one finished output row: r = (out_scale * acc + add_scale * sum(adds[dst])) * row_scale[dst] -> y[dst].
+__device__ __forceinline__ void finish_row(const float4 &acc, int64_t dst, int t, const SpmmEpilogue &ep, float *__restrict__ y, int64_t ldy)
+{
+    float4 r = make_float4(acc.x * ep.out_scale, acc.y * ep.out_scale, acc.z * ep.out_scale, acc.w * ep.out_scale);
+    if (ep.n_adds > 0) {
+        float4 s = f4_zero();
+        for (int i = 0; i < ep.n_adds; ++i)
+            f4_add(s, *reinterpret_cast<const float4 *>(ep.add[i] + dst * ldy + 4 * t));
+        f4_fma(r, ep.add_scale, s);
+    }
+    if (ep.row_scale) {
+        const float rs = ep.row_scale[dst];
+        r.x *= rs; r.y *= rs; r.z *= rs; r.w *= rs;
+    }
+    *reinterpret_cast<float4 *>(y + dst * ldy + 4 * t) = r;
+}
+
+// ---- cut rows folded inside the launch (round 5) -------------------------------------------------------------------------------
+// A row cut into segments used to be finished by a second kernel (spmm_long_rows_reduce_kernel: 5 us, launch-bound — 15 of the
+// 337 us of the headline pass, 29 us of a training step).  Now the wave that delivers a row's LAST partial sum adds the row up:
+//   * a segment's partial sum is stored with AGENT scope (sc1: written through to the memory side — the row's other segments ran on
+//     other XCDs, whose L2s are private), the wave waits for its stores (vmcnt(0)) and then counts the segment in with an
+//     agent-scope atomic on the row's arrival counter (igcn_long_row.arrived);
+//   * the wave that reads n_slots - 1 back is the last: every other partial sum of the row was complete before its owner's
+//     increment, hence before this one.  It loads the row's n_slots partial sums with agent scope (never from its own L2),
+//     adds them in SLOT ORDER, one lane group, a chain of its own per column — the bits do not depend on who arrives last, on the
+//     grid, or on the kernel variant —, applies the epilogue and puts the counter back to zero for the next launch.
+// Segments come first in every list of the dealing order, so the fold happens early in the launch, under the other waves' rows.
+// (one 16-byte store with the agent-scope bit, written by hand: four __hip_atomic_store of a float each cost the kernel four
+// registers and a wave per SIMD — 67 instead of 63 VGPRs at d = 64)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_partial_agent(float *p, const float4 &v)
+{
+    const f32x4_t q = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(q) : "memory");
+}
+__device__ __forceinline__ float4 load_partial_agent(const float *p)
+{
+    float4 v;
+    v.x = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.z = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v.w = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
+// the n_slots partial sums of a cut row, added in slot order (four loads in flight; one addition chain per column)
+__device__ __forceinline__ float4 sum_partials_in_slot_order(const float *base, int n_slots, int d, bool agent)
+{
+    float4 acc = f4_zero();
+    int s = 0;
+    for (; s + 4 <= n_slots; s += 4) {
+        float4 p0, p1, p2, p3;
+        if (agent) {
+            p0 = load_partial_agent(base + (int64_t)s * d); p1 = load_partial_agent(base + (int64_t)(s + 1) * d);
+            p2 = load_partial_agent(base + (int64_t)(s + 2) * d); p3 = load_partial_agent(base + (int64_t)(s + 3) * d);
+        } else {
+            p0 = *reinterpret_cast<const float4 *>(base + (int64_t)s * d); p1 = *reinterpret_cast<const float4 *>(base + (int64_t)(s + 1) * d);
+            p2 = *reinterpret_cast<const float4 *>(base + (int64_t)(s + 2) * d); p3 = *reinterpret_cast<const float4 *>(base + (int64_t)(s + 3) * d);
+        }
+        f4_add(acc, p0); f4_add(acc, p1); f4_add(acc, p2); f4_add(acc, p3);
+    }
+    for (; s < n_slots; ++s)
+        f4_add(acc, agent ? load_partial_agent(base + (int64_t)s * d) : *reinterpret_cast<const float4 *>(base + (int64_t)s * d));
+    return acc;
+}
+// Called by all lanes that computed segment `li`'s partial sum (a wave, or one sub-wave of it), after the stores and the wait:
+// `leader` = one lane of them, `lead_lane` its lane id (for the broadcast), `writer` = the lanes that hold output columns (group 0).
+__device__ __forceinline__ void fold_cut_row(igcn_long_row *long_rows, int li, bool leader, int lead_lane, bool writer, int t, int d,
+                                             const float *partial, const SpmmEpilogue &ep, float *__restrict__ y, int64_t ldy)
+{
+    igcn_long_row *lr = long_rows + li;
+    int old = 0;
+    if (leader) old = __hip_atomic_fetch_add(&lr->arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __shfl(old, lead_lane);
+    const int n_slots = lr->n_slots;
+    if (old != n_slots - 1) return;
+    if (writer) {
+        const float4 acc = sum_partials_in_slot_order(partial + (int64_t)lr->first_slot * d + 4 * t, n_slots, d, true);
+        finish_row(acc, lr->row, t, ep, y, ldy);
+    }
+    if (leader) __hip_atomic_store(&lr->arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // 80 scalar registers at most: a wave is charged its SGPRs + 16 (rounded up to 16) out of 800 per SIMD, so 80 is
 // the most that still lets 8 waves share a SIMD; without the cap the d = 32 variant took 100 and ran 6 (-15 %).
 template <int LPR, bool DROPOUT>
@@ -100,7 +186,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
     const igcn_row_segment *__restrict__ segments, int64_t n_segments,
     float *__restrict__ partial, int long_threshold,
     const uint8_t *__restrict__ row_mask, int masked_rows_zero, const int32_t *__restrict__ row_order,
-    const int64_t *__restrict__ xcd_off)
+    const int64_t *__restrict__ xcd_off, igcn_long_row *__restrict__ long_rows)
 {
     constexpr int G = kWave / LPR;           // source rows per gather instruction
     const int lane = threadIdx.x & (kWave - 1);
@@ -133,7 +219,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
             }
         } else {
             const igcn_row_segment s = segments[v - n_rows];
-            if (row_mask && !row_mask[s.row]) continue;
+            if (row_mask && !row_mask[s.row]) {
+                // (folded launches have no reduce kernel to zero a masked cut row: its first segment does)
+                if (long_rows && masked_rows_zero && long_rows[s.long_index].first_slot == s.slot && g == 0 && lane_on)
+                    *reinterpret_cast<float4 *>(y + (int64_t)s.row * ldy + 4 * t) = f4_zero();
+                continue;
+            }
             start = s.start;
             end = s.start + s.len;
             dst = s.slot;
@@ -190,21 +281,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
 
         if (g == 0 && lane_on) {
             if (to_partial) {
-                *reinterpret_cast<float4 *>(partial + dst * (int64_t)d + 4 * t) = acc;
+                store_partial_agent(partial + dst * (int64_t)d + 4 * t, acc);   // (agent scope in either form: one code path)
             } else {
-                float4 r = make_float4(acc.x * ep.out_scale, acc.y * ep.out_scale, acc.z * ep.out_scale, acc.w * ep.out_scale);
-                if (ep.n_adds > 0) {
-                    float4 s = f4_zero();
-                    for (int i = 0; i < ep.n_adds; ++i)
-                        f4_add(s, *reinterpret_cast<const float4 *>(ep.add[i] + dst * ldy + 4 * t));
-                    f4_fma(r, ep.add_scale, s);
-                }
-                if (ep.row_scale) {
-                    const float rs = ep.row_scale[dst];
-                    r.x *= rs; r.y *= rs; r.z *= rs; r.w *= rs;
-                }
-                *reinterpret_cast<float4 *>(y + dst * ldy + 4 * t) = r;
+                finish_row(acc, dst, t, ep, y, ldy);
             }
+        }
+        if (long_rows && to_partial) {                                        // (wave-uniform)
+            asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+            const int lane_c = cold(lane);                                   // (the fold's addresses are made here, not before the gather loop)
+            fold_cut_row(long_rows, segments[dst].long_index, lane_c == 0, 0, lane_c < LPR && 4 * lane_c < d, lane_c, d, partial, ep, y, ldy);   // (slot == index in `segments`)
         }
     }
 #ifdef IGCN_SPMM_TRACE
@@ -225,14 +310,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
 // arithmetic per row (each lane group sums its neighbours in storage order, groups folded in a fixed
 // order); every control decision is per sub-wave, so the loops run while ANY sub-wave has work.
 template <int LPR, int R, bool DROPOUT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void spmm_csr_multirow_kernel(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) IGCN_X_WAVES void spmm_csr_multirow_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy,
     int64_t n_rows, int d, SpmmEpilogue ep, SpmmDropout dr,
     const igcn_row_segment *__restrict__ segments, int64_t n_segments,
     float *__restrict__ partial, int long_threshold,
     const uint8_t *__restrict__ row_mask, int masked_rows_zero, const int32_t *__restrict__ row_order,
-    const int64_t *__restrict__ xcd_off)
+    const int64_t *__restrict__ xcd_off, igcn_long_row *__restrict__ long_rows)
 {
     constexpr int S = kWave / R;             // lanes of a sub-wave
     constexpr int G = S / LPR;               // source rows per gather instruction and sub-wave
@@ -256,19 +341,24 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
         const int64_t vv = vb + lane / S;                         // this sub-wave's entry of the dealing order
         const int64_t v = vv >= deal.end ? n_virtual : row_order ? (int64_t)row_order[vv] : vv;
         // kind: 0 nothing, 1 ordinary row -> y, 2 row segment -> partial, 3 masked row that must read as zero
-        int64_t start = 0, dst = 0;
+        int64_t start = 0;
+        int dst = 0;                                             // row or slot (< 2^31): widened where an address is formed
         int len = 0, kind = 0;
         if (v < n_rows) {
             const int64_t s0 = rowptr[v], e0 = rowptr[v + 1];
             const bool is_long = !xcd_off && n_segments > 0 && e0 - s0 > long_threshold;    // (a plan's lists hold no cut row)
             const bool masked = row_mask && !row_mask[v];
-            start = s0; len = (int)(e0 - s0); dst = v;
+            start = s0; len = (int)(e0 - s0); dst = (int)v;
             kind = is_long ? 0 : masked ? (masked_rows_zero ? 3 : 0) : 1;
         } else if (v < n_virtual) {
             const igcn_row_segment sg = segments[v - n_rows];
             const bool masked = row_mask && !row_mask[sg.row];
             start = sg.start; len = sg.len; dst = sg.slot;
             kind = masked ? 0 : 2;
+            // (folded launches have no reduce kernel to zero a masked cut row: its first segment does)
+#ifndef IGCN_X_NOK3
+            if (masked && long_rows && masked_rows_zero && long_rows[sg.long_index].first_slot == sg.slot) { kind = 3; dst = sg.row; }
+#endif
         }
         if (kind != 1 && kind != 2) len = 0;
 #ifdef IGCN_SPMM_TRACE
@@ -317,24 +407,23 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
 
         if (g == 0 && lane_on) {
             if (kind == 3) {
-                *reinterpret_cast<float4 *>(y + dst * ldy + 4 * t) = f4_zero();
+                *reinterpret_cast<float4 *>(y + (int64_t)dst * ldy + 4 * t) = f4_zero();
             } else if (kind == 2) {
-                *reinterpret_cast<float4 *>(partial + dst * (int64_t)d + 4 * t) = acc;
+                store_partial_agent(partial + (int64_t)dst * d + 4 * t, acc);   // (agent scope in either form: one code path)
             } else if (kind == 1) {
-                float4 r = make_float4(acc.x * ep.out_scale, acc.y * ep.out_scale, acc.z * ep.out_scale, acc.w * ep.out_scale);
-                if (ep.n_adds > 0) {
-                    float4 sum = f4_zero();
-                    for (int i = 0; i < ep.n_adds; ++i)
-                        f4_add(sum, *reinterpret_cast<const float4 *>(ep.add[i] + dst * ldy + 4 * t));
-                    f4_fma(r, ep.add_scale, sum);
-                }
-                if (ep.row_scale) {
-                    const float rs = ep.row_scale[dst];
-                    r.x *= rs; r.y *= rs; r.z *= rs; r.w *= rs;
-                }
-                *reinterpret_cast<float4 *>(y + dst * ldy + 4 * t) = r;
+                finish_row(acc, dst, t, ep, y, ldy);
             }
         }
+#ifndef IGCN_X_NOFOLD
+        if (long_rows && __any(kind == 2)) {
+            asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+            // (a segment's slot IS its index in `segments`: the row's entry is read back here instead of being carried through the loop)
+            if (kind == 2) {
+                const int sl_c = cold(sl);                       // (the fold's addresses are made here, not before the gather loop)
+                fold_cut_row(long_rows, segments[dst].long_index, sl_c == 0, cold(lane) - sl_c, sl_c < LPR && 4 * sl_c < d, sl_c, d, partial, ep, y, ldy);
+            }
+        }
+#endif
     }
 #ifdef IGCN_SPMM_TRACE
     {
@@ -352,54 +441,26 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
 #endif
 }
 
-// Adds the partial sums of each long row and applies the epilogue.  One wave per
-// long row; the G lane groups each sum a strided subset of the slots (4 loads in
-// flight), then the groups are folded — a fixed order, so results are reproducible.
+// The two-launch form (igcn_set_tuning("spmm_fold", 0); also the reference the folded launches are checked against): adds the
+// partial sums of each cut row in slot order — the same chain per column as fold_cut_row, hence the same bits — and applies the
+// epilogue.  One wave per long row, its first lane group at work.
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void spmm_long_rows_reduce_kernel(
     const igcn_long_row *__restrict__ long_rows, int64_t n_long, const float *__restrict__ partial,
     float *__restrict__ y, int64_t ldy, int d, SpmmEpilogue ep, const uint8_t *__restrict__ row_mask, int masked_rows_zero)
 {
-    constexpr int G = kWave / LPR;
     const int lane = threadIdx.x & (kWave - 1);
     const int g = lane / LPR, t = lane % LPR;
     const bool lane_on = (4 * t) < d;
     const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-    if (wave >= n_long) return;
+    if (wave >= n_long || g != 0 || !lane_on) return;
     const igcn_long_row lr = long_rows[wave];
     if (row_mask && !row_mask[lr.row]) {
-        if (masked_rows_zero && g == 0 && lane_on) *reinterpret_cast<float4 *>(y + (int64_t)lr.row * ldy + 4 * t) = f4_zero();
+        if (masked_rows_zero) *reinterpret_cast<float4 *>(y + (int64_t)lr.row * ldy + 4 * t) = f4_zero();
         return;
     }
-    const float *base = partial + (int64_t)lr.first_slot * d + 4 * t;
-    float4 acc = f4_zero();
-    if (lane_on) {
-        int s = g;
-        for (; s + 3 * G < lr.n_slots; s += 4 * G) {
-            const float4 p0 = *reinterpret_cast<const float4 *>(base + (int64_t)s * d);
-            const float4 p1 = *reinterpret_cast<const float4 *>(base + (int64_t)(s + G) * d);
-            const float4 p2 = *reinterpret_cast<const float4 *>(base + (int64_t)(s + 2 * G) * d);
-            const float4 p3 = *reinterpret_cast<const float4 *>(base + (int64_t)(s + 3 * G) * d);
-            f4_add(acc, p0); f4_add(acc, p1); f4_add(acc, p2); f4_add(acc, p3);
-        }
-        for (; s < lr.n_slots; s += G) f4_add(acc, *reinterpret_cast<const float4 *>(base + (int64_t)s * d));
-    }
-#pragma unroll
-    for (int off = LPR; off < kWave; off <<= 1) f4_add(acc, f4_shfl_xor(acc, off));
-    if (g != 0 || !lane_on) return;
-    const int64_t dst = lr.row;
-    float4 r = make_float4(acc.x * ep.out_scale, acc.y * ep.out_scale, acc.z * ep.out_scale, acc.w * ep.out_scale);
-    if (ep.n_adds > 0) {
-        float4 sum = f4_zero();
-        for (int i = 0; i < ep.n_adds; ++i)
-            f4_add(sum, *reinterpret_cast<const float4 *>(ep.add[i] + dst * ldy + 4 * t));
-        f4_fma(r, ep.add_scale, sum);
-    }
-    if (ep.row_scale) {
-        const float rs = ep.row_scale[dst];
-        r.x *= rs; r.y *= rs; r.z *= rs; r.w *= rs;
-    }
-    *reinterpret_cast<float4 *>(y + dst * ldy + 4 * t) = r;
+    const float4 acc = sum_partials_in_slot_order(partial + (int64_t)lr.first_slot * d + 4 * t, lr.n_slots, d, false);
+    finish_row(acc, lr.row, t, ep, y, ldy);
 }
 
 // Any d (not a multiple of 4, or misaligned leading dimensions): one wave per
@@ -522,7 +583,7 @@ static int launch_rows(bool dropout, int64_t blocks, hipStream_t st,
                        const int64_t *rowptr, const int32_t *col, const float *val, const float *x, int64_t ldx,
                        float *y, int64_t ldy, int64_t n_rows, int d, const SpmmEpilogue &ep, const SpmmDropout &dr,
                        const igcn_row_segment *segments, int64_t n_segments, float *partial, int long_threshold,
-                       const igcn_long_row *long_rows, int64_t n_long, const uint8_t *row_mask, int masked_rows_zero,
+                       igcn_long_row *long_rows, int64_t n_long, const uint8_t *row_mask, int masked_rows_zero,
                        int64_t nnz, const int32_t *row_order, const int64_t *xcd_off)
 {
     // Grid: `blocks` on entry = one wave per row.  Fewer, longer-lived waves amortise the per-wave set-up;
@@ -556,24 +617,26 @@ static int launch_rows(bool dropout, int64_t blocks, hipStream_t st,
     // by that); at d >= 128 one row already fills the wave's loads (2: +1...6 %)
     constexpr int R = LPR >= 32 ? 1 : LPR >= 8 ? 2 : 4;
     const bool multirow = R > 1 && tune.multirow;
+    // cut rows are added up inside the launch by the wave that delivers their last partial sum ("spmm_fold" 0: by a second kernel)
+    igcn_long_row *fold = n_long > 0 && tuning_get(IGCN_TUNE_SPMM_FOLD) > 0 ? long_rows : nullptr;     // (off until measured: see DESIGN 4.1)
     if (multirow) {
         if constexpr (R > 1) {
             if (dropout)
                 hipLaunchKernelGGL((spmm_csr_multirow_kernel<LPR, R, true>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y,
-                                   ldy, n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order, xcd_off);
+                                   ldy, n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order, xcd_off, fold);
             else
                 hipLaunchKernelGGL((spmm_csr_multirow_kernel<LPR, R, false>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y,
-                                   ldy, n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order, xcd_off);
+                                   ldy, n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order, xcd_off, fold);
         }
     } else if (dropout)
         hipLaunchKernelGGL((spmm_csr_rows_kernel<LPR, true>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
-                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order, xcd_off);
+                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order, xcd_off, fold);
     else
         hipLaunchKernelGGL((spmm_csr_rows_kernel<LPR, false>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
-                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order, xcd_off);
+                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order, xcd_off, fold);
     int rc = launch_status();
     if (rc != IGCN_OK) return rc;
-    if (n_long > 0) {
+    if (n_long > 0 && !fold) {
         const int64_t blocks = (n_long + (kBlock / kWave) - 1) / (kBlock / kWave);
         hipLaunchKernelGGL((spmm_long_rows_reduce_kernel<LPR>), dim3((unsigned)blocks), dim3(kBlock), 0, st,
                            long_rows, n_long, partial, y, ldy, d, ep, row_mask, masked_rows_zero);
@@ -620,14 +683,15 @@ extern "C" int igcn_spmm_plan_fill_host(const int64_t *rowptr_host, int64_t n_ro
         long_rows_host[il].row = (int32_t)r;
         long_rows_host[il].first_slot = (int32_t)is;
         long_rows_host[il].n_slots = (int32_t)n;
-        long_rows_host[il].reserved = 0;
+        long_rows_host[il].arrived = 0;
+        const int32_t this_long = (int32_t)il;
         ++il;
         for (int64_t p = s; p < e; p += segment_len, ++is) {
             segments_host[is].start = p;
             segments_host[is].len = (int32_t)((e - p) < segment_len ? (e - p) : segment_len);
             segments_host[is].slot = (int32_t)is;
             segments_host[is].row = (int32_t)r;
-            segments_host[is].reserved = 0;
+            segments_host[is].long_index = this_long;
         }
     }
     return (il == n_long_rows && is == n_segments) ? IGCN_OK : IGCN_E_SHAPE;
@@ -638,7 +702,7 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
                                  int64_t n_rows, int64_t n_cols, int32_t d,
                                  float out_scale, const float *const *adds_host, int32_t n_adds,
                                  float add_scale, const float *row_scale, const float *col_scale,
-                                 const igcn_long_row *long_rows, int64_t n_long_rows,
+                                 igcn_long_row *long_rows, int64_t n_long_rows,
                                  const igcn_row_segment *segments, int64_t n_segments,
                                  float *partial, int32_t long_threshold,
                                  const int32_t *edge_id, uint64_t seed, float keep_prob,
@@ -767,7 +831,7 @@ extern "C" int igcn_set_tuning(const char *name, int32_t value)
     static const char *const names[IGCN_TUNE_COUNT] = {"spmm_blocks_per_cu", "spmm_multirow", "topk_slots",
                                                        "topk_waves_per_cu", "topk_cap", "topk_stagger", "topk_fast_mode",
                                                        "topk_fast_order", "topk_fast_exit", "topk_fast_wide", "topk_fast_extra", "topk_fast_give_up", "topk_fast_narrow", "topk_fast_share",
-                                                       "topk_fast_fallback", "topk_fast_early_checks", "topk_fast_warm", "topk_fast_filter", "topk_fast_pieces"};
+                                                       "topk_fast_fallback", "topk_fast_early_checks", "topk_fast_warm", "topk_fast_filter", "topk_fast_pieces", "spmm_fold"};
     if (!name) return IGCN_E_NULL;
     for (int i = 0; i < IGCN_TUNE_COUNT; ++i)
         if (strcmp(name, names[i]) == 0) { g_tuning[i] = value < 0 ? 0 : value + 1; return IGCN_OK; }

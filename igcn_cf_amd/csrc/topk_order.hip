@@ -117,9 +117,12 @@ __global__ __launch_bounds__(kBlock) void order_place_kernel(const uint32_t *__r
     const int leader = peers ? __ffsll((long long)peers) - 1 : lane;
     start = (uint32_t)__shfl((int)start, leader);
     if (active) {
+        // (pos < n whenever the bins arrived zeroed; the guard keeps a caller's broken ordering — bins that were not — from becoming
+        // a write outside the workspace: the lists are then wrong, which the caller can see, instead of a GPU fault, which takes the
+        // process and possibly the node with it)
         const uint32_t pos = group_base[bin >> 10] + start + (uint32_t)__popcll(below);
-        perm[pos] = (int32_t)i;
-        inv[i] = (int32_t)pos;
+        if ((int64_t)pos < n) perm[pos] = (int32_t)i;
+        inv[i] = (int64_t)pos < n ? (int32_t)pos : (int32_t)i;
     }
 }
 
@@ -385,8 +388,8 @@ int topk_order_build(const TopkOrderLayout &L, char *ws, int64_t n_items, const 
         const uint8_t *needed = nullptr;
         if (user_ids || batch < excl_rows) {
             uint8_t *flags = reinterpret_cast<uint8_t *>(ws + L.needed);
-            hipError_t me = hipMemsetAsync(flags, 0, (size_t)excl_rows, st);
-            if (me != hipSuccess) return (int)me;
+            const int me = zero_async(flags, (size_t)excl_rows, st);          // (a kernel, not a memset node: common.h)
+            if (me != IGCN_OK) return me;
             hipLaunchKernelGGL(excl_mark_rows_kernel, dim3((unsigned)((batch + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, user_ids, batch,
                                excl_rows, flags);
             needed = flags;

@@ -354,6 +354,9 @@ def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assi
             raise ValueError('every cut row needs its own run of segments (rows sorted, nonzeros stored row by row)')
         long_rows[:, 0], long_rows[:, 1] = long_ids.int(), firsts.int()
         long_rows[:, 2] = torch.diff(torch.cat([firsts, torch.tensor([n_seg], **i64)])).int()
+        # igcn_row_segment.long_index: the segment's row as an entry of long_rows (the launch folds a cut row through it);
+        # long_rows[:, 3] = igcn_long_row.arrived, the row's arrival counter: zero here, zero after every launch
+        segments[:, 5] = (torch.cumsum(is_first.to(torch.int64), 0) - 1).int()
 
     # deal the blocks, one after the other, keeping the lists' total work level
     load = torch.zeros(NL, dtype=torch.float64, device=dev)

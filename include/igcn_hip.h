@@ -31,8 +31,8 @@ extern "C" {
 #define IGCN_E_ALIGN      -3   /* a pointer / stride misses its alignment  */
 #define IGCN_E_RANGE      -4   /* a scalar argument is out of range        */
 #define IGCN_E_NO_DEVICE  -5   /* no HIP device is available               */
-#define IGCN_E_CAPTURE    -6   /* the stream is capturing and a kernel of the call carries scratch (never the case for
-                                  the library as built: its kernels have no private segment; see csrc/common.h) */
+#define IGCN_E_CAPTURE    -6   /* the stream is capturing and the call cannot be captured: igcn_csr_transpose (rocPRIM's sort),
+                                  or a kernel that carries scratch (none does in the library as built; csrc/common.h) */
 
 #define IGCN_MAX_ADDS      8   /* epilogue addends of igcn_spmm_csr_f32     */
 #define IGCN_MAX_TOPK    256   /* k of igcn_score_topk_f32                  */
@@ -56,22 +56,25 @@ const char *igcn_error_string(int code);
 int igcn_set_tuning(const char *name, int32_t value);
 
 /* One piece of a long CSR row (a "row segment"): nonzeros [start, start+len)
- * of row `row`, whose partial sum goes to partial[slot].  Built once per graph
- * by igcn_spmm_plan_fill_host. */
+ * of row `row`, whose partial sum goes to partial[slot]; long_index = the row's
+ * entry in the igcn_long_row array (ABI v8; was a reserved word).  Built once
+ * per graph by igcn_spmm_plan_fill_host. */
 typedef struct igcn_row_segment {
     int64_t start;
     int32_t len;
     int32_t slot;
     int32_t row;
-    int32_t reserved;
+    int32_t long_index;
 } igcn_row_segment;
 
-/* One long row: its partial sums are partial[first_slot .. first_slot+n_slots). */
+/* One long row: its partial sums are partial[first_slot .. first_slot+n_slots), slots in the order of the row's nonzeros.
+ * arrived (ABI v8; was a reserved word): the row's arrival counter inside a launch — ZERO when the array is handed to the
+ * library and zero again when a launch has finished; the library writes it, nobody else does (see igcn_spmm_csr_f32). */
 typedef struct igcn_long_row {
     int32_t row;
     int32_t first_slot;
     int32_t n_slots;
-    int32_t reserved;
+    int32_t arrived;
 } igcn_long_row;
 
 /* Host-side schedule for rows longer than `long_threshold` nonzeros (power-law
@@ -141,7 +144,7 @@ int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *va
                       int64_t n_rows, int64_t n_cols, int32_t d,
                       float out_scale, const float *const *adds_host, int32_t n_adds,
                       float add_scale, const float *row_scale, const float *col_scale,
-                      const igcn_long_row *long_rows, int64_t n_long_rows,
+                      igcn_long_row *long_rows, int64_t n_long_rows,
                       const igcn_row_segment *segments, int64_t n_segments,
                       float *partial, int32_t long_threshold,
                       const int32_t *edge_id, uint64_t seed, float keep_prob,
@@ -278,9 +281,10 @@ int igcn_score_topk_bounded_f32(const float *user_rows, int64_t ldu, const int64
  * reads flagged[0] afterwards and re-does only positions flagged[1 + IGCN_FAST_FALLBACK_MAX ..] with
  * igcn_score_topk_bounded_f32 (bounds flagged_lower_bound[IGCN_FAST_FALLBACK_MAX ..]); with flagged_lower_bound NULL
  * every flagged user is the caller's (igcn_score_topk_fast_finished_max tells how many the call finishes).  No host synchronisation
- * inside, and no kernel of the call carries a private segment (round 5; round 4's sweep kernels spilled 32-76 bytes a lane, and ROCm 7.2
- * faulted when a graph holding them was replayed by a queue that had never run a scratch-using kernel): the call can be captured into a
- * HIP graph by the standard recipe — warm up on a side stream, capture, replay on any stream.  (Late round 4: of those first users, the ones whose bound is
+ * inside, no runtime memset (round 5: the call's state is zeroed by a kernel of the library's own — a captured hipMemsetAsync becomes a
+ * memset NODE, which ROCm 7.2 does not order against the kernel nodes behind it; round 4's replay fault, found under rocgdb) and no
+ * kernel with a private segment: the call can be captured into a HIP graph by the standard recipe — warm up on a side stream,
+ * capture, replay on any stream.  (Late round 4: of those first users, the ones whose bound is
  * the k-th exact score of a complete candidate list first take a streaming filter — every (user, item) pair scored once with the
  * fp32 sweep's arithmetic, the pairs that reach the bound kept and ranked — and the bounded sweep runs for the rest: users whose wave
  * gave up on them, users without a bound, users whose ties overflow the filter's 256 entries.  Same lists either way.)

@@ -6,7 +6,8 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, 'liboracle_c.so')
+# IGCN_ORACLE_LIB_PATH: developer override (the ASan / UBSan build of scripts/sanitize_host.sh); the built file is never overwritten
+LIB = os.environ.get('IGCN_ORACLE_LIB_PATH') or os.path.join(HERE, 'liboracle_c.so')
 _lib = None
 
 

@@ -1,7 +1,8 @@
 """Child process of tests/test_score_bpr_gpu.py::test_two_stage_call_replays_from_a_captured_hip_graph: a FRESH process in which
 nothing has run on the replaying stream, and PyTorch's documented capture recipe — warm-up on a side stream, capture, replay on the
-current stream.  (Round 4: this sequence faulted the GPU on the first replay, the sweep kernels carried a private segment and the
-replaying queue had never been given scratch; since round 5 no kernel of the calls has one.)  Prints 'ok <n>' per replay checked."""
+current stream.  (Round 4: this sequence faulted the GPU on the first replay.  Round 5, under rocgdb: order_place_kernel wrote out of
+bounds because its bins had not been zeroed — the call's hipMemsetAsync, captured as a memset NODE, is not ordered against the kernel
+nodes behind it on ROCm 7.2; the library now zeroes with a kernel of its own.)  Prints 'ok <n>' per replay checked."""
 import os
 import sys
 

@@ -45,10 +45,10 @@ def test_library_is_loaded_behind_torch_in_a_fresh_process():
 
 def test_no_kernel_of_the_built_library_carries_a_private_segment():
     """Read out of the SHIPPED code object (the offload bundles inside libigcn_hip.so, their AMDGPU metadata notes — no compile, no
-    GPU): every kernel of the library has private_segment_fixed_size == 0 and no dynamic stack.  A kernel with scratch cannot be
-    replayed from a HIP graph by a queue that never ran one eagerly (round 4: the candidate sweeps spilled 32-76 bytes a lane and
-    the first replay of a captured igcn_score_topk_fast_f32 faulted the GPU); a later edit that brings spills back fails here —
-    and fails build() — instead of on a caller's GPU.  rocPRIM's radix sort (igcn_csr_transpose, a graph-build utility) is the one
+    GPU): every kernel of the library has private_segment_fixed_size == 0 and no dynamic stack — nothing of a call depends on
+    per-queue scratch (round 4 blamed a replay fault on the 32-76 bytes a lane the candidate sweeps spilled then; the fault turned
+    out to be the captured memset node, csrc/common.h, but the rule stays).  A later edit that brings spills back fails here — and
+    fails build() — instead of showing up as a slower kernel or on a caller's GPU.  rocPRIM's radix sort (igcn_csr_transpose, a graph-build utility) is the one
     exception, and that entry point refuses a capturing stream (IGCN_E_CAPTURE)."""
     from igcn_cf_amd import _build, _lib
     meta = _build.kernel_metadata(_lib.LIB_PATH)
@@ -67,6 +67,19 @@ def test_no_kernel_of_the_built_library_carries_a_private_segment():
         one_wave = 'ILi256E' in name or 'ILi128ELi2ELb1ELi2E' in name
         assert regs <= (512 if one_wave else 256), (name, regs)
     assert _lib.lib().igcn_error_string(-6).decode().startswith('stream is capturing')
+
+
+def test_no_entry_point_relies_on_a_runtime_memset_node():
+    """A hipMemsetAsync inside a captured call becomes a memset NODE, which ROCm 7.2 does not order against the kernel nodes behind
+    it (round 5, profiles/r05b_capture_fault_rocgdb.txt): the library zeroes with its own kernel (common.h: zero_async).  No source
+    of the shipped library calls the runtime's memset / memcpy."""
+    csrc = os.path.join(ROOT, 'igcn_cf_amd', 'csrc')
+    for name in sorted(os.listdir(csrc)):
+        if name == 'roof_probe.hip' or not name.endswith(('.hip', '.h')):     # (bench.py's measurement kernels: a library of their own)
+            continue
+        code = re.sub(r'//[^\n]*', '', open(os.path.join(csrc, name)).read())
+        # (hipMemcpyFrom/ToSymbol: the developer trace builds' read-back, compiled out of the shipped library)
+        assert not re.search(r'\bhipMem(set|cpy)(?!FromSymbol|ToSymbol)\w*\s*\(', code), name
 
 
 def test_a_library_of_another_abi_version_is_refused_at_load_time():

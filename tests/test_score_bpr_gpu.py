@@ -750,12 +750,12 @@ def test_two_stage_second_whole_sweep_of_a_wave_counts_its_own_leavers():
 
 
 def test_two_stage_call_replays_from_a_captured_hip_graph():
-    """igcn_score_topk_fast_f32 makes no host read and no allocation, and no kernel of it carries a private segment (include/igcn_hip.h,
+    """igcn_score_topk_fast_f32 makes no host read, no allocation and no runtime memset, and no kernel of it carries a private segment (include/igcn_hip.h,
     ABI v8): the whole evaluation — row statistics, order build, row sorts, candidate sweep, re-scoring, the flagged users' filter and
     bounded sweep — can be captured into ONE HIP graph by PyTorch's documented recipe (warm-up on a side stream, capture, replay on the
     current stream) and replayed on new table contents; so can the fp32 sweep (igcn_score_topk_f32).  Run in a FRESH child process
-    (tests/capture_child.py), where the replaying stream has run nothing eagerly — the sequence that faulted the GPU in round 4, when
-    the sweep kernels still spilled.  d = 64 and 128, three refills each (flat norms: warm-up pass; spread norms: early exits): the lists
+    (tests/capture_child.py), where the replaying stream has run nothing eagerly — the sequence that faulted the GPU in round 4 (the
+    call's captured hipMemsetAsync, a memset node, was not ordered against the kernels behind it: csrc/common.h, zero_async).  d = 64 and 128, three refills each (flat norms: warm-up pass; spread norms: early exits): the lists
     are the fp32 sweep's every time and flagged[0] stays within what the call finishes itself.  The child also checks that
     igcn_csr_transpose (rocPRIM's sort, the one kernel family with scratch) REFUSES a capturing stream with IGCN_E_CAPTURE."""
     import subprocess
