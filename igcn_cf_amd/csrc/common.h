@@ -135,6 +135,9 @@ __host__ __device__ __forceinline__ uint32_t hash_counter(uint64_t counter, uint
 // they cost a wave per SIMD.  Costs no instruction.
 __device__ __forceinline__ int cold(int x) { asm volatile("" : "+v"(x)); return x; }
 
+// a zero row made where it is stored (a cold path: masked rows that must read as zero) — f4_zero() there is hoisted out of the row
+// loop as four registers of zeros carried across the gather loop
+__device__ __forceinline__ float4 f4_zero_here() { const float z = __int_as_float(cold(0)); return make_float4(z, z, z, z); }
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ void f4_fma(float4 &a, float w, const float4 &x) {
     a.x = fmaf(w, x.x, a.x); a.y = fmaf(w, x.y, a.y); a.z = fmaf(w, x.z, a.z); a.w = fmaf(w, x.w, a.w);

@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
             to_partial = false;
             if (row_mask && !row_mask[v]) {                                   // output not needed
                 if (masked_rows_zero && g == 0 && lane_on)
-                    *reinterpret_cast<float4 *>(y + dst * ldy + 4 * t) = f4_zero();
+                    *reinterpret_cast<float4 *>(y + dst * ldy + 4 * t) = f4_zero_here();
                 continue;
             }
         } else {
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
             if (row_mask && !row_mask[s.row]) {
                 // (folded launches have no reduce kernel to zero a masked cut row: its first segment does)
                 if (long_rows && masked_rows_zero && long_rows[s.long_index].first_slot == s.slot && g == 0 && lane_on)
-                    *reinterpret_cast<float4 *>(y + (int64_t)s.row * ldy + 4 * t) = f4_zero();
+                    *reinterpret_cast<float4 *>(y + (int64_t)s.row * ldy + 4 * t) = f4_zero_here();
                 continue;
             }
             start = s.start;
@@ -287,9 +287,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
             }
         }
         if (long_rows && to_partial) {                                        // (wave-uniform)
+#ifndef IGCN_X_FOLD_NOWAIT
             asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+#endif
+#ifndef IGCN_X_FOLD_NOATOMIC
             const int lane_c = cold(lane);                                   // (the fold's addresses are made here, not before the gather loop)
             fold_cut_row(long_rows, segments[dst].long_index, lane_c == 0, 0, lane_c < LPR && 4 * lane_c < d, lane_c, d, partial, ep, y, ldy);   // (slot == index in `segments`)
+#endif
         }
     }
 #ifdef IGCN_SPMM_TRACE
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) IGCN_X
 
         if (g == 0 && lane_on) {
             if (kind == 3) {
-                *reinterpret_cast<float4 *>(y + (int64_t)dst * ldy + 4 * t) = f4_zero();
+                *reinterpret_cast<float4 *>(y + (int64_t)dst * ldy + 4 * t) = f4_zero_here();
             } else if (kind == 2) {
                 store_partial_agent(partial + (int64_t)dst * d + 4 * t, acc);   // (agent scope in either form: one code path)
             } else if (kind == 1) {
@@ -416,12 +420,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) IGCN_X
         }
 #ifndef IGCN_X_NOFOLD
         if (long_rows && __any(kind == 2)) {
+            // (developer ablations, never shipped: IGCN_X_FOLD_NOWAIT / _NOATOMIC give wrong results and the cost of each part)
+#ifndef IGCN_X_FOLD_NOWAIT
             asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+#endif
+#ifndef IGCN_X_FOLD_NOATOMIC
             // (a segment's slot IS its index in `segments`: the row's entry is read back here instead of being carried through the loop)
             if (kind == 2) {
                 const int sl_c = cold(sl);                       // (the fold's addresses are made here, not before the gather loop)
                 fold_cut_row(long_rows, segments[dst].long_index, sl_c == 0, cold(lane) - sl_c, sl_c < LPR && 4 * sl_c < d, sl_c, d, partial, ep, y, ldy);
             }
+#endif
         }
 #endif
     }

@@ -42,6 +42,24 @@ def _dist_on():
     return dist.is_available() and dist.is_initialized()
 
 
+class TorchCollectives:
+    """The collectives of the sharded path: torch.distributed over the process group (RCCL on the GPUs, gloo in the CPU
+    tests).  A seam, not an abstraction layer: tests pass an object of the same shape whose copies complete as LATE as RCCL's
+    may (at wait(), tests/test_dist_cpu.py) — gloo's wait() blocks the host, so a missing wait goes unnoticed under it."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def active(self):
+        return _dist_on()
+
+    def all_gather_into_tensor(self, out, inp, async_op):
+        return dist.all_gather_into_tensor(out, inp, group=self.group, async_op=async_op)
+
+    def all_reduce(self, buf):
+        dist.all_reduce(buf, group=self.group)
+
+
 class ShardLayout:
     """Contiguous user / item blocks per rank and the padded layout of the replicated buffers.
 
@@ -140,7 +158,8 @@ class RowShardedPropagator:
 
     def __init__(self, train_array, n_users, n_items, n_layers, rank, world, device, group=None,
                  spmm_fn=None, csr_factory=None, adjacency=None, exchange=None, balance=True,
-                 layout=None, local_blocks=None, global_nnz=None):
+                 layout=None, local_blocks=None, global_nnz=None, collectives=None):
+        self.collectives = collectives if collectives is not None else TorchCollectives(group)
         if exchange is None:
             exchange = 'fused' if (n_users + n_items) * 256 <= FUSED_EXCHANGE_MAX_BYTES else 'halves'
         if exchange not in ('fused', 'halves'):
@@ -221,10 +240,10 @@ class RowShardedPropagator:
         return rep[:L.pu] if part == 'u' else rep[L.pu:]
 
     def _allgather(self, out, inp, async_op):
-        if not _dist_on():
+        if not self.collectives.active():
             out.copy_(inp)                               # one rank without a process group
             return None
-        return dist.all_gather_into_tensor(out, inp, group=self.group, async_op=async_op)
+        return self.collectives.all_gather_into_tensor(out, inp, async_op)
 
     def load_local_embedding(self, emb_u_local, emb_i_local):
         """Owned rows of the layer-0 embeddings -> own[0], then exchange X_0 into rep[0]."""
@@ -367,8 +386,8 @@ class _BatchRowsFn(torch.autograd.Function):
                 buf[sel, c0:c0 + widths[t]] = rows
                 c0 += widths[t]
             ctx.sel, ctx.loc, ctx.bu = sel, loc, L.bu
-        if _dist_on():
-            dist.all_reduce(buf, group=prop.group)
+        if prop.collectives.active():
+            prop.collectives.all_reduce(buf)
         outs, c0 = [], 0
         for w in widths:
             outs.append(buf[:, c0:c0 + w])
@@ -428,12 +447,12 @@ class ShardedLightGCN(torch.nn.Module):
 
     def __init__(self, dataset, embedding_size, n_layers, rank, world, device, group=None, seed=2021,
                  spmm_fn=None, csr_factory=None, loss_fn=None, full_embedding=None, exchange=None, balance=True,
-                 adjacency=None):
+                 adjacency=None, collectives=None):
         super().__init__()
         self.n_users, self.n_items, self.n_layers = dataset.n_users, dataset.n_items, n_layers
         self.prop = RowShardedPropagator(dataset.train_array, dataset.n_users, dataset.n_items, n_layers, rank, world,
                                          device, group=group, spmm_fn=spmm_fn, csr_factory=csr_factory, exchange=exchange,
-                                         balance=balance, adjacency=adjacency)
+                                         balance=balance, adjacency=adjacency, collectives=collectives)
         L = self.prop.layout
         (ulo, uhi), (ilo, ihi) = L.user_rows(rank), L.item_rows(rank)
         if full_embedding is None:                       # normal_(std=0.1), model.py:82 — same table on every rank

@@ -20,3 +20,16 @@ def golden(request):
     g['name'] = request.param
     g['path'] = os.path.join(GOLDEN, request.param)
     return g
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _developer_tuning():
+    """IGCN_TEST_TUNING="spmm_fold=0,topk_fast_mode=2": run the whole suite under non-default launch knobs (developer A/Bs of a
+    kernel form that is not the default).  Unset: the library's defaults."""
+    spec = os.environ.get('IGCN_TEST_TUNING', '')
+    if spec:
+        from igcn_cf_amd import _lib
+        for item in spec.split(','):
+            name, value = item.split('=')
+            _lib.set_tuning(name.strip(), int(value))
+    yield

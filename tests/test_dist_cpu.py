@@ -337,3 +337,233 @@ def test_local_blocks_are_checked_against_their_layout():
         RowShardedPropagator(None, 60, 30, 2, 0, 2, 'cpu', spmm_fn=cpu_spmm, exchange='halves', layout=L3, local_blocks=blocks)
     with pytest.raises(ValueError):                                  # users and items swapped
         RowShardedPropagator(None, 60, 30, 2, 0, 2, 'cpu', spmm_fn=cpu_spmm, exchange='halves', layout=L, local_blocks=blocks[::-1])
+
+
+# ---- the exchange logic under RCCL's completion semantics (no node needed) ----------------------------------------------------
+class LateCollectives:
+    """The collectives of `world` ranks that run as THREADS of this process, completing as late as RCCL's may.
+
+    gloo's `work.wait()` blocks the host until the copy is done; RCCL's only orders streams — the copy lands at some point
+    between the call and the completion of the wait.  This object takes the adversarial legal schedule:
+      * at the CALL of an all-gather the destination is poisoned (NaN): whoever reads it before the wait reads garbage;
+        the source is snapshotted;
+      * a rank's copy happens inside ITS wait(), once every rank has issued the same collective, from the sources as they are
+        THEN — a source overwritten before its collective completed is detected (compared with the snapshot) and reported;
+      * a wait() returns only when every rank has taken its copy (a source is free again when its owner's wait returns).
+    An all-gather whose wait the code under test forgets (`skip_wait`, the negative control) never lands on that rank: its
+    destination stays poisoned, the other ranks are not kept waiting for it.  all_reduce is blocking and in place (as in the code
+    under test): every rank contributes once, the sums replace the buffers when all have arrived."""
+
+    def __init__(self, world, timeout=60.0):
+        import threading
+        self.world, self.timeout = world, timeout
+        self.cv = threading.Condition()
+        self.pending = {}                  # sequence number -> {rank: (out, inp, snapshot)}
+        self.copied = {}                   # sequence number -> ranks that took their copy (or will never take it)
+        self.issued = [0] * world
+        self.reduce_slots, self.reduce_read = {}, {}
+        self.reduced = [0] * world
+        self.errors = []
+        self.n_async = 0
+        self.skip_wait = None              # (rank, nth asynchronous all-gather of that rank): its wait() is a no-op
+
+    def bind(self, rank):
+        return _RankView(self, rank)
+
+    def _until(self, cond):
+        with self.cv:
+            if not self.cv.wait_for(cond, self.timeout):
+                raise TimeoutError('a rank never reached the collective the others are in')
+
+
+class _Work:
+    def __init__(self, owner, rank, seq):
+        self.owner, self.rank, self.seq = owner, rank, seq
+
+    def wait(self):
+        o = self.owner
+        o._until(lambda: len(o.pending.get(self.seq, {})) == o.world)      # every rank has issued this collective
+        entries = o.pending[self.seq]
+        out = entries[self.rank][0]
+        rows = entries[self.rank][1].shape[0]
+        for q in range(o.world):
+            _, inp, snap = entries[q]
+            if not torch.equal(inp, snap):
+                with o.cv:
+                    o.errors.append('rank %d overwrote the source of all-gather %d before it completed' % (q, self.seq))
+            out[q * rows:(q + 1) * rows].copy_(inp)
+        with o.cv:
+            o.copied.setdefault(self.seq, set()).add(self.rank)
+            o.cv.notify_all()
+        o._until(lambda: len(o.copied[self.seq]) == o.world)               # every rank has its copy: the sources are free again
+        return True
+
+
+class _RankView:
+    def __init__(self, owner, rank):
+        self.owner, self.rank, self.n_async = owner, rank, 0
+
+    def active(self):
+        return True
+
+    def all_gather_into_tensor(self, out, inp, async_op):
+        o = self.owner
+        assert out.shape[0] == inp.shape[0] * o.world and out.is_contiguous() and inp.is_contiguous()
+        out.fill_(float('nan'))                                 # the collective may write its destination from now on
+        forget = bool(async_op) and o.skip_wait == (self.rank, self.n_async)
+        with o.cv:
+            seq = o.issued[self.rank]
+            o.issued[self.rank] += 1
+            o.pending.setdefault(seq, {})[self.rank] = (out, inp, inp.clone())
+            o.n_async += bool(async_op)
+            if forget:
+                o.copied.setdefault(seq, set()).add(self.rank)  # (this rank will never take its copy)
+            o.cv.notify_all()
+        work = _Work(o, self.rank, seq)
+        if not async_op:
+            work.wait()
+            return None
+        self.n_async += 1
+        return type('ForgottenWait', (), {'wait': lambda self: True})() if forget else work
+
+    def all_reduce(self, buf):
+        o = self.owner
+        with o.cv:
+            seq = o.reduced[self.rank]
+            o.reduced[self.rank] += 1
+            o.reduce_slots.setdefault(seq, {})[self.rank] = buf
+            o.cv.notify_all()
+        o._until(lambda: len(o.reduce_slots[seq]) == o.world)
+        total = sum(o.reduce_slots[seq][q].clone() for q in range(o.world))
+        with o.cv:
+            o.reduce_read.setdefault(seq, set()).add(self.rank)
+            o.cv.notify_all()
+        o._until(lambda: len(o.reduce_read[seq]) == o.world)             # everybody has read everybody's contribution
+        buf.copy_(total)
+
+
+def _run_ranks(world, fn):
+    """fn(rank) on one thread per rank; exceptions of any rank are re-raised here."""
+    import threading
+    results, errors = [None] * world, []
+
+    def body(r):
+        try:
+            results[r] = fn(r)
+        except BaseException as e:                              # noqa: BLE001 (a broken barrier in one rank must not hide the cause in another)
+            errors.append((r, e))
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    if errors:
+        raise errors[0][1]
+    return results
+
+
+def _late_pass(golden, world, n_layers, exchange, skip_wait=None):
+    from igcn_cf_amd.dist import RowShardedPropagator
+    nu, ni = int(golden['n_users']), int(golden['n_items'])
+    ta = golden['train_array']
+    rng = np.random.default_rng(0)
+    emb = (rng.standard_normal((nu + ni, 8)) * 0.1).astype(np.float32)
+    coll = LateCollectives(world)
+    coll.skip_wait = skip_wait
+
+    def rank_fn(rank):
+        prop = RowShardedPropagator(ta, nu, ni, n_layers, rank, world, 'cpu', spmm_fn=cpu_spmm,
+                                    csr_factory=lambda rp, c, v, shape: CpuCsr(rp, c, v, shape), exchange=exchange,
+                                    collectives=coll.bind(rank))
+        L = prop.layout
+        (ulo, uhi), (ilo, ihi) = L.user_rows(rank), L.item_rows(rank)
+        outs = []
+        for _ in range(2):                                      # two passes: the buffers of the first are re-used by the second
+            prop.load_local_embedding(torch.from_numpy(emb[ulo:uhi]), torch.from_numpy(emb[nu + ilo:nu + ihi]))
+            ru, ri = prop.propagate()
+            outs.append((ru[:uhi - ulo].numpy().copy(), ri[:ihi - ilo].numpy().copy()))
+        return outs, (ulo, uhi, ilo, ihi)
+    res = _run_ranks(world, rank_fn)
+    ref = O.lightgcn_get_rep(O.lightgcn_norm_adj(ta, nu, ni), emb, n_layers)
+    return res, ref, coll, nu
+
+
+@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('exchange', ['fused', 'halves'])
+@pytest.mark.parametrize('n_layers', [1, 2, 3, 4])
+def test_exchange_logic_holds_when_collectives_complete_as_late_as_rccl_allows(golden, world, exchange, n_layers):
+    """RowShardedPropagator.propagate keeps an all-gather in flight under the other half's SpMM ('halves') and re-uses two
+    replicated buffers in turn.  Under gloo a missing or misplaced wait() is invisible (its wait blocks the host and the copy is
+    long done); RCCL only orders streams.  Here the copies land at the latest legal moment, destinations are poisoned while a
+    collective is in flight and sources are checked at completion: every owned row equals the unsharded oracle, in both of two
+    consecutive passes, and nobody touched a source early.  world 2 and 3, K = 1 ... 4, both exchanges."""
+    res, ref, coll, nu = _late_pass(golden, world, n_layers, exchange)
+    assert not coll.errors, coll.errors
+    if exchange == 'halves' and n_layers > 1:
+        assert coll.n_async > 0                                  # the overlapped form really was exercised
+    for outs, (ulo, uhi, ilo, ihi) in res:
+        for ru, ri in outs:
+            assert np.isfinite(ru).all() and np.isfinite(ri).all()
+            np.testing.assert_allclose(ru, ref[ulo:uhi], rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(ri, ref[nu + ilo:nu + ihi], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize('nth', [0, 1, 2, 3, 4, 5])
+def test_a_forgotten_wait_is_noticed_by_the_late_collectives(golden, nth):
+    """Negative control of the harness: the same pass ('halves', K = 3, two ranks) with ONE wait of rank 0 turned into a no-op —
+    each of the six asynchronous all-gathers of a pass in turn (the two of the X_0 exchange, the four half-layer gathers).  The
+    half-layer that reads the section still in flight sees the poison: rank 0's result is not the oracle's, every time."""
+    res, ref, coll, nu = _late_pass(golden, 2, 3, 'halves', skip_wait=(0, nth))
+    outs, (ulo, uhi, ilo, ihi) = res[0]
+    ru, ri = outs[0]
+    assert not (np.isfinite(ru).all() and np.isfinite(ri).all())
+
+
+@pytest.mark.parametrize('world,exchange', [(2, 'fused'), (3, 'halves')])
+def test_sharded_training_steps_under_late_collectives(golden, world, exchange):
+    """Two Adam steps of ShardedLightGCN — forward pass, the batch rows' all-reduce (_BatchRowsFn), backward pass through the
+    same sharded operator — with every collective completing late: losses and the gathered table equal the dense unsharded
+    chain's, world 2 and 3."""
+    from igcn_cf_amd.dataset import ProcessedDataset
+    from igcn_cf_amd.dist import ShardedLightGCN
+    nu, ni = int(golden['n_users']), int(golden['n_items'])
+    ta = golden['train_array']
+    n_layers = 3
+    rng = np.random.default_rng(1)
+    emb = (rng.standard_normal((nu + ni, 8)) * 0.1).astype(np.float32)
+    batch = np.stack([rng.integers(0, nu, 64), rng.integers(0, ni, 64), rng.integers(0, ni, 64)], axis=1).astype(np.int64)
+    row, col, val = O.lightgcn_norm_adj(ta, nu, ni)
+    a = torch.sparse_coo_tensor(np.stack([row, col]), val, (nu + ni, nu + ni)).to_dense()
+    e = torch.nn.Parameter(torch.from_numpy(emb.copy()))
+    opt = torch.optim.Adam([e], lr=1e-2)
+    b = torch.from_numpy(batch)
+    ref_losses = []
+    for _ in range(2):
+        x, layers = e, [e]
+        for _l in range(n_layers):
+            x = a @ x
+            layers.append(x)
+        terms = torch_bpr_terms(torch.stack(layers).mean(0), e, b[:, 0], b[:, 1], b[:, 2], nu)
+        loss = terms[0] + 1e-2 * terms[1]
+        opt.zero_grad(); loss.backward(); opt.step()
+        ref_losses.append(float(loss.detach()))
+    coll = LateCollectives(world)
+    ds = ProcessedDataset({'name': 'ProcessedDataset', 'path': golden['path'], 'device': 'cpu'})
+
+    def rank_fn(rank):
+        model = ShardedLightGCN(ds, emb.shape[1], n_layers, rank, world, 'cpu', spmm_fn=cpu_spmm,
+                                csr_factory=lambda rp, c, v, shape: CpuCsr(rp, c, v, shape), loss_fn=torch_bpr_terms_rows,
+                                full_embedding=torch.from_numpy(emb), exchange=exchange, collectives=coll.bind(rank))
+        o = torch.optim.Adam(model.parameters(), lr=1e-2)
+        losses = []
+        for _ in range(2):
+            terms = model.bpr_loss_terms(b[:, 0], b[:, 1], b[:, 2])
+            l = terms[0] + 1e-2 * terms[1]
+            o.zero_grad(); l.backward(); o.step()
+            losses.append(float(l))
+        return losses, model.full_embedding().numpy().copy()
+    res = _run_ranks(world, rank_fn)
+    assert not coll.errors, coll.errors
+    for losses, full in res:
+        np.testing.assert_allclose(losses, ref_losses, rtol=1e-5)
+        np.testing.assert_allclose(full, e.detach().numpy(), rtol=1e-4, atol=1e-6)
