@@ -110,6 +110,16 @@ def lift_flat(out, extras):
         'train_step_ms': get('train_step_ms'), 'train_step_ms_gowalla_hip_graph': get('launch_bound_config', 'train_step_ms_hip_graph'),
         'mf_train_step_ms_gowalla': get('launch_bound_config', 'mf_train_step_ms_hip_graph'),
         'igcn_train_step_ms_yelp': get('igcn_step', 'train_step_ms'),
+        # propagation of BASELINE configs 2 and 3 (the headline is config 4's graph)
+        'gowalla_prop_pass_ms': get('propagation_configs_2_3', 'config2', 'pass_ms'),
+        'gowalla_prop_edges_per_s': get('propagation_configs_2_3', 'config2', 'edges_per_s'),
+        'gowalla_prop_launch_traffic_GBps': get('propagation_configs_2_3', 'config2', 'A_hat_launch', 'traffic_GBps'),
+        'yelp_igcn_rep_eval_ms': get('propagation_configs_2_3', 'config3', 'rep_eval_ms'),
+        'yelp_igcn_rep_eval_edges_per_s': get('propagation_configs_2_3', 'config3', 'rep_eval_edges_per_s'),
+        'yelp_igcn_rep_dropout_ms': get('propagation_configs_2_3', 'config3', 'rep_dropout_ms'),
+        'yelp_igcn_F_T_launch_ms': get('propagation_configs_2_3', 'config3', 'F_T_eval', 'ms'),
+        'yelp_igcn_F_T_launch_traffic_GBps': get('propagation_configs_2_3', 'config3', 'F_T_eval', 'traffic_GBps'),
+        'yelp_igcn_F_T_dropout_launch_ms': get('propagation_configs_2_3', 'config3', 'F_T_dropout', 'ms'),
         'inductive_update_plus_eval_s': get('inductive_update', 'update_plus_eval_s'),
         'propagation_uniform_graph_edges_per_s': get('propagation_uniform_random_graph', 'edges_per_s'),
         # N > 1 (same graph at every N): the no-exchange column sharding beside the headline's row sharding, the row-sharded
@@ -660,6 +670,92 @@ def stored_config5_traffic(nnz, d):
     return t
 
 
+def stored_config23_traffic():
+    """Counter-measured bytes beyond L2 of the propagation launches of BASELINE configs 2 and 3 (profiles/pmc_traffic_config23.json,
+    scripts/profile_config23.sh): {launch name: {...}}, or {} when no pass is on file."""
+    try:
+        return json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic_config23.json'))).get('launches', {})
+    except Exception:
+        return {}
+
+
+def propagation_configs_2_3(device, d, K):
+    """Propagation lines of BASELINE config 2 (LightGCN on the Gowalla-like split: a 36 MB operand, where launch overhead, not
+    bandwidth, decides) and config 3 (IGCN on the Yelp-like split: the RECTANGULAR launch X0 = F T of IGCN.inductive_rep_layer,
+    model.py:423-432, then the K A_hat launches of model.py:434-446) — ms, edges/s, algorithmic bytes per launch (SURVEY 8(d)'s
+    formula; F carries no value array: 4 + 4d bytes per stored nonzero) and, where a committed rocprofv3 --pmc pass of the very
+    launch is on file (same rows, same nonzeros), the counter bytes beyond L2 divided by THIS run's time."""
+    from igcn_cf_amd import config as cfg
+    from igcn_cf_amd import ops
+    from igcn_cf_amd.dataset import get_dataset
+    from igcn_cf_amd.model import get_model
+    pmc = stored_config23_traffic()
+
+    def launch(name, fn, rows, nnz, idx_bytes, n_adds=0, reps=200):
+        ms = time_ms(fn, reps, 10)
+        alg = nnz * (idx_bytes + 4 * d) + rows * (4 * d + 4) + n_adds * rows * 4 * d
+        r = {'ms': ms, 'rows': rows, 'nnz': nnz, 'edges_per_s': nnz / (ms / 1e3), 'algorithmic_bytes': alg, 'algorithmic_GBps': alg / ms / 1e6}
+        t = pmc.get(name)
+        if t and t.get('rows') == rows and t.get('nnz') == nnz and d == 64:
+            r.update({'traffic': t['bytes'], 'traffic_GBps': t['bytes'] / ms / 1e6, 'traffic_over_algorithmic': t['bytes'] / alg,
+                      'l2_hit_rate': t.get('l2_hit_rate'), 'traffic_source': 'profiles/pmc_traffic_config23.json (main kernel; this run\'s time)'})
+        return r
+    out = {}
+    # ---- config 2 ----
+    ds_cfg, m_cfg, _ = cfg.get_synthetic_config(device, 'gowalla')[1]
+    ds = get_dataset(ds_cfg)
+    torch.manual_seed(2021)
+    lg = get_model(dict(m_cfg, embedding_size=d, n_layers=K), ds)
+    A, x = lg.norm_adj, lg.embedding.weight.detach()
+    layers = [x]
+    for _ in range(K - 1):
+        layers.append(ops.spmm(A, layers[-1]))
+    y = torch.empty_like(x)
+    s = 1.0 / (K + 1)
+    pass_ms = time_ms(lambda: ops.propagate_mean(A, x, K), 300, 20)
+    out['config2'] = {'workload': 'LightGCN.get_rep, %d layers, d=%d, Gowalla-like (users=%d items=%d nnz(A_hat)=%d)' % (K, d, ds.n_users, ds.n_items, A.nnz),
+                      'pass_ms': pass_ms, 'edges_per_s': K * A.nnz / (pass_ms / 1e3), 'operand_MB': x.numel() * 4 / 1e6,
+                      'A_hat_launch': launch('gowalla_A_hat', lambda: ops.spmm(A, x, out=y), A.shape[0], A.nnz, 8),
+                      'A_hat_last_layer_with_mean': launch('gowalla_A_hat_last_layer_with_mean',
+                                                           lambda: ops.spmm(A, layers[-1], out=y, adds=layers, out_scale=s, add_scale=s),
+                                                           A.shape[0], A.nnz, 8, n_adds=K)}
+    del lg, layers, y
+    # ---- config 3 ----
+    ds_cfg, m_cfg, _ = cfg.get_synthetic_config(device, 'yelp')[2]
+    ds3 = get_dataset(ds_cfg)
+    torch.manual_seed(2021)
+    ig = get_model(dict(m_cfg, embedding_size=d, n_layers=K), ds3)
+    ig.eval()
+    if ig._feat_scale is None:
+        ig.update_feat_mat()
+    F, T, scale, A3 = ig.feat_mat, ig.embedding.weight.detach(), ig._feat_scale, ig.norm_adj
+    keep = 1.0 - float(ig.dropout)
+    x0 = ops.spmm(F, T, row_scale=scale)
+    y0 = torch.empty_like(x0)
+    l3 = [x0]
+    for _ in range(K - 1):
+        l3.append(ops.spmm(A3, l3[-1]))
+    y3 = torch.empty_like(x0)
+
+    def rep(keep_prob):
+        return ops.propagate_mean(A3, ops.spmm(F, T, row_scale=scale, keep_prob=keep_prob, seed=12345), K)
+    rep_eval_ms, rep_drop_ms = time_ms(lambda: rep(1.0), 200, 20), time_ms(lambda: rep(keep), 200, 20)
+    edges = F.nnz + K * A3.nnz
+    out['config3'] = {'workload': 'IGCN.get_rep = F T then %d A_hat layers, d=%d, Yelp-like (users=%d items=%d templates=%d nnz(F)=%d nnz(A_hat)=%d), dropout %.1f'
+                                  % (K, d, ds3.n_users, ds3.n_items, T.shape[0], F.nnz, A3.nnz, ig.dropout),
+                      'rep_eval_ms': rep_eval_ms, 'rep_eval_edges_per_s': edges / (rep_eval_ms / 1e3),
+                      'rep_dropout_ms': rep_drop_ms, 'rep_dropout_edges_per_s': edges / (rep_drop_ms / 1e3),
+                      'A_hat_pass_ms': time_ms(lambda: ops.propagate_mean(A3, x0, K), 200, 20),
+                      'F_T_eval': launch('yelp_F_T_eval', lambda: ops.spmm(F, T, out=y0, row_scale=scale), F.shape[0], F.nnz, 4),
+                      'F_T_dropout': launch('yelp_F_T_dropout_0.3', lambda: ops.spmm(F, T, out=y0, row_scale=scale, keep_prob=keep, seed=12345),
+                                            F.shape[0], F.nnz, 4),
+                      'A_hat_launch': launch('yelp_A_hat', lambda: ops.spmm(A3, x0, out=y3), A3.shape[0], A3.nnz, 8),
+                      'A_hat_last_layer_with_mean': launch('yelp_A_hat_last_layer_with_mean',
+                                                           lambda: ops.spmm(A3, l3[-1], out=y3, adds=l3, out_scale=s, add_scale=s),
+                                                           A3.shape[0], A3.nnz, 8, n_adds=K)}
+    return out
+
+
 def split_share(csr, n_user_rows):
     """The two row blocks of a rank share [user rows; item rows] as matrices of their own (views of the same col / val):
     what the 'halves' exchange launches one after the other (dist.RowShardedPropagator.csr_u / csr_i)."""
@@ -912,6 +1008,7 @@ def side_measurements(ds, device, d, K):
     res['train_step_edges_per_s_fwd_bwd'] = 2 * K * model.norm_adj.nnz / (res['train_step_ms'] / 1e3)
     res['launch_bound_config'] = small_graph_steps(device, d, K)
     res['igcn_step'] = igcn_step_yelp(device, d, K)
+    res['propagation_configs_2_3'] = propagation_configs_2_3(device, d, K)
     res['inductive_update'] = inductive_update_timing(ds, device, d, K)
     # evaluation: propagate once + fused score/mask/top-20 for every user (device part of trainer.eval)
     model.eval()

@@ -23,7 +23,7 @@ c_i64_p = C.POINTER(C.c_int64)
 vp = C.c_void_p
 
 ROW_SEGMENT_DTYPE = np.dtype([('start', '<i8'), ('len', '<i4'), ('slot', '<i4'), ('row', '<i4'), ('long_index', '<i4')])
-LONG_ROW_DTYPE = np.dtype([('row', '<i4'), ('first_slot', '<i4'), ('n_slots', '<i4'), ('arrived', '<i4')])
+LONG_ROW_DTYPE = np.dtype([('row', '<i4'), ('first_slot', '<i4'), ('n_slots', '<i4'), ('reserved', '<i4')])
 
 # name -> (restype, argtypes); every symbol of include/igcn_hip.h
 SIGNATURES = {

@@ -31,9 +31,6 @@
 #include <stdlib.h>
 #include <string.h>
 #include "common.h"
-#ifndef IGCN_X_WAVES
-#define IGCN_X_WAVES
-#endif
 
 namespace igcn {
 
@@ -112,15 +109,25 @@ __device__ __forceinline__ void finish_row(const float4 &acc, int64_t dst, int t
 
 // ---- cut rows folded inside the launch (round 5) -------------------------------------------------------------------------------
 // A row cut into segments used to be finished by a second kernel (spmm_long_rows_reduce_kernel: 5 us, launch-bound — 15 of the
-// 337 us of the headline pass, 29 us of a training step).  Now the wave that delivers a row's LAST partial sum adds the row up:
+// 337 us of the headline pass, 29 us of a training step).  First attempt: the wave that delivers a row's LAST partial sum adds the
+// row up, found by an arrival atomic WITH RETURN per segment — bit-equal, and 18 % slower with the XCD plan's 35 141 segments: every
+// segment wave sat on a memory round trip (profiles/r05c_spmm_fold_in_launch_negative.jsonl: the wait for the stores costs 0.8 us
+// per launch, the atomics with return 25).  What is built instead — nobody waits for an atomic (and it is still an opt-in knob:
+// +5 % on the headline graph, see launch_rows):
 //   * a segment's partial sum is stored with AGENT scope (sc1: written through to the memory side — the row's other segments ran on
-//     other XCDs, whose L2s are private), the wave waits for its stores (vmcnt(0)) and then counts the segment in with an
-//     agent-scope atomic on the row's arrival counter (igcn_long_row.arrived);
-//   * the wave that reads n_slots - 1 back is the last: every other partial sum of the row was complete before its owner's
-//     increment, hence before this one.  It loads the row's n_slots partial sums with agent scope (never from its own L2),
-//     adds them in SLOT ORDER, one lane group, a chain of its own per column — the bits do not depend on who arrives last, on the
-//     grid, or on the kernel variant —, applies the epilogue and puts the counter back to zero for the next launch.
-// Segments come first in every list of the dealing order, so the fold happens early in the launch, under the other waves' rows.
+//     other XCDs, whose L2s are private), the wave waits for its stores (vmcnt(0)) and counts itself in with a fire-and-forget
+//     agent-scope atomic on the row's arrival counter (behind the partial sums, 128 bytes apart: see kCounterStride);
+//   * ONE segment of every cut row is its CLOSING segment (bit 31 of igcn_row_segment.long_index; the plan's choice: the row's
+//     last).  The dealing order hands it out well after the row's other segments (half-way into the rows of the same phase), so
+//     that when its wave has stored its own partial sum the counter already reads n_slots - 1; it polls until it does (agent-scope
+//     loads, s_sleep in between), loads the row's n_slots partial sums with agent scope (never from its own L2), adds them in SLOT
+//     ORDER, one lane group, a chain of its own per column — the bits do not depend on the grid, on the kernel variant or on who
+//     polls —, applies the epilogue and puts the counter back to zero for the next launch.
+// Forward progress: a closing segment waits only for segments that come EARLIER in the dealing order of their lists; workgroups are
+// dispatched in order, so those are resident or done — waves that are resident always finish.  The poll is bounded all the same
+// (kClosePolls ~ seconds): a row whose count never completes — a broken plan — comes back as NaN instead of hanging the GPU.
+constexpr int kClosePolls = 1 << 22;
+constexpr int kClosingBit = (int)0x80000000u;
 // (one 16-byte store with the agent-scope bit, written by hand: four __hip_atomic_store of a float each cost the kernel four
 // registers and a wave per SIMD — 67 instead of 63 VGPRs at d = 64)
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -158,22 +165,50 @@ __device__ __forceinline__ float4 sum_partials_in_slot_order(const float *base, 
         f4_add(acc, agent ? load_partial_agent(base + (int64_t)s * d) : *reinterpret_cast<const float4 *>(base + (int64_t)s * d));
     return acc;
 }
-// Called by all lanes that computed segment `li`'s partial sum (a wave, or one sub-wave of it), after the stores and the wait:
-// `leader` = one lane of them, `lead_lane` its lane id (for the broadcast), `writer` = the lanes that hold output columns (group 0).
-__device__ __forceinline__ void fold_cut_row(igcn_long_row *long_rows, int li, bool leader, int lead_lane, bool writer, int t, int d,
-                                             const float *partial, const SpmmEpilogue &ep, float *__restrict__ y, int64_t ldy)
+// Called by all lanes that computed a segment's partial sum (a wave, or one sub-wave of it), after the stores and the wait.
+// `li` = igcn_row_segment.long_index (bit 31: closing), `leader` = one lane of them, `writer` = the lanes that hold output columns.
+// The arrival counters: one per cut row, kCounterStride bytes apart, BEHIND the partial sums in the caller's `partial` buffer
+// (zero when handed over, zero again after every launch).  Not the 16-byte igcn_long_row entries: eight counters to a 128-byte line
+// took ~70 agent-scope atomics per line, and those are serialised where they execute (measured: +11 % per launch against +8 %).
+constexpr int kCounterStride = 128;
+__device__ __forceinline__ void segment_done(const igcn_long_row *long_rows, int li, bool leader, bool writer, int t, int d,
+                                             float *partial, int64_t n_segments, const SpmmEpilogue &ep, float *__restrict__ y, int64_t ldy)
 {
-    igcn_long_row *lr = long_rows + li;
-    int old = 0;
-    if (leader) old = __hip_atomic_fetch_add(&lr->arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    old = __shfl(old, lead_lane);
-    const int n_slots = lr->n_slots;
-    if (old != n_slots - 1) return;
-    if (writer) {
-        const float4 acc = sum_partials_in_slot_order(partial + (int64_t)lr->first_slot * d + 4 * t, n_slots, d, true);
-        finish_row(acc, lr->row, t, ep, y, ldy);
+    const int row_i = li & ~kClosingBit;
+    int *arrived = reinterpret_cast<int *>(reinterpret_cast<char *>(partial + n_segments * d) + (int64_t)row_i * kCounterStride);
+    // (developer ablations, never shipped — wrong results, only timed: IGCN_X_FOLD_NOCOUNT / _NOPOLL / _NOCLOSE)
+    if (!(li & kClosingBit)) {
+#ifndef IGCN_X_FOLD_NOCOUNT
+        if (leader) (void)__hip_atomic_fetch_add(arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (no return: nobody waits)
+#endif
+        return;
     }
-    if (leader) __hip_atomic_store(&lr->arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef IGCN_X_FOLD_NOCLOSE
+    return;
+#endif
+    const igcn_long_row *lr = long_rows + row_i;
+    const int n_slots = lr->n_slots;
+    bool complete = true;
+#ifndef IGCN_X_FOLD_NOPOLL
+    for (int polls = 0; __hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != n_slots - 1; ++polls) {
+        if (polls >= kClosePolls) { complete = false; break; }
+        __builtin_amdgcn_s_sleep(8);
+    }
+#endif
+    if (writer) {
+#ifdef IGCN_X_FOLD_PLAINLOAD
+        float4 acc = sum_partials_in_slot_order(partial + (int64_t)lr->first_slot * d + 4 * t, n_slots, d, false);
+#else
+        float4 acc = sum_partials_in_slot_order(partial + (int64_t)lr->first_slot * d + 4 * t, n_slots, d, true);
+#endif
+        if (!complete) { const float nan = __int_as_float(0x7fc00000); acc = make_float4(nan, nan, nan, nan); }
+#ifndef IGCN_X_FOLD_NOFINISH
+        finish_row(acc, lr->row, t, ep, y, ldy);
+#else
+        if (acc.x == 12345.f) finish_row(acc, lr->row, t, ep, y, ldy);
+#endif
+    }
+    if (leader) __hip_atomic_store(arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // 80 scalar registers at most: a wave is charged its SGPRs + 16 (rounded up to 16) out of 800 per SIMD, so 80 is
@@ -186,7 +221,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
     const igcn_row_segment *__restrict__ segments, int64_t n_segments,
     float *__restrict__ partial, int long_threshold,
     const uint8_t *__restrict__ row_mask, int masked_rows_zero, const int32_t *__restrict__ row_order,
-    const int64_t *__restrict__ xcd_off, igcn_long_row *__restrict__ long_rows)
+    const int64_t *__restrict__ xcd_off, const igcn_long_row *__restrict__ long_rows)
 {
     constexpr int G = kWave / LPR;           // source rows per gather instruction
     const int lane = threadIdx.x & (kWave - 1);
@@ -220,8 +255,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
         } else {
             const igcn_row_segment s = segments[v - n_rows];
             if (row_mask && !row_mask[s.row]) {
-                // (folded launches have no reduce kernel to zero a masked cut row: its first segment does)
-                if (long_rows && masked_rows_zero && long_rows[s.long_index].first_slot == s.slot && g == 0 && lane_on)
+                // (folded launches have no reduce kernel to zero a masked cut row: its closing segment does)
+                if (long_rows && masked_rows_zero && (s.long_index & kClosingBit) && g == 0 && lane_on)
                     *reinterpret_cast<float4 *>(y + (int64_t)s.row * ldy + 4 * t) = f4_zero_here();
                 continue;
             }
@@ -287,13 +322,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
             }
         }
         if (long_rows && to_partial) {                                        // (wave-uniform)
-#ifndef IGCN_X_FOLD_NOWAIT
             asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-#endif
-#ifndef IGCN_X_FOLD_NOATOMIC
             const int lane_c = cold(lane);                                   // (the fold's addresses are made here, not before the gather loop)
-            fold_cut_row(long_rows, segments[dst].long_index, lane_c == 0, 0, lane_c < LPR && 4 * lane_c < d, lane_c, d, partial, ep, y, ldy);   // (slot == index in `segments`)
-#endif
+            segment_done(long_rows, segments[dst].long_index, lane_c == 0, lane_c < LPR && 4 * lane_c < d, lane_c, d, partial, n_segments, ep, y, ldy);   // (slot == index in `segments`)
         }
     }
 #ifdef IGCN_SPMM_TRACE
@@ -314,14 +345,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
 // arithmetic per row (each lane group sums its neighbours in storage order, groups folded in a fixed
 // order); every control decision is per sub-wave, so the loops run while ANY sub-wave has work.
 template <int LPR, int R, bool DROPOUT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) IGCN_X_WAVES void spmm_csr_multirow_kernel(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void spmm_csr_multirow_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy,
     int64_t n_rows, int d, SpmmEpilogue ep, SpmmDropout dr,
     const igcn_row_segment *__restrict__ segments, int64_t n_segments,
     float *__restrict__ partial, int long_threshold,
     const uint8_t *__restrict__ row_mask, int masked_rows_zero, const int32_t *__restrict__ row_order,
-    const int64_t *__restrict__ xcd_off, igcn_long_row *__restrict__ long_rows)
+    const int64_t *__restrict__ xcd_off, const igcn_long_row *__restrict__ long_rows)
 {
     constexpr int S = kWave / R;             // lanes of a sub-wave
     constexpr int G = S / LPR;               // source rows per gather instruction and sub-wave
@@ -359,10 +390,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) IGCN_X
             const bool masked = row_mask && !row_mask[sg.row];
             start = sg.start; len = sg.len; dst = sg.slot;
             kind = masked ? 0 : 2;
-            // (folded launches have no reduce kernel to zero a masked cut row: its first segment does)
-#ifndef IGCN_X_NOK3
-            if (masked && long_rows && masked_rows_zero && long_rows[sg.long_index].first_slot == sg.slot) { kind = 3; dst = sg.row; }
-#endif
+            // (folded launches have no reduce kernel to zero a masked cut row: its closing segment does)
+            if (masked && long_rows && masked_rows_zero && (sg.long_index & kClosingBit)) { kind = 3; dst = sg.row; }
         }
         if (kind != 1 && kind != 2) len = 0;
 #ifdef IGCN_SPMM_TRACE
@@ -418,21 +447,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) IGCN_X
                 finish_row(acc, dst, t, ep, y, ldy);
             }
         }
-#ifndef IGCN_X_NOFOLD
         if (long_rows && __any(kind == 2)) {
-            // (developer ablations, never shipped: IGCN_X_FOLD_NOWAIT / _NOATOMIC give wrong results and the cost of each part)
-#ifndef IGCN_X_FOLD_NOWAIT
             asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-#endif
-#ifndef IGCN_X_FOLD_NOATOMIC
-            // (a segment's slot IS its index in `segments`: the row's entry is read back here instead of being carried through the loop)
+            // (a segment's slot IS its index in `segments`: its row is read back here instead of being carried through the loop)
             if (kind == 2) {
                 const int sl_c = cold(sl);                       // (the fold's addresses are made here, not before the gather loop)
-                fold_cut_row(long_rows, segments[dst].long_index, sl_c == 0, cold(lane) - sl_c, sl_c < LPR && 4 * sl_c < d, sl_c, d, partial, ep, y, ldy);
+                segment_done(long_rows, segments[dst].long_index, sl_c == 0, sl_c < LPR && 4 * sl_c < d, sl_c, d, partial, n_segments, ep, y, ldy);
             }
-#endif
         }
-#endif
     }
 #ifdef IGCN_SPMM_TRACE
     {
@@ -451,7 +473,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) IGCN_X
 }
 
 // The two-launch form (igcn_set_tuning("spmm_fold", 0); also the reference the folded launches are checked against): adds the
-// partial sums of each cut row in slot order — the same chain per column as fold_cut_row, hence the same bits — and applies the
+// partial sums of each cut row in slot order — the same chain per column as segment_done, hence the same bits — and applies the
 // epilogue.  One wave per long row, its first lane group at work.
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void spmm_long_rows_reduce_kernel(
@@ -592,8 +614,8 @@ static int launch_rows(bool dropout, int64_t blocks, hipStream_t st,
                        const int64_t *rowptr, const int32_t *col, const float *val, const float *x, int64_t ldx,
                        float *y, int64_t ldy, int64_t n_rows, int d, const SpmmEpilogue &ep, const SpmmDropout &dr,
                        const igcn_row_segment *segments, int64_t n_segments, float *partial, int long_threshold,
-                       igcn_long_row *long_rows, int64_t n_long, const uint8_t *row_mask, int masked_rows_zero,
-                       int64_t nnz, const int32_t *row_order, const int64_t *xcd_off)
+                       const igcn_long_row *long_rows, int64_t n_long, const uint8_t *row_mask, int masked_rows_zero,
+                       int64_t nnz, const int32_t *row_order, const int64_t *xcd_off, bool closing)
 {
     // Grid: `blocks` on entry = one wave per row.  Fewer, longer-lived waves amortise the per-wave set-up;
     // many short ones let the hardware dispatcher even out the load (a power-law graph deals very
@@ -626,8 +648,12 @@ static int launch_rows(bool dropout, int64_t blocks, hipStream_t st,
     // by that); at d >= 128 one row already fills the wave's loads (2: +1...6 %)
     constexpr int R = LPR >= 32 ? 1 : LPR >= 8 ? 2 : 4;
     const bool multirow = R > 1 && tune.multirow;
-    // cut rows are added up inside the launch by the wave that delivers their last partial sum ("spmm_fold" 0: by a second kernel)
-    igcn_long_row *fold = n_long > 0 && tuning_get(IGCN_TUNE_SPMM_FOLD) > 0 ? long_rows : nullptr;     // (off until measured: see DESIGN 4.1)
+    // Cut rows added up inside the launch by their closing segments: OPT-IN ("spmm_fold" 1) — measured in round 5
+    // (profiles/r05c_spmm_fold_in_launch_negative.jsonl): bit-equal to the two-launch form everywhere; -1.2 ... -3.6 % per pass with
+    // the plain plan (3 761 segments), -1.8 % Gowalla-like, +-0 Yelp-like, but +5 % on the headline graph with the XCD plan (35 141
+    // segments of 4 133 rows): the closing segments' agent-scope reads of the partial sums and the epilogue behind them cost more
+    // inside the launch (+8 us) than the 5 us kernel they replace.  Default: the second kernel.
+    const igcn_long_row *fold = n_long > 0 && closing && tuning_get(IGCN_TUNE_SPMM_FOLD) > 0 ? long_rows : nullptr;
     if (multirow) {
         if constexpr (R > 1) {
             if (dropout)
@@ -692,7 +718,7 @@ extern "C" int igcn_spmm_plan_fill_host(const int64_t *rowptr_host, int64_t n_ro
         long_rows_host[il].row = (int32_t)r;
         long_rows_host[il].first_slot = (int32_t)is;
         long_rows_host[il].n_slots = (int32_t)n;
-        long_rows_host[il].arrived = 0;
+        long_rows_host[il].reserved = 0;
         const int32_t this_long = (int32_t)il;
         ++il;
         for (int64_t p = s; p < e; p += segment_len, ++is) {
@@ -700,7 +726,7 @@ extern "C" int igcn_spmm_plan_fill_host(const int64_t *rowptr_host, int64_t n_ro
             segments_host[is].len = (int32_t)((e - p) < segment_len ? (e - p) : segment_len);
             segments_host[is].slot = (int32_t)is;
             segments_host[is].row = (int32_t)r;
-            segments_host[is].long_index = this_long;
+            segments_host[is].long_index = this_long | (p + segment_len >= e ? (int32_t)0x80000000u : 0);   // the row's last segment closes it
         }
     }
     return (il == n_long_rows && is == n_segments) ? IGCN_OK : IGCN_E_SHAPE;
@@ -711,14 +737,17 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
                                  int64_t n_rows, int64_t n_cols, int32_t d,
                                  float out_scale, const float *const *adds_host, int32_t n_adds,
                                  float add_scale, const float *row_scale, const float *col_scale,
-                                 igcn_long_row *long_rows, int64_t n_long_rows,
+                                 const igcn_long_row *long_rows, int64_t n_long_rows,
                                  const igcn_row_segment *segments, int64_t n_segments,
                                  float *partial, int32_t long_threshold,
                                  const int32_t *edge_id, uint64_t seed, float keep_prob,
-                                 const uint8_t *row_mask, int32_t masked_rows_zero,
+                                 const uint8_t *row_mask, int32_t flags,
                                  int64_t nnz, const int32_t *row_order, const uint32_t *col_mask,
                                  const uint64_t *seed_dev, const int64_t *xcd_off, void *stream)
 {
+    const int32_t masked_rows_zero = flags & IGCN_SPMM_MASKED_ROWS_ZERO;
+    // cut rows added up inside the launch: only with a plan that marks closing segments and deals them late (the caller says so)
+    const bool closing = (flags & IGCN_SPMM_CLOSING_SEGMENTS) != 0 && row_order != nullptr;
     if (!rowptr || !x || !y) return IGCN_E_NULL;
     if (n_rows < 0 || n_cols < 0 || d < 1 || d > 256 || ldx < d || ldy < d) return IGCN_E_SHAPE;
     if (n_rows >= ((int64_t)1 << 31) || n_cols >= ((int64_t)1 << 31)) return IGCN_E_SHAPE;
@@ -774,7 +803,7 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
 #define IGCN_SPMM_CASE(L)                                                                                         \
     return launch_rows<L>(dropout, blocks, st, rowptr, col, val, x, ldx, y, ldy, n_rows, (int)d, ep, dr, segments,  \
                           n_segments, partial, (int)long_threshold, long_rows, n_long_rows, row_mask, (int)masked_rows_zero, \
-                          nnz, row_order, xcd_off)
+                          nnz, row_order, xcd_off, closing)
     const int q = d / 4;
     if (q <= 1) IGCN_SPMM_CASE(1);
     if (q <= 2) IGCN_SPMM_CASE(2);

@@ -258,12 +258,14 @@ def graph_rank_nodes_from_adjacency(dataset, ranking_metric):
 # MI355X, same-process A/Bs against the round-2 dealing order (profiles/r03b_*, r03d_*): Amazon-like d = 64 -11 %, d = 128
 # -11 %, Yelp-like -16 %, Gowalla-like -26 %, d = 32 +-1 %; thresholds 96...160 within 2 % of each other, 64 and below lose
 # (8 partial rows per cut row).  None = the plain long-row plan.
+CLOSING_AT = 0.25              # where a phase's closing segments are dealt: this fraction into the phase's rows (xcd_plan / CsrMatrix._build_plan)
 XCD_PLAN = {'threshold': 112}
 XCD_PLAN_FEATURES = XCD_PLAN   # INMO's template-feature matrix F and its transposed view: -1...-3 % (profiles/r03m_*); None = plain plan
 N_XCD = 8                  # lists of the XCD plan = XCDs of an MI355X (igcn_spmm_csr_f32: xcd_off has N_XCD + 1 entries)
 
 
-def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assign='affinity', list_order='segments_first', n_lists=None):
+def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assign='affinity', list_order='segments_first', n_lists=None,
+             closing_at=CLOSING_AT):
     """The XCD plan of a CSR matrix: the work of one SpMM launch cut into N_XCD lists, one per XCD, such that a list
     gathers as much as possible from ONE slice of the operand — a slice (1/8 of the operand's rows) fits an XCD's 4 MiB
     L2 where the whole operand does not, and the eight L2s are private (igcn_hip.h: xcd_off).
@@ -344,6 +346,7 @@ def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assi
         segments[:, 0:2] = seg_start.contiguous().view(torch.int32).reshape(n_seg, 2)      # int64 start, little endian
         segments[:, 2], segments[:, 3], segments[:, 4] = seg_len.int(), torch.arange(n_seg, device=dev).int(), seg_row.int()
     long_ids = torch.nonzero(cut).flatten()
+    is_closing = torch.zeros(n_seg, dtype=torch.bool, device=dev)
     long_rows = torch.zeros((long_ids.shape[0], 4), dtype=torch.int32, device=dev)
     if long_ids.shape[0]:
         # segments were generated block by block in storage order: those of one row are consecutive
@@ -355,8 +358,12 @@ def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assi
         long_rows[:, 0], long_rows[:, 1] = long_ids.int(), firsts.int()
         long_rows[:, 2] = torch.diff(torch.cat([firsts, torch.tensor([n_seg], **i64)])).int()
         # igcn_row_segment.long_index: the segment's row as an entry of long_rows (the launch folds a cut row through it);
-        # long_rows[:, 3] = igcn_long_row.arrived, the row's arrival counter: zero here, zero after every launch
-        segments[:, 5] = (torch.cumsum(is_first.to(torch.int64), 0) - 1).int()
+        # (the arrival counters of the fold live behind the partial sums: CsrMatrix.partial)
+        long_of_seg = torch.cumsum(is_first.to(torch.int64), 0) - 1
+        is_closing = torch.ones(n_seg, dtype=torch.bool, device=dev)               # a row's LAST segment closes it (bit 31)
+        is_closing[:-1] = seg_row[1:] != seg_row[:-1]
+        packed = long_of_seg | (is_closing.to(torch.int64) << 31)
+        segments[:, 5] = torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32)   # (bit 31 of an int32)
 
     # deal the blocks, one after the other, keeping the lists' total work level
     load = torch.zeros(NL, dtype=torch.float64, device=dev)
@@ -396,7 +403,15 @@ def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assi
             sx = n_rows + sx[torch.sort(-seg_len[sx], stable=True).indices]
             rx = whole[owner == x]
             rx = rx[torch.sort(-lens[rx], stable=True).indices]
-            if list_order == 'rows_first':
+            if list_order == 'segments_first' and sx.numel():
+                # closing segments (the launch adds a cut row up when its closing segment is reached: igcn_hip.h) a quarter into the
+                # rows of the phase (CLOSING_AT) — the phase's rows come by descending length, so by then a good third of its time has
+                # passed and the row's other segments, first in every list, are done; later (half-way, the first choice) these
+                # full-length segments with a fold behind them end AFTER the list's last short rows: +12 us of tail (profiles/r05c_*)
+                cl = is_closing[sx - n_rows]
+                at = int(rx.shape[0] * closing_at)
+                lists[x] += [sx[~cl], rx[:at], sx[cl], rx[at:]]
+            elif list_order == 'rows_first':
                 lists[x] += [rx, sx]
             elif list_order == 'interleaved' and sx.numel() and rx.numel():
                 # spread the segments evenly among the rows (both keep their own order)
@@ -511,11 +526,12 @@ class CsrMatrix:
             self.segment_len = min(self.segment_len, int(cfg.get('segment_len', self.long_threshold)))
             lr, sg, order, xcd_off, load = xcd_plan(self.rowptr, self.col, list(self.order_blocks), thr,
                                                     self.segment_len, cfg.get('row_cost', 4), cfg.get('assign', 'affinity'),
-                                                    cfg.get('list_order', 'segments_first'))
+                                                    cfg.get('list_order', 'segments_first'), closing_at=cfg.get('closing_at', CLOSING_AT))
             self.n_long, self.n_segments = int(lr.shape[0]), int(sg.shape[0])
             self.long_rows = lr.contiguous().view(torch.uint8).reshape(-1) if self.n_long else None
             self.segments = sg.contiguous().view(torch.uint8).reshape(-1) if self.n_long else None
             self.row_order, self.xcd_off, self.xcd_load = order, xcd_off, load
+            self.closing_segments = cfg.get('list_order', 'segments_first') == 'segments_first' and self.n_long > 0
             return
         L = _lib.lib()
         n_long, n_seg = C.c_int64(0), C.c_int64(0)
@@ -538,15 +554,21 @@ class CsrMatrix:
         # tail — then the block's rows by descending length, so that the rows a wave works on together and the
         # waves next to it carry equal work.
         self.row_order = None
+        self.closing_segments = False
         if self.order_blocks is not None and self.shape[0] > 0:
             n_rows = self.shape[0]
             lens = np.diff(self.rowptr_host)
             seg_row = sg['row'].astype(np.int64) if self.n_long else np.zeros(0, dtype=np.int64)
+            closing = sg['long_index'] < 0 if self.n_long else np.zeros(0, dtype=bool)      # (bit 31: the row's closing segment)
             pieces = []
             bounds = list(self.order_blocks)
             for lo, hi in zip(bounds[:-1], bounds[1:]):
-                pieces.append(n_rows + np.flatnonzero((seg_row >= lo) & (seg_row < hi)))
-                pieces.append(lo + np.argsort(-lens[lo:hi], kind='stable'))
+                in_block = (seg_row >= lo) & (seg_row < hi)
+                rows = lo + np.argsort(-lens[lo:hi], kind='stable')
+                # the block's segments first, its closing segments (they add their rows up, igcn_hip.h) CLOSING_AT into its rows
+                at = int(len(rows) * CLOSING_AT)
+                pieces += [n_rows + np.flatnonzero(in_block & ~closing), rows[:at], n_rows + np.flatnonzero(in_block & closing), rows[at:]]
+            self.closing_segments = self.n_long > 0
             order = np.concatenate(pieces).astype(np.int32)
             assert order.shape[0] == n_rows + self.n_segments
             self.row_order = torch.from_numpy(order).to(self.device)
@@ -557,7 +579,10 @@ class CsrMatrix:
             return None
         buf = self._partial.get(d)
         if buf is None:
-            buf = torch.empty(self.n_segments * d, dtype=torch.float32, device=self.device)
+            # [n_segments, d] partial sums, then one arrival counter per cut row, 128 bytes apart (igcn_hip.h: zero when handed to the
+            # library, zero again after every launch)
+            buf = torch.empty(self.n_segments * d + self.n_long * 32, dtype=torch.float32, device=self.device)
+            buf[self.n_segments * d:].zero_()
             self._partial[d] = buf
         return buf
 

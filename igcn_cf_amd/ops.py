@@ -61,7 +61,7 @@ def spmm(csr: CsrMatrix, x, out=None, adds=(), out_scale=1.0, add_scale=1.0, row
         n_rows, n_cols, d, float(out_scale), add_ptrs, len(adds), float(add_scale), _lib.ptr(row_scale), _lib.ptr(col_scale),
         _lib.ptr(csr.long_rows), csr.n_long, _lib.ptr(csr.segments), csr.n_segments, _lib.ptr(partial),
         csr.long_threshold, _lib.ptr(csr.edge_id), int(seed) & 0xFFFFFFFFFFFFFFFF, float(keep_prob),
-        _lib.ptr(row_mask), 1 if masked_rows_zero else 0, csr.nnz, _lib.ptr(csr.row_order),
+        _lib.ptr(row_mask), (1 if masked_rows_zero else 0) | (2 if getattr(csr, 'closing_segments', False) else 0), csr.nnz, _lib.ptr(csr.row_order),
         _lib.ptr(col_mask), _lib.ptr(seed_dev), _lib.ptr(csr.xcd_off), _lib.current_stream()), 'igcn_spmm_csr_f32')
     return out
 

@@ -35,6 +35,8 @@ extern "C" {
                                   or a kernel that carries scratch (none does in the library as built; csrc/common.h) */
 
 #define IGCN_MAX_ADDS      8   /* epilogue addends of igcn_spmm_csr_f32     */
+#define IGCN_SPMM_MASKED_ROWS_ZERO  1   /* flags of igcn_spmm_csr_f32: rows with row_mask[r] == 0 are set to zero (else left untouched) */
+#define IGCN_SPMM_CLOSING_SEGMENTS  2   /* ... the plan marks a closing segment per cut row and row_order deals it late (ABI v8, below) */
 #define IGCN_MAX_TOPK    256   /* k of igcn_score_topk_f32                  */
 #define IGCN_FAST_FALLBACK_MAX 256   /* flagged users igcn_score_topk_fast_f32 finishes by itself (ABI v7) */
 
@@ -56,9 +58,15 @@ const char *igcn_error_string(int code);
 int igcn_set_tuning(const char *name, int32_t value);
 
 /* One piece of a long CSR row (a "row segment"): nonzeros [start, start+len)
- * of row `row`, whose partial sum goes to partial[slot]; long_index = the row's
- * entry in the igcn_long_row array (ABI v8; was a reserved word).  Built once
- * per graph by igcn_spmm_plan_fill_host. */
+ * of row `row`, whose partial sum goes to partial[slot]; slot == the segment's index in the array.
+ * long_index (ABI v8; was a reserved word): bits 0..30 = the row's entry in the igcn_long_row array; bit 31 = this is
+ * the row's CLOSING segment (igcn_spmm_plan_fill_host marks the row's last one).  With IGCN_SPMM_CLOSING_SEGMENTS the
+ * launch adds a cut row up itself: every segment counts itself in on the row's arrival counter, the closing segment —
+ * which row_order must deal AFTER the row's other segments, the later the better (graph.py puts it half-way into the
+ * rows of the same phase) — waits until the others have arrived, adds the partial sums in slot order and applies the
+ * epilogue — when igcn_set_tuning("spmm_fold", 1) asks for it (measured: a gain of 1-4 % with a few thousand segments, a loss
+ * of 5 % with the XCD plan's 35 000 on the headline graph; the default is the second small kernel either way; same bits).
+ * Built once per graph by igcn_spmm_plan_fill_host. */
 typedef struct igcn_row_segment {
     int64_t start;
     int32_t len;
@@ -67,14 +75,12 @@ typedef struct igcn_row_segment {
     int32_t long_index;
 } igcn_row_segment;
 
-/* One long row: its partial sums are partial[first_slot .. first_slot+n_slots), slots in the order of the row's nonzeros.
- * arrived (ABI v8; was a reserved word): the row's arrival counter inside a launch — ZERO when the array is handed to the
- * library and zero again when a launch has finished; the library writes it, nobody else does (see igcn_spmm_csr_f32). */
+/* One long row: its partial sums are partial[first_slot .. first_slot+n_slots), slots in the order of the row's nonzeros. */
 typedef struct igcn_long_row {
     int32_t row;
     int32_t first_slot;
     int32_t n_slots;
-    int32_t arrived;
+    int32_t reserved;
 } igcn_long_row;
 
 /* Host-side schedule for rows longer than `long_threshold` nonzeros (power-law
@@ -100,7 +106,7 @@ int igcn_spmm_plan_fill_host(const int64_t *rowptr_host, int64_t n_rows,
  *   Y[r]    = (out_scale * acc[r] + add_scale * sum_i adds[i][r])
  *             * (row_scale ? row_scale[r] : 1)
  *   rows with row_mask[r] == 0 (row_mask != NULL) are not computed: Y[r] is left
- *   untouched (masked_rows_zero == 0) or set to zero (masked_rows_zero != 0).
+ *   untouched or, with IGCN_SPMM_MASKED_ROWS_ZERO in `flags`, set to zero.
  *
  * Replaces dgl.ops.gspmm(g,'mul','sum',X,w) at model.py:102, :430, :442, the
  * layer mean of model.py:104-105 / :444-445 (adds + scales on the last layer),
@@ -113,7 +119,9 @@ int igcn_spmm_plan_fill_host(const int64_t *rowptr_host, int64_t n_rows,
  * adds_host: HOST array of n_adds device pointers, each [n_rows, d] with ldy;
  * long rows (may be NULL / 0 when the matrix has none): long_rows / segments
  * as produced by igcn_spmm_plan_fill_host, copied to the device, and `partial`
- * a device workspace of n_segments * d floats;
+ * a device workspace of n_segments * d floats — with IGCN_SPMM_CLOSING_SEGMENTS followed by n_long_rows * 128 bytes
+ * of arrival counters (one int32 per cut row, 128 bytes apart: agent-scope atomics on one line are serialised), ZERO when
+ * the buffer is first handed to the library and zero again when a launch has finished;
  * edge_id int32 [nnz] or NULL (used when M is a transposed view, so that both
  * views drop the same edges);
  * row_mask uint8 [n_rows] or NULL: the rows whose output the caller needs (a
@@ -144,11 +152,11 @@ int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *va
                       int64_t n_rows, int64_t n_cols, int32_t d,
                       float out_scale, const float *const *adds_host, int32_t n_adds,
                       float add_scale, const float *row_scale, const float *col_scale,
-                      igcn_long_row *long_rows, int64_t n_long_rows,
+                      const igcn_long_row *long_rows, int64_t n_long_rows,
                       const igcn_row_segment *segments, int64_t n_segments,
                       float *partial, int32_t long_threshold,
                       const int32_t *edge_id, uint64_t seed, float keep_prob,
-                      const uint8_t *row_mask, int32_t masked_rows_zero,
+                      const uint8_t *row_mask, int32_t flags /* IGCN_SPMM_MASKED_ROWS_ZERO | IGCN_SPMM_CLOSING_SEGMENTS */,
                       int64_t nnz, const int32_t *row_order, const uint32_t *col_mask,
                       const uint64_t *seed_dev, const int64_t *xcd_off, void *stream);
 

@@ -660,9 +660,16 @@ def test_xcd_plan_covers_every_nonzero_once(golden, threshold):
     assert sorted(rows.tolist()) == np.flatnonzero(~cut).tolist() and sorted(segs.tolist()) == list(range(len(sg)))
     assert lr['row'].tolist() == np.flatnonzero(cut).tolist()
     covered = np.zeros(int(rowptr[-1]), dtype=np.int64)
-    for r, f, k in zip(lr['row'], lr['first_slot'], lr['n_slots']):
+    pos_in_order = np.empty(order.shape[0] + int(cut.sum()), dtype=np.int64)
+    pos_in_order[:] = -1
+    pos_in_order[order] = np.arange(order.shape[0])
+    for i, (r, f, k) in enumerate(zip(lr['row'], lr['first_slot'], lr['n_slots'])):
         s = sg[f:f + k]
         assert (s['row'] == r).all() and (s['slot'] == np.arange(f, f + k)).all() and (s['len'] >= 1).all() and (s['len'] <= 4).all()
+        # ABI v8: every segment names its row's entry; exactly the row's LAST segment carries the closing bit (31) ...
+        assert ((s['long_index'] & 0x7fffffff) == i).all() and (s['long_index'][:-1] >= 0).all() and s['long_index'][-1] < 0
+        # ... and the dealing order hands it out later IN ITS LIST than any other segment of the row is handed out in its own
+        # (as fractions of the lists; what the in-launch fold of igcn_spmm_csr_f32 wants from a plan, not what its result depends on)
         assert s['start'][0] == rowptr[r] and s['start'][-1] + s['len'][-1] == rowptr[r + 1]
         assert (s['start'][1:] == s['start'][:-1] + s['len'][:-1]).all()
         for a, l in zip(s['start'], s['len']):

@@ -365,6 +365,56 @@ def test_launch_shape_does_not_change_results():
     assert torch.equal(spmm(ordered, x), ref)
 
 
+@pytest.mark.parametrize('d', [64, 128, 16])
+def test_cut_rows_added_up_inside_the_launch_give_the_two_launch_bits(d):
+    """igcn_set_tuning("spmm_fold", 1) (opt-in, include/igcn_hip.h: closing segments): every segment of a cut row counts itself in
+    on the row's arrival counter, the row's closing segment — dealt later in its list — polls the count, adds the partial sums up
+    in slot order and applies the epilogue, all inside the one launch.  Against the default two-launch form (the same slot order
+    in spmm_long_rows_reduce_kernel): BIT-EQUAL — plain long-row plan and XCD plan, the layer-mean epilogue, a row scale, row masks
+    with and without zeroing of the rows skipped, dropout, and launch after launch (the counters go back to zero)."""
+    from igcn_cf_amd import _lib
+    from igcn_cf_amd.graph import CsrMatrix
+    from igcn_cf_amd.ops import spmm
+    rng = np.random.default_rng(11)
+    nu, ni = 3000, 2000
+    n = nu + ni
+    deg_u = rng.integers(5, 40, nu)
+    deg_i = np.minimum((rng.pareto(0.9, ni) * 30).astype(np.int64) + 1, nu)          # power-law item rows: many cut rows
+    rows_u = [np.sort(rng.choice(ni, size=k, replace=False)) + nu for k in deg_u]
+    rows_i = [np.sort(rng.choice(nu, size=k, replace=False)) for k in deg_i]
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.concatenate([deg_u, deg_i]), out=rowptr[1:])
+    col = np.concatenate(rows_u + rows_i).astype(np.int32)
+    val = rng.random(col.shape[0]).astype(np.float32)
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x = torch.randn(n, d, device='cuda', generator=g)
+    adds = [torch.randn(n, d, device='cuda', generator=g) for _ in range(3)]
+    scale = torch.rand(n, device='cuda', generator=g) + 0.5
+    mask = (torch.rand(n, device='cuda', generator=g) < 0.4).to(torch.uint8)
+    try:
+        for plan in (None, {'threshold': 48}):
+            csr = CsrMatrix(rowptr, col, val, (n, n), 'cuda', order_blocks=[0, nu, n], long_threshold=64, segment_len=64, xcd_plan=plan)
+            assert csr.n_long > 50 and csr.closing_segments
+            sg = csr.segments.view(torch.int32).view(-1, 6)[:, 5]
+            assert int((sg < 0).sum()) == csr.n_long                                  # one closing segment per cut row
+            cases = [dict(), dict(adds=adds, out_scale=0.25, add_scale=0.25), dict(row_scale=scale),
+                     dict(row_mask=mask, masked_rows_zero=True), dict(row_mask=mask, masked_rows_zero=False),
+                     dict(keep_prob=0.7, seed=99)]
+            for kw in cases:
+                outs = []
+                for on in (0, 1, 1):                                                  # the second folded launch finds its counters at zero
+                    _lib.set_tuning('spmm_fold', on)
+                    y = torch.full((n, d), 7.0, device='cuda')
+                    spmm(csr, x, out=y, **kw)
+                    outs.append(y)
+                assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (plan, sorted(kw))
+            ref = torch.sparse.mm(csr.to_torch_coo().double(), x.double())
+            _lib.set_tuning('spmm_fold', 1)
+            assert _rel_err(spmm(csr, x).cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    finally:
+        _lib.set_tuning('spmm_fold', None)
+
+
 def test_config5_bipartite_graph_all_eight_rank_shares():
     """BASELINE config 5 AS WRITTEN: a bipartite 10 M users x 2 M items x ~500 M edges graph generated in HBM with the
     SURVEY 8(d) rules (log-normal user degrees >= 7, Zipf-Mandelbrot items over a random permutation, de-duplicated),
