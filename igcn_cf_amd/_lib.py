@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # overwritten for that (scripts/sanitize_host.sh used to copy its ASan build over it)
 LIB_PATH = os.environ.get('IGCN_LIB_PATH') or os.path.join(_PKG, 'libigcn_hip.so')
 
-EXPECTED_ABI = 8                 # IGCN_ABI_VERSION of include/igcn_hip.h this binding was written against
+EXPECTED_ABI = int(os.environ.get('IGCN_EXPECT_ABI') or 8)   # IGCN_ABI_VERSION of include/igcn_hip.h this binding was written against (env: developer A/Bs against a build of an earlier round)
 MAX_ADDS = 8
 MAX_TOPK = 256
 MAX_METRIC_CUTS = 8

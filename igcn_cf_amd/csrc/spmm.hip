@@ -133,6 +133,9 @@ constexpr int kClosingBit = (int)0x80000000u;
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_partial_agent(float *p, const float4 &v)
 {
+#ifdef IGCN_X_PLAINSTORE
+    *reinterpret_cast<float4 *>(p) = v; return;
+#endif
     const f32x4_t q = {v.x, v.y, v.z, v.w};
     asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(q) : "memory");
 }
@@ -145,35 +148,65 @@ __device__ __forceinline__ float4 load_partial_agent(const float *p)
     v.w = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return v;
 }
-// the n_slots partial sums of a cut row, added in slot order (four loads in flight; one addition chain per column)
-__device__ __forceinline__ float4 sum_partials_in_slot_order(const float *base, int n_slots, int d, bool agent)
+// The n_slots partial sums of a cut row, added in a FIXED order that does not depend on who adds: four chains per column — chain c
+// adds slots c, c + 4, c + 8, ... in that order — and total = (chain 0 + chain 1) + (chain 2 + chain 3).  (Round 5 first summed all
+// slots in one chain, one lane group at work: the reduce kernel's longest row — a popular template of INMO's transposed feature
+// matrix, dozens of slots — then took 59 us instead of 16 and an IGCN training step 0.686 instead of 0.637 ms.)  G lane groups of
+// LPR lanes take part (G >= 4: groups 0..3 a chain each; 2: two chains each; 1: all four), IF loads in flight per chain; `base`
+// already points at this lane's four columns of slot 0, `on` = the lane holds real columns.  Every taking-part lane gets the total.
+template <int G, int LPR, int IF>
+__device__ __forceinline__ float4 sum_partials_four_chains(const float *base, int n_slots, int d, int g, bool on, bool agent)
 {
-    float4 acc = f4_zero();
-    int s = 0;
-    for (; s + 4 <= n_slots; s += 4) {
-        float4 p0, p1, p2, p3;
-        if (agent) {
-            p0 = load_partial_agent(base + (int64_t)s * d); p1 = load_partial_agent(base + (int64_t)(s + 1) * d);
-            p2 = load_partial_agent(base + (int64_t)(s + 2) * d); p3 = load_partial_agent(base + (int64_t)(s + 3) * d);
-        } else {
-            p0 = *reinterpret_cast<const float4 *>(base + (int64_t)s * d); p1 = *reinterpret_cast<const float4 *>(base + (int64_t)(s + 1) * d);
-            p2 = *reinterpret_cast<const float4 *>(base + (int64_t)(s + 2) * d); p3 = *reinterpret_cast<const float4 *>(base + (int64_t)(s + 3) * d);
+    constexpr int CPG = G >= 4 ? 1 : 4 / G;                      // chains per group
+    float4 ch[CPG];
+#pragma unroll
+    for (int k = 0; k < CPG; ++k) {
+        ch[k] = f4_zero();
+        const int c = g + k * G;                                 // (G >= 4: groups 4.. hold no chain)
+        if (c < 4 && on) {
+            int s = c;
+            for (; s + 4 * (IF - 1) < n_slots; s += 4 * IF) {
+                float4 p[IF];
+#pragma unroll
+                for (int i = 0; i < IF; ++i)
+                    p[i] = agent ? load_partial_agent(base + (int64_t)(s + 4 * i) * d) : *reinterpret_cast<const float4 *>(base + (int64_t)(s + 4 * i) * d);
+#pragma unroll
+                for (int i = 0; i < IF; ++i) f4_add(ch[k], p[i]);
+            }
+            for (; s < n_slots; s += 4)
+                f4_add(ch[k], agent ? load_partial_agent(base + (int64_t)s * d) : *reinterpret_cast<const float4 *>(base + (int64_t)s * d));
         }
-        f4_add(acc, p0); f4_add(acc, p1); f4_add(acc, p2); f4_add(acc, p3);
     }
-    for (; s < n_slots; ++s)
-        f4_add(acc, agent ? load_partial_agent(base + (int64_t)s * d) : *reinterpret_cast<const float4 *>(base + (int64_t)s * d));
-    return acc;
+    if constexpr (G >= 4) {
+        float4 t = ch[0];
+        f4_add(t, f4_shfl_xor(ch[0], LPR));                      // groups 0, 1: chain 0 + chain 1; groups 2, 3: chain 2 + chain 3 (a + b == b + a)
+        float4 r = t;
+        f4_add(r, f4_shfl_xor(t, 2 * LPR));
+        return r;
+    } else if constexpr (G == 2) {
+        float4 t01 = ch[0], t23 = ch[1];
+        f4_add(t01, f4_shfl_xor(ch[0], LPR));                    // group 0 holds chains 0, 2; group 1 chains 1, 3
+        f4_add(t23, f4_shfl_xor(ch[1], LPR));
+        f4_add(t01, t23);
+        return t01;
+    } else {
+        float4 t01 = ch[0], t23 = ch[2];
+        f4_add(t01, ch[1]);
+        f4_add(t23, ch[3]);
+        f4_add(t01, t23);
+        return t01;
+    }
 }
-// Called by all lanes that computed a segment's partial sum (a wave, or one sub-wave of it), after the stores and the wait.
-// `li` = igcn_row_segment.long_index (bit 31: closing), `leader` = one lane of them, `writer` = the lanes that hold output columns.
+
 // The arrival counters: one per cut row, kCounterStride bytes apart, BEHIND the partial sums in the caller's `partial` buffer
 // (zero when handed over, zero again after every launch).  Not the 16-byte igcn_long_row entries: eight counters to a 128-byte line
 // took ~70 agent-scope atomics per line, and those are serialised where they execute (measured: +11 % per launch against +8 %).
 constexpr int kCounterStride = 128;
-__device__ __forceinline__ void segment_done(const igcn_long_row *long_rows, int li, bool leader, bool writer, int t, int d,
+template <int G, int LPR>
+__device__ __forceinline__ void segment_done(const igcn_long_row *long_rows, int li, bool leader, int g, int t, int d,
                                              float *partial, int64_t n_segments, const SpmmEpilogue &ep, float *__restrict__ y, int64_t ldy)
 {
+    const bool on = 4 * t < d, writer = g == 0 && on;
     const int row_i = li & ~kClosingBit;
     int *arrived = reinterpret_cast<int *>(reinterpret_cast<char *>(partial + n_segments * d) + (int64_t)row_i * kCounterStride);
     // (developer ablations, never shipped — wrong results, only timed: IGCN_X_FOLD_NOCOUNT / _NOPOLL / _NOCLOSE)
@@ -195,17 +228,18 @@ __device__ __forceinline__ void segment_done(const igcn_long_row *long_rows, int
         __builtin_amdgcn_s_sleep(8);
     }
 #endif
-    if (writer) {
+    {
+        constexpr int kInFlight = G >= 2 ? 2 : 1;                                   // (a cold path of the hot kernel: few registers before speed)
 #ifdef IGCN_X_FOLD_PLAINLOAD
-        float4 acc = sum_partials_in_slot_order(partial + (int64_t)lr->first_slot * d + 4 * t, n_slots, d, false);
+        float4 acc = sum_partials_four_chains<G, LPR, kInFlight>(partial + (int64_t)lr->first_slot * d + 4 * t, n_slots, d, g, on, false);
 #else
-        float4 acc = sum_partials_in_slot_order(partial + (int64_t)lr->first_slot * d + 4 * t, n_slots, d, true);
+        float4 acc = sum_partials_four_chains<G, LPR, kInFlight>(partial + (int64_t)lr->first_slot * d + 4 * t, n_slots, d, g, on, true);
 #endif
         if (!complete) { const float nan = __int_as_float(0x7fc00000); acc = make_float4(nan, nan, nan, nan); }
 #ifndef IGCN_X_FOLD_NOFINISH
-        finish_row(acc, lr->row, t, ep, y, ldy);
+        if (writer) finish_row(acc, lr->row, t, ep, y, ldy);
 #else
-        if (acc.x == 12345.f) finish_row(acc, lr->row, t, ep, y, ldy);
+        if (writer && acc.x == 12345.f) finish_row(acc, lr->row, t, ep, y, ldy);
 #endif
     }
     if (leader) __hip_atomic_store(arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -213,7 +247,9 @@ __device__ __forceinline__ void segment_done(const igcn_long_row *long_rows, int
 
 // 80 scalar registers at most: a wave is charged its SGPRs + 16 (rounded up to 16) out of 800 per SIMD, so 80 is
 // the most that still lets 8 waves share a SIMD; without the cap the d = 32 variant took 100 and ran 6 (-15 %).
-template <int LPR, bool DROPOUT>
+// FOLD: the cut rows are added up inside the launch (opt-in, see segment_done); an instantiation of its own, so that the default
+// kernels carry nothing of it (its mere presence cost the headline launch 0.4 %).
+template <int LPR, bool DROPOUT, bool FOLD = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void spmm_csr_rows_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy,
@@ -256,7 +292,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
             const igcn_row_segment s = segments[v - n_rows];
             if (row_mask && !row_mask[s.row]) {
                 // (folded launches have no reduce kernel to zero a masked cut row: its closing segment does)
-                if (long_rows && masked_rows_zero && (s.long_index & kClosingBit) && g == 0 && lane_on)
+                if (FOLD && masked_rows_zero && (s.long_index & kClosingBit) && g == 0 && lane_on)
                     *reinterpret_cast<float4 *>(y + (int64_t)s.row * ldy + 4 * t) = f4_zero_here();
                 continue;
             }
@@ -316,15 +352,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
 
         if (g == 0 && lane_on) {
             if (to_partial) {
-                store_partial_agent(partial + dst * (int64_t)d + 4 * t, acc);   // (agent scope in either form: one code path)
+                if constexpr (FOLD) store_partial_agent(partial + dst * (int64_t)d + 4 * t, acc);
+                else *reinterpret_cast<float4 *>(partial + dst * (int64_t)d + 4 * t) = acc;
             } else {
                 finish_row(acc, dst, t, ep, y, ldy);
             }
         }
-        if (long_rows && to_partial) {                                        // (wave-uniform)
+        if (FOLD && to_partial) {                                             // (wave-uniform)
             asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
             const int lane_c = cold(lane);                                   // (the fold's addresses are made here, not before the gather loop)
-            segment_done(long_rows, segments[dst].long_index, lane_c == 0, lane_c < LPR && 4 * lane_c < d, lane_c, d, partial, n_segments, ep, y, ldy);   // (slot == index in `segments`)
+            segment_done<G, LPR>(long_rows, segments[dst].long_index, lane_c == 0, lane_c / LPR, lane_c % LPR, d, partial, n_segments, ep, y, ldy);   // (slot == index in `segments`)
         }
     }
 #ifdef IGCN_SPMM_TRACE
@@ -344,7 +381,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
 // chain, not by bandwidth; R independent chains per wave give R times the requests in flight.  Same
 // arithmetic per row (each lane group sums its neighbours in storage order, groups folded in a fixed
 // order); every control decision is per sub-wave, so the loops run while ANY sub-wave has work.
-template <int LPR, int R, bool DROPOUT>
+template <int LPR, int R, bool DROPOUT, bool FOLD = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void spmm_csr_multirow_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy,
@@ -391,7 +428,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
             start = sg.start; len = sg.len; dst = sg.slot;
             kind = masked ? 0 : 2;
             // (folded launches have no reduce kernel to zero a masked cut row: its closing segment does)
-            if (masked && long_rows && masked_rows_zero && (sg.long_index & kClosingBit)) { kind = 3; dst = sg.row; }
+            if (FOLD && masked && masked_rows_zero && (sg.long_index & kClosingBit)) { kind = 3; dst = sg.row; }
         }
         if (kind != 1 && kind != 2) len = 0;
 #ifdef IGCN_SPMM_TRACE
@@ -442,17 +479,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
             if (kind == 3) {
                 *reinterpret_cast<float4 *>(y + (int64_t)dst * ldy + 4 * t) = f4_zero_here();
             } else if (kind == 2) {
-                store_partial_agent(partial + (int64_t)dst * d + 4 * t, acc);   // (agent scope in either form: one code path)
+                if constexpr (FOLD) store_partial_agent(partial + (int64_t)dst * d + 4 * t, acc);
+                else *reinterpret_cast<float4 *>(partial + (int64_t)dst * d + 4 * t) = acc;
             } else if (kind == 1) {
                 finish_row(acc, dst, t, ep, y, ldy);
             }
         }
-        if (long_rows && __any(kind == 2)) {
+        if (FOLD && __any(kind == 2)) {
             asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
             // (a segment's slot IS its index in `segments`: its row is read back here instead of being carried through the loop)
             if (kind == 2) {
                 const int sl_c = cold(sl);                       // (the fold's addresses are made here, not before the gather loop)
-                segment_done(long_rows, segments[dst].long_index, sl_c == 0, sl_c < LPR && 4 * sl_c < d, sl_c, d, partial, n_segments, ep, y, ldy);
+                segment_done<G, LPR>(long_rows, segments[dst].long_index, sl_c == 0, sl_c / LPR, sl_c % LPR, d, partial, n_segments, ep, y, ldy);
             }
         }
     }
@@ -472,26 +510,27 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
 #endif
 }
 
-// The two-launch form (igcn_set_tuning("spmm_fold", 0); also the reference the folded launches are checked against): adds the
-// partial sums of each cut row in slot order — the same chain per column as segment_done, hence the same bits — and applies the
-// epilogue.  One wave per long row, its first lane group at work.
+// The two-launch form (the default; "spmm_fold" 1 adds the rows up inside the launch instead): adds the partial sums of each cut row
+// in the four-chain order of sum_partials_four_chains — the same bits as the in-launch form — and applies the epilogue.  One wave
+// per long row, all its lane groups at work.
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void spmm_long_rows_reduce_kernel(
     const igcn_long_row *__restrict__ long_rows, int64_t n_long, const float *__restrict__ partial,
     float *__restrict__ y, int64_t ldy, int d, SpmmEpilogue ep, const uint8_t *__restrict__ row_mask, int masked_rows_zero)
 {
+    constexpr int G = kWave / LPR;
     const int lane = threadIdx.x & (kWave - 1);
     const int g = lane / LPR, t = lane % LPR;
     const bool lane_on = (4 * t) < d;
     const int64_t wave = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-    if (wave >= n_long || g != 0 || !lane_on) return;
+    if (wave >= n_long) return;
     const igcn_long_row lr = long_rows[wave];
     if (row_mask && !row_mask[lr.row]) {
-        if (masked_rows_zero) *reinterpret_cast<float4 *>(y + (int64_t)lr.row * ldy + 4 * t) = f4_zero();
+        if (masked_rows_zero && g == 0 && lane_on) *reinterpret_cast<float4 *>(y + (int64_t)lr.row * ldy + 4 * t) = f4_zero();
         return;
     }
-    const float4 acc = sum_partials_in_slot_order(partial + (int64_t)lr.first_slot * d + 4 * t, lr.n_slots, d, false);
-    finish_row(acc, lr.row, t, ep, y, ldy);
+    const float4 acc = sum_partials_four_chains<G, LPR, 4>(partial + (int64_t)lr.first_slot * d + 4 * t, lr.n_slots, d, g, lane_on, false);
+    if (g == 0 && lane_on) finish_row(acc, lr.row, t, ep, y, ldy);
 }
 
 // Any d (not a multiple of 4, or misaligned leading dimensions): one wave per
@@ -654,21 +693,19 @@ static int launch_rows(bool dropout, int64_t blocks, hipStream_t st,
     // segments of 4 133 rows): the closing segments' agent-scope reads of the partial sums and the epilogue behind them cost more
     // inside the launch (+8 us) than the 5 us kernel they replace.  Default: the second kernel.
     const igcn_long_row *fold = n_long > 0 && closing && tuning_get(IGCN_TUNE_SPMM_FOLD) > 0 ? long_rows : nullptr;
+#define IGCN_SPMM_LAUNCH(...)                                                                                                          \
+    hipLaunchKernelGGL((__VA_ARGS__), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy, n_rows, d, ep, dr, segments, n_segments, \
+                       partial, long_threshold, row_mask, masked_rows_zero, row_order, xcd_off, fold)
     if (multirow) {
         if constexpr (R > 1) {
-            if (dropout)
-                hipLaunchKernelGGL((spmm_csr_multirow_kernel<LPR, R, true>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y,
-                                   ldy, n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order, xcd_off, fold);
-            else
-                hipLaunchKernelGGL((spmm_csr_multirow_kernel<LPR, R, false>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y,
-                                   ldy, n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order, xcd_off, fold);
+            if (fold) { if (dropout) IGCN_SPMM_LAUNCH(spmm_csr_multirow_kernel<LPR, R, true, true>); else IGCN_SPMM_LAUNCH(spmm_csr_multirow_kernel<LPR, R, false, true>); }
+            else if (dropout) IGCN_SPMM_LAUNCH(spmm_csr_multirow_kernel<LPR, R, true, false>);
+            else IGCN_SPMM_LAUNCH(spmm_csr_multirow_kernel<LPR, R, false, false>);
         }
-    } else if (dropout)
-        hipLaunchKernelGGL((spmm_csr_rows_kernel<LPR, true>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
-                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order, xcd_off, fold);
-    else
-        hipLaunchKernelGGL((spmm_csr_rows_kernel<LPR, false>), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy,
-                           n_rows, d, ep, dr, segments, n_segments, partial, long_threshold, row_mask, masked_rows_zero, row_order, xcd_off, fold);
+    } else if (fold) { if (dropout) IGCN_SPMM_LAUNCH(spmm_csr_rows_kernel<LPR, true, true>); else IGCN_SPMM_LAUNCH(spmm_csr_rows_kernel<LPR, false, true>); }
+    else if (dropout) IGCN_SPMM_LAUNCH(spmm_csr_rows_kernel<LPR, true, false>);
+    else IGCN_SPMM_LAUNCH(spmm_csr_rows_kernel<LPR, false, false>);
+#undef IGCN_SPMM_LAUNCH
     int rc = launch_status();
     if (rc != IGCN_OK) return rc;
     if (n_long > 0 && !fold) {
