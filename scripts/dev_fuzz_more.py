@@ -19,7 +19,7 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
     for case in range(80):
         n_users = int(rng.integers(1, 600))
         n_items = int(rng.integers(1, 6000))
-        d = int(rng.choice([4, 8, 16, 20, 32, 64, 64, 64, 100, 128]))
+        d = int(rng.choice([4, 8, 16, 20, 32, 64, 64, 64, 100, 128, 200, 256]))      # (round 5: 129 ... 256 runs one wave per SIMD)
         k = int(rng.integers(1, min(n_items, 256) + 1))
         if case % 3 == 1:
             _lib.set_tuning('topk_slots', int(rng.integers(1, 8)))
@@ -124,9 +124,12 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
         rowptr, col, val = normalized_adjacency_host(np.stack([users, items], 1), nu, ni)
         n = nu + ni
         T = int(rng.choice([4, 16, 64, 112, 300]))
+        # (round 5: cut rows added up inside the launch or by the second kernel, the closing segments anywhere in their phase's rows)
+        _lib.set_tuning('spmm_fold', int(rng.integers(0, 2)))
         csr = CsrMatrix(rowptr, col, val, (n, n), 'cuda', order_blocks=[0, nu, n],
-                        xcd_plan={'threshold': T, 'assign': str(rng.choice(['affinity', 'spread'])),
-                                  'list_order': str(rng.choice(['segments_first', 'rows_first', 'interleaved']))})
+                        xcd_plan={'threshold': T, 'assign': str(rng.choice(['affinity', 'spread'])), 'closing_at': float(rng.random()),
+                                  'list_order': str(rng.choice(['segments_first', 'rows_first', 'interleaved']))} if case % 4 else None,
+                        long_threshold=max(T, 8), segment_len=max(T, 8))
         x = rng.standard_normal((n, d)).astype(np.float32)
         y = spmm(csr, torch.from_numpy(x).cuda()).cpu().numpy()
         row = np.repeat(np.arange(n, dtype=np.int64), np.diff(rowptr))
@@ -135,4 +138,5 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 5):
         if err > 1e-4:
             n_bad += 1
             print('XCD SPMM MISMATCH', seed, case, nu, ni, d, T, err, flush=True)
+_lib.set_tuning('spmm_fold', None)
 print('done, mismatches:', n_bad)
