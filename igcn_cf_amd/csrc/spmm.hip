@@ -118,11 +118,12 @@ __device__ __forceinline__ void finish_row(const float4 &acc, int64_t dst, int t
 //     other XCDs, whose L2s are private), the wave waits for its stores (vmcnt(0)) and counts itself in with a fire-and-forget
 //     agent-scope atomic on the row's arrival counter (behind the partial sums, 128 bytes apart: see kCounterStride);
 //   * ONE segment of every cut row is its CLOSING segment (bit 31 of igcn_row_segment.long_index; the plan's choice: the row's
-//     last).  The dealing order hands it out well after the row's other segments (half-way into the rows of the same phase), so
-//     that when its wave has stored its own partial sum the counter already reads n_slots - 1; it polls until it does (agent-scope
-//     loads, s_sleep in between), loads the row's n_slots partial sums with agent scope (never from its own L2), adds them in SLOT
-//     ORDER, one lane group, a chain of its own per column — the bits do not depend on the grid, on the kernel variant or on who
-//     polls —, applies the epilogue and puts the counter back to zero for the next launch.
+//     last).  The dealing order hands it out well after the row's other segments (a quarter into the rows of the same phase:
+//     graph.CLOSING_AT), so that when its wave has stored its own partial sum the counter already reads n_slots - 1; it polls until
+//     it does (agent-scope loads, s_sleep in between), loads the row's n_slots partial sums with agent scope (never from its own
+//     L2), adds them in the fixed four-chain order of sum_partials_four_chains — the reduce kernel's order: the bits do not
+//     depend on the grid, on the kernel variant or on who polls —, applies the epilogue and puts the counter back to zero for the
+//     next launch.
 // Forward progress: a closing segment waits only for segments that come EARLIER in the dealing order of their lists; workgroups are
 // dispatched in order, so those are resident or done — waves that are resident always finish.  The poll is bounded all the same
 // (kClosePolls ~ seconds): a row whose count never completes — a broken plan — comes back as NaN instead of hanging the GPU.
