@@ -281,10 +281,21 @@ def main():
     # building an idle MI355X needs ~100 passes (~35 ms) of this 0.34 ms step to reach them — `--steps 20 --warmup 5` read
     # 0.362 ms per step, `--warmup 300` 0.339, with identical kernels.  The W warm-up steps and the K timed steps are what the
     # contract says; only the order of the untimed measurements around them changed.
-    pre_g = pre_st = None
+    pre_g = pre_st = pre_ms_launch = None
     if not sharded:
         pre_st = measured_stream(device)
         pre_g = gather_roof(device, csr.col, csr.val, x0, n, d)     # (last: the probe whose access pattern is the SpMM's own)
+    else:
+        # (the same at N > 1 — every rank times its local product and runs the gather probe BEFORE the warm-up steps: the driver
+        # computes scaling efficiency from these lines, and the N = 1 line must not be the only one measured on a warm GPU)
+        step()                                                            # (buffers allocated, X_0 exchanged once)
+        local_csr = prop.csr if prop.exchange == 'fused' else prop.csr_u
+        own, rep = prop._buffers(d)
+        y_loc = own[1] if prop.exchange == 'fused' else prop._part(own[1], 'u')
+        pre_st = measured_stream(device)
+        pre_ms_launch = time_ms(lambda: ops.spmm(local_csr, rep[0], out=y_loc), 50, 5)
+        pre_g = gather_roof(device, local_csr.col, local_csr.val, rep[0], y_loc.shape[0], d)
+        barrier_sync()
     for _ in range(args.warmup):
         step()
     barrier_sync()
@@ -340,14 +351,11 @@ def main():
         g = pre_g
     else:
         # the timed region holds collectives: the local product is timed on its own, same operands, same stream
-        local_csr = prop.csr if prop.exchange == 'fused' else prop.csr_u
-        own, rep = prop._buffers(d)
-        y = own[1] if prop.exchange == 'fused' else prop._part(own[1], 'u')
-        ms_launch = time_ms(lambda: ops.spmm(local_csr, rep[0], out=y), 50, 5)
+        ms_launch = pre_ms_launch
         if prop.exchange != 'fused':
             b_alg = local_csr.nnz * (8 + 4 * d) + L.bu * (4 * d + 4)
         launch_note = 'HIP events around 50 back-to-back launches of the rank-local product (timed region also holds collectives)'
-        g = gather_roof(device, local_csr.col, local_csr.val, rep[0], y.shape[0], d)
+        g = pre_g
     ach = b_alg / ms_launch / 1e6
     x_mb = n * d * 4 / 1e6
     gathered = local_nnz * 4 * d / ms_launch / 1e6                  # GB/s of gathered operand rows alone
@@ -386,6 +394,7 @@ def main():
             roof['l2_hit_rate'] = t.get('l2_hit_rate')
     else:
         roof['traffic'] = None
+        roof['hbm_stream_read_GBps'], roof['hbm_stream_copy_GBps'] = pre_st['read_GBps'], pre_st['copy_GBps']      # (this rank's GPU)
     out['roofline'] = roof
     extras = {}
     stream_probe = None if sharded else st
