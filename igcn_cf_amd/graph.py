@@ -265,7 +265,7 @@ N_XCD = 8                  # lists of the XCD plan = XCDs of an MI355X (igcn_spm
 
 
 def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assign='affinity', list_order='segments_first', n_lists=None,
-             closing_at=CLOSING_AT):
+             closing_at=CLOSING_AT, late_every=0):
     """The XCD plan of a CSR matrix: the work of one SpMM launch cut into N_XCD lists, one per XCD, such that a list
     gathers as much as possible from ONE slice of the operand — a slice (1/8 of the operand's rows) fits an XCD's 4 MiB
     L2 where the whole operand does not, and the eight L2s are private (igcn_hip.h: xcd_off).
@@ -365,6 +365,11 @@ def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assi
         packed = long_of_seg | (is_closing.to(torch.int64) << 31)
         segments[:, 5] = torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32)   # (bit 31 of an int32)
 
+    # segments dealt late in their lists: the closing ones (developer sweeps: also every late_every-th segment of a row, counted from its end)
+    is_late = is_closing
+    if late_every and long_ids.shape[0]:
+        from_end = (long_rows[:, 1] + long_rows[:, 2] - 1).to(torch.int64)[long_of_seg] - torch.arange(n_seg, **i64)
+        is_late = is_closing | (from_end % int(late_every) == 0)
     # deal the blocks, one after the other, keeping the lists' total work level
     load = torch.zeros(NL, dtype=torch.float64, device=dev)
     lists = [[] for _ in range(NL)]
@@ -408,7 +413,7 @@ def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assi
                 # rows of the phase (CLOSING_AT) — the phase's rows come by descending length, so by then a good third of its time has
                 # passed and the row's other segments, first in every list, are done; later (half-way, the first choice) these
                 # full-length segments with a fold behind them end AFTER the list's last short rows: +12 us of tail (profiles/r05c_*)
-                cl = is_closing[sx - n_rows]
+                cl = is_late[sx - n_rows]
                 at = int(rx.shape[0] * closing_at)
                 lists[x] += [sx[~cl], rx[:at], sx[cl], rx[at:]]
             elif list_order == 'rows_first':
@@ -526,7 +531,8 @@ class CsrMatrix:
             self.segment_len = min(self.segment_len, int(cfg.get('segment_len', self.long_threshold)))
             lr, sg, order, xcd_off, load = xcd_plan(self.rowptr, self.col, list(self.order_blocks), thr,
                                                     self.segment_len, cfg.get('row_cost', 4), cfg.get('assign', 'affinity'),
-                                                    cfg.get('list_order', 'segments_first'), closing_at=cfg.get('closing_at', CLOSING_AT))
+                                                    cfg.get('list_order', 'segments_first'), closing_at=cfg.get('closing_at', CLOSING_AT),
+                                                    late_every=cfg.get('late_every', 0))
             self.n_long, self.n_segments = int(lr.shape[0]), int(sg.shape[0])
             self.long_rows = lr.contiguous().view(torch.uint8).reshape(-1) if self.n_long else None
             self.segments = sg.contiguous().view(torch.uint8).reshape(-1) if self.n_long else None

@@ -22,8 +22,10 @@ for preset in os.environ.get('PRESETS', 'amazon,gowalla,yelp').split(','):
     x = torch.randn(n, 64, device='cuda') * 0.1
     y = torch.empty_like(x)
     variants = {}
-    for at in (0.0, 0.1, 0.25, 0.4, 0.6):
+    for at in (0.0, 0.25):
         variants['segments_first closing_at=%.2f' % at] = {'threshold': 112, 'closing_at': at}
+    for le, at in ((4, 0.25), (2, 0.25), (1, 0.25), (2, 0.1), (1, 0.1), (1, 0.05)):
+        variants['late_every=%d closing_at=%.2f' % (le, at)] = {'threshold': 112, 'closing_at': at, 'late_every': le}
     variants['interleaved'] = {'threshold': 112, 'list_order': 'interleaved'}
     variants['rows_first'] = {'threshold': 112, 'list_order': 'rows_first'}
     mats = {k: CsrMatrix(rowptr, col, val, (n, n), 'cuda', order_blocks=[0, nu, n], xcd_plan=v) for k, v in variants.items()}
