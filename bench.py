@@ -489,7 +489,7 @@ def config5_sharded_leg(device, rank, world, rehearsal, barrier_sync, job_max, K
     generator on every rank), rows of A_hat cut with ShardLayout.balanced(world); every rank builds ONLY its own two
     blocks in HBM (synth.rank_blocks: padded rows, padded column ids — no CSR of the whole graph anywhere), then K = 3
     layers at d = 128 under the 'halves' exchange: per layer two local SpMMs and two all-gathers (RCCL over xGMI), each
-    all-gather in flight under the OTHER half's SpMM, the layer mean in the last launches' epilogue
+    all-gather in flight under the OTHER half's SpMM, the layer mean through the launches' epilogues (ops.mean_plan: two addends at K = 3)
     (dist.RowShardedPropagator; the layer sharded is model.py:96-106).  A step = X_0 exchange + the K-layer pass.
     At world = 1 the same code runs the whole graph on the one GPU (the N = 1 point of this leg's curve).
     rehearsal (every rank on cuda:0, gloo): a reduced graph (1 M x 200 k x ~50 M edges); timings are not measurements."""
@@ -534,9 +534,10 @@ def config5_sharded_leg(device, rank, world, rehearsal, barrier_sync, job_max, K
     ms = {}
     for p_, csr in parts.items():
         ms[p_] = time_ms(lambda: ops.spmm(csr, rep[0], out=prop._part(own[1], p_)), reps, 1)
-        ms[p_ + '_last'] = time_ms(lambda: ops.spmm(csr, rep[0], out=prop._part(own[K], p_), adds=[prop._part(o, p_) for o in own[:K]],
-                                                    out_scale=s, add_scale=s), reps, 1)
-    local_ms = (K - 1) * (ms['u'] + ms['i']) + ms['u_last'] + ms['i_last']
+        ms[p_ + '_add'] = time_ms(lambda: ops.spmm(csr, rep[0], out=prop._part(own[K], p_), adds=[prop._part(own[0], p_)],
+                                                   out_scale=s, add_scale=s), reps, 1)
+    n_add = sum(a is not None for a in ops.mean_plan(K))              # launches of the pass that carry an epilogue addend
+    local_ms = (K - n_add) * (ms['u'] + ms['i']) + n_add * (ms['u_add'] + ms['i_add'])
     # the pass's all-gathers alone (X_0 + K - 1 layers, two halves each), nothing computed beside them
     def gathers():
         for _ in range(K):
@@ -556,7 +557,8 @@ def config5_sharded_leg(device, rank, world, rehearsal, barrier_sync, job_max, K
            'world': world, 'users': n_users, 'items': n_items, 'edges': n_edges, 'nnz': nnz, 'd': d, 'n_layers': K,
            'pass_ms': pass_ms, 'edges_per_s': K * nnz / (pass_ms / 1e3),
            'local_spmm_ms': local_ms, 'exposed_exchange_ms': max(pass_ms - local_ms, 0.0), 'allgathers_alone_ms': gather_ms,
-           'user_block_ms': ms['u'], 'item_block_ms': ms['i'], 'user_block_last_layer_ms': ms['u_last'], 'item_block_last_layer_ms': ms['i_last'],
+           'user_block_ms': ms['u'], 'item_block_ms': ms['i'], 'user_block_with_addend_ms': ms['u_add'], 'item_block_with_addend_ms': ms['i_add'],
+           'launches_with_addend': n_add,
            'local_nnz': prop.local_nnz, 'rank_algorithmic_GBps': b_alg / local_layer_ms / 1e6,
            'rank_algorithmic_frac_of_hbm_peak': b_alg / local_layer_ms / 1e6 / HBM_PEAK_GBPS,
            'exchanged_bytes_per_rank_per_pass': K * (world - 1) * (layout.bu + layout.bi) * d * 4,
@@ -735,18 +737,34 @@ def propagation_configs_2_3(device, d, K):
     torch.manual_seed(2021)
     lg = get_model(dict(m_cfg, embedding_size=d, n_layers=K), ds)
     A, x = lg.norm_adj, lg.embedding.weight.detach()
-    layers = [x]
-    for _ in range(K - 1):
-        layers.append(ops.spmm(A, layers[-1]))
+    # the K launches of ops.mean_plan: launch l + 1 reads table l (+ one addend table where the plan has one); at K = 3 the
+    # second launch adds X_0 and the last one adds its own operand (U + A U)
+    plan = ops.mean_plan(K)
+    mid = next((l for l in range(K - 1) if plan[l] is not None), None)
+
+    def plan_tables(M, first):
+        tables = [first]
+        for l in range(K - 1):
+            tables.append(ops.spmm(M, tables[-1], adds=[tables[plan[l]]] if plan[l] is not None else ()))
+        return tables
+    layers = plan_tables(A, x)
     y = torch.empty_like(x)
     s = 1.0 / (K + 1)
+
+    def epilogue_launches(prefix, M, tables, out_buf):
+        r = {'A_hat_last_launch': launch(prefix + '_A_hat_last_launch',
+                                         lambda: ops.spmm(M, tables[-1], out=out_buf, adds=[tables[plan[-1]]], out_scale=s, add_scale=s),
+                                         M.shape[0], M.nnz, 8, n_adds=1)}
+        if mid is not None:
+            r['A_hat_launch_with_addend'] = launch(prefix + '_A_hat_launch_with_addend',
+                                                   lambda: ops.spmm(M, tables[mid], out=out_buf, adds=[tables[plan[mid]]]),
+                                                   M.shape[0], M.nnz, 8, n_adds=1)
+        return r
     pass_ms = time_ms(lambda: ops.propagate_mean(A, x, K), 300, 20)
     out['config2'] = {'workload': 'LightGCN.get_rep, %d layers, d=%d, Gowalla-like (users=%d items=%d nnz(A_hat)=%d)' % (K, d, ds.n_users, ds.n_items, A.nnz),
                       'pass_ms': pass_ms, 'edges_per_s': K * A.nnz / (pass_ms / 1e3), 'operand_MB': x.numel() * 4 / 1e6,
-                      'A_hat_launch': launch('gowalla_A_hat', lambda: ops.spmm(A, x, out=y), A.shape[0], A.nnz, 8),
-                      'A_hat_last_layer_with_mean': launch('gowalla_A_hat_last_layer_with_mean',
-                                                           lambda: ops.spmm(A, layers[-1], out=y, adds=layers, out_scale=s, add_scale=s),
-                                                           A.shape[0], A.nnz, 8, n_adds=K)}
+                      'A_hat_launch': launch('gowalla_A_hat', lambda: ops.spmm(A, x, out=y), A.shape[0], A.nnz, 8)}
+    out['config2'].update(epilogue_launches('gowalla', A, layers, y))
     del lg, layers, y
     # ---- config 3 ----
     ds_cfg, m_cfg, _ = cfg.get_synthetic_config(device, 'yelp')[2]
@@ -760,9 +778,7 @@ def propagation_configs_2_3(device, d, K):
     keep = 1.0 - float(ig.dropout)
     x0 = ops.spmm(F, T, row_scale=scale)
     y0 = torch.empty_like(x0)
-    l3 = [x0]
-    for _ in range(K - 1):
-        l3.append(ops.spmm(A3, l3[-1]))
+    l3 = plan_tables(A3, x0)
     y3 = torch.empty_like(x0)
 
     def rep(keep_prob):
@@ -777,10 +793,8 @@ def propagation_configs_2_3(device, d, K):
                       'F_T_eval': launch('yelp_F_T_eval', lambda: ops.spmm(F, T, out=y0, row_scale=scale), F.shape[0], F.nnz, 4),
                       'F_T_dropout': launch('yelp_F_T_dropout_0.3', lambda: ops.spmm(F, T, out=y0, row_scale=scale, keep_prob=keep, seed=12345),
                                             F.shape[0], F.nnz, 4),
-                      'A_hat_launch': launch('yelp_A_hat', lambda: ops.spmm(A3, x0, out=y3), A3.shape[0], A3.nnz, 8),
-                      'A_hat_last_layer_with_mean': launch('yelp_A_hat_last_layer_with_mean',
-                                                           lambda: ops.spmm(A3, l3[-1], out=y3, adds=l3, out_scale=s, add_scale=s),
-                                                           A3.shape[0], A3.nnz, 8, n_adds=K)}
+                      'A_hat_launch': launch('yelp_A_hat', lambda: ops.spmm(A3, x0, out=y3), A3.shape[0], A3.nnz, 8)}
+    out['config3'].update(epilogue_launches('yelp', A3, l3, y3))
     return out
 
 

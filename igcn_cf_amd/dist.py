@@ -221,7 +221,8 @@ class RowShardedPropagator:
 
     # ---- buffers -----------------------------------------------------------------
     def _buffers(self, d):
-        """own[l]: this rank's rows of X_l ([block, d]; user rows first), l = 0..K; rep[0..1]: the two
+        """own[l]: this rank's rows of table l of ops.mean_plan ([block, d]; user rows first; table 0 = X_0, table K = the
+        mean), l = 0..K; rep[0..1]: the two
         replicated buffers used in turn."""
         if self._d != d:
             L, K = self.layout, self.n_layers
@@ -263,21 +264,27 @@ class RowShardedPropagator:
         return rep[0]
 
     # ---- the sharded K-layer pass -------------------------------------------------
-    def propagate(self):
+    def propagate(self, plan=None):
         """mean(X_0..X_K) on the owned rows: (rep_users [bu, d], rep_items [bi, d]) — views of one
-        [block, d] buffer that the next call overwrites.  X_0 is what load_local_embedding left."""
+        [block, d] buffer that the next call overwrites.  X_0 is what load_local_embedding left.  The K launches are
+        those of ops.mean_plan (own[l] = the owned rows of its table l), as on one GPU: every launch's output but the
+        last is exchanged, so the number and size of the all-gathers is that of the plain layer loop."""
         own, rep = self._buffers(self._d)
         K, L = self.n_layers, self.layout
         s = 1.0 / (K + 1)
         if K == 0:
             return self._part(own[0], 'u'), self._part(own[0], 'i')
+        from .ops import mean_plan, plan_addends
+        if plan is None:
+            plan = mean_plan(K)
         if self.exchange == 'fused':
-            for l in range(K):
+            for l, add in enumerate(plan):               # own[l + 1] = A own-rows-of(table l) (+ own[add]), ops.mean_plan
                 src = rep[l % 2]
+                adds = plan_addends(add, own)
                 if l == K - 1:
-                    self.spmm(self.csr, src, out=own[K], adds=own[:K], out_scale=s, add_scale=s)
+                    self.spmm(self.csr, src, out=own[K], adds=adds, out_scale=s, add_scale=s)
                 else:
-                    self.spmm(self.csr, src, out=own[l + 1])
+                    self.spmm(self.csr, src, out=own[l + 1], adds=adds)
                     self._allgather(rep[(l + 1) % 2], own[l + 1], False)
             return self._part(own[K], 'u'), self._part(own[K], 'i')
         pending = {}                                     # (layer, part) -> in-flight all-gather
@@ -291,13 +298,13 @@ class RowShardedPropagator:
                 w = pending.pop((l, other), None)        # this half reads X_l[other], replicated
                 if w is not None:
                     w.wait()
+                adds = [self._part(o, part) for o in plan_addends(plan[l], own)]
                 if last:
-                    self.spmm(csr[part], src, out=self._part(own[K], part), adds=[self._part(o, part) for o in own[:K]],
-                              out_scale=s, add_scale=s)
+                    self.spmm(csr[part], src, out=self._part(own[K], part), adds=adds, out_scale=s, add_scale=s)
                 else:
-                    # the half of X_{l+1} computed here is read by the OTHER half of layer l+1; the replicated buffer
-                    # it goes to was last read by layer l-1, whose two halves are done
-                    self.spmm(csr[part], src, out=self._part(own[l + 1], part))
+                    # the half of table l+1 computed here is read by the OTHER half of launch l+1; the replicated buffer
+                    # it goes to was last read by launch l-1, whose two halves are done
+                    self.spmm(csr[part], src, out=self._part(own[l + 1], part), adds=adds)
                     pending[(l + 1, part)] = self._allgather(self._section(rep[(l + 1) % 2], part),
                                                              self._part(own[l + 1], part), True)
         for w in pending.values():                        # nothing should be left; be safe

@@ -91,56 +91,96 @@ def mark_rows(csr: CsrMatrix, ids, with_neighbours=True):
     return masks[0], masks[1], bits[0], bits[1]
 
 
-def propagate_mean(csr: CsrMatrix, x0, n_layers, row_scale_last=None, masks=None, zero_masked=True):
+def mean_plan(n_layers, form='factored'):
+    """The K launches that give (X_0 + A X_0 + ... + A^K X_0) with as few epilogue addends as the polynomial allows.
+
+    Returns `adds`, one entry per launch: table l + 1 = A @ table l (+ table adds[l] if not None), table 0 = X_0; the last
+    table is the sum.  form='stack': the reference's own association instead — every X_l kept, all of them added in the last
+    launch ([None, ..., (0, 1, ..., K - 1)]; an entry may be a tuple of tables) — kept for A/Bs.  The layer loop of model.py:101-105 keeps every X_l and averages the stack — K extra row reads
+    however they are spread (Horner's rule: X_0 once per launch).  1 + x + ... + x^K factors instead:
+    K odd: (1 + x) p_m(x^2), m = (K - 1) / 2; K even: 1 + x p_(K-1)(x) — K = 3, the depth every reference config uses, is
+    (I + A)(I + A^2) X_0: U = X_0 + A (A X_0), then U + A U: two addend reads instead of three (-3.2 % of a pass at the
+    headline size, -4.6 % Gowalla-like; float64 error of the result not larger; scripts/dev_r05_factorized_mean.py).
+    The sums are associated differently from the reference's stack().mean(): fp32 rounding, ~1e-7 relative."""
+    if form == 'stack':
+        return [None] * (n_layers - 1) + [tuple(range(n_layers))] if n_layers else []
+    if form != 'factored':
+        raise ValueError("form must be 'factored' or 'stack'")
+    adds = []
+
+    def poly(k, stride):                                  # table index of p_k(A^stride) X_0
+        if k == 0:
+            return 0
+        if k % 2:
+            w = poly((k - 1) // 2, 2 * stride)           # p_k(y) = (1 + y) p_m(y^2)
+            last_add = w
+        else:
+            w = poly(k - 1, stride)                      # p_k(y) = 1 + y p_(k-1)(y)
+            last_add = 0
+        assert w == len(adds)                            # every launch reads the table the one before it wrote
+        adds.extend([None] * (stride - 1) + [last_add])
+        return len(adds)
+
+    poly(n_layers, 1)
+    return adds
+
+
+def plan_addends(entry, tables):
+    """The addend tables of one mean_plan entry (None, an index or a tuple of indices)."""
+    if entry is None:
+        return ()
+    return [tables[i] for i in (entry if isinstance(entry, tuple) else (entry,))]
+
+
+def propagate_mean(csr: CsrMatrix, x0, n_layers, row_scale_last=None, masks=None, zero_masked=True, plan=None):
     """mean(X_0..X_K), X_{l+1} = csr @ X_l — the layer loop + stack/mean of
-    model.py:101-105.  The mean is the epilogue of the last SpMM (no stack).
+    model.py:101-105, as the K launches of mean_plan(); the 1 / (K + 1) is the last launch's epilogue (no stack).
 
     masks = (rows, rows_and_neighbours) from mark_rows(): only the listed rows of the result are
     needed (a training step reads the propagated rows of its batch only, model.py:114-115).  The
-    last layer is then computed for those rows alone (others are zero) and the layer before it for
+    last launch is then computed for those rows alone (others are zero) and the one before it for
     their neighbourhood alone (other rows of that intermediate are never read) — same values on
     the needed rows, ~45 % fewer edges at Amazon scale with a 2048-triplet batch."""
     if n_layers == 0:
         return x0.clone()
-    if n_layers > _lib.MAX_ADDS:
-        raise _lib.IgcnError('n_layers > %d not supported' % _lib.MAX_ADDS)
-    layers = [x0]
+    tables = [x0]
     s = 1.0 / (n_layers + 1)
-    for l in range(n_layers):
+    for l, add in enumerate(plan if plan is not None else mean_plan(n_layers)):
+        adds = plan_addends(add, tables)
         if l == n_layers - 1:
-            y = spmm(csr, layers[-1], adds=layers, out_scale=s, add_scale=s, row_scale=row_scale_last,
+            y = spmm(csr, tables[-1], adds=adds, out_scale=s, add_scale=s, row_scale=row_scale_last,
                      row_mask=masks[0] if masks else None, masked_rows_zero=zero_masked)
         elif l == n_layers - 2 and masks:
-            y = spmm(csr, layers[-1], row_mask=masks[1], masked_rows_zero=False)
+            y = spmm(csr, tables[-1], adds=adds, row_mask=masks[1], masked_rows_zero=False)
         else:
-            y = spmm(csr, layers[-1])
-        layers.append(y)
-    return layers[-1]
+            y = spmm(csr, tables[-1], adds=adds)
+        tables.append(y)
+    return tables[-1]
 
 
 def propagate_mean_backward(csr_t: CsrMatrix, grad, n_layers, row_scale=None, masks=None):
-    """d/dX_0 of propagate_mean:  s * sum_l (M^T)^l g  by Horner's rule,
-    G <- s*g + M^T G, K times — one SpMM per layer with the add fused.
-    row_scale (optional) multiplies the final rows (used by the INMO path).
+    """d/dX_0 of propagate_mean:  s * sum_l (M^T)^l g — the same polynomial in M^T, the same mean_plan() launches
+    applied to g.  row_scale (optional) multiplies the final rows (used by the INMO path).
     With masks (g is zero outside masks[0]) the first hop is non-zero only on masks[1]: it is computed for those
     rows alone and gathers only the rows of g in masks[0]; the second hop gathers only the rows in masks[1]
     (about 70 % of the rows at B = 2048 on the Amazon-like graph: 124 -> 116 us)."""
     s = 1.0 / (n_layers + 1)
     if n_layers == 0:
         return grad.clone()
-    g = grad.contiguous()
-    cur = None
-    for l in range(n_layers):
+    tables = [grad.contiguous()]
+    for l, add in enumerate(mean_plan(n_layers)):
         last = l == n_layers - 1
-        rs = row_scale if last else None
-        if cur is None:
+        adds = [tables[add]] if add is not None else ()
+        scale = s if last else 1.0
+        if l == 0:
             # rows outside masks[1] are zero: written as zeros only when this hop is the result, else never read
-            cur = spmm(csr_t, g, adds=[g], out_scale=s, add_scale=s, row_scale=rs,
-                       row_mask=masks[1] if masks else None, masked_rows_zero=last, col_mask=masks[2] if masks else None)
+            y = spmm(csr_t, tables[-1], adds=adds, out_scale=scale, add_scale=scale, row_scale=row_scale if last else None,
+                     row_mask=masks[1] if masks else None, masked_rows_zero=last, col_mask=masks[2] if masks else None)
         else:
-            cur = spmm(csr_t, cur, adds=[g], out_scale=1.0, add_scale=s, row_scale=rs,
-                       col_mask=masks[3] if masks and l == 1 else None)
-    return cur
+            y = spmm(csr_t, tables[-1], adds=adds, out_scale=scale, add_scale=scale, row_scale=row_scale if last else None,
+                     col_mask=masks[3] if masks and l == 1 else None)
+        tables.append(y)
+    return tables[-1]
 
 
 class PropagateFn(torch.autograd.Function):

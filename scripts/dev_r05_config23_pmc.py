@@ -1,6 +1,7 @@
 """The launches whose counters profiles/pmc_traffic_config23.json holds (run under rocprofv3 by scripts/profile_config23.sh):
-BASELINE config 2 (LightGCN on the Gowalla-like split) and config 3 (IGCN on the Yelp-like split), d = 64 — one A_hat launch and
-the last-layer launch with the mean's epilogue of each graph, and the RECTANGULAR feature launch X0 = F T of IGCN.inductive_rep_layer
+BASELINE config 2 (LightGCN on the Gowalla-like split) and config 3 (IGCN on the Yelp-like split), d = 64 — of each graph one plain
+A_hat launch and the two launches of the pass that carry an epilogue addend (ops.mean_plan at K = 3: U = X_0 + A X_1, then the
+result s (U + A U)), and the RECTANGULAR feature launch X0 = F T of IGCN.inductive_rep_layer
 (model.py:423-432) in eval mode and with the config's edge dropout 0.3.  Each variant N_LAUNCH times IN THIS ORDER with no other
 dispatch of the main SpMM kernels in between, so that the summariser can tell them apart by dispatch order.  Prints one JSON line
 with the sizes, the algorithmic bytes and the HIP-event times of the same launches."""
@@ -28,12 +29,14 @@ torch.manual_seed(2021)
 lg = get_model(dict(m_cfg, embedding_size=d, n_layers=K), ds)
 A = lg.norm_adj
 x = lg.embedding.weight.detach()
+assert ops.mean_plan(K) == [None, 0, 2]
 layers = [x, ops.spmm(A, x), None]
-layers[2] = ops.spmm(A, layers[1])
+layers[2] = ops.spmm(A, layers[1], adds=[x])
 y = torch.empty_like(x)
 variants.append(('gowalla_A_hat', lambda A=A, x=x, y=y: ops.spmm(A, x, out=y), A.shape[0], A.nnz, 8, 0))
-variants.append(('gowalla_A_hat_last_layer_with_mean', lambda A=A, l=layers, y=y: ops.spmm(A, l[2], out=y, adds=l, out_scale=0.25, add_scale=0.25),
-                 A.shape[0], A.nnz, 8, 3))
+variants.append(('gowalla_A_hat_launch_with_addend', lambda A=A, l=layers, y=y: ops.spmm(A, l[1], out=y, adds=[l[0]]), A.shape[0], A.nnz, 8, 1))
+variants.append(('gowalla_A_hat_last_launch', lambda A=A, l=layers, y=y: ops.spmm(A, l[2], out=y, adds=[l[2]], out_scale=0.25, add_scale=0.25),
+                 A.shape[0], A.nnz, 8, 1))
 keep += [lg, layers, y]
 
 ds_cfg, m_cfg, _ = cfg.get_synthetic_config(dev, 'yelp')[2]
@@ -50,10 +53,11 @@ variants.append(('yelp_F_T_eval', lambda: ops.spmm(F, T, out=y0, row_scale=scale
 variants.append(('yelp_F_T_dropout_0.3', lambda: ops.spmm(F, T, out=y0, row_scale=scale, keep_prob=0.7, seed=12345), F.shape[0], F.nnz, 4, 0))
 A3 = ig.norm_adj
 l3 = [x0, ops.spmm(A3, x0), None]
-l3[2] = ops.spmm(A3, l3[1])
+l3[2] = ops.spmm(A3, l3[1], adds=[x0])
 y3 = torch.empty_like(x0)
 variants.append(('yelp_A_hat', lambda: ops.spmm(A3, x0, out=y3), A3.shape[0], A3.nnz, 8, 0))
-variants.append(('yelp_A_hat_last_layer_with_mean', lambda: ops.spmm(A3, l3[2], out=y3, adds=l3, out_scale=0.25, add_scale=0.25), A3.shape[0], A3.nnz, 8, 3))
+variants.append(('yelp_A_hat_launch_with_addend', lambda: ops.spmm(A3, l3[1], out=y3, adds=[l3[0]]), A3.shape[0], A3.nnz, 8, 1))
+variants.append(('yelp_A_hat_last_launch', lambda: ops.spmm(A3, l3[2], out=y3, adds=[l3[2]], out_scale=0.25, add_scale=0.25), A3.shape[0], A3.nnz, 8, 1))
 
 out = {'d': d, 'n_layers': K, 'n_launch': N_LAUNCH, 'order': [v[0] for v in variants], 'launches': {},
        'gowalla': {'users': ds.n_users, 'items': ds.n_items, 'nnz_A_hat': A.nnz},

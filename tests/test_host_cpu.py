@@ -783,3 +783,25 @@ def test_every_tuning_knob_the_header_names_is_accepted_and_unknown_ones_are_ref
         _lib.set_tuning(name, None)
     with pytest.raises(_lib.IgcnError):
         _lib.set_tuning('topk_no_such_knob', 1)
+
+
+def test_mean_plan_is_the_polynomial_with_the_fewest_addends():
+    """ops.mean_plan(K): K launches, launch l + 1 reads the table launch l wrote (+ one earlier table), and the last table is
+    X_0 + A X_0 + ... + A^K X_0 — checked on coefficient vectors (a table = the polynomial in A it holds).  K = 3, the depth of
+    every reference config: (I + A)(I + A^2), two addends; the layer loop of model.py:101-105 reads three."""
+    from igcn_cf_amd.ops import mean_plan
+    assert mean_plan(0) == [] and mean_plan(1) == [0] and mean_plan(3) == [None, 0, 2]
+    for K in range(0, 33):
+        plan = mean_plan(K)
+        assert len(plan) == K
+        tables = [np.eye(1, K + 1, 0, dtype=np.int64)[0]]
+        for add in plan:
+            assert add is None or 0 <= add < len(tables)
+            shifted = np.concatenate([[0], tables[-1][:-1]])               # A @ (table before)
+            assert tables[-1][-1] == 0                                       # (nothing of degree K is multiplied again)
+            tables.append(shifted + (tables[add] if add is not None else 0))
+        assert np.array_equal(tables[-1], np.ones(K + 1, dtype=np.int64))
+        n_adds = sum(a is not None for a in plan)
+        assert n_adds <= K and (K < 3 or n_adds < K)                        # never more reads than Horner's rule, fewer from K = 3
+        if K + 1 == 1 << (K + 1).bit_length() - 1 and K:                    # K + 1 a power of two: log2(K + 1) addends
+            assert n_adds == (K + 1).bit_length() - 1

@@ -154,6 +154,32 @@ def test_propagate_matches_oracle_on_golden_toys(golden):
         assert _rel_err(rep, O.lightgcn_get_rep(adj, emb, 3)) < TOL
 
 
+@pytest.mark.parametrize('K', [1, 2, 3, 4, 5, 6, 7])
+def test_layer_mean_by_the_factored_polynomial_is_the_stack_mean(K):
+    """ops.mean_plan evaluates X_0 + A X_0 + ... + A^K X_0 through the factors of 1 + x + ... + x^K (K = 3: (I + A)(I + A^2) X_0,
+    one addend read less than stack().mean(), model.py:101-105): against the layer loop in float64, forward and backward, on a
+    graph with long rows."""
+    from igcn_cf_amd.dataset import SyntheticDataset
+    from igcn_cf_amd.graph import XCD_PLAN, CsrMatrix, normalized_adjacency_host
+    from igcn_cf_amd.ops import mean_plan, propagate_mean, propagate_mean_backward
+    ds = SyntheticDataset({'name': 'SyntheticDataset', 'n_users': 3000, 'n_items': 2000, 'n_inter': 120000, 'seed': 3})
+    n = ds.n_users + ds.n_items
+    rowptr, col, val = normalized_adjacency_host(ds.train_array, ds.n_users, ds.n_items)
+    csr = CsrMatrix(rowptr, col, val, (n, n), 'cuda', order_blocks=[0, ds.n_users, n], xcd_plan=XCD_PLAN)
+    assert len(mean_plan(K)) == K
+    g = torch.Generator(device='cuda').manual_seed(K)
+    x = torch.randn(n, 64, device='cuda', generator=g) * 0.1
+    a = csr.to_torch_coo().double()
+    cur, acc = x.double(), x.double().clone()
+    for _ in range(K):
+        cur = torch.sparse.mm(a, cur)
+        acc += cur
+    ref = acc / (K + 1)
+    for got in (propagate_mean(csr, x, K), propagate_mean_backward(csr, x, K)):        # A_hat is symmetric: the same operator
+        err = (got.double() - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-30)
+        assert float(err.max()) < 1e-6                                                   # (north_star's bound is 1e-4)
+
+
 def test_propagate_backward_is_adjoint():
     """Linearity + adjointness at full Amazon-book-like size (size-independent
     properties): <P x, z> == <x, P^T z> for P = mean of powers of A_hat."""
@@ -281,7 +307,7 @@ def test_spmm_row_masks_and_pruned_propagation():
     xp = x.clone(); xp[~m2.bool()] = float('nan')
     assert torch.equal(spmm(csr, xp, col_mask=b2), want)
     assert torch.equal(spmm(csr, xp, col_mask=b2, row_mask=m1, masked_rows_zero=True)[keep], want[keep])
-    for K in (1, 2, 3, 4):
+    for K in (1, 2, 3, 4, 5):
         e_full = x.clone().requires_grad_(True)
         e_prun = x.clone().requires_grad_(True)
         r_full = PropagateFn.apply(e_full, csr, csr, K)
