@@ -109,7 +109,8 @@ int igcn_spmm_plan_fill_host(const int64_t *rowptr_host, int64_t n_rows,
  *   untouched or, with IGCN_SPMM_MASKED_ROWS_ZERO in `flags`, set to zero.
  *
  * Replaces dgl.ops.gspmm(g,'mul','sum',X,w) at model.py:102, :430, :442, the
- * layer mean of model.py:104-105 / :444-445 (adds + scales on the last layer),
+ * layer mean of model.py:104-105 / :444-445 (adds + scales: the callers evaluate
+ * the mean as a factored polynomial, one addend table per launch — ops.mean_plan),
  * NGCF.dropout_sp_mat as used at model.py:435 (drop_p, no structure rebuild)
  * and the row-constant values of IGCN.update_feat_mat, model.py:374-377
  * (val == NULL, row_scale = row_sum^exponent; the transposed view used by the
