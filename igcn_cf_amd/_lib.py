@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # overwritten for that (scripts/sanitize_host.sh used to copy its ASan build over it)
 LIB_PATH = os.environ.get('IGCN_LIB_PATH') or os.path.join(_PKG, 'libigcn_hip.so')
 
-EXPECTED_ABI = int(os.environ.get('IGCN_EXPECT_ABI') or 8)   # IGCN_ABI_VERSION of include/igcn_hip.h this binding was written against (env: developer A/Bs against a build of an earlier round)
+EXPECTED_ABI = int(os.environ.get('IGCN_EXPECT_ABI') or 9)   # IGCN_ABI_VERSION of include/igcn_hip.h this binding was written against (env: developer A/Bs against a build of an earlier round)
 MAX_ADDS = 8
 MAX_TOPK = 256
 MAX_METRIC_CUTS = 8
@@ -35,9 +35,10 @@ SIGNATURES = {
     'igcn_spmm_csr_f32': (C.c_int, [vp, vp, vp, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                     C.c_float, C.POINTER(vp), C.c_int32, C.c_float, vp, vp,
                                     vp, C.c_int64, vp, C.c_int64, vp, C.c_int32,
-                                    vp, C.c_uint64, C.c_float, vp, C.c_int32, C.c_int64, vp, vp, vp, vp, vp]),
+                                    vp, C.c_uint64, C.c_float, vp, C.c_int32, C.c_int64, vp, vp, vp, vp, vp, vp]),
     'igcn_mark_rows': (C.c_int, [vp, C.c_int64, vp, vp, vp, vp, C.c_int64, vp]),
     'igcn_pack_mask_bits': (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int32, vp, vp]),
+    'igcn_pack_mask_bits_ordered': (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int32, vp, vp, C.c_int64, vp, C.c_int64, vp, vp]),
     'igcn_csr_from_sorted_coo': (C.c_int, [vp, C.c_int64, C.c_int64, vp, vp]),
     'igcn_csr_transpose_workspace_bytes': (C.c_int64, [C.c_int64]),
     'igcn_csr_transpose': (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, vp, vp]),

@@ -90,6 +90,53 @@ __device__ __forceinline__ DealRange deal_range(const int64_t *__restrict__ xcd_
     return r;
 }
 
+// The entries a wave visits.  SKIP = false: every entry of its deal range, `first`, `first + stride`, ...  SKIP = true (launches
+// whose row mask leaves most rows out and that need not zero them — the last forward launch of a training step computes the ~6 000
+// batch rows of 206 151): a masked-out entry used to cost the wave a dependent chain — row_order[vv] -> row_mask / rowptr -> nothing —
+// of ~0.6 us, 59 times per wave = the whole 38 us of that launch.  `bits` holds the mask in DEALING order (bit vv = the row of entry
+// vv is wanted; igcn_pack_mask_bits_ordered), so a wave reads the bits of its next 64 visits in one load (lane j those of visit j:
+// the PER entries vv .. vv + PER - 1, which may straddle two words — the array is padded), ballots, and walks the set bits only.
+// A set bit whose row turns out masked costs one visit (the body checks row_mask as before); a missing bit would lose a row.
+template <bool SKIP, int PER>
+struct DealCursor {
+    DealRange r;
+    const uint32_t *bits;
+    int lane;
+    int64_t batch;
+    unsigned long long todo;
+    __device__ __forceinline__ int64_t begin()
+    {
+        if constexpr (!SKIP) return r.first;
+        batch = r.first - 64 * r.stride;
+        todo = 0ull;
+        return next();
+    }
+    __device__ __forceinline__ int64_t after(int64_t vb)
+    {
+        if constexpr (!SKIP) return vb + r.stride;
+        return next();
+    }
+    __device__ __forceinline__ int64_t next()
+    {
+        while (!todo) {
+            batch += 64 * r.stride;
+            if (batch >= r.end) return r.end;
+            const int64_t mine = batch + lane * r.stride;
+            bool some = false;
+            if (mine < r.end) {
+                const int64_t wi = mine >> 5;
+                unsigned long long win = bits[wi];
+                if (PER > 1) win |= (unsigned long long)bits[wi + 1] << 32;
+                some = ((win >> (mine & 31)) & ((1ull << PER) - 1ull)) != 0ull;
+            }
+            todo = __ballot(some);
+        }
+        const int k = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        return batch + k * r.stride;
+    }
+};
+
 // Epilogue of one finished output row: r = (out_scale * acc + add_scale * sum(adds[dst])) * row_scale[dst] -> y[dst].
 __device__ __forceinline__ void finish_row(const float4 &acc, int64_t dst, int t, const SpmmEpilogue &ep, float *__restrict__ y, int64_t ldy)
 {
@@ -250,7 +297,7 @@ __device__ __forceinline__ void segment_done(const igcn_long_row *long_rows, int
 // the most that still lets 8 waves share a SIMD; without the cap the d = 32 variant took 100 and ran 6 (-15 %).
 // FOLD: the cut rows are added up inside the launch (opt-in, see segment_done); an instantiation of its own, so that the default
 // kernels carry nothing of it (its mere presence cost the headline launch 0.4 %).
-template <int LPR, bool DROPOUT, bool FOLD = false>
+template <int LPR, bool DROPOUT, bool FOLD = false, bool SKIP = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void spmm_csr_rows_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy,
@@ -258,7 +305,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
     const igcn_row_segment *__restrict__ segments, int64_t n_segments,
     float *__restrict__ partial, int long_threshold,
     const uint8_t *__restrict__ row_mask, int masked_rows_zero, const int32_t *__restrict__ row_order,
-    const int64_t *__restrict__ xcd_off, const igcn_long_row *__restrict__ long_rows)
+    const int64_t *__restrict__ xcd_off, const igcn_long_row *__restrict__ long_rows, const uint32_t *__restrict__ order_bits)
 {
     constexpr int G = kWave / LPR;           // source rows per gather instruction
     const int lane = threadIdx.x & (kWave - 1);
@@ -274,7 +321,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
     unsigned long long tr_rows = 0, tr_nnz = 0, tr_chunks = 0;
 #endif
 
-    for (int64_t vv = deal.first; vv < deal.end; vv += deal.stride) {
+    DealCursor<SKIP, 1> cursor{deal, order_bits, lane, 0, 0ull};
+    for (int64_t vv = cursor.begin(); vv < deal.end; vv = cursor.after(vv)) {
         int64_t start, end, dst;
         bool to_partial;
         const int64_t v = row_order ? (int64_t)row_order[vv] : vv;
@@ -382,7 +430,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
 // chain, not by bandwidth; R independent chains per wave give R times the requests in flight.  Same
 // arithmetic per row (each lane group sums its neighbours in storage order, groups folded in a fixed
 // order); every control decision is per sub-wave, so the loops run while ANY sub-wave has work.
-template <int LPR, int R, bool DROPOUT, bool FOLD = false>
+template <int LPR, int R, bool DROPOUT, bool FOLD = false, bool SKIP = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void spmm_csr_multirow_kernel(
     const int64_t *__restrict__ rowptr, const int32_t *__restrict__ col, const float *__restrict__ val,
     const float *__restrict__ x, int64_t ldx, float *__restrict__ y, int64_t ldy,
@@ -390,7 +438,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
     const igcn_row_segment *__restrict__ segments, int64_t n_segments,
     float *__restrict__ partial, int long_threshold,
     const uint8_t *__restrict__ row_mask, int masked_rows_zero, const int32_t *__restrict__ row_order,
-    const int64_t *__restrict__ xcd_off, const igcn_long_row *__restrict__ long_rows)
+    const int64_t *__restrict__ xcd_off, const igcn_long_row *__restrict__ long_rows, const uint32_t *__restrict__ order_bits)
 {
     constexpr int S = kWave / R;             // lanes of a sub-wave
     constexpr int G = S / LPR;               // source rows per gather instruction and sub-wave
@@ -410,7 +458,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_num_sgpr(80))) void s
     unsigned long long tr_rows = 0, tr_nnz = 0;
 #endif
 
-    for (int64_t vb = deal.first; vb < deal.end; vb += deal.stride) {
+    DealCursor<SKIP, R> cursor{deal, order_bits, lane, 0, 0ull};
+    for (int64_t vb = cursor.begin(); vb < deal.end; vb = cursor.after(vb)) {
         const int64_t vv = vb + lane / S;                         // this sub-wave's entry of the dealing order
         const int64_t v = vv >= deal.end ? n_virtual : row_order ? (int64_t)row_order[vv] : vv;
         // kind: 0 nothing, 1 ordinary row -> y, 2 row segment -> partial, 3 masked row that must read as zero
@@ -632,6 +681,45 @@ __global__ __launch_bounds__(kBlock) void pack_mask_bits_kernel(const uint8_t *_
     }
 }
 
+// pack_mask_bits_kernel + the FIRST mask once more in the dealing order of a matrix (DealCursor): bit vv of order_bits = the row of
+// entry vv — row_order[vv], or the row of the segment it names — is set in masks[0].  One launch (a captured training step pays
+// ~5 us per kernel node); the waves behind the packing ones do the ordered bits; the last of them zeroes the two padding words.
+__global__ __launch_bounds__(kBlock) void pack_mask_bits_ordered_kernel(const uint8_t *__restrict__ masks, int64_t n, int64_t stride,
+                                                                        int64_t words, int64_t pairs, int n_masks, uint32_t *__restrict__ bits,
+                                                                        const int32_t *__restrict__ row_order,
+                                                                        const igcn_row_segment *__restrict__ segments, int64_t n_virtual,
+                                                                        int64_t pairs_o, uint32_t *__restrict__ order_bits)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wv = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (wv < pairs * n_masks) {
+        const int64_t m = wv / pairs, pair = wv % pairs;
+        const int64_t e = pair * kWave + lane;
+        const bool on = e < n && masks[m * stride + e] != 0;
+        const unsigned long long b = __ballot(on);
+        if (lane == 0) {
+            bits[m * words + 2 * pair] = (uint32_t)b;
+            if (2 * pair + 1 < words) bits[m * words + 2 * pair + 1] = (uint32_t)(b >> 32);
+        }
+        return;
+    }
+    const int64_t pair = wv - pairs * n_masks;
+    if (pair >= pairs_o) return;
+    const int64_t vv = pair * kWave + lane;
+    bool on = false;
+    if (vv < n_virtual) {
+        const int64_t v = row_order ? (int64_t)row_order[vv] : vv;
+        const int64_t row = v < n ? v : (int64_t)segments[v - n].row;
+        on = masks[row] != 0;
+    }
+    const unsigned long long b = __ballot(on);
+    if (lane == 0) {
+        order_bits[2 * pair] = (uint32_t)b;
+        order_bits[2 * pair + 1] = (uint32_t)(b >> 32);
+        if (pair == pairs_o - 1) { order_bits[2 * pairs_o] = 0u; order_bits[2 * pairs_o + 1] = 0u; }
+    }
+}
+
 // Workgroups of this kernel variant that a CU really holds at once (a floor for the grid).  Rows are
 // dealt to the waves round-robin, so a grid only slightly larger than what is resident is the worst
 // case: measured on MI355X (scripts/dev_spmm_trace.py), 8 workgroups per CU of the d = 64 variant left 1
@@ -655,7 +743,7 @@ static int launch_rows(bool dropout, int64_t blocks, hipStream_t st,
                        float *y, int64_t ldy, int64_t n_rows, int d, const SpmmEpilogue &ep, const SpmmDropout &dr,
                        const igcn_row_segment *segments, int64_t n_segments, float *partial, int long_threshold,
                        const igcn_long_row *long_rows, int64_t n_long, const uint8_t *row_mask, int masked_rows_zero,
-                       int64_t nnz, const int32_t *row_order, const int64_t *xcd_off, bool closing)
+                       int64_t nnz, const int32_t *row_order, const int64_t *xcd_off, bool closing, const uint32_t *order_bits)
 {
     // Grid: `blocks` on entry = one wave per row.  Fewer, longer-lived waves amortise the per-wave set-up;
     // many short ones let the hardware dispatcher even out the load (a power-law graph deals very
@@ -696,8 +784,13 @@ static int launch_rows(bool dropout, int64_t blocks, hipStream_t st,
     const igcn_long_row *fold = n_long > 0 && closing && tuning_get(IGCN_TUNE_SPMM_FOLD) > 0 ? long_rows : nullptr;
 #define IGCN_SPMM_LAUNCH(...)                                                                                                          \
     hipLaunchKernelGGL((__VA_ARGS__), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy, n_rows, d, ep, dr, segments, n_segments, \
-                       partial, long_threshold, row_mask, masked_rows_zero, row_order, xcd_off, fold)
-    if (multirow) {
+                       partial, long_threshold, row_mask, masked_rows_zero, row_order, xcd_off, fold, skip)
+    // (skipping by the mask in dealing order: only where masked rows need no zeros, nothing is dropped out and no row is folded)
+    const uint32_t *skip = row_mask && !masked_rows_zero && !dropout && !fold ? order_bits : nullptr;
+    if (skip) {
+        if (multirow) { if constexpr (R > 1) IGCN_SPMM_LAUNCH(spmm_csr_multirow_kernel<LPR, R, false, false, true>); }
+        else IGCN_SPMM_LAUNCH(spmm_csr_rows_kernel<LPR, false, false, true>);
+    } else if (multirow) {
         if constexpr (R > 1) {
             if (fold) { if (dropout) IGCN_SPMM_LAUNCH(spmm_csr_multirow_kernel<LPR, R, true, true>); else IGCN_SPMM_LAUNCH(spmm_csr_multirow_kernel<LPR, R, false, true>); }
             else if (dropout) IGCN_SPMM_LAUNCH(spmm_csr_multirow_kernel<LPR, R, true, false>);
@@ -781,7 +874,7 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
                                  const int32_t *edge_id, uint64_t seed, float keep_prob,
                                  const uint8_t *row_mask, int32_t flags,
                                  int64_t nnz, const int32_t *row_order, const uint32_t *col_mask,
-                                 const uint64_t *seed_dev, const int64_t *xcd_off, void *stream)
+                                 const uint64_t *seed_dev, const int64_t *xcd_off, const uint32_t *order_bits, void *stream)
 {
     const int32_t masked_rows_zero = flags & IGCN_SPMM_MASKED_ROWS_ZERO;
     // cut rows added up inside the launch: only with a plan that marks closing segments and deals them late (the caller says so)
@@ -795,6 +888,7 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
         return IGCN_E_NULL;
     if (n_segments > 0 && long_threshold < 1) return IGCN_E_RANGE;
     if (xcd_off && !row_order) return IGCN_E_NULL;
+    if (order_bits && !row_mask) return IGCN_E_NULL;       // the mask in dealing order comes with the mask itself
     if (x == y) return IGCN_E_RANGE;     // in-place propagation would read rows being written
     if (n_rows == 0) return IGCN_OK;
     // col may be NULL only for a matrix without stored entries (rowptr all zero): it is never read then
@@ -841,7 +935,7 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
 #define IGCN_SPMM_CASE(L)                                                                                         \
     return launch_rows<L>(dropout, blocks, st, rowptr, col, val, x, ldx, y, ldy, n_rows, (int)d, ep, dr, segments,  \
                           n_segments, partial, (int)long_threshold, long_rows, n_long_rows, row_mask, (int)masked_rows_zero, \
-                          nnz, row_order, xcd_off, closing)
+                          nnz, row_order, xcd_off, closing, order_bits)
     const int q = d / 4;
     if (q <= 1) IGCN_SPMM_CASE(1);
     if (q <= 2) IGCN_SPMM_CASE(2);
@@ -874,6 +968,26 @@ extern "C" int igcn_pack_mask_bits(const uint8_t *masks, int64_t n, int64_t stri
     const int64_t waves = pairs * n_masks;
     hipLaunchKernelGGL(pack_mask_bits_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
                        masks, n, stride, words, pairs, (int)n_masks, bits);
+    return launch_status();
+}
+
+extern "C" int igcn_pack_mask_bits_ordered(const uint8_t *masks, int64_t n, int64_t stride, int32_t n_masks, uint32_t *bits,
+                                           const int32_t *row_order, int64_t n_order, const igcn_row_segment *segments,
+                                           int64_t n_segments, uint32_t *order_bits, void *stream)
+{
+    if (!masks || !bits || !order_bits) return IGCN_E_NULL;
+    if (n < 0 || n_masks < 1 || stride < n || n_segments < 0) return IGCN_E_SHAPE;
+    if (n_segments > 0 && !segments) return IGCN_E_NULL;
+    if (n + n_segments >= ((int64_t)1 << 31)) return IGCN_E_SHAPE;
+    // entries of the dealing order: all rows and segments without one; with one, what it lists (a plan's lists hold no cut row)
+    if (!row_order) n_order = n + n_segments;
+    if (n_order < 0 || n_order > n + n_segments) return IGCN_E_SHAPE;
+    if (n == 0) return IGCN_OK;
+    const int64_t words = (n + 31) / 32, pairs = (n + kWave - 1) / kWave;
+    const int64_t n_virtual = n_order, pairs_o = (n_virtual + kWave - 1) / kWave;
+    const int64_t waves = pairs * n_masks + pairs_o;
+    hipLaunchKernelGGL(pack_mask_bits_ordered_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       masks, n, stride, words, pairs, (int)n_masks, bits, row_order, segments, n_virtual, pairs_o, order_bits);
     return launch_status();
 }
 

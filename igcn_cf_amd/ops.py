@@ -20,9 +20,10 @@ def _require_gpu_f32(t, name):
 
 
 def spmm(csr: CsrMatrix, x, out=None, adds=(), out_scale=1.0, add_scale=1.0, row_scale=None, col_scale=None,
-         keep_prob=1.0, seed=0, row_mask=None, masked_rows_zero=False, col_mask=None):
+         keep_prob=1.0, seed=0, row_mask=None, masked_rows_zero=False, col_mask=None, order_bits=None):
     """out = (out_scale * csr @ x + add_scale * sum(adds)) * row_scale  (see igcn_spmm_csr_f32).
     col_mask: bit mask over the columns (int32 words, pack_mask_bits): rows of x whose bit is clear are all zero and are not read.
+    order_bits: row_mask once more in THIS matrix's dealing order (mark_rows(...).order_bits): the launch visits the wanted entries only.
     seed: an int, or a one-element int64 tensor on the GPU (read by the kernel: HIP-graph replays see its current value)."""
     _require_gpu_f32(x, 'x')
     n_rows, n_cols = csr.shape
@@ -48,6 +49,10 @@ def spmm(csr: CsrMatrix, x, out=None, adds=(), out_scale=1.0, add_scale=1.0, row
         raise _lib.IgcnError('col_mask must be a bit mask (int32 words, ops.pack_mask_bits) over the columns, on the GPU')
     if col_scale is not None and (col_scale.dtype != torch.float32 or col_scale.numel() < n_cols or not col_scale.is_cuda):
         raise _lib.IgcnError('col_scale must be float32 [n_cols] on the GPU')
+    if order_bits is not None:
+        need = 2 * ((n_rows + csr.n_segments + 63) // 64) + 2
+        if row_mask is None or order_bits.dtype != torch.int32 or not order_bits.is_cuda or order_bits.numel() < need:
+            raise _lib.IgcnError('order_bits: int32 [%d] on the GPU (mark_rows(...).order_bits of this matrix), together with row_mask' % need)
     add_ptrs = (C.c_void_p * max(1, len(adds)))(*[a.data_ptr() for a in adds])
     partial = csr.partial(d)
     seed_dev = None
@@ -62,7 +67,7 @@ def spmm(csr: CsrMatrix, x, out=None, adds=(), out_scale=1.0, add_scale=1.0, row
         _lib.ptr(csr.long_rows), csr.n_long, _lib.ptr(csr.segments), csr.n_segments, _lib.ptr(partial),
         csr.long_threshold, _lib.ptr(csr.edge_id), int(seed) & 0xFFFFFFFFFFFFFFFF, float(keep_prob),
         _lib.ptr(row_mask), (1 if masked_rows_zero else 0) | (2 if getattr(csr, 'closing_segments', False) else 0), csr.nnz, _lib.ptr(csr.row_order),
-        _lib.ptr(col_mask), _lib.ptr(seed_dev), _lib.ptr(csr.xcd_off), _lib.current_stream()), 'igcn_spmm_csr_f32')
+        _lib.ptr(col_mask), _lib.ptr(seed_dev), _lib.ptr(csr.xcd_off), _lib.ptr(order_bits), _lib.current_stream()), 'igcn_spmm_csr_f32')
     return out
 
 
@@ -78,17 +83,35 @@ def pack_mask_bits(masks):
     return bits if two else bits[0]
 
 
+class RowMarks(tuple):
+    """(mask1, mask2, bits1, bits2) of mark_rows, plus `order_bits`: mask1 in the dealing order of the matrix `order_of` (what
+    spmm's order_bits takes for THAT matrix only), or None."""
+    order_bits = None
+    order_of = None
+
+    def order_bits_for(self, csr):
+        return self.order_bits if self.order_of is csr else None
+
+
 def mark_rows(csr: CsrMatrix, ids, with_neighbours=True):
     """(mask1, mask2, bits1, bits2): uint8 [n_rows] masks — mask1 = the listed rows, mask2 = those rows and their
-    neighbourhood in `csr` (igcn_mark_rows) — and the same two as bit masks (what spmm's col_mask takes)."""
+    neighbourhood in `csr` (igcn_mark_rows) — and the same two as bit masks (what spmm's col_mask takes).  The tuple also
+    carries mask1 in the dealing order of `csr` (RowMarks.order_bits; same launch as the bit masks)."""
     _require_i64(ids, 'ids')
     n_rows = csr.shape[0]
     masks = torch.zeros((2, n_rows), dtype=torch.uint8, device=ids.device)
     _lib.check(_lib.lib().igcn_mark_rows(ids.data_ptr(), ids.numel(), csr.rowptr.data_ptr(), csr.col.data_ptr(),
                                          masks[0].data_ptr(), masks[1].data_ptr() if with_neighbours else None, n_rows,
                                          _lib.current_stream()), 'igcn_mark_rows')
-    bits = pack_mask_bits(masks)
-    return masks[0], masks[1], bits[0], bits[1]
+    bits = torch.empty((2, (n_rows + 31) // 32), dtype=torch.int32, device=ids.device)
+    order_bits = torch.empty(2 * ((n_rows + csr.n_segments + 63) // 64) + 2, dtype=torch.int32, device=ids.device)
+    _lib.check(_lib.lib().igcn_pack_mask_bits_ordered(masks.data_ptr(), n_rows, masks.stride(0), 2, bits.data_ptr(),
+                                                      _lib.ptr(csr.row_order), csr.row_order.numel() if csr.row_order is not None else 0,
+                                                      _lib.ptr(csr.segments), csr.n_segments,
+                                                      order_bits.data_ptr(), _lib.current_stream()), 'igcn_pack_mask_bits_ordered')
+    marks = RowMarks((masks[0], masks[1], bits[0], bits[1]))
+    marks.order_bits, marks.order_of = order_bits, csr
+    return marks
 
 
 def mean_plan(n_layers, form='factored'):
@@ -148,8 +171,10 @@ def propagate_mean(csr: CsrMatrix, x0, n_layers, row_scale_last=None, masks=None
     for l, add in enumerate(plan if plan is not None else mean_plan(n_layers)):
         adds = plan_addends(add, tables)
         if l == n_layers - 1:
+            # (rows outside the mask left untouched: the launch walks the wanted entries only — RowMarks.order_bits)
+            skip = masks.order_bits_for(csr) if masks and not zero_masked and isinstance(masks, RowMarks) else None
             y = spmm(csr, tables[-1], adds=adds, out_scale=s, add_scale=s, row_scale=row_scale_last,
-                     row_mask=masks[0] if masks else None, masked_rows_zero=zero_masked)
+                     row_mask=masks[0] if masks else None, masked_rows_zero=zero_masked, order_bits=skip)
         elif l == n_layers - 2 and masks:
             y = spmm(csr, tables[-1], adds=adds, row_mask=masks[1], masked_rows_zero=False)
         else:

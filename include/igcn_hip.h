@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IGCN_ABI_VERSION 8
+#define IGCN_ABI_VERSION 9
 
 #define IGCN_OK            0
 #define IGCN_E_NULL       -1   /* a required pointer is NULL               */
@@ -140,6 +140,13 @@ int igcn_spmm_plan_fill_host(const int64_t *rowptr_host, int64_t n_rows,
  * caller knows to be all zero (bit clear) are not read —
  * the first backward hops of a training step, whose operand is non-zero on the batch rows / their neighbourhood
  * only.  Edges whose weight comes out zero (masked here, or dropped out) issue no gather at all;
+ * order_bits (ABI v9): NULL, or row_mask once more as one BIT per entry of the DEALING order (bit vv of word vv >> 5 set when the
+ * row of entry vv — row_order[vv], or the row of the segment it names; vv itself without a row_order — has row_mask != 0),
+ * 2 * ceil((n_rows + n_segments) / 64) + 2 words, written by igcn_pack_mask_bits_ordered.  Needs row_mask.  A launch that
+ * need not zero its masked rows (no IGCN_SPMM_MASKED_ROWS_ZERO), drops nothing out and folds nothing then reads the bits of 64
+ * visits at a time and visits only the wanted entries: a masked-out entry otherwise costs its wave a chain of dependent loads
+ * (row_order -> row_mask / rowptr), which was ALL the time of the last forward launch of a training step (38 us for ~6 000
+ * of 206 151 rows on the Amazon-book-like graph).  Ignored where it does not apply; same result with and without;
  * seed_dev: NULL, or the dropout seed in device memory (overrides `seed`): a launch captured in a HIP graph reads it
  * at every replay, so the caller changes the dropped edges by writing 8 bytes, not by re-capturing;
  * xcd_off (ABI v5): NULL, or int64 [9] in device memory: row_order then holds EIGHT lists back to back, list x =
@@ -159,7 +166,7 @@ int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *va
                       const int32_t *edge_id, uint64_t seed, float keep_prob,
                       const uint8_t *row_mask, int32_t flags /* IGCN_SPMM_MASKED_ROWS_ZERO | IGCN_SPMM_CLOSING_SEGMENTS */,
                       int64_t nnz, const int32_t *row_order, const uint32_t *col_mask,
-                      const uint64_t *seed_dev, const int64_t *xcd_off, void *stream);
+                      const uint64_t *seed_dev, const int64_t *xcd_off, const uint32_t *order_bits, void *stream);
 
 /* Row masks for igcn_spmm_csr_f32.  mask1[ids[i] + offsets...] = 1 for every listed row;
  * when rowptr/col are given, mask2[r] = 1 for every listed row r and every column
@@ -172,6 +179,15 @@ int igcn_mark_rows(const int64_t *ids, int64_t n, const int64_t *rowptr, const i
  * uint32 words per mask (mask m at bits + m * words): the form igcn_spmm_csr_f32's col_mask takes — 8x smaller, so
  * the lookups of a launch stay in the CU's L1 instead of going to L2. */
 int igcn_pack_mask_bits(const uint8_t *masks, int64_t n, int64_t stride, int32_t n_masks, uint32_t *bits, void *stream);
+
+/* igcn_pack_mask_bits and, in the same launch, masks[0] in the dealing order of a matrix with n rows: order_bits as
+ * igcn_spmm_csr_f32 takes it (uint32, room for 2 * ceil((n + n_segments) / 64) + 2 words; the two padding words behind the
+ * last entry are zeroed here).  row_order int32 [n_order] / segments: the matrix's (n_order = n + n_segments for a plain
+ * dealing order, fewer with an XCD plan, whose lists hold no cut row; row_order NULL = rows, then segments, in index order —
+ * what the launch visits then; n_order is ignored). */
+int igcn_pack_mask_bits_ordered(const uint8_t *masks, int64_t n, int64_t stride, int32_t n_masks, uint32_t *bits,
+                                const int32_t *row_order, int64_t n_order, const igcn_row_segment *segments,
+                                int64_t n_segments, uint32_t *order_bits, void *stream);
 
 /* Device-side index utilities for the graph-swap path (model.py:402-421 is_updating,
  * run/dropui/igcn_dropui.py:26-35): the reference rebuilds its sparse structures on the host

@@ -26,8 +26,8 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert getattr(_lib.lib(), name) is not None
-    assert _lib.lib().igcn_abi_version() == _lib.EXPECTED_ABI == 8
-    assert re.search(r'#define IGCN_ABI_VERSION\s+8\b', header)
+    assert _lib.lib().igcn_abi_version() == _lib.EXPECTED_ABI == 9
+    assert re.search(r'#define IGCN_ABI_VERSION\s+9\b', header)
     assert _lib.lib().igcn_error_string(-1).decode().startswith('a required pointer')
 
 
@@ -40,7 +40,7 @@ def test_library_is_loaded_behind_torch_in_a_fresh_process():
             "assert 'torch' in sys.modules; print(v)")
     p = subprocess.run([sys.executable, '-c', code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 0, p.stderr.decode()[-1000:]
-    assert p.stdout.decode().strip() == '8'
+    assert p.stdout.decode().strip() == '9'
 
 
 def test_no_kernel_of_the_built_library_carries_a_private_segment():
@@ -89,11 +89,12 @@ def test_a_library_of_another_abi_version_is_refused_at_load_time():
     """the build keeps a .so that is newer than its sources, so a stale library could load silently and the wrappers would
     then mis-read its contract.  _lib.handle() compares igcn_abi_version() with the version it was written against."""
     import subprocess
+    from igcn_cf_amd import _lib
     code = ("from igcn_cf_amd import _lib\n_lib.EXPECTED_ABI = 7\n"
             "try:\n    _lib.lib().igcn_abi_version()\nexcept _lib.IgcnError as e:\n    print('refused:', e)\n")
     p = subprocess.run([sys.executable, '-c', code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 0, p.stderr.decode()[-1000:]
-    assert 'refused:' in p.stdout.decode() and 'ABI version 8' in p.stdout.decode()
+    assert 'refused:' in p.stdout.decode() and 'ABI version %d' % _lib.EXPECTED_ABI in p.stdout.decode()
 
 
 def test_the_bench_line_keeps_what_grades_it_inside_the_drivers_24_key_window():

@@ -223,7 +223,7 @@ def test_c_abi_error_codes_without_launch():
 
     def call(rowptr_p, x_p, y_p, d=64, ldx=64, n_adds=0, keep=1.0, n_rows=8):
         return L.igcn_spmm_csr_f32(rowptr_p, col.data_ptr(), None, x_p, ldx, y_p, 64, n_rows, 8, d, 1.0, nul, n_adds, 1.0,
-                                   None, None, None, 0, None, 0, None, 256, None, 0, keep, None, 0, 0, None, None, None, None, None)
+                                   None, None, None, 0, None, 0, None, 256, None, 0, keep, None, 0, 0, None, None, None, None, None, None)
     assert call(None, x.data_ptr(), y.data_ptr()) == -1                       # IGCN_E_NULL
     assert call(rowptr.data_ptr(), x.data_ptr(), y.data_ptr(), d=0) == -2     # IGCN_E_SHAPE
     assert call(rowptr.data_ptr(), x.data_ptr(), y.data_ptr(), d=300) == -2
@@ -243,7 +243,11 @@ def test_c_abi_error_codes_without_launch():
     xo = torch.zeros(9, dtype=torch.int64, device='cuda')
     assert L.igcn_spmm_csr_f32(rowptr.data_ptr(), col.data_ptr(), None, x.data_ptr(), 64, y.data_ptr(), 64, 8, 8, 64, 1.0, nul, 0, 1.0,
                                None, None, None, 0, None, 0, None, 256, None, 0, 1.0, None, 0, 0, None, None, None, xo.data_ptr(),
-                               None) == -1
+                               None, None) == -1
+    # ABI v9: the mask in dealing order comes with the mask itself
+    assert L.igcn_spmm_csr_f32(rowptr.data_ptr(), col.data_ptr(), None, x.data_ptr(), 64, y.data_ptr(), 64, 8, 8, 64, 1.0, nul, 0, 1.0,
+                               None, None, None, 0, None, 0, None, 256, None, 0, 1.0, None, 0, 0, None, None, None, None,
+                               xo.data_ptr(), None) == -1
     items = torch.randn(100, 64, device='cuda')
     oi = torch.empty(8, 5, dtype=torch.int64, device='cuda'); ov = torch.empty(8, 5, device='cuda')
     ws = torch.empty(1 << 22, dtype=torch.uint8, device='cuda')
@@ -319,6 +323,60 @@ def test_spmm_row_masks_and_pruned_propagation():
         assert torch.allclose(e_prun.grad, e_full.grad, rtol=1e-5, atol=1e-8)
 
 
+@pytest.mark.parametrize('d', [64, 128, 16])
+@pytest.mark.parametrize('plan', ['xcd', 'ordered', 'plain'])
+def test_row_mask_in_dealing_order_visits_only_the_wanted_rows(d, plan):
+    """igcn_pack_mask_bits_ordered + igcn_spmm_csr_f32(order_bits): the launch walks the set bits of the mask in dealing order instead
+    of every entry — same rows computed (bit for bit), every other row untouched, cut rows included; the bit array is the mask
+    permuted by row_order (segments: their row's bit) with two zero words behind it."""
+    from igcn_cf_amd.dataset import SyntheticDataset
+    from igcn_cf_amd.graph import XCD_PLAN, CsrMatrix, normalized_adjacency_host
+    from igcn_cf_amd import _lib
+    from igcn_cf_amd.ops import RowMarks, mark_rows, spmm
+    ds = SyntheticDataset({'name': 'SyntheticDataset', 'n_users': 3000, 'n_items': 2000, 'n_inter': 120000, 'zipf_q': 0., 'seed': 5})
+    n = ds.n_users + ds.n_items
+    rowptr, col, val = normalized_adjacency_host(ds.train_array, ds.n_users, ds.n_items)
+    kw = {'xcd': dict(order_blocks=[0, ds.n_users, n], xcd_plan=XCD_PLAN), 'ordered': dict(order_blocks=[0, ds.n_users, n]), 'plain': {}}[plan]
+    csr = CsrMatrix(rowptr, col, val, (n, n), 'cuda', long_threshold=64, segment_len=64, **kw)
+    assert csr.n_long > 0 and (csr.row_order is not None) == (plan != 'plain')
+    g = torch.Generator(device='cuda').manual_seed(d)
+    x = torch.randn(n, d, device='cuda', generator=g) * 0.1
+    for n_ids in (1, 40, 700):
+        ids = torch.randint(0, n, (n_ids,), device='cuda', generator=g)
+        if n_ids == 40:
+            ids[0] = int(np.argmax(np.diff(rowptr)))                # a cut row among the wanted ones
+        marks = mark_rows(csr, ids)
+        assert isinstance(marks, RowMarks) and marks.order_bits_for(csr) is marks.order_bits and marks.order_bits_for(object()) is None
+        m1 = marks[0]
+        # the bit array, against numpy
+        n_virtual = n + csr.n_segments
+        order = csr.row_order.cpu().numpy().astype(np.int64) if csr.row_order is not None else np.arange(n_virtual)
+        n_order = order.shape[0]                                   # (an XCD plan's lists hold no cut row: fewer entries than n_virtual)
+        seg_row = (np.frombuffer(csr.segments.cpu().numpy().tobytes(), dtype=_lib.ROW_SEGMENT_DTYPE)['row'].astype(np.int64)
+                   if csr.n_segments else np.zeros(1, dtype=np.int64))
+        rows_of = np.where(order < n, order, seg_row[np.maximum(order - n, 0)])
+        want_bits = m1.cpu().numpy()[rows_of].astype(bool)
+        words = marks.order_bits.cpu().numpy().view(np.uint32)
+        assert words.shape[0] == 2 * ((n_virtual + 63) // 64) + 2
+        used = 2 * ((n_order + 63) // 64) + 2
+        got_bits = ((words[:used, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).astype(bool).ravel()
+        assert np.array_equal(got_bits[:n_order], want_bits) and not got_bits[n_order:].any()
+        # the launch
+        ref = torch.full((n, d), 7.0, device='cuda')
+        spmm(csr, x, out=ref, row_mask=m1, masked_rows_zero=False, adds=[x], out_scale=0.5, add_scale=0.25)
+        got = torch.full((n, d), 7.0, device='cuda')
+        spmm(csr, x, out=got, row_mask=m1, masked_rows_zero=False, adds=[x], out_scale=0.5, add_scale=0.25, order_bits=marks.order_bits)
+        assert torch.equal(got, ref)
+        keep = m1.bool()
+        assert torch.all(got[~keep] == 7.0) and torch.allclose(got[keep], (0.5 * spmm(csr, x) + 0.25 * x)[keep], rtol=1e-6, atol=1e-7)
+        # where masked rows must read as zero the bits are ignored, not misused
+        z = torch.full((n, d), 7.0, device='cuda')
+        spmm(csr, x, out=z, row_mask=m1, masked_rows_zero=True, order_bits=marks.order_bits)
+        assert torch.all(z[~keep] == 0.0) and torch.equal(z[keep], spmm(csr, x)[keep])
+    with pytest.raises(Exception):
+        spmm(csr, x, order_bits=marks.order_bits)                   # bits without the mask they restate
+
+
 def test_spmm_matrix_without_entries():
     """A graph with no train pairs: every row is empty, col is an empty array (NULL pointer)."""
     from igcn_cf_amd.graph import CsrMatrix
@@ -383,7 +441,7 @@ def test_launch_shape_does_not_change_results():
                                           y.data_ptr(), d, n_rows, n_cols, d, 1.0, nul, 0, 0.0, None, None,
                                           _lib.ptr(csr.long_rows), csr.n_long, _lib.ptr(csr.segments), csr.n_segments,
                                           _lib.ptr(csr.partial(d)), csr.long_threshold, None, 0, 1.0, None, 0, nnz_hint, None, None, None, None,
-                                          torch.cuda.current_stream().cuda_stream)
+                                          None, torch.cuda.current_stream().cuda_stream)
         assert rc == 0 and torch.equal(y, ref)
     # a row order (rows dealt to the waves by descending length inside two blocks) changes who computes a row, not the result
     ordered = CsrMatrix(rowptr, col, val, (n_rows, n_cols), 'cuda', order_blocks=[0, n_rows // 3, n_rows])
