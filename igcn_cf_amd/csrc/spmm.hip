@@ -93,7 +93,7 @@ __device__ __forceinline__ DealRange deal_range(const int64_t *__restrict__ xcd_
 // The entries a wave visits.  SKIP = false: every entry of its deal range, `first`, `first + stride`, ...  SKIP = true (launches
 // whose row mask leaves most rows out and that need not zero them — the last forward launch of a training step computes the ~6 000
 // batch rows of 206 151): a masked-out entry used to cost the wave a dependent chain — row_order[vv] -> row_mask / rowptr -> nothing —
-// of ~0.6 us, 59 times per wave = the whole 38 us of that launch.  `bits` holds the mask in DEALING order (bit vv = the row of entry
+// of a few hundred ns, 59 times per wave: 8 of that launch's 38 us (the rest is the wanted rows' own nonzeros).  `bits` holds the mask in DEALING order (bit vv = the row of entry
 // vv is wanted; igcn_pack_mask_bits_ordered), so a wave reads the bits of its next 64 visits in one load (lane j those of visit j:
 // the PER entries vv .. vv + PER - 1, which may straddle two words — the array is padded), ballots, and walks the set bits only.
 // A set bit whose row turns out masked costs one visit (the body checks row_mask as before); a missing bit would lose a row.

@@ -145,8 +145,8 @@ int igcn_spmm_plan_fill_host(const int64_t *rowptr_host, int64_t n_rows,
  * 2 * ceil((n_rows + n_segments) / 64) + 2 words, written by igcn_pack_mask_bits_ordered.  Needs row_mask.  A launch that
  * need not zero its masked rows (no IGCN_SPMM_MASKED_ROWS_ZERO), drops nothing out and folds nothing then reads the bits of 64
  * visits at a time and visits only the wanted entries: a masked-out entry otherwise costs its wave a chain of dependent loads
- * (row_order -> row_mask / rowptr), which was ALL the time of the last forward launch of a training step (38 us for ~6 000
- * of 206 151 rows on the Amazon-book-like graph).  Ignored where it does not apply; same result with and without;
+ * (row_order -> row_mask / rowptr): 8 of the 38 us of the last forward launch of a training step (~6 000 of 206 151 rows
+ * on the Amazon-book-like graph).  Ignored where it does not apply; same result with and without;
  * seed_dev: NULL, or the dropout seed in device memory (overrides `seed`): a launch captured in a HIP graph reads it
  * at every replay, so the caller changes the dropped edges by writing 8 bytes, not by re-capturing;
  * xcd_off (ABI v5): NULL, or int64 [9] in device memory: row_order then holds EIGHT lists back to back, list x =
