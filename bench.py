@@ -20,7 +20,7 @@ value = edges/s = steps * n_layers * nnz(A_hat) / time (whole job, max over rank
 Also reported (outside `value`, flat keys + copies inside `roofline`, whose values the driver keeps): full-evaluation users/s
 (propagate once + fused score/mask/top-20 over every user; the fp32 sweep's MFMA fraction beside it), the full training step, and
 
-roofline: the dominant kernel is spmm_csr_multirow_kernel<16,2,false,false> (LPR, rows per wave, dropout, in-launch fold); `achieved` = algorithmic bytes per launch
+roofline: the dominant kernel is spmm_csr_multirow_kernel<16,2,false,false,false> (LPR, rows per wave, dropout, in-launch fold, mask walk); `achieved` = algorithmic bytes per launch
 (nnz*(8+4d) + N*(4d+4)) / average launch duration measured with HIP events over the timed region; `peak` = the
 8 TB/s HBM spec and `frac` = achieved / peak.  The 52.8 MB operand of this workload lives in the 256 MiB Infinity Cache, so that
 fraction EXCEEDS 1 and bounds nothing here: `bound` says "mall-gather", and next to it the line carries the rate of gathered rows
@@ -28,7 +28,7 @@ against the guide's 8.6 TB/s for Infinity-Cache gathers, the counter-measured by
 (`traffic`, profiles/pmc_traffic.json), the L2 hit rate, and an in-run rowless gather over the same index stream
 (igcn_cf_amd/csrc/roof_probe.hip; a sibling kernel, not a roof).
 The HBM-bound leg — one GPU's 1/8 row share of BASELINE config 5 (125 M nonzeros against a 12 M x 128 operand = 6.1 GB, kernel
-spmm_csr_rows_kernel<32,false,false>), its user block and its item block as launches of their own — is timed in the same run
+spmm_csr_rows_kernel<32,false,false,false>), its user block and its item block as launches of their own — is timed in the same run
 (extras.roofline_hbm_bound, flat hbm_bound_*): counter bytes (2*FETCH_SIZE + WRITE_SIZE of the committed pass of these very
 launches, profiles/pmc_traffic_config5.json) / this run's time against the 8 TB/s spec and against what this box streams
 (hbm_stream_read_GBps / hbm_stream_copy_GBps: roof_probe.hip's stream kernels, 2 GiB buffers); the algorithmic figure is kept
@@ -343,8 +343,8 @@ def main():
     # ---- roofline of the dominant kernel (per launch, this rank) ----------------------------------
     b_alg = local_nnz * (8 + 4 * d) + local_rows * (4 * d + 4)
     b_min = local_nnz * 8 + (n + local_rows) * 4 * d + local_rows * 4
-    kernel_name = ('spmm_csr_multirow_kernel<%d,%d,false,false>' % (max(1, d // 4), 2 if d >= 32 else 4)) if d <= 64 \
-        else 'spmm_csr_rows_kernel<%d,false,false>' % (d // 4)
+    kernel_name = ('spmm_csr_multirow_kernel<%d,%d,false,false,false>' % (max(1, d // 4), 2 if d >= 32 else 4)) if d <= 64 \
+        else 'spmm_csr_rows_kernel<%d,false,false,false>' % (d // 4)
     if not sharded:
         ms_launch = dev_ms / (args.steps * launches_per_step)
         launch_note = 'HIP events over the timed region / launches; one call = main kernel + long-row reduce (~5 us) + gap'   # < 120 chars
@@ -815,7 +815,7 @@ def hbm_bound_leg(device, reps=5, ranks=(0,), stream_probe=None):
     (igcn_cf_amd/synth.py, SURVEY 8(d) generator rules), cut with ShardLayout.balanced(world = 8); rank 0's share (its
     user block gathering item rows + its item block gathering user rows, ~125 M nonzeros) against the full replicated
     operand X (12 M x 128 fp32 = 6.1 GB, far beyond the Infinity Cache).  One launch of igcn_spmm_csr_f32
-    (spmm_csr_rows_kernel<32,false,false>) per share; `ranks` = the shares to run (scripts/dev_config5_shares.py runs all 8).
+    (spmm_csr_rows_kernel<32,false,false,false>) per share; `ranks` = the shares to run (scripts/dev_config5_shares.py runs all 8).
 
     Three rates per launch, never mixed: ALGORITHMIC bytes / time (every gathered row counted, cache-served
     or not — can exceed what HBM streams); COUNTER bytes / time (2 x FETCH_SIZE + WRITE_SIZE of the committed rocprofv3
@@ -863,7 +863,7 @@ def hbm_bound_leg(device, reps=5, ranks=(0,), stream_probe=None):
                         'gathers_from': ('the 2 M item rows (1.0 GB, popularity-skewed: hot head in the Infinity Cache)' if name == 'user_block'
                                          else 'the 10 M user rows (5.1 GB, near-uniform: nothing to cache)')}
     st = stream_probe or measured_stream(device)
-    out = {'kernel': 'spmm_csr_rows_kernel<32,false,false>', 'unit': 'GB/s', 'peak': HBM_PEAK_GBPS, 'avg_launch_ms': ms,
+    out = {'kernel': 'spmm_csr_rows_kernel<32,false,false,false>', 'unit': 'GB/s', 'peak': HBM_PEAK_GBPS, 'avg_launch_ms': ms,
            'algorithmic_bytes_per_launch': b_alg, 'algorithmic_GBps': ach, 'algorithmic_frac': ach / HBM_PEAK_GBPS,
            'algorithmic_note': 'SURVEY 8(d) bytes (every gathered row counted) / time: exceeds what HBM streams when gathers hit caches',
            'stream_read_GBps': st['read_GBps'], 'stream_copy_GBps': st['copy_GBps'],

@@ -47,7 +47,7 @@ def main():
             raise SystemExit('no counter csv under ' + sub)
         vals[counter] = per_variant(f, counter, info)
     mean = lambda xs: sum(xs) / len(xs)
-    out = {'tag': tag, 'kernel': 'void spmm_csr_rows_kernel<32, false, false>', 'd': info['d'], 'world': info['world'], 'rank': info['rank'],
+    out = {'tag': tag, 'kernel': 'void spmm_csr_rows_kernel<32, false, false, false>', 'd': info['d'], 'world': info['world'], 'rank': info['rank'],
            'correction': 'bytes = 2 x FETCH_SIZE x 1024 (gfx950 tallies 128-B requests at 64 B) + WRITE_SIZE x 1024; what leaves L2, '
                          'Infinity-Cache hits included; averages over launches 2..%d of each variant' % info['n_launch'],
            'launches': {}}
