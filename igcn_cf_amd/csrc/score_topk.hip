@@ -787,6 +787,10 @@ __global__ __launch_bounds__(kWave, ((MODE == 2 && D == 128 && NG == 2) || D == 
             asm volatile("" : : "v"(exm[0]) : "memory");
             st_10 += IGCN_CLOCK() - t_m;
 #endif
+#ifdef IGCN_X_KEEPEXM
+#pragma unroll
+            for (int g = 0; g < NG; ++g) asm volatile("" : : "v"(exm[g]));      // developer ablation: the masks are computed, then not used
+#endif
         };
         // One part of the selection of group g, quad q4 (rows 4 q4 .. 4 q4 + 3 of the lane): s = 0, 1 fold the
         // quad's maximum, s = 2 compares it with the user's threshold into a wave-wide mask (scalar registers).
@@ -836,29 +840,32 @@ __global__ __launch_bounds__(kWave, ((MODE == 2 && D == 128 && NG == 2) || D == 
             IGCN_STAT(1, 1);
             if (prio_boost) __builtin_amdgcn_s_setprio(3);
             const int item_h = tile_base + 4 * h;
-            auto run = [&](auto masks_c) {
-                constexpr bool masks = decltype(masks_c)::value;
+            // ONE copy of this loop (round 5: with a masked and an unmasked instantiation of it, chosen per tile, the default sweep was
+            // 99 KB of code against a 64 KB instruction cache: one copy is 64 KB and 1-2 % faster); the tile's mask state picks the form
+            // of the four staging stores only.
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
+            for (int g = 0; g < NG; ++g) {
 #pragma unroll
-                    for (int q4 = 0; q4 < kQuad; ++q4) {
-                        if (qmask[g][q4]) {
-                            IGCN_STAT(2, 1);
+                for (int q4 = 0; q4 < kQuad; ++q4) {
+                    if (qmask[g][q4]) {
+                        IGCN_STAT(2, 1);
 #ifdef IGCN_X_NOFLUSH
-                            { const unsigned lim = stage_first(g) + ((unsigned)(cap - 4) << 9); wpos[g] = wpos[g] > lim ? lim : wpos[g]; }   // developer ablation: wrong results, no drain
+                        { const unsigned lim = stage_first(g) + ((unsigned)(cap - 4) << 9); wpos[g] = wpos[g] > lim ? lim : wpos[g]; }   // developer ablation: wrong results, no drain
 #else
-                            const bool full = wpos[g] > stage_first(g) + ((unsigned)(cap - 4) << 9);     // fewer than 4 free slots
-                            if (__any(full)) {
-                                if constexpr (kHotTrack) hot[g] += full ? 1 : 0;
-                                flush();
-                            }
-#endif
-                            stage_quad(cur[g], g, q4, item_h, masks);
+                        const bool full = wpos[g] > stage_first(g) + ((unsigned)(cap - 4) << 9);     // fewer than 4 free slots
+                        if (__any(full)) {
+                            if constexpr (kHotTrack) hot[g] += full ? 1 : 0;
+                            flush();
                         }
+#endif
+#ifdef IGCN_X_NOMASKSTAGE
+                        stage_quad(cur[g], g, q4, item_h, false);           // developer ablation build (never shipped): masked items are staged as they are
+#else
+                        if (mflag) stage_quad(cur[g], g, q4, item_h, true); else stage_quad(cur[g], g, q4, item_h, false);
+#endif
                     }
                 }
-            };
-            if (mflag) run(std::true_type{}); else run(std::false_type{});
+            }
             if (prio_boost) set_base_priority(prio_slot);
 #ifdef IGCN_TOPK_STATS
             asm volatile("s_waitcnt lgkmcnt(0)" : : "v"(wpos[0]) : "memory");

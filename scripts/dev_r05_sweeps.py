@@ -42,7 +42,7 @@ def main():
         out_val = torch.empty((n_users, k), dtype=torch.float32, device='cuda')
         ws = torch.empty(max(L.igcn_score_topk_workspace_bytes(n_users, ds.n_items, d, k), 8), dtype=torch.uint8, device='cuda')
         flops = 2.0 * n_users * ds.n_items * d
-        for masks in (False, True):
+        for masks in (() if os.environ.get('IGCN_SWEEPS_FAST_ONLY') else (False, True)):
             a = (rp.data_ptr(), cl.data_ptr()) if masks else (None, None)
 
             def exact():
@@ -57,13 +57,16 @@ def main():
             flagged = torch.empty(n_users + 1, dtype=torch.int32, device='cuda')
             bounds = torch.empty(n_users, dtype=torch.float32, device='cuda')
 
-            def fast():
-                _lib.check(L.igcn_score_topk_fast_f32(U.data_ptr(), U.stride(0), None, n_users, I.data_ptr(), I.stride(0), ds.n_items, d,
-                                                      rp.data_ptr(), cl.data_ptr(), n_users, cl.numel(), None, k, out_idx.data_ptr(), out_val.data_ptr(),
-                                                      flagged.data_ptr(), bounds.data_ptr(), wp, _lib.current_stream()), 'fast')
-            samples = sorted(time_ms(fast, 5, 2) for _ in range(5))
-            print(json.dumps(dict(lib=tag, call='igcn_score_topk_fast_f32', d=d, users=n_users, masks=True, ms_min=round(samples[0], 3),
-                                  ms_median=round(samples[2], 3), flagged=int(flagged[0]))), flush=True)
+            for masks in (True, False):
+                ex = (rp.data_ptr(), cl.data_ptr(), n_users, cl.numel()) if masks else (None, None, 0, 0)
+
+                def fast():
+                    _lib.check(L.igcn_score_topk_fast_f32(U.data_ptr(), U.stride(0), None, n_users, I.data_ptr(), I.stride(0), ds.n_items, d,
+                                                          ex[0], ex[1], ex[2], ex[3], None, k, out_idx.data_ptr(), out_val.data_ptr(),
+                                                          flagged.data_ptr(), bounds.data_ptr(), wp, _lib.current_stream()), 'fast')
+                samples = sorted(time_ms(fast, 5, 2) for _ in range(5))
+                print(json.dumps(dict(lib=tag, call='igcn_score_topk_fast_f32', d=d, users=n_users, masks=masks, ms_min=round(samples[0], 3),
+                                      ms_median=round(samples[2], 3), flagged=int(flagged[0]))), flush=True)
 
 
 if __name__ == '__main__':
