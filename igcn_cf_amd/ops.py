@@ -119,8 +119,9 @@ def mean_plan(n_layers, form='factored'):
 
     Returns `adds`, one entry per launch: table l + 1 = A @ table l (+ table adds[l] if not None), table 0 = X_0; the last
     table is the sum.  form='stack': the reference's own association instead — every X_l kept, all of them added in the last
-    launch ([None, ..., (0, 1, ..., K - 1)]; an entry may be a tuple of tables) — kept for A/Bs.  The layer loop of model.py:101-105 keeps every X_l and averages the stack — K extra row reads
-    however they are spread (Horner's rule: X_0 once per launch).  1 + x + ... + x^K factors instead:
+    launch ([None, ..., (0, 1, ..., K - 1)]; an entry may be a tuple of tables) — kept for A/Bs.
+    The layer loop of model.py:101-105 keeps every X_l and averages the stack — K extra row reads however they are spread
+    (Horner's rule: X_0 once per launch).  1 + x + ... + x^K factors instead:
     K odd: (1 + x) p_m(x^2), m = (K - 1) / 2; K even: 1 + x p_(K-1)(x) — K = 3, the depth every reference config uses, is
     (I + A)(I + A^2) X_0: U = X_0 + A (A X_0), then U + A U: two addend reads instead of three (-3.2 % of a pass at the
     headline size, -4.6 % Gowalla-like; float64 error of the result not larger; scripts/dev_r05_factorized_mean.py).
