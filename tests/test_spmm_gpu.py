@@ -175,7 +175,8 @@ def test_layer_mean_by_the_factored_polynomial_is_the_stack_mean(K):
         cur = torch.sparse.mm(a, cur)
         acc += cur
     ref = acc / (K + 1)
-    for got in (propagate_mean(csr, x, K), propagate_mean_backward(csr, x, K)):        # A_hat is symmetric: the same operator
+    # (the third: the reference's own association — every layer kept, all added in the last launch — through the same entry point)
+    for got in (propagate_mean(csr, x, K), propagate_mean_backward(csr, x, K), propagate_mean(csr, x, K, plan=mean_plan(K, 'stack'))):
         err = (got.double() - ref).norm(dim=1) / ref.norm(dim=1).clamp_min(1e-30)
         assert float(err.max()) < 1e-6                                                   # (north_star's bound is 1e-4)
 
