@@ -144,6 +144,14 @@ def lift_flat(out, extras):
                   'config5_pass_ms', 'config5_edges_per_s', 'config5_exposed_exchange_ms', 'config5_local_spmm_ms'):
             if flat.get(k) is not None:
                 r[k] = flat[k]
+        if out.get('n_gpus', 1) > 1:
+            # N > 1: the window's evaluation / training slots carry the SHARDED legs (user-sharded evaluation, row-sharded training
+            # step — `eval_sharding_note` says so), so that the driver's record of a multi-GPU run is not a row of nulls
+            for dst, src in (('eval_users_per_s', 'user_sharded_eval_users_per_s'), ('eval_ms', 'user_sharded_eval_ms'),
+                             ('train_step_ms', 'row_sharded_train_step_ms')):
+                if r.get(dst) is None and flat.get(src) is not None:
+                    r[dst] = flat[src]
+            r['eval_sharding_note'] = 'N > 1: eval_* = user-sharded evaluation, train_step_ms = row-sharded training step (all ranks)'
         out['roofline'] = order_roofline(r)
 
 
@@ -395,6 +403,12 @@ def main():
     else:
         roof['traffic'] = None
         roof['hbm_stream_read_GBps'], roof['hbm_stream_copy_GBps'] = pre_st['read_GBps'], pre_st['copy_GBps']      # (this rank's GPU)
+        # where a sharded step's time goes: the rank-local products timed alone (rank 0; plain launches, the epilogue addends not
+        # counted) against the step — the rest is the exchange (RCCL all-gathers over xGMI) that nothing hid, and waits on slower ranks
+        local_ms = pre_ms_launch * launches_per_step          # ('halves': the user-block launch stands for both halves)
+        roof['local_spmm_ms_per_step'] = local_ms
+        roof['exposed_exchange_ms_per_step'] = max(out['ms_per_step'] - local_ms, 0.0)
+        roof['exchange_note'] = 'step = X_0 exchange + K launches with an all-gather behind each but the last; local = launches alone'
     out['roofline'] = roof
     extras = {}
     stream_probe = None if sharded else st
