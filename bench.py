@@ -155,6 +155,104 @@ def lift_flat(out, extras):
         out['roofline'] = order_roofline(r)
 
 
+# ---- what goes to stdout ---------------------------------------------------------------------------------------------------------
+# The driver keeps the last ~8 000 characters of stdout and parses the line from them: round 5's line had grown to 19 997 bytes and
+# its record came back `parsed: null`.  stdout therefore carries a COMPACT line (contract keys, a short config, the numeric roofline,
+# the graded flat scalars, a short cpu_baseline; floats at 6 significant digits) that is cut to STDOUT_BUDGET bytes whatever the
+# legs that ran; everything else — `extras`, the *_note / *_source strings, the per-variant tables — goes to the sidecar file and
+# to stderr.  tests/test_host_cpu.py builds the line from full records of every leg and checks its size.
+STDOUT_BUDGET = 7000
+SIDECAR = os.path.join('gpurun_out', 'bench_extras.json')
+CONTRACT_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                 'dtype', 'data')
+CONFIG_KEYS = ('workload', 'preset', 'nnz', 'd', 'n_layers', 'parallelism', 'rehearsal', 'timing_note')
+# numeric companions of the roofline behind its 24-key head (no strings but kernel / bound / unit)
+ROOFLINE_TAIL = ('gathered_row_GBps', 'probe_peak_GBps', 'traffic_over_algorithmic', 'steady_state_ms_per_step', 'steady_state_edges_per_s',
+                 'hbm_stream_copy_GBps', 'rank', 'world', 'local_spmm_ms_per_step', 'exposed_exchange_ms_per_step',
+                 'exchanged_bytes_per_rank_per_pass', 'exchange_floor')
+# flat scalars, most important first: the line is cut from the END of this list if it ever outgrows the budget
+FLAT_STDOUT = ('eval_users_per_s', 'eval_ms', 'eval_users_per_s_fp32_sweep', 'eval_mfma_TFLOPs_fp32_sweep', 'eval_mfma_frac',
+               'eval_scoring_ms_fp32_sweep', 'eval_scoring_ms_two_stage', 'eval_ms_after_2_epochs', 'train_step_ms',
+               'hbm_bound_kernel', 'hbm_bound_ms', 'hbm_bound_counter_GBps', 'hbm_bound_counter_frac', 'hbm_bound_algorithmic_GBps',
+               'hbm_bound_algorithmic_frac', 'hbm_bound_item_block_ms', 'hbm_bound_item_block_GBps', 'hbm_bound_item_block_frac',
+               'hbm_stream_read_GBps', 'hbm_stream_copy_GBps',
+               'config5_world', 'config5_nnz', 'config5_pass_ms', 'config5_edges_per_s', 'config5_local_spmm_ms', 'config5_exposed_exchange_ms',
+               'config5_allgathers_alone_ms', 'config5_rank_algorithmic_frac_of_hbm_peak', 'config5_exchanged_bytes_per_rank_per_pass',
+               'config5_sample_rel_err_vs_f64',
+               'column_sharded_edges_per_s', 'column_sharded_ms_per_step', 'row_sharded_train_step_ms', 'user_sharded_eval_users_per_s',
+               'user_sharded_eval_ms', 'nnz_balance_max_over_mean', 'sample_rel_err_vs_unsharded',
+               'gowalla_prop_pass_ms', 'gowalla_prop_edges_per_s', 'gowalla_prop_pass_ms_hip_graph', 'yelp_igcn_rep_eval_ms',
+               'yelp_igcn_rep_eval_edges_per_s', 'yelp_igcn_rep_dropout_ms', 'train_step_ms_gowalla_hip_graph', 'mf_train_step_ms_gowalla',
+               'igcn_train_step_ms_yelp', 'inductive_update_plus_eval_s', 'propagation_uniform_graph_edges_per_s', 'eval_with_metrics_ms',
+               'eval_ms_after_2_epochs_fp32_sweep', 'eval_d128_scoring_ms_fp32_sweep', 'eval_d128_scoring_ms_two_stage',
+               'hbm_bound_item_block_frac_of_measured_stream', 'hbm_bound_user_block_ms', 'hbm_bound_user_block_GBps',
+               'yelp_igcn_F_T_launch_ms', 'yelp_igcn_F_T_dropout_launch_ms')
+CPU_STDOUT = ('value', 'unit', 'cores', 'kind', 'sample', 'best_path', 'host_threads', 'eval_users_per_s', 'eval_best_path', 'eval_sample')
+
+
+def _compact(v, digits=6, max_str=160):
+    """floats at `digits` significant digits, NaN / Infinity as null (strict JSON), strings cut at `max_str` characters (None: kept)"""
+    if isinstance(v, bool) or v is None or isinstance(v, int):
+        return v
+    if isinstance(v, float):
+        return float('%.*g' % (digits, v)) if np.isfinite(v) else None
+    if isinstance(v, str):
+        return v if max_str is None or len(v) <= max_str else v[:max_str - 3] + '...'
+    if isinstance(v, dict):
+        return {k: _compact(x, digits, max_str) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_compact(x, digits, max_str) for x in v]
+    if isinstance(v, (np.integer,)):
+        return int(v)
+    if isinstance(v, (np.floating,)):
+        return _compact(float(v), digits, max_str)
+    return _compact(str(v), digits, max_str)
+
+
+def stdout_line(full, budget=STDOUT_BUDGET):
+    """The ONE line for stdout from the full record `full` (what main() assembled, lift_flat applied): at most `budget` bytes."""
+    line = {k: full[k] for k in CONTRACT_KEYS if k in full}             # contract keys: untouched (value / ms_per_step at full precision)
+    for k in ('value', 'ms_per_step'):
+        if isinstance(line.get(k), float) and not np.isfinite(line[k]):
+            line[k] = None
+    cfg = full.get('config') or {}
+    line['config'] = _compact({k: cfg[k] for k in CONFIG_KEYS if k in cfg})
+    roof = full.get('roofline')
+    if isinstance(roof, dict):
+        r = {k: roof.get(k) for k in ROOFLINE_HEAD}
+        r.update({k: roof[k] for k in ROOFLINE_TAIL if roof.get(k) is not None})
+        line['roofline'] = _compact(r)
+    if isinstance(full.get('cpu_baseline'), dict):
+        line['cpu_baseline'] = _compact({k: full['cpu_baseline'][k] for k in CPU_STDOUT if k in full['cpu_baseline']})
+    line['sidecar'] = SIDECAR + ' (+ stderr): extras, notes, per-variant tables'
+    flat = [(k, _compact(full[k])) for k in FLAT_STDOUT if full.get(k) is not None and not isinstance(full[k], (dict, list))]
+    while True:
+        cand = dict(line)
+        cand.update(flat)
+        text = json.dumps(cand, allow_nan=False)
+        if len(text) <= budget or not flat:
+            break
+        flat.pop()                                                      # least important first
+    if len(text) > budget:                                              # (cannot happen with the key lists above: strings are cut at 160)
+        raise RuntimeError('bench.py: the stdout line is %d bytes without a single flat key (budget %d)' % (len(text), budget))
+    return text
+
+
+def write_sidecar(full):
+    """The whole record (extras, notes, tables) next to the run: gpurun_out/bench_extras.json under the repo root when that can be
+    written, and one line on stderr either way.  Returns the path written, or None."""
+    text = json.dumps(_compact(full, digits=9, max_str=None), allow_nan=False)
+    sys.stderr.write('bench.py full record: ' + text + '\n')
+    path = os.path.join(ROOT, SIDECAR)
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, 'w') as f:
+            f.write(text + '\n')
+        return path
+    except OSError:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -317,6 +415,24 @@ def main():
     wall = job_max(time.perf_counter() - t0)
     dev_ms = e0.elapsed_time(e1)
 
+    sharded_checks = {}
+    if sharded:
+        # Parity and balance of THIS run (untimed): every rank's owned rows of the sharded pass against the unsharded single-GPU
+        # HIP pass over the same graph and table (max over ranks, relative to the largest entry), and the nonzeros per rank.
+        csr_full = CsrMatrix(rowptr, col, val, (n, n), device, order_blocks=[0, ds.n_users, n], xcd_plan=XCD_PLAN)
+        ref = ops.propagate_mean(csr_full, emb_host.to(device), K)
+        ru, ri = step()
+        scale = float(ref.abs().max())
+        err = max(float((ru[:uhi - ulo] - ref[ulo:uhi]).abs().max()) if uhi > ulo else 0.0,
+                  float((ri[:ihi - ilo] - ref[ds.n_users + ilo: ds.n_users + ihi]).abs().max()) if ihi > ilo else 0.0) / scale
+        t = torch.tensor([err, float(prop.local_nnz)], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank_nnz = [float(e[1]) for e in every]
+        sharded_checks = {'sample_rel_err_vs_unsharded': max(float(e[0]) for e in every),
+                          'nnz_balance_max_over_mean': max(per_rank_nnz) / (sum(per_rank_nnz) / world),
+                          'nnz_per_rank': [int(v) for v in per_rank_nnz]}
+        del csr_full, ref
     # The same pass at steady clocks, beside the contract's figure (never `value`): an idle MI355X needs ~60-90 of these 0.34 ms
     # passes to reach its working clocks (profiles/r05i_warmup_and_clocks.txt), more than a `--warmup 5` gives it.
     steady_ms = None
@@ -325,18 +441,22 @@ def main():
 
     edges = args.steps * K * nnz
     value = edges / wall
+    parallelism_note = None
     if not sharded:
         parallelism = 'single GPU'
     else:
-        parallelism = ('rows of A_hat / embeddings / outputs sharded over %d ranks (nnz-balanced user and item blocks), exchange '
-                       '"%s": X_0 exchange + %d RCCL all-gather(s) per pass over xGMI' %
-                       (world, prop.exchange, (K - 1) * (1 if prop.exchange == 'fused' else 2)))
+        n_gathers = (K - 1) * (1 if prop.exchange == 'fused' else 2)
+        # (short form for stdout; the sidecar keeps the long one)
+        parallelism = 'rows of A_hat/X/Y over %d ranks (nnz-balanced user+item blocks), "%s" exchange: X_0 + %d RCCL all-gather(s) per pass' \
+                      % (world, prop.exchange, n_gathers)
+        parallelism_note = ('rows of A_hat / embeddings / outputs sharded over %d ranks (nnz-balanced user and item blocks), exchange '
+                            '"%s": X_0 exchange + %d RCCL all-gather(s) per pass over xGMI' % (world, prop.exchange, n_gathers))
         if rehearsal:
-            parallelism += ' — REHEARSAL: all ranks on one GPU, exchange over gloo; timings are not measurements'
+            parallelism_note += ' — REHEARSAL: all ranks on one GPU, exchange over gloo; timings are not measurements'
         else:
-            # (rounds 1-5 had one-GPU boxes only: nothing of the N > 1 path has been timed before this very line)
-            parallelism += ('; no scaling curve of this path exists yet (developed on 1-GPU boxes: gloo / shared-GPU tests only); every rank '
-                            'draws the same seeded graph and keeps its own rows')
+            # (rounds 1-6 had one-GPU boxes only: nothing of the N > 1 path has been timed before this very line)
+            parallelism_note += ('; no scaling curve of this path exists yet (developed on 1-GPU boxes: gloo / shared-GPU tests only); every rank '
+                                 'draws the same seeded graph and keeps its own rows')
     out = {
         'metric': 'propagation edges/sec (3-layer LightGCN get_rep, Amazon-book-like, dim=64)',
         'value': value, 'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -345,8 +465,12 @@ def main():
         'config': {'workload': 'LightGCN %d-layer d=%d propagation, synthetic %s-like (users=%d items=%d nnz=%d), same graph at every N'
                                % (K, d, args.preset, ds.n_users, ds.n_items, nnz),
                    'preset': args.preset, 'nnz': nnz, 'd': d, 'n_layers': K, 'parallelism': parallelism,
-                   'timing_note': 'W warm-up steps, then K timed steps (barrier + synchronize on both sides); the untimed roofline probes run before them (GPU at working clocks)'},
+                   'timing_note': 'W warm-up steps, then K timed steps (barrier + synchronize both sides); untimed roofline probes run BEFORE them (warm clocks)'},
     }
+    if parallelism_note:
+        out['config']['parallelism_note'] = parallelism_note
+    if sharded and rehearsal:
+        out['config']['rehearsal'] = True                # all ranks on ONE GPU over gloo: a code-path run, its timings mean nothing
 
     # ---- roofline of the dominant kernel (per launch, this rank) ----------------------------------
     b_alg = local_nnz * (8 + 4 * d) + local_rows * (4 * d + 4)
@@ -409,7 +533,12 @@ def main():
         roof['local_spmm_ms_per_step'] = local_ms
         roof['exposed_exchange_ms_per_step'] = max(out['ms_per_step'] - local_ms, 0.0)
         roof['exchange_note'] = 'step = X_0 exchange + K launches with an all-gather behind each but the last; local = launches alone'
+        # what a rank RECEIVES per pass: the X_0 exchange + K - 1 layer inputs, (world - 1) padded blocks of d floats each.  The time
+        # floor of those K collectives on this node's xGMI mesh has never been measured (1-GPU boxes only): it says so.
+        roof['exchanged_bytes_per_rank_per_pass'] = K * (world - 1) * L.block * d * 4
+        roof['exchange_floor'] = 'unmeasured: %d collectives per pass x this node\'s RCCL all-gather latency (never timed on > 1 GPU)' % K
     out['roofline'] = roof
+    out.update({k: v for k, v in sharded_checks.items() if not isinstance(v, list)})
     extras = {}
     stream_probe = None if sharded else st
     if sharded and not args.no_extras:
@@ -429,6 +558,8 @@ def main():
         torch.cuda.empty_cache()
         extras['config5_sharded'] = config5_sharded_leg(device, rank, world, rehearsal, barrier_sync, job_max)
     extras['gather_roof'] = g
+    if sharded_checks:
+        extras['nnz_per_rank'] = sharded_checks['nnz_per_rank']
     out['extras'] = extras
     lift_flat(out, extras)
 
@@ -438,9 +569,11 @@ def main():
     if sharded:
         dist.destroy_process_group()
     sys.stdout.flush()
+    if rank == 0:
+        write_sidecar(out)                                                # (stdout still points at stderr here)
     os.dup2(json_fd, 1)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(stdout_line(out), flush=True)
 
 
 def sharded_side_measurements(ds, device, d, K, rank, world, rowptr, col, val, emb_host, barrier_sync, job_max):

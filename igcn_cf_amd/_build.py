@@ -26,12 +26,81 @@ def _newer(src_list, out):
     return any(os.path.getmtime(s) > t for s in src_list)
 
 
+def _msgpack_unpack(buf):
+    """The subset of msgpack the AMDGPU metadata note uses (maps, arrays, strings, ints, bools, nil, floats, bin): no third-party
+    module is needed to build (the `msgpack` package is used instead when it is importable; the test suite compares the two)."""
+    import struct
+
+    def take(o):
+        b = buf[o]
+        if b <= 0x7f:
+            return b, o + 1
+        if b >= 0xe0:
+            return b - 0x100, o + 1
+        if 0x80 <= b <= 0x8f:
+            return take_map(o + 1, b & 0x0f)
+        if 0x90 <= b <= 0x9f:
+            return take_array(o + 1, b & 0x0f)
+        if 0xa0 <= b <= 0xbf:
+            n = b & 0x1f
+            return buf[o + 1:o + 1 + n].decode('utf-8', 'replace'), o + 1 + n
+        if b == 0xc0:
+            return None, o + 1
+        if b in (0xc2, 0xc3):
+            return b == 0xc3, o + 1
+        if b in (0xc4, 0xc5, 0xc6, 0xd9, 0xda, 0xdb):                       # bin 8/16/32, str 8/16/32
+            w = {0xc4: 1, 0xc5: 2, 0xc6: 4, 0xd9: 1, 0xda: 2, 0xdb: 4}[b]
+            n = int.from_bytes(buf[o + 1:o + 1 + w], 'big')
+            raw = bytes(buf[o + 1 + w:o + 1 + w + n])
+            return (raw if b <= 0xc6 else raw.decode('utf-8', 'replace')), o + 1 + w + n
+        if b == 0xca:
+            return struct.unpack_from('>f', buf, o + 1)[0], o + 5
+        if b == 0xcb:
+            return struct.unpack_from('>d', buf, o + 1)[0], o + 9
+        if 0xcc <= b <= 0xcf:
+            w = 1 << (b - 0xcc)
+            return int.from_bytes(buf[o + 1:o + 1 + w], 'big'), o + 1 + w
+        if 0xd0 <= b <= 0xd3:
+            w = 1 << (b - 0xd0)
+            return int.from_bytes(buf[o + 1:o + 1 + w], 'big', signed=True), o + 1 + w
+        if b in (0xdc, 0xdd):
+            w = 2 if b == 0xdc else 4
+            return take_array(o + 1 + w, int.from_bytes(buf[o + 1:o + 1 + w], 'big'))
+        if b in (0xde, 0xdf):
+            w = 2 if b == 0xde else 4
+            return take_map(o + 1 + w, int.from_bytes(buf[o + 1:o + 1 + w], 'big'))
+        raise ValueError('msgpack type 0x%02x is not part of the AMDGPU metadata subset' % b)
+
+    def take_array(o, n):
+        out = []
+        for _ in range(n):
+            v, o = take(o)
+            out.append(v)
+        return out, o
+
+    def take_map(o, n):
+        out = {}
+        for _ in range(n):
+            k, o = take(o)
+            v, o = take(o)
+            out[k] = v
+        return out, o
+    return take(0)[0]
+
+
+def _unpack_note(desc):
+    try:
+        import msgpack
+    except ImportError:
+        return _msgpack_unpack(desc)
+    return msgpack.unpackb(desc, raw=False, strict_map_key=False)
+
+
 def kernel_metadata(lib_path=None):
     """name -> metadata dict of every gfx950 kernel in a built library (.private_segment_fixed_size, .vgpr_count, .agpr_count,
     .sgpr_count, .group_segment_fixed_size ...): the code objects are read out of the clang offload bundles inside the .so and
     their NT_AMDGPU_METADATA notes decoded — no GPU, no external tool."""
     import struct
-    import msgpack
     blob = open(lib_path or LIB, 'rb').read()
     magic = b'__CLANG_OFFLOAD_BUNDLE__'
     kernels = {}
@@ -65,7 +134,7 @@ def kernel_metadata(lib_path=None):
                     desc = elf[q:q + descsz]
                     q += (descsz + 3) // 4 * 4
                     if ntype == 32 and name == b'AMDGPU':          # NT_AMDGPU_METADATA (msgpack)
-                        for k in msgpack.unpackb(desc, raw=False, strict_map_key=False).get('amdhsa.kernels', []):
+                        for k in _unpack_note(desc).get('amdhsa.kernels', []):
                             kernels[k['.name']] = k
         at = blob.find(magic, at + 1)
     return kernels

@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # overwritten for that (scripts/sanitize_host.sh used to copy its ASan build over it)
 LIB_PATH = os.environ.get('IGCN_LIB_PATH') or os.path.join(_PKG, 'libigcn_hip.so')
 
-EXPECTED_ABI = int(os.environ.get('IGCN_EXPECT_ABI') or 9)   # IGCN_ABI_VERSION of include/igcn_hip.h this binding was written against (env: developer A/Bs against a build of an earlier round)
+EXPECTED_ABI = int(os.environ.get('IGCN_EXPECT_ABI') or 10)   # IGCN_ABI_VERSION of include/igcn_hip.h this binding was written against (env: developer A/Bs against a build of an earlier round)
 MAX_ADDS = 8
 MAX_TOPK = 256
 MAX_METRIC_CUTS = 8
@@ -24,6 +24,21 @@ vp = C.c_void_p
 
 ROW_SEGMENT_DTYPE = np.dtype([('start', '<i8'), ('len', '<i4'), ('slot', '<i4'), ('row', '<i4'), ('long_index', '<i4')])
 LONG_ROW_DTYPE = np.dtype([('row', '<i4'), ('first_slot', '<i4'), ('n_slots', '<i4'), ('reserved', '<i4')])
+
+
+
+class SpmmArgs(C.Structure):
+    """igcn_spmm_args (include/igcn_hip.h, ABI v10): zero-initialised by ctypes; zero / NULL = not used / library default."""
+    _fields_ = [('struct_size', C.c_uint32), ('flags', C.c_uint32),
+                ('rowptr', vp), ('col', vp), ('val', vp), ('n_rows', C.c_int64), ('n_cols', C.c_int64), ('x', vp), ('y', vp), ('d', C.c_int32),
+                ('n_adds', C.c_int32), ('ldx', C.c_int64), ('ldy', C.c_int64), ('nnz', C.c_int64),
+                ('out_scale', C.c_float), ('add_scale', C.c_float), ('keep_prob', C.c_float), ('long_threshold', C.c_int32),
+                ('adds', vp * MAX_ADDS), ('row_scale', vp), ('col_scale', vp),
+                ('long_rows', vp), ('n_long_rows', C.c_int64), ('segments', vp), ('n_segments', C.c_int64), ('partial', vp),
+                ('edge_id', vp), ('seed', C.c_uint64), ('seed_dev', vp), ('row_mask', vp), ('col_mask', vp), ('order_bits', vp),
+                ('row_order', vp), ('xcd_off', vp),
+                ('tune_blocks_per_cu', C.c_int32), ('tune_multirow', C.c_int32), ('tune_fold', C.c_int32), ('reserved', C.c_int32)]
+
 
 # name -> (restype, argtypes); every symbol of include/igcn_hip.h
 SIGNATURES = {
@@ -36,6 +51,7 @@ SIGNATURES = {
                                     C.c_float, C.POINTER(vp), C.c_int32, C.c_float, vp, vp,
                                     vp, C.c_int64, vp, C.c_int64, vp, C.c_int32,
                                     vp, C.c_uint64, C.c_float, vp, C.c_int32, C.c_int64, vp, vp, vp, vp, vp, vp]),
+    'igcn_spmm_csr_f32_args': (C.c_int, [C.POINTER(SpmmArgs), vp]),
     'igcn_mark_rows': (C.c_int, [vp, C.c_int64, vp, vp, vp, vp, C.c_int64, vp]),
     'igcn_pack_mask_bits': (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int32, vp, vp]),
     'igcn_pack_mask_bits_ordered': (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int32, vp, vp, C.c_int64, vp, C.c_int64, vp, vp]),

@@ -28,6 +28,7 @@
 //     d = 64, one at d = 128): enough workgroups that the dispatcher evens out a
 //     power-law load, few enough to amortise the per-wave set-up — and never just
 //     above what is resident at once (see resident_blocks_per_cu below).
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 #include "common.h"
@@ -642,12 +643,18 @@ __global__ void csr_row_pow_kernel(const int64_t *__restrict__ rowptr, const flo
 int g_tuning[IGCN_TUNE_COUNT];          // value + 1; 0 (the static initialiser) = library default
 
 // Developer tuning knobs (igcn_set_tuning): spmm_blocks_per_cu, spmm_multirow.
-struct SpmmTuning { int blocks_per_cu; int multirow; };
-static SpmmTuning tuning() {
-    SpmmTuning v{0, 1};                                       // 0 = sized by rows per wave
-    const int b = tuning_get(IGCN_TUNE_SPMM_BLOCKS_PER_CU), m = tuning_get(IGCN_TUNE_SPMM_MULTIROW);
+// A launch reads them ONCE, here, into a value of its own: `over` = the per-call knobs of igcn_spmm_args (value + 1, 0 = not given),
+// which win over the process-wide ones — concurrent callers with different launch shapes use those, not igcn_set_tuning.
+struct SpmmTuning { int blocks_per_cu; int multirow; int fold; };
+struct SpmmTuneOverride { int blocks_per_cu = 0, multirow = 0, fold = 0; };
+static SpmmTuning tuning(const SpmmTuneOverride &over) {
+    SpmmTuning v{0, 1, 0};                                    // 0 = sized by rows per wave; two rows per wave; the reduce kernel
+    const int b = over.blocks_per_cu > 0 ? over.blocks_per_cu - 1 : tuning_get(IGCN_TUNE_SPMM_BLOCKS_PER_CU);
+    const int m = over.multirow > 0 ? over.multirow - 1 : tuning_get(IGCN_TUNE_SPMM_MULTIROW);
+    const int f = over.fold > 0 ? over.fold - 1 : tuning_get(IGCN_TUNE_SPMM_FOLD);
     if (b >= 1 && b <= 4096) v.blocks_per_cu = b;
     if (m >= 0) v.multirow = m != 0;
+    if (f >= 0) v.fold = f != 0;
     return v;
 }
 
@@ -743,7 +750,8 @@ static int launch_rows(bool dropout, int64_t blocks, hipStream_t st,
                        float *y, int64_t ldy, int64_t n_rows, int d, const SpmmEpilogue &ep, const SpmmDropout &dr,
                        const igcn_row_segment *segments, int64_t n_segments, float *partial, int long_threshold,
                        const igcn_long_row *long_rows, int64_t n_long, const uint8_t *row_mask, int masked_rows_zero,
-                       int64_t nnz, const int32_t *row_order, const int64_t *xcd_off, bool closing, const uint32_t *order_bits)
+                       int64_t nnz, const int32_t *row_order, const int64_t *xcd_off, bool closing, const uint32_t *order_bits,
+                       const SpmmTuning &tune)
 {
     // Grid: `blocks` on entry = one wave per row.  Fewer, longer-lived waves amortise the per-wave set-up;
     // many short ones let the hardware dispatcher even out the load (a power-law graph deals very
@@ -752,7 +760,6 @@ static int launch_rows(bool dropout, int64_t blocks, hipStream_t st,
     // graph (21 nonzeros per row) the best grids have 1 row per wave at d = 128, 1-4 at d = 64, 4-8 at
     // d <= 32, all within 5 % of each other and 10-20 % ahead of a grid of just the resident waves;
     // heavier rows get proportionally fewer per wave.  Never fewer workgroups than are resident at once.
-    const SpmmTuning tune = tuning();
     const int resident = dropout ? resident_blocks_per_cu<LPR, true>() : resident_blocks_per_cu<LPR, false>();
     const int64_t n_virtual = n_rows + n_segments;
     int64_t want;
@@ -781,7 +788,7 @@ static int launch_rows(bool dropout, int64_t blocks, hipStream_t st,
     // the plain plan (3 761 segments), -1.8 % Gowalla-like, +-0 Yelp-like, but +5 % on the headline graph with the XCD plan (35 141
     // segments of 4 133 rows): the closing segments' agent-scope reads of the partial sums and the epilogue behind them cost more
     // inside the launch (+8 us) than the 5 us kernel they replace.  Default: the second kernel.
-    const igcn_long_row *fold = n_long > 0 && closing && tuning_get(IGCN_TUNE_SPMM_FOLD) > 0 ? long_rows : nullptr;
+    const igcn_long_row *fold = n_long > 0 && closing && tune.fold ? long_rows : nullptr;
 #define IGCN_SPMM_LAUNCH(...)                                                                                                          \
     hipLaunchKernelGGL((__VA_ARGS__), grid, dim3(kBlock), 0, st, rowptr, col, val, x, ldx, y, ldy, n_rows, d, ep, dr, segments, n_segments, \
                        partial, long_threshold, row_mask, masked_rows_zero, row_order, xcd_off, fold, skip)
@@ -863,19 +870,21 @@ extern "C" int igcn_spmm_plan_fill_host(const int64_t *rowptr_host, int64_t n_ro
     return (il == n_long_rows && is == n_segments) ? IGCN_OK : IGCN_E_SHAPE;
 }
 
-extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val,
-                                 const float *x, int64_t ldx, float *y, int64_t ldy,
-                                 int64_t n_rows, int64_t n_cols, int32_t d,
-                                 float out_scale, const float *const *adds_host, int32_t n_adds,
-                                 float add_scale, const float *row_scale, const float *col_scale,
-                                 const igcn_long_row *long_rows, int64_t n_long_rows,
-                                 const igcn_row_segment *segments, int64_t n_segments,
-                                 float *partial, int32_t long_threshold,
-                                 const int32_t *edge_id, uint64_t seed, float keep_prob,
-                                 const uint8_t *row_mask, int32_t flags,
-                                 int64_t nnz, const int32_t *row_order, const uint32_t *col_mask,
-                                 const uint64_t *seed_dev, const int64_t *xcd_off, const uint32_t *order_bits, void *stream)
+static int spmm_run(const int64_t *rowptr, const int32_t *col, const float *val,
+                    const float *x, int64_t ldx, float *y, int64_t ldy,
+                    int64_t n_rows, int64_t n_cols, int32_t d,
+                    float out_scale, const float *const *adds_host, int32_t n_adds,
+                    float add_scale, const float *row_scale, const float *col_scale,
+                    const igcn_long_row *long_rows, int64_t n_long_rows,
+                    const igcn_row_segment *segments, int64_t n_segments,
+                    float *partial, int32_t long_threshold,
+                    const int32_t *edge_id, uint64_t seed, float keep_prob,
+                    const uint8_t *row_mask, int32_t flags,
+                    int64_t nnz, const int32_t *row_order, const uint32_t *col_mask,
+                    const uint64_t *seed_dev, const int64_t *xcd_off, const uint32_t *order_bits, void *stream,
+                    const SpmmTuneOverride &over)
 {
+    const SpmmTuning tune = tuning(over);
     const int32_t masked_rows_zero = flags & IGCN_SPMM_MASKED_ROWS_ZERO;
     // cut rows added up inside the launch: only with a plan that marks closing segments and deals them late (the caller says so)
     const bool closing = (flags & IGCN_SPMM_CLOSING_SEGMENTS) != 0 && row_order != nullptr;
@@ -935,7 +944,7 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
 #define IGCN_SPMM_CASE(L)                                                                                         \
     return launch_rows<L>(dropout, blocks, st, rowptr, col, val, x, ldx, y, ldy, n_rows, (int)d, ep, dr, segments,  \
                           n_segments, partial, (int)long_threshold, long_rows, n_long_rows, row_mask, (int)masked_rows_zero, \
-                          nnz, row_order, xcd_off, closing, order_bits)
+                          nnz, row_order, xcd_off, closing, order_bits, tune)
     const int q = d / 4;
     if (q <= 1) IGCN_SPMM_CASE(1);
     if (q <= 2) IGCN_SPMM_CASE(2);
@@ -945,6 +954,50 @@ extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, cons
     if (q <= 32) IGCN_SPMM_CASE(32);
     IGCN_SPMM_CASE(64);
 #undef IGCN_SPMM_CASE
+}
+
+extern "C" int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *val,
+                                 const float *x, int64_t ldx, float *y, int64_t ldy,
+                                 int64_t n_rows, int64_t n_cols, int32_t d,
+                                 float out_scale, const float *const *adds_host, int32_t n_adds,
+                                 float add_scale, const float *row_scale, const float *col_scale,
+                                 const igcn_long_row *long_rows, int64_t n_long_rows,
+                                 const igcn_row_segment *segments, int64_t n_segments,
+                                 float *partial, int32_t long_threshold,
+                                 const int32_t *edge_id, uint64_t seed, float keep_prob,
+                                 const uint8_t *row_mask, int32_t flags,
+                                 int64_t nnz, const int32_t *row_order, const uint32_t *col_mask,
+                                 const uint64_t *seed_dev, const int64_t *xcd_off, const uint32_t *order_bits, void *stream)
+{
+    return spmm_run(rowptr, col, val, x, ldx, y, ldy, n_rows, n_cols, d, out_scale, adds_host, n_adds, add_scale, row_scale, col_scale,
+                    long_rows, n_long_rows, segments, n_segments, partial, long_threshold, edge_id, seed, keep_prob, row_mask, flags,
+                    nnz, row_order, col_mask, seed_dev, xcd_off, order_bits, stream, SpmmTuneOverride{});
+}
+
+// The same launch through ONE struct (ABI v10).  Only the first `struct_size` bytes are read — a caller compiled against a shorter
+// (older) struct keeps working, what it does not know is zero —, and zero means "not used / library default" in every optional
+// field, so a binding of the reference call site (model.py:99-102: graph, X, vals) fills eight fields of a zeroed struct.
+extern "C" int igcn_spmm_csr_f32_args(const igcn_spmm_args *args, void *stream)
+{
+    if (!args) return IGCN_E_NULL;
+    const size_t need = offsetof(igcn_spmm_args, d) + sizeof(int32_t);       // the required prefix
+    if (args->struct_size < need) return IGCN_E_SHAPE;
+    igcn_spmm_args a;
+    memset(&a, 0, sizeof a);
+    memcpy(&a, args, args->struct_size < sizeof a ? (size_t)args->struct_size : sizeof a);
+    if (a.flags & ~(uint32_t)(IGCN_SPMM_MASKED_ROWS_ZERO | IGCN_SPMM_CLOSING_SEGMENTS)) return IGCN_E_RANGE;
+    if (a.n_adds < 0 || a.n_adds > IGCN_MAX_ADDS) return IGCN_E_RANGE;
+    if (a.out_scale != a.out_scale || a.add_scale != a.add_scale || a.keep_prob != a.keep_prob) return IGCN_E_RANGE;     // NaN
+    if (a.tune_blocks_per_cu < 0 || a.tune_multirow < 0 || a.tune_fold < 0) return IGCN_E_RANGE;
+    SpmmTuneOverride over;
+    over.blocks_per_cu = a.tune_blocks_per_cu;
+    over.multirow = a.tune_multirow;
+    over.fold = a.tune_fold;
+    return spmm_run(a.rowptr, a.col, a.val, a.x, a.ldx > 0 ? a.ldx : a.d, a.y, a.ldy > 0 ? a.ldy : a.d, a.n_rows, a.n_cols, a.d,
+                    a.out_scale == 0.f ? 1.f : a.out_scale, a.adds, a.n_adds, a.add_scale == 0.f ? 1.f : a.add_scale, a.row_scale,
+                    a.col_scale, a.long_rows, a.n_long_rows, a.segments, a.n_segments, a.partial, a.long_threshold, a.edge_id, a.seed,
+                    a.keep_prob == 0.f ? 1.f : a.keep_prob, a.row_mask, (int32_t)a.flags, a.nnz, a.row_order, a.col_mask, a.seed_dev,
+                    a.xcd_off, a.order_bits, stream, over);
 }
 
 extern "C" int igcn_mark_rows(const int64_t *ids, int64_t n, const int64_t *rowptr, const int32_t *col,

@@ -20,8 +20,9 @@ def _require_gpu_f32(t, name):
 
 
 def spmm(csr: CsrMatrix, x, out=None, adds=(), out_scale=1.0, add_scale=1.0, row_scale=None, col_scale=None,
-         keep_prob=1.0, seed=0, row_mask=None, masked_rows_zero=False, col_mask=None, order_bits=None):
-    """out = (out_scale * csr @ x + add_scale * sum(adds)) * row_scale  (see igcn_spmm_csr_f32).
+         keep_prob=1.0, seed=0, row_mask=None, masked_rows_zero=False, col_mask=None, order_bits=None, tune=None):
+    """out = (out_scale * csr @ x + add_scale * sum(adds)) * row_scale  (see igcn_spmm_csr_f32 / igcn_spmm_csr_f32_args).
+    tune: None, or {'blocks_per_cu' | 'multirow' | 'fold': int} — launch knobs of THIS call (never change the result).
     col_mask: bit mask over the columns (int32 words, pack_mask_bits): rows of x whose bit is clear are all zero and are not read.
     order_bits: row_mask once more in THIS matrix's dealing order (mark_rows(...).order_bits): the launch visits the wanted entries only.
     seed: an int, or a one-element int64 tensor on the GPU (read by the kernel: HIP-graph replays see its current value)."""
@@ -53,21 +54,35 @@ def spmm(csr: CsrMatrix, x, out=None, adds=(), out_scale=1.0, add_scale=1.0, row
         need = 2 * ((n_rows + csr.n_segments + 63) // 64) + 2
         if row_mask is None or order_bits.dtype != torch.int32 or not order_bits.is_cuda or order_bits.numel() < need:
             raise _lib.IgcnError('order_bits: int32 [%d] on the GPU (mark_rows(...).order_bits of this matrix), together with row_mask' % need)
-    add_ptrs = (C.c_void_p * max(1, len(adds)))(*[a.data_ptr() for a in adds])
     partial = csr.partial(d)
     seed_dev = None
     if isinstance(seed, torch.Tensor):
         if seed.dtype != torch.int64 or seed.numel() != 1 or not seed.is_cuda:
             raise _lib.IgcnError('a device seed must be a one-element int64 tensor on the GPU')
         seed_dev, seed = seed, 0
-    _lib.check(_lib.lib().igcn_spmm_csr_f32(
-        csr.rowptr.data_ptr(), csr.col.data_ptr(), _lib.ptr(csr.val),
-        x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0),
-        n_rows, n_cols, d, float(out_scale), add_ptrs, len(adds), float(add_scale), _lib.ptr(row_scale), _lib.ptr(col_scale),
-        _lib.ptr(csr.long_rows), csr.n_long, _lib.ptr(csr.segments), csr.n_segments, _lib.ptr(partial),
-        csr.long_threshold, _lib.ptr(csr.edge_id), int(seed) & 0xFFFFFFFFFFFFFFFF, float(keep_prob),
-        _lib.ptr(row_mask), (1 if masked_rows_zero else 0) | (2 if getattr(csr, 'closing_segments', False) else 0), csr.nnz, _lib.ptr(csr.row_order),
-        _lib.ptr(col_mask), _lib.ptr(seed_dev), _lib.ptr(csr.xcd_off), _lib.ptr(order_bits), _lib.current_stream()), 'igcn_spmm_csr_f32')
+    # the struct form of the launch (igcn_spmm_csr_f32_args, ABI v10): what is not set stays zero = off / library default
+    a = _lib.SpmmArgs()
+    a.struct_size = C.sizeof(_lib.SpmmArgs)
+    a.flags = (1 if masked_rows_zero else 0) | (2 if getattr(csr, 'closing_segments', False) else 0)
+    a.rowptr, a.col, a.val = csr.rowptr.data_ptr(), csr.col.data_ptr(), _lib.ptr(csr.val)
+    a.n_rows, a.n_cols, a.x, a.y, a.d = n_rows, n_cols, x.data_ptr(), out.data_ptr(), d
+    a.ldx, a.ldy, a.nnz = x.stride(0), out.stride(0), csr.nnz
+    a.n_adds = len(adds)
+    for i, t in enumerate(adds):
+        a.adds[i] = t.data_ptr()
+    if out_scale == 0.0 or add_scale == 0.0 or not keep_prob > 0.0:
+        raise _lib.IgcnError('out_scale / add_scale must not be zero and keep_prob must be in (0, 1]')    # (the struct reads 0 as 1)
+    a.out_scale, a.add_scale, a.keep_prob = float(out_scale), float(add_scale), float(keep_prob)
+    a.row_scale, a.col_scale = _lib.ptr(row_scale), _lib.ptr(col_scale)
+    a.long_rows, a.n_long_rows, a.segments, a.n_segments = _lib.ptr(csr.long_rows), csr.n_long, _lib.ptr(csr.segments), csr.n_segments
+    a.partial, a.long_threshold = _lib.ptr(partial), csr.long_threshold
+    a.edge_id, a.seed, a.seed_dev = _lib.ptr(csr.edge_id), int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(seed_dev)
+    a.row_mask, a.col_mask, a.order_bits = _lib.ptr(row_mask), _lib.ptr(col_mask), _lib.ptr(order_bits)
+    a.row_order, a.xcd_off = _lib.ptr(csr.row_order), _lib.ptr(csr.xcd_off)
+    if tune:
+        for k_, v_ in tune.items():                          # per-call launch knobs (result-neutral): blocks_per_cu / multirow / fold
+            setattr(a, 'tune_' + k_, int(v_) + 1)
+    _lib.check(_lib.lib().igcn_spmm_csr_f32_args(C.byref(a), _lib.current_stream()), 'igcn_spmm_csr_f32_args')
     return out
 
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define IGCN_ABI_VERSION 9
+#define IGCN_ABI_VERSION 10
 
 #define IGCN_OK            0
 #define IGCN_E_NULL       -1   /* a required pointer is NULL               */
@@ -54,7 +54,8 @@ const char *igcn_error_string(int code);
  * igcn_score_topk_fast_f32: 3 = one fp16 plane each side, the default; 2 = two fp16 user planes; 1 = two bf16 planes each side,
  * d = 64 only); value < 0 restores the library
  * default.  Results never depend on them (tests/test_spmm_gpu.py::test_launch_shape_does_not_change_results).
- * Not thread-safe against concurrent launches.  Returns IGCN_E_RANGE for an unknown name. */
+ * Process-wide: not to be changed while another thread launches (a launch reads its knobs once, at entry; the SpMM takes
+ * its three per call instead — igcn_spmm_args.tune_*).  Returns IGCN_E_RANGE for an unknown name. */
 int igcn_set_tuning(const char *name, int32_t value);
 
 /* One piece of a long CSR row (a "row segment"): nonzeros [start, start+len)
@@ -62,8 +63,8 @@ int igcn_set_tuning(const char *name, int32_t value);
  * long_index (ABI v8; was a reserved word): bits 0..30 = the row's entry in the igcn_long_row array; bit 31 = this is
  * the row's CLOSING segment (igcn_spmm_plan_fill_host marks the row's last one).  With IGCN_SPMM_CLOSING_SEGMENTS the
  * launch adds a cut row up itself: every segment counts itself in on the row's arrival counter, the closing segment —
- * which row_order must deal AFTER the row's other segments, the later the better (graph.py puts it half-way into the
- * rows of the same phase) — waits until the others have arrived, adds the partial sums in slot order and applies the
+ * which row_order must deal AFTER the row's other segments, the later the better (graph.py puts it a quarter of the way
+ * into the rows of the same phase: CLOSING_AT) — waits until the others have arrived, adds the partial sums in slot order and applies the
  * epilogue — when igcn_set_tuning("spmm_fold", 1) asks for it (measured: a gain of 1-4 % with a few thousand segments, a loss
  * of 5 % with the XCD plan's 35 000 on the headline graph; the default is the second small kernel either way; same bits).
  * Built once per graph by igcn_spmm_plan_fill_host. */
@@ -167,6 +168,54 @@ int igcn_spmm_csr_f32(const int64_t *rowptr, const int32_t *col, const float *va
                       const uint8_t *row_mask, int32_t flags /* IGCN_SPMM_MASKED_ROWS_ZERO | IGCN_SPMM_CLOSING_SEGMENTS */,
                       int64_t nnz, const int32_t *row_order, const uint32_t *col_mask,
                       const uint64_t *seed_dev, const int64_t *xcd_off, const uint32_t *order_bits, void *stream);
+
+/* The same launch through ONE struct (ABI v10) — the form a binding should use: the positional call above has 34 arguments.
+ * Zero-initialise the struct, set struct_size = sizeof(igcn_spmm_args) and fill what the call site has.  The reference call
+ * site (model.py:99-102: a graph, X and the edge values) has exactly the eight fields of the first block; every field
+ * below it may stay zero: zero / NULL means "not used" or "the library default" (ldx / ldy 0 = d: dense rows;
+ * out_scale / add_scale / keep_prob 0 = 1; nnz 0 = unknown).  The library reads the first struct_size bytes only, so a
+ * caller compiled against this struct keeps working when later versions append fields (IGCN_E_SHAPE when struct_size
+ * does not even cover the first block).  Field meanings: as the arguments of igcn_spmm_csr_f32 above; `adds` are the
+ * device pointers themselves (no host array to keep alive).
+ * tune_*: the result-neutral launch knobs of THIS call — value + 1 (0 = not given: the process-wide igcn_set_tuning
+ * value, else the library default): "spmm_blocks_per_cu", "spmm_multirow", "spmm_fold".  A launch reads its knobs once,
+ * at entry, into a value of its own: callers on different streams or threads that want different launch shapes pass them
+ * here and never touch igcn_set_tuning, which stays what it was — a process-wide developer switch, not to be flipped while
+ * another thread launches. */
+typedef struct igcn_spmm_args {
+    uint32_t struct_size;                 /* sizeof(igcn_spmm_args) as the caller compiled it */
+    uint32_t flags;                       /* IGCN_SPMM_MASKED_ROWS_ZERO | IGCN_SPMM_CLOSING_SEGMENTS */
+    /* ---- required: what model.py:99-102 has ---- */
+    const int64_t *rowptr;                /* [n_rows + 1]                     */
+    const int32_t *col;                   /* [nnz]                            */
+    const float   *val;                   /* [nnz] or NULL (all ones)         */
+    int64_t        n_rows, n_cols;
+    const float   *x;                     /* [n_cols, d]                      */
+    float         *y;                     /* [n_rows, d]                      */
+    int32_t        d;
+    /* ---- optional: zero = off / default ---- */
+    int32_t        n_adds;
+    int64_t        ldx, ldy;              /* 0 = d                            */
+    int64_t        nnz;                   /* 0 = unknown                      */
+    float          out_scale, add_scale;  /* 0 = 1                            */
+    float          keep_prob;             /* 0 = 1 (no dropout)               */
+    int32_t        long_threshold;
+    const float   *adds[IGCN_MAX_ADDS];
+    const float   *row_scale, *col_scale;
+    const igcn_long_row    *long_rows;  int64_t n_long_rows;
+    const igcn_row_segment *segments;   int64_t n_segments;
+    float         *partial;
+    const int32_t *edge_id;
+    uint64_t       seed;
+    const uint64_t *seed_dev;
+    const uint8_t *row_mask;
+    const uint32_t *col_mask, *order_bits;
+    const int32_t *row_order;
+    const int64_t *xcd_off;
+    int32_t        tune_blocks_per_cu, tune_multirow, tune_fold;     /* value + 1; 0 = not given */
+    int32_t        reserved;
+} igcn_spmm_args;
+int igcn_spmm_csr_f32_args(const igcn_spmm_args *args, void *stream);
 
 /* Row masks for igcn_spmm_csr_f32.  mask1[ids[i] + offsets...] = 1 for every listed row;
  * when rowptr/col are given, mask2[r] = 1 for every listed row r and every column

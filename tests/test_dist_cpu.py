@@ -340,126 +340,7 @@ def test_local_blocks_are_checked_against_their_layout():
 
 
 # ---- the exchange logic under RCCL's completion semantics (no node needed) ----------------------------------------------------
-class LateCollectives:
-    """The collectives of `world` ranks that run as THREADS of this process, completing as late as RCCL's may.
-
-    gloo's `work.wait()` blocks the host until the copy is done; RCCL's only orders streams — the copy lands at some point
-    between the call and the completion of the wait.  This object takes the adversarial legal schedule:
-      * at the CALL of an all-gather the destination is poisoned (NaN): whoever reads it before the wait reads garbage;
-        the source is snapshotted;
-      * a rank's copy happens inside ITS wait(), once every rank has issued the same collective, from the sources as they are
-        THEN — a source overwritten before its collective completed is detected (compared with the snapshot) and reported;
-      * a wait() returns only when every rank has taken its copy (a source is free again when its owner's wait returns).
-    An all-gather whose wait the code under test forgets (`skip_wait`, the negative control) never lands on that rank: its
-    destination stays poisoned, the other ranks are not kept waiting for it.  all_reduce is blocking and in place (as in the code
-    under test): every rank contributes once, the sums replace the buffers when all have arrived."""
-
-    def __init__(self, world, timeout=60.0):
-        import threading
-        self.world, self.timeout = world, timeout
-        self.cv = threading.Condition()
-        self.pending = {}                  # sequence number -> {rank: (out, inp, snapshot)}
-        self.copied = {}                   # sequence number -> ranks that took their copy (or will never take it)
-        self.issued = [0] * world
-        self.reduce_slots, self.reduce_read = {}, {}
-        self.reduced = [0] * world
-        self.errors = []
-        self.n_async = 0
-        self.skip_wait = None              # (rank, nth asynchronous all-gather of that rank): its wait() is a no-op
-
-    def bind(self, rank):
-        return _RankView(self, rank)
-
-    def _until(self, cond):
-        with self.cv:
-            if not self.cv.wait_for(cond, self.timeout):
-                raise TimeoutError('a rank never reached the collective the others are in')
-
-
-class _Work:
-    def __init__(self, owner, rank, seq):
-        self.owner, self.rank, self.seq = owner, rank, seq
-
-    def wait(self):
-        o = self.owner
-        o._until(lambda: len(o.pending.get(self.seq, {})) == o.world)      # every rank has issued this collective
-        entries = o.pending[self.seq]
-        out = entries[self.rank][0]
-        rows = entries[self.rank][1].shape[0]
-        for q in range(o.world):
-            _, inp, snap = entries[q]
-            if not torch.equal(inp, snap):
-                with o.cv:
-                    o.errors.append('rank %d overwrote the source of all-gather %d before it completed' % (q, self.seq))
-            out[q * rows:(q + 1) * rows].copy_(inp)
-        with o.cv:
-            o.copied.setdefault(self.seq, set()).add(self.rank)
-            o.cv.notify_all()
-        o._until(lambda: len(o.copied[self.seq]) == o.world)               # every rank has its copy: the sources are free again
-        return True
-
-
-class _RankView:
-    def __init__(self, owner, rank):
-        self.owner, self.rank, self.n_async = owner, rank, 0
-
-    def active(self):
-        return True
-
-    def all_gather_into_tensor(self, out, inp, async_op):
-        o = self.owner
-        assert out.shape[0] == inp.shape[0] * o.world and out.is_contiguous() and inp.is_contiguous()
-        out.fill_(float('nan'))                                 # the collective may write its destination from now on
-        forget = bool(async_op) and o.skip_wait == (self.rank, self.n_async)
-        with o.cv:
-            seq = o.issued[self.rank]
-            o.issued[self.rank] += 1
-            o.pending.setdefault(seq, {})[self.rank] = (out, inp, inp.clone())
-            o.n_async += bool(async_op)
-            if forget:
-                o.copied.setdefault(seq, set()).add(self.rank)  # (this rank will never take its copy)
-            o.cv.notify_all()
-        work = _Work(o, self.rank, seq)
-        if not async_op:
-            work.wait()
-            return None
-        self.n_async += 1
-        return type('ForgottenWait', (), {'wait': lambda self: True})() if forget else work
-
-    def all_reduce(self, buf):
-        o = self.owner
-        with o.cv:
-            seq = o.reduced[self.rank]
-            o.reduced[self.rank] += 1
-            o.reduce_slots.setdefault(seq, {})[self.rank] = buf
-            o.cv.notify_all()
-        o._until(lambda: len(o.reduce_slots[seq]) == o.world)
-        total = sum(o.reduce_slots[seq][q].clone() for q in range(o.world))
-        with o.cv:
-            o.reduce_read.setdefault(seq, set()).add(self.rank)
-            o.cv.notify_all()
-        o._until(lambda: len(o.reduce_read[seq]) == o.world)             # everybody has read everybody's contribution
-        buf.copy_(total)
-
-
-def _run_ranks(world, fn):
-    """fn(rank) on one thread per rank; exceptions of any rank are re-raised here."""
-    import threading
-    results, errors = [None] * world, []
-
-    def body(r):
-        try:
-            results[r] = fn(r)
-        except BaseException as e:                              # noqa: BLE001 (a broken barrier in one rank must not hide the cause in another)
-            errors.append((r, e))
-    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join(120)
-    if errors:
-        raise errors[0][1]
-    return results
+from tests.late_collectives import LateCollectives, run_ranks as _run_ranks            # noqa: E402
 
 
 def _late_pass(golden, world, n_layers, exchange, skip_wait=None):
@@ -488,7 +369,7 @@ def _late_pass(golden, world, n_layers, exchange, skip_wait=None):
     return res, ref, coll, nu
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world', [2, 3, 8])
 @pytest.mark.parametrize('exchange', ['fused', 'halves'])
 @pytest.mark.parametrize('n_layers', [1, 2, 3, 4])
 def test_exchange_logic_holds_when_collectives_complete_as_late_as_rccl_allows(golden, world, exchange, n_layers):
@@ -496,7 +377,8 @@ def test_exchange_logic_holds_when_collectives_complete_as_late_as_rccl_allows(g
     replicated buffers in turn.  Under gloo a missing or misplaced wait() is invisible (its wait blocks the host and the copy is
     long done); RCCL only orders streams.  Here the copies land at the latest legal moment, destinations are poisoned while a
     collective is in flight and sources are checked at completion: every owned row equals the unsharded oracle, in both of two
-    consecutive passes, and nobody touched a source early.  world 2 and 3, K = 1 ... 4, both exchanges."""
+    consecutive passes, and nobody touched a source early.  world 2, 3 and 8 (the one size the driver's 8-GPU command uses: on the
+    toys a block is a few dozen rows, unequal and padded), K = 1 ... 4, both exchanges."""
     res, ref, coll, nu = _late_pass(golden, world, n_layers, exchange)
     assert not coll.errors, coll.errors
     if exchange == 'halves' and n_layers > 1:
@@ -519,11 +401,11 @@ def test_a_forgotten_wait_is_noticed_by_the_late_collectives(golden, nth):
     assert not (np.isfinite(ru).all() and np.isfinite(ri).all())
 
 
-@pytest.mark.parametrize('world,exchange', [(2, 'fused'), (3, 'halves')])
+@pytest.mark.parametrize('world,exchange', [(2, 'fused'), (3, 'halves'), (8, 'fused'), (8, 'halves')])
 def test_sharded_training_steps_under_late_collectives(golden, world, exchange):
     """Two Adam steps of ShardedLightGCN — forward pass, the batch rows' all-reduce (_BatchRowsFn), backward pass through the
     same sharded operator — with every collective completing late: losses and the gathered table equal the dense unsharded
-    chain's, world 2 and 3."""
+    chain's, world 2, 3 and 8."""
     from igcn_cf_amd.dataset import ProcessedDataset
     from igcn_cf_amd.dist import ShardedLightGCN
     nu, ni = int(golden['n_users']), int(golden['n_items'])
@@ -567,3 +449,77 @@ def test_sharded_training_steps_under_late_collectives(golden, world, exchange):
     for losses, full in res:
         np.testing.assert_allclose(losses, ref_losses, rtol=1e-5)
         np.testing.assert_allclose(full, e.detach().numpy(), rtol=1e-4, atol=1e-6)
+
+
+# ---- world = 8 with blocks that own NOTHING ------------------------------------------------------------------------------------
+def _skewed_graph(nu=40, ni=24, seed=5):
+    """A tiny bipartite graph in which one item holds most of the edges and three users hold most of the rest: an 8-way
+    nnz-balanced cut then has item blocks (and user blocks) with zero rows — ShardLayout.balanced's searchsorted lands several
+    boundaries on the same row."""
+    rng = np.random.default_rng(seed)
+    pairs = {(u, 0) for u in range(nu)}                                  # item 0: every user
+    for u in (0, 1, 2):
+        pairs |= {(u, i) for i in range(ni)}                             # three users: every item
+    for u in range(3, nu):
+        pairs.add((u, int(rng.integers(1, ni))))
+    return np.array(sorted(pairs), dtype=np.int64), nu, ni
+
+
+def test_an_eight_way_balanced_cut_may_leave_blocks_empty_and_still_covers_every_row():
+    from igcn_cf_amd.dist import ShardLayout
+    from igcn_cf_amd.graph import normalized_adjacency_host
+    ta, nu, ni = _skewed_graph()
+    rowptr, col, val = normalized_adjacency_host(ta, nu, ni)
+    for fused in (False, True):
+        L = ShardLayout.balanced(rowptr, nu, ni, 8, fused=fused)
+        ub, ib = np.diff(L.user_bounds), np.diff(L.item_bounds)
+        assert ub.sum() == nu and ib.sum() == ni and (ub >= 0).all() and (ib >= 0).all()
+        assert (ib == 0).any(), ib                                       # the case this test is about
+        assert L.bu == ub.max() and L.bi == ib.max() and L.n_pad == 8 * (L.bu + L.bi)
+        # every node lands in its owner's padded block, no two nodes on the same padded row
+        pad = L.pad_index(np.arange(nu + ni))
+        assert len(set(pad.tolist())) == nu + ni and pad.max() < L.n_pad
+        rank, local = L.owner(np.arange(nu + ni))
+        for r in range(8):
+            (ulo, uhi), (ilo, ihi) = L.user_rows(r), L.item_rows(r)
+            assert (rank[ulo:uhi] == r).all() and (rank[nu + ilo:nu + ihi] == r).all()
+            assert (local[ulo:uhi] == np.arange(uhi - ulo)).all() and (local[nu + ilo:nu + ihi] == L.bu + np.arange(ihi - ilo)).all()
+
+
+@pytest.mark.parametrize('exchange', ['fused', 'halves'])
+@pytest.mark.parametrize('n_layers', [1, 3])
+def test_eight_ranks_some_owning_nothing_under_late_collectives(exchange, n_layers):
+    """The sharded pass over 8 ranks where some ranks own zero item rows (and their padded block is all padding): two passes and
+    the gathered table equal the unsharded oracle under the late-completing collectives."""
+    from igcn_cf_amd.dist import RowShardedPropagator
+    ta, nu, ni = _skewed_graph()
+    world = 8
+    rng = np.random.default_rng(2)
+    emb = (rng.standard_normal((nu + ni, 8)) * 0.1).astype(np.float32)
+    coll = LateCollectives(world)
+
+    def rank_fn(rank):
+        prop = RowShardedPropagator(ta, nu, ni, n_layers, rank, world, 'cpu', spmm_fn=cpu_spmm,
+                                    csr_factory=lambda rp, c, v, shape: CpuCsr(rp, c, v, shape), exchange=exchange,
+                                    collectives=coll.bind(rank))
+        L = prop.layout
+        (ulo, uhi), (ilo, ihi) = L.user_rows(rank), L.item_rows(rank)
+        outs = []
+        for _ in range(2):
+            prop.load_local_embedding(torch.from_numpy(emb[ulo:uhi]), torch.from_numpy(emb[nu + ilo:nu + ihi]))
+            ru, ri = prop.propagate()
+            outs.append((ru[:uhi - ulo].numpy().copy(), ri[:ihi - ilo].numpy().copy()))
+        full = prop.gather_full_rep(ru, ri).numpy().copy()
+        return outs, full, (ulo, uhi, ilo, ihi), prop.local_nnz
+    res = _run_ranks(world, rank_fn)
+    assert not coll.errors, coll.errors
+    ref = O.lightgcn_get_rep(O.lightgcn_norm_adj(ta, nu, ni), emb, n_layers)
+    empties = 0
+    for outs, full, (ulo, uhi, ilo, ihi), _ in res:
+        empties += (ihi == ilo) + (uhi == ulo)
+        for ru, ri in outs:
+            np.testing.assert_allclose(ru, ref[ulo:uhi], rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(ri, ref[nu + ilo:nu + ihi], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(full, ref, rtol=1e-5, atol=1e-7)
+    assert empties > 0
+    assert sum(r[3] for r in res) == 2 * len(ta)

@@ -26,9 +26,38 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert getattr(_lib.lib(), name) is not None
-    assert _lib.lib().igcn_abi_version() == _lib.EXPECTED_ABI == 9
-    assert re.search(r'#define IGCN_ABI_VERSION\s+9\b', header)
+    assert _lib.lib().igcn_abi_version() == _lib.EXPECTED_ABI == 10
+    assert re.search(r'#define IGCN_ABI_VERSION\s+10\b', header)
     assert _lib.lib().igcn_error_string(-1).decode().startswith('a required pointer')
+
+
+def test_the_struct_of_the_spmm_entry_point_is_laid_out_as_the_binding_declares_it(tmp_path):
+    """igcn_spmm_args (ABI v10) as a C compiler lays it out from include/igcn_hip.h against _lib.SpmmArgs (ctypes): every field at
+    the same offset, the same total size; the header compiles as plain C (gcc, no HIP).  And without a GPU the struct entry point
+    still rejects bad structs with IGCN_E_* before touching the device."""
+    import subprocess
+    from igcn_cf_amd import _lib
+    fields = [f[0] for f in _lib.SpmmArgs._fields_]
+    src = tmp_path / 'layout.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "igcn_hip.h"\nint main(void) {\n'
+                   + ''.join('    printf("%s %%zu\\n", offsetof(igcn_spmm_args, %s));\n' % (f, f) for f in fields)
+                   + '    printf("sizeof %zu\\n", sizeof(igcn_spmm_args));\n    return 0;\n}\n')
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, stdout=subprocess.PIPE).stdout.decode().splitlines())
+    for f in fields:
+        assert int(got[f]) == getattr(_lib.SpmmArgs, f).offset, f
+    assert int(got['sizeof']) == C.sizeof(_lib.SpmmArgs)
+    assert fields[:10] == ['struct_size', 'flags', 'rowptr', 'col', 'val', 'n_rows', 'n_cols', 'x', 'y', 'd']     # the required block
+    L = _lib.lib()
+    assert L.igcn_spmm_csr_f32_args(None, None) == -1
+    a = _lib.SpmmArgs()
+    a.struct_size = 16
+    assert L.igcn_spmm_csr_f32_args(C.byref(a), None) == -2                        # does not cover the required block
+    a.struct_size = C.sizeof(_lib.SpmmArgs)
+    assert L.igcn_spmm_csr_f32_args(C.byref(a), None) == -1                        # no rowptr / x / y
+    a.flags = 8
+    assert L.igcn_spmm_csr_f32_args(C.byref(a), None) == -4
 
 
 def test_library_is_loaded_behind_torch_in_a_fresh_process():
@@ -40,7 +69,7 @@ def test_library_is_loaded_behind_torch_in_a_fresh_process():
             "assert 'torch' in sys.modules; print(v)")
     p = subprocess.run([sys.executable, '-c', code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 0, p.stderr.decode()[-1000:]
-    assert p.stdout.decode().strip() == '9'
+    assert p.stdout.decode().strip() == '10'
 
 
 def test_no_kernel_of_the_built_library_carries_a_private_segment():
@@ -70,6 +99,28 @@ def test_no_kernel_of_the_built_library_carries_a_private_segment():
         one_wave = 'ILi256E' in name or 'ILi128ELi2ELb1ELi2E' in name
         assert regs <= (512 if one_wave else 256), (name, regs)
     assert _lib.lib().igcn_error_string(-6).decode().startswith('stream is capturing')
+
+
+def test_the_build_reads_kernel_metadata_without_a_third_party_module(monkeypatch):
+    """build() ends with scratch_report(), which decodes the msgpack notes of the code objects.  `msgpack` is no declared dependency:
+    where it cannot be imported the build's own decoder of the subset those notes use takes over — same dictionaries."""
+    import builtins
+    from igcn_cf_amd import _build, _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('library not built')
+    with_module = _build.kernel_metadata(_lib.LIB_PATH)
+    real_import = builtins.__import__
+
+    def no_msgpack(name, *a, **k):
+        if name == 'msgpack':
+            raise ImportError('msgpack is not installed (test)')
+        return real_import(name, *a, **k)
+    monkeypatch.setattr(builtins, '__import__', no_msgpack)
+    monkeypatch.delitem(sys.modules, 'msgpack', raising=False)
+    own = _build.kernel_metadata(_lib.LIB_PATH)
+    assert own == with_module and len(own) >= 60
+    assert _build.scratch_report(_lib.LIB_PATH) == []
+    assert _build._msgpack_unpack(bytes([0x82, 0xa1, 0x61, 0xcd, 0x01, 0x00, 0xa1, 0x62, 0x93, 0xc0, 0xc3, 0xd0, 0xff])) == {'a': 256, 'b': [None, True, -1]}
 
 
 def test_no_entry_point_relies_on_a_runtime_memset_node():
@@ -139,6 +190,90 @@ def test_the_bench_line_keeps_what_grades_it_inside_the_drivers_24_key_window():
     assert list(out2['roofline'])[:24] == want and out2['roofline']['eval_users_per_s'] is None and out2['roofline']['rank'] == 1
     json_line = __import__('json').dumps(out)
     assert json_line.index('"traffic"') < json_line.index('"frac_note"')
+
+
+def _strict_loads(text):
+    import json
+
+    def refuse(name):
+        raise AssertionError('non-strict JSON constant %s on the bench line' % name)
+    return json.loads(text, parse_constant=refuse)
+
+
+def test_the_bench_stdout_line_stays_under_8000_bytes_whatever_legs_ran():
+    """The driver parses the line out of the last ~8 000 characters of stdout: round 5's line was 19 997 bytes and its record came
+    back `parsed: null` (no value, no roofline, no cpu_baseline for the round).  bench.stdout_line builds a compact line (contract
+    keys, short config, numeric roofline, graded flat scalars, short cpu_baseline) and cuts flat keys from the end of its priority
+    list if it ever outgrows STDOUT_BUDGET; everything else goes to the sidecar.  Checked on the full records of real runs with every
+    leg present (N = 1: round 5's final bench; N = 2: a rehearsal) and on a worst case where every key is present and long."""
+    import json
+    import bench
+    assert bench.STDOUT_BUDGET <= 7500
+    graded = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline')
+    for name in ('r05zz_bench_final.json', 'r04l_bench_rehearsal_2_ranks_one_gpu.json'):
+        full = json.load(open(os.path.join(ROOT, 'profiles', name)))
+        text = bench.stdout_line(full)
+        assert len(text) < 8000 and len(text) <= bench.STDOUT_BUDGET and '\n' not in text, (name, len(text))
+        line = _strict_loads(text)
+        for k in graded:
+            assert k in line, (name, k)
+        assert line['value'] == full['value'] and line['ms_per_step'] == full['ms_per_step']      # contract keys: untouched
+        assert list(line['roofline'])[:24] == list(bench.ROOFLINE_HEAD)
+        assert 'extras' not in line and not any(k.endswith(('_note', '_source')) for k in line['roofline'])
+        assert 'workload' in line['config'] and 'model' not in line['config']
+        if full['n_gpus'] == 1:
+            cb = line['cpu_baseline']
+            for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+                assert cb[k] == full['cpu_baseline'][k] or abs(cb[k] / full['cpu_baseline'][k] - 1) < 1e-5, k
+            r, fr = line['roofline'], full['roofline']
+            for k in ('achieved', 'peak', 'frac', 'traffic', 'avg_launch_ms', 'eval_users_per_s', 'hbm_bound_item_block_frac'):
+                assert abs(r[k] / fr[k] - 1) < 1e-5, k
+            assert line['eval_users_per_s'] == r['eval_users_per_s'] and line['config5_pass_ms'] == r['config5_pass_ms']
+    # worst case: every key the line may carry is present, floats at 17 digits, strings far too long, NaN / Infinity among them
+    long_float = 0.12345678901234567
+    full = {k: long_float for k in bench.FLAT_STDOUT}
+    full.update({k: long_float for k in bench.CONTRACT_KEYS})
+    full.update(metric='m' * 80, unit='edges/s', higher_is_better=True, scaling='strong', vs_baseline=None, dtype='f32', data='synthetic',
+                n_gpus=8, steps=20, warmup=5, hbm_bound_kernel='k' * 400)
+    full['config'] = {k: 'c' * 1000 for k in bench.CONFIG_KEYS}
+    full['config']['parallelism_note'] = 'p' * 3000
+    full['roofline'] = {k: long_float for k in bench.ROOFLINE_HEAD + bench.ROOFLINE_TAIL}
+    full['roofline'].update(kernel='spmm' * 100, bound='hbm', unit='GB/s', frac=float('nan'), traffic=float('inf'), frac_note='n' * 500)
+    full['cpu_baseline'] = {k: 's' * 1000 for k in bench.CPU_STDOUT}
+    full['cpu_baseline']['c_port_thread_sweep'] = {str(t): long_float for t in range(64)}
+    full['extras'] = {'blob': ['x' * 100] * 500}
+    text = bench.stdout_line(full)
+    assert len(text) <= bench.STDOUT_BUDGET
+    line = _strict_loads(text)
+    assert line['roofline']['frac'] is None and line['roofline']['traffic'] is None          # NaN / Infinity never reach stdout
+    assert set(graded) <= set(line) and 'cpu_baseline' in line and 'extras' not in line
+    assert len(line['config']['workload']) <= 160 and 'parallelism_note' not in line['config']
+    # the cut takes flat keys from the END of the priority list: with a tiny budget the most important ones survive
+    small = bench.stdout_line(full, budget=len(text) - 600)
+    kept = [k for k in bench.FLAT_STDOUT if k in _strict_loads(small)]
+    assert kept and kept == list(bench.FLAT_STDOUT[:len(kept)])
+
+
+def test_the_bench_sidecar_holds_what_stdout_dropped(tmp_path, monkeypatch, capsys):
+    """bench.write_sidecar: the whole record as strict JSON in gpurun_out/bench_extras.json under the repo root and on stderr; a
+    root that cannot be written costs the file, never the run."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, 'profiles', 'r05zz_bench_final.json')))
+    full['roofline']['frac'] = float('nan')
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    path = bench.write_sidecar(full)
+    assert path == str(tmp_path / 'gpurun_out' / 'bench_extras.json')
+    side = _strict_loads(open(path).read())
+    assert side['extras']['eval_roofline'] and side['roofline']['frac'] is None and side['roofline']['frac_note']
+    assert abs(side['value'] / full['value'] - 1) < 1e-8
+    err = capsys.readouterr().err
+    assert _strict_loads(err.split('bench.py full record: ', 1)[1]) == side
+    blocker = tmp_path / 'file_in_the_way'
+    blocker.write_text('x')
+    monkeypatch.setattr(bench, 'ROOT', str(blocker))                  # gpurun_out/ cannot be created under a FILE
+    assert bench.write_sidecar(full) is None
 
 
 def test_bench_launcher_refuses_without_enough_gpus_before_starting_anything():

@@ -450,6 +450,120 @@ def test_launch_shape_does_not_change_results():
     assert torch.equal(spmm(ordered, x), ref)
 
 
+def test_struct_entry_point_the_minimal_binding_fills_eight_fields():
+    """igcn_spmm_csr_f32_args (ABI v10): the launch through ONE zero-initialised struct.  What the reference call site has
+    (model.py:99-102: a graph, X, the edge values) is the struct's first block — rowptr, col, val, n_rows, n_cols, x, y, d — and
+    a binding that fills only those (plus struct_size) gets Y = M X: every optional field reads zero as "off / default".
+    Checked against the 34-argument call (same bits), with a SHORTER struct_size (a caller compiled against an older header: the
+    library must not read past it), and for the error codes of a struct that is too short / carries unknown flags."""
+    import ctypes as C
+    from igcn_cf_amd import _lib
+    rng = np.random.default_rng(11)
+    n_rows, n_cols, d = 3000, 1500, 64
+    degs = rng.integers(0, 40, n_rows)                                  # (no row above the cut threshold: no plan needed)
+    rowptr, col, val = _random_csr(rng, n_rows, n_cols, degs)
+    rp, cl, vl = (torch.from_numpy(a).cuda() for a in (rowptr, col, val))
+    x = torch.randn(n_cols, d, device='cuda')
+    L = _lib.lib()
+    nul = (C.c_void_p * 1)()
+    ref = torch.empty(n_rows, d, device='cuda')
+    assert L.igcn_spmm_csr_f32(rp.data_ptr(), cl.data_ptr(), vl.data_ptr(), x.data_ptr(), d, ref.data_ptr(), d, n_rows, n_cols, d, 1.0, nul, 0,
+                               1.0, None, None, None, 0, None, 0, None, 256, None, 0, 1.0, None, 0, 0, None, None, None, None, None, None) == 0
+    want = _oracle(rowptr, col, val, x.cpu().numpy(), n_rows)
+    assert _rel_err(ref.cpu().numpy(), want) < TOL
+    a = _lib.SpmmArgs()                                                 # ctypes zero-initialises
+    a.struct_size = C.sizeof(_lib.SpmmArgs)
+    a.rowptr, a.col, a.val, a.n_rows, a.n_cols, a.d = rp.data_ptr(), cl.data_ptr(), vl.data_ptr(), n_rows, n_cols, d
+    y = torch.full((n_rows, d), float('nan'), device='cuda')
+    a.x, a.y = x.data_ptr(), y.data_ptr()
+    assert L.igcn_spmm_csr_f32_args(C.byref(a), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref)
+    # a caller compiled against a shorter struct: only the required block (up to and including d)
+    prefix = _lib.SpmmArgs.d.offset + 4
+    raw = (C.c_uint8 * C.sizeof(_lib.SpmmArgs))()
+    C.memmove(raw, C.byref(a), prefix)
+    for i in range(prefix, len(raw)):
+        raw[i] = 0xFF                                                   # garbage behind what the caller declared: must not be read
+    short = C.cast(raw, C.POINTER(_lib.SpmmArgs))
+    short.contents.struct_size = prefix
+    y.fill_(float('nan'))
+    assert L.igcn_spmm_csr_f32_args(short, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref)
+    short.contents.struct_size = prefix - 4
+    assert L.igcn_spmm_csr_f32_args(short, None) == -2                  # IGCN_E_SHAPE: the required block is not covered
+    assert L.igcn_spmm_csr_f32_args(None, None) == -1
+    a.flags = 4
+    assert L.igcn_spmm_csr_f32_args(C.byref(a), None) == -4             # unknown flag bit
+    a.flags = 0
+    a.n_adds = 9
+    assert L.igcn_spmm_csr_f32_args(C.byref(a), None) == -4
+    a.n_adds = 1                                                        # an addend announced, none given
+    assert L.igcn_spmm_csr_f32_args(C.byref(a), None) == -1
+    a.n_adds = 0
+    a.tune_fold = -1
+    assert L.igcn_spmm_csr_f32_args(C.byref(a), None) == -4
+    a.tune_fold = 0
+    a.y = x.data_ptr()
+    assert L.igcn_spmm_csr_f32_args(C.byref(a), None) == -4             # in place
+    # the struct's layout is what the header says: 8-byte aligned pointers, no hidden padding in the required block
+    assert _lib.SpmmArgs.rowptr.offset == 8 and _lib.SpmmArgs.d.offset == 64 and C.sizeof(_lib.SpmmArgs) % 8 == 0
+
+
+def test_per_call_launch_knobs_keep_concurrent_streams_apart():
+    """igcn_set_tuning is process-wide; the SpMM's three result-neutral knobs can instead ride in the call (igcn_spmm_args.tune_* /
+    ops.spmm(tune=...)).  Launches on several streams and threads at once, each with its own grid / rows-per-wave / fold choice and
+    none touching the process-wide switch: every result equals the default launch's — bit for bit where only the grid differs, to
+    rounding where the lanes that add a row up differ — and the process-wide values are what they were."""
+    import threading
+    from igcn_cf_amd import _lib
+    from igcn_cf_amd.graph import CsrMatrix
+    from igcn_cf_amd.ops import spmm
+    rng = np.random.default_rng(5)
+    n_rows, n_cols, d = 30000, 4000, 64
+    degs = np.minimum((rng.pareto(1.2, n_rows) * 5).astype(np.int64), n_cols)
+    rowptr, col, val = _random_csr(rng, n_rows, n_cols, degs)
+    x = torch.randn(n_cols, d, device='cuda')
+    base = CsrMatrix(rowptr, col, val, (n_rows, n_cols), 'cuda', order_blocks=[0, n_rows])
+    assert base.n_segments > 0
+    ref = spmm(base, x)
+    torch.cuda.synchronize()
+    knobs = [{'blocks_per_cu': 1}, {'blocks_per_cu': 64}, {'multirow': 0}, {'fold': 1}, {'blocks_per_cu': 7, 'fold': 1}, None]
+    results, errors = [None] * len(knobs), []
+
+    def body(i):
+        try:
+            csr = CsrMatrix(rowptr, col, val, (n_rows, n_cols), 'cuda', order_blocks=[0, n_rows])      # (its own partial-sum workspace)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                xs = x.clone()
+                for _ in range(20):
+                    y = spmm(csr, xs, tune=knobs[i])
+            st.synchronize()
+            results[i] = y
+        except BaseException as e:                                       # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=body, args=(i,)) for i in range(len(knobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
+    for i, k in enumerate(knobs):
+        if k and 'multirow' in k:
+            assert _rel_err(results[i].cpu().numpy(), ref.cpu().numpy()) < 1e-5, k
+        else:
+            assert torch.equal(results[i], ref), k
+    assert torch.equal(spmm(base, x), ref)                               # the process-wide defaults were never touched
+    # a per-call knob wins over the process-wide one, and only for its call
+    _lib.set_tuning('spmm_blocks_per_cu', 3)
+    try:
+        assert torch.equal(spmm(base, x, tune={'blocks_per_cu': 4096}), ref) and torch.equal(spmm(base, x), ref)
+    finally:
+        _lib.set_tuning('spmm_blocks_per_cu', None)
+
+
 @pytest.mark.parametrize('d', [64, 128, 16])
 def test_cut_rows_added_up_inside_the_launch_give_the_two_launch_bits(d):
     """igcn_set_tuning("spmm_fold", 1) (opt-in, include/igcn_hip.h: closing segments): every segment of a cut row counts itself in
