@@ -171,7 +171,7 @@ def plan_addends(entry, tables):
     return [tables[i] for i in (entry if isinstance(entry, tuple) else (entry,))]
 
 
-def propagate_mean(csr: CsrMatrix, x0, n_layers, row_scale_last=None, masks=None, zero_masked=True, plan=None):
+def propagate_mean(csr: CsrMatrix, x0, n_layers, row_scale_last=None, masks=None, zero_masked=True, plan=None, tune=None, out=None):
     """mean(X_0..X_K), X_{l+1} = csr @ X_l — the layer loop + stack/mean of
     model.py:101-105, as the K launches of mean_plan(); the 1 / (K + 1) is the last launch's epilogue (no stack).
 
@@ -179,9 +179,11 @@ def propagate_mean(csr: CsrMatrix, x0, n_layers, row_scale_last=None, masks=None
     needed (a training step reads the propagated rows of its batch only, model.py:114-115).  The
     last launch is then computed for those rows alone (others are zero) and the one before it for
     their neighbourhood alone (other rows of that intermediate are never read) — same values on
-    the needed rows, ~45 % fewer edges at Amazon scale with a 2048-triplet batch."""
+    the needed rows, ~45 % fewer edges at Amazon scale with a 2048-triplet batch.
+    tune: per-call launch knobs handed to every spmm (result-neutral); out: the [N, d] buffer the result goes to (a captured pass
+    writes to the same tensor at every replay)."""
     if n_layers == 0:
-        return x0.clone()
+        return x0.clone() if out is None else out.copy_(x0)
     tables = [x0]
     s = 1.0 / (n_layers + 1)
     for l, add in enumerate(plan if plan is not None else mean_plan(n_layers)):
@@ -189,12 +191,12 @@ def propagate_mean(csr: CsrMatrix, x0, n_layers, row_scale_last=None, masks=None
         if l == n_layers - 1:
             # (rows outside the mask left untouched: the launch walks the wanted entries only — RowMarks.order_bits)
             skip = masks.order_bits_for(csr) if masks and not zero_masked and isinstance(masks, RowMarks) else None
-            y = spmm(csr, tables[-1], adds=adds, out_scale=s, add_scale=s, row_scale=row_scale_last,
-                     row_mask=masks[0] if masks else None, masked_rows_zero=zero_masked, order_bits=skip)
+            y = spmm(csr, tables[-1], out=out, adds=adds, out_scale=s, add_scale=s, row_scale=row_scale_last,
+                     row_mask=masks[0] if masks else None, masked_rows_zero=zero_masked, order_bits=skip, tune=tune)
         elif l == n_layers - 2 and masks:
-            y = spmm(csr, tables[-1], adds=adds, row_mask=masks[1], masked_rows_zero=False)
+            y = spmm(csr, tables[-1], adds=adds, row_mask=masks[1], masked_rows_zero=False, tune=tune)
         else:
-            y = spmm(csr, tables[-1], adds=adds)
+            y = spmm(csr, tables[-1], adds=adds, tune=tune)
         tables.append(y)
     return tables[-1]
 
