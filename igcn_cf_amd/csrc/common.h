@@ -108,6 +108,7 @@ enum {
     IGCN_TUNE_TOPK_FAST_FILTER,         // 0: the flagged users of the two-stage path all take the bounded fp32 sweep (default: a streaming filter first, the sweep for what overflows it)
     IGCN_TUNE_TOPK_FAST_PIECES,         // 0: the narrow bounded sweep is cut into at most 58 pieces per group (default: up to 232, four lists per lane of its merge)
     IGCN_TUNE_SPMM_FOLD,                // 1: cut rows are added up inside the launch by their closing segments (default, unset or 0: by a second kernel, spmm_long_rows_reduce_kernel — faster on the headline graph)
+    IGCN_TUNE_TOPK_FAST_POISON,         // TEST ONLY, 1: igcn_score_topk_fast_f32 does NOT clear the order build's counting bins (they keep what the caller's workspace held): the build must notice and fall back to the id order
     IGCN_TUNE_COUNT
 };
 extern int g_tuning[IGCN_TUNE_COUNT];   // defined in spmm.hip; holds value + 1, 0 = unset

@@ -1704,7 +1704,8 @@ __global__ __launch_bounds__(kBlock) void topk_row_stats_both_kernel(const float
 __global__ __launch_bounds__(kBlock) void topk_pack_items_f16_kernel(const float *__restrict__ item_rows, int64_t ldi, int64_t n_items,
                                                                      int n_tiles, int ks, const unsigned int *__restrict__ stats,
                                                                      const int32_t *__restrict__ perm, float4 *__restrict__ packed,
-                                                                     const float *__restrict__ norm2, float *__restrict__ tile_bound)
+                                                                     const float *__restrict__ norm2, float *__restrict__ tile_bound,
+                                                                     const uint32_t *__restrict__ order_status)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)n_tiles * ks * kWave) return;
@@ -1715,7 +1716,10 @@ __global__ __launch_bounds__(kBlock) void topk_pack_items_f16_kernel(const float
     if (tile_bound && lane == 0 && s == 0)
         // the tile's first row is its longest up to the sort's granularity (norms ordered on 16 bits: < 2^-8 apart
         // in |row|^2 inside a bucket); 1 % covers that, the fp16 rounding of the plane and the fp32 accumulation
-        tile_bound[tile] = 1.01f * sqrtf(norm2[perm[item]]) * ldexpf(1.f, -scale_exp(__uint_as_float(stats[1])));
+        // (order_status != 0: the order build fell back to the id order, topk_order.hip — rows no longer get shorter along the sweep,
+        // so no tile bounds the ones behind it: a bound nobody gets below keeps every wave in the sweep to its end)
+        tile_bound[tile] = order_status && order_status[0] ? 3.0e38f
+                                                           : 1.01f * sqrtf(norm2[perm[item]]) * ldexpf(1.f, -scale_exp(__uint_as_float(stats[1])));
     float4 lo = f4_zero(), hi = f4_zero();
     if (item < n_items) {
         const float *src = item_rows + (int64_t)(perm ? perm[item] : item) * ldi + 16 * s + 8 * (lane >> 5);
@@ -2207,7 +2211,9 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
     if (L.order != L.exit_state + fb_state + align256(batch) + align256(batch * 4) || L.ord.bins != 0) return IGCN_E_RANGE;   // (the layout this memset relies on)
     // (the library's own zeroing kernel, not hipMemsetAsync: a memset NODE of a captured graph is not ordered against the kernels behind
     // it on ROCm 7.2 — see zero_async in common.h)
-    rc = zero_async(norm_bits, (size_t)(256 + kFilterState + fb_state + align256(batch) + align256(batch * 4) + (by_norm ? kOrderBinsBytes : 0)), st);
+    // (test-only knob "topk_fast_poison": the bins are left as the caller's workspace held them — the order build has to notice)
+    const bool clear_bins = by_norm && tuning_get(IGCN_TUNE_TOPK_FAST_POISON) <= 0;
+    rc = zero_async(norm_bits, (size_t)(256 + kFilterState + fb_state + align256(batch) + align256(batch * 4) + (clear_bins ? kOrderBinsBytes : 0)), st);
     if (rc != IGCN_OK) return rc;
     const int n_tiles = (int)((n_items + 31) / 32);
     const int64_t pack_threads = (int64_t)n_tiles * ks * kWave;
@@ -2236,7 +2242,8 @@ extern "C" int igcn_score_topk_fast_f32(const float *user_rows, int64_t ldu, con
         hipLaunchKernelGGL(topk_pack_items_f16_kernel, dim3((unsigned)((pack_threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                            item_rows, ldi, n_items, n_tiles, ks, norm_bits, perm, packed,
                            early_exit ? reinterpret_cast<const float *>(ows + L.ord.norm2) : (const float *)nullptr,
-                           early_exit ? tile_bound : (float *)nullptr);
+                           early_exit ? tile_bound : (float *)nullptr,
+                           by_norm ? reinterpret_cast<const uint32_t *>(ows + L.ord.status) : (const uint32_t *)nullptr);
     } else {
         hipLaunchKernelGGL(topk_pack_items_kernel, dim3((unsigned)((pack_threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, st,
                            item_rows, ldi, n_items, n_tiles, perm, packed);

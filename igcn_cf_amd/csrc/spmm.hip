@@ -176,6 +176,7 @@ __device__ __forceinline__ void finish_row(const float4 &acc, int64_t dst, int t
 // dispatched in order, so those are resident or done — waves that are resident always finish.  The poll is bounded all the same
 // (kClosePolls ~ seconds): a row whose count never completes — a broken plan — comes back as NaN instead of hanging the GPU.
 constexpr int kClosePolls = 1 << 22;
+constexpr int kClosePoison = -(1 << 30);   // what a timed-out row's arrival counter is left at (segment_done)
 constexpr int kClosingBit = (int)0x80000000u;
 // (one 16-byte store with the agent-scope bit, written by hand: four __hip_atomic_store of a float each cost the kernel four
 // registers and a wave per SIMD — 67 instead of 63 VGPRs at d = 64)
@@ -291,7 +292,10 @@ __device__ __forceinline__ void segment_done(const igcn_long_row *long_rows, int
         if (writer && acc.x == 12345.f) finish_row(acc, lr->row, t, ep, y, ldy);
 #endif
     }
-    if (leader) __hip_atomic_store(arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // A row that timed out keeps a POISONED counter (late arrivals only add to it): every later launch on this matrix times out on
+    // the row again and writes NaN again, instead of adding up a mixture of two launches' segments behind a counter that was put
+    // back to zero too early.  (A plan whose closing segments sit next to their siblings is not folded at all: graph.py.)
+    if (leader) __hip_atomic_store(arrived, complete ? 0 : kClosePoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // 80 scalar registers at most: a wave is charged its SGPRs + 16 (rounded up to 16) out of 800 per SIMD, so 80 is
@@ -1074,7 +1078,8 @@ extern "C" int igcn_set_tuning(const char *name, int32_t value)
     static const char *const names[IGCN_TUNE_COUNT] = {"spmm_blocks_per_cu", "spmm_multirow", "topk_slots",
                                                        "topk_waves_per_cu", "topk_cap", "topk_stagger", "topk_fast_mode",
                                                        "topk_fast_order", "topk_fast_exit", "topk_fast_wide", "topk_fast_extra", "topk_fast_give_up", "topk_fast_narrow", "topk_fast_share",
-                                                       "topk_fast_fallback", "topk_fast_early_checks", "topk_fast_warm", "topk_fast_filter", "topk_fast_pieces", "spmm_fold"};
+                                                       "topk_fast_fallback", "topk_fast_early_checks", "topk_fast_warm", "topk_fast_filter", "topk_fast_pieces", "spmm_fold",
+                                                       "topk_fast_poison"};
     if (!name) return IGCN_E_NULL;
     for (int i = 0; i < IGCN_TUNE_COUNT; ++i)
         if (strcmp(name, names[i]) == 0) { g_tuning[i] = value < 0 ? 0 : value + 1; return IGCN_OK; }

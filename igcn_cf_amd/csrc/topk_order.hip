@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kBlock) void order_count_kernel(const float *__rest
 // counts -> start positions, in place, in two levels: workgroup q of 64 scans the 1 024 bins q << 10 ... (their counters are 64 slots
 // apart: order_slot) and leaves their total in totals[q]; the 64 totals are scanned by whoever needs a position (order_place_kernel).
 // (One workgroup scanning all 65 536 counters — 64 per thread, 384 shuffles each — took 45 us.)
-__global__ __launch_bounds__(1024) void order_scan_kernel(uint32_t *__restrict__ bins, uint32_t *__restrict__ totals)
+__global__ __launch_bounds__(1024) void order_scan_kernel(uint32_t *__restrict__ bins, uint32_t *__restrict__ totals, uint32_t *__restrict__ status)
 {
     __shared__ uint32_t wave_tot[1024 / kWave];
     const uint32_t slot = ((uint32_t)threadIdx.x << 6) | blockIdx.x;
@@ -90,24 +90,38 @@ __global__ __launch_bounds__(1024) void order_scan_kernel(uint32_t *__restrict__
     for (int w = 0; w < 1024 / kWave; ++w) { const uint32_t t = wave_tot[w]; before += w < wave ? t : 0u; all += t; }
     bins[slot] = before + incl - v;
     if (threadIdx.x == 0) totals[blockIdx.x] = all;
+    if (threadIdx.x == 0 && blockIdx.x == 0) status[0] = 0u;       // (order_place_kernel, queued behind, reports into it)
 }
 
-// positions: a wave's lanes of one bin take consecutive positions (ascending id among themselves); perm and its inverse
+// positions: a wave's lanes of one bin take consecutive positions (ascending id among themselves); perm and its inverse.
+// The counts are only right when the bins arrived ZEROED (the caller's job: igcn_score_topk_fast_f32 clears them with its own state).
+// Should that ordering ever break again (round 4's captured memset node did it: profiles/r05b_*), the counts are inflated and the
+// 64 group totals no longer add up to n — every workgroup sees that from the totals it scans anyway and falls back, all of them
+// alike, to the IDENTITY order (the sweep then meets the items by id: the same lists, a slower sweep) and status[0] says so (1).
+// The `pos < n` guard behind it cannot trip when the totals add up (status[0] = 2 if it ever does): kept so that no ordering bug
+// can become a write outside the workspace.
 __global__ __launch_bounds__(kBlock) void order_place_kernel(const uint32_t *__restrict__ keys, int64_t n, uint32_t *__restrict__ bins,
                                                              const uint32_t *__restrict__ totals, int32_t *__restrict__ perm,
-                                                             int32_t *__restrict__ inv)
+                                                             int32_t *__restrict__ inv, uint32_t *__restrict__ status)
 {
     __shared__ uint32_t group_base[kOrderBins / 1024];   // items in the bins before group q of 1 024 bins
+    __shared__ uint32_t grand_total;
     if (threadIdx.x < kWave) {
         const uint32_t t = totals[threadIdx.x];
         uint32_t incl = t;
 #pragma unroll
         for (int o = 1; o < kWave; o <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)incl, o); if ((int)threadIdx.x >= o) incl += u; }
         group_base[threadIdx.x] = incl - t;
+        if (threadIdx.x == kWave - 1) grand_total = incl;
     }
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool active = i < n;
+    if ((int64_t)grand_total != n) {                     // (uniform over the whole grid: every workgroup reads the same totals)
+        if (active) { perm[i] = (int32_t)i; inv[i] = (int32_t)i; }
+        if (i == 0) status[0] = 1u;
+        return;
+    }
     const uint32_t bin = active ? keys[i] : 0u;
     const unsigned long long peers = same_bin_lanes(bin, active);
     const int lane = threadIdx.x & (kWave - 1);
@@ -117,12 +131,9 @@ __global__ __launch_bounds__(kBlock) void order_place_kernel(const uint32_t *__r
     const int leader = peers ? __ffsll((long long)peers) - 1 : lane;
     start = (uint32_t)__shfl((int)start, leader);
     if (active) {
-        // (pos < n whenever the bins arrived zeroed; the guard keeps a caller's broken ordering — bins that were not — from becoming
-        // a write outside the workspace: the lists are then wrong, which the caller can see, instead of a GPU fault, which takes the
-        // process and possibly the node with it)
         const uint32_t pos = group_base[bin >> 10] + start + (uint32_t)__popcll(below);
-        if ((int64_t)pos < n) perm[pos] = (int32_t)i;
-        inv[i] = (int64_t)pos < n ? (int32_t)pos : (int32_t)i;
+        if ((int64_t)pos < n) { perm[pos] = (int32_t)i; inv[i] = (int32_t)pos; }
+        else { inv[i] = (int32_t)i; status[0] = 2u; }
     }
 }
 
@@ -353,6 +364,7 @@ int topk_order_layout(int64_t n_items, int64_t excl_rows, int64_t excl_nnz, Topk
     int64_t off = 0;
     L->bins = off; off += kOrderBinsBytes;                                       // (first: see topk_order.h)
     L->totals = off; off += 256;                                                 // items per group of 1 024 bins
+    L->status = off; off += 256;                                                 // [0]: 0 = ordered by norm; 1 = the bins did not arrive zeroed, identity order taken; 2 = a position out of range
     L->norm2 = off; off += al256(n_items * 4);
     L->keys = off; off += al256(n_items * 4);
     L->perm = off; off += al256(n_items * 4);
@@ -375,8 +387,9 @@ int topk_order_build(const TopkOrderLayout &L, char *ws, int64_t n_items, const 
     int32_t *huge = excl_nnz > 0 ? reinterpret_cast<int32_t *>(ws + L.huge) : nullptr;
     hipLaunchKernelGGL(order_count_kernel, dim3(ib), dim3(kBlock), 0, st, norm2, n_items, keys, bins, huge);
     uint32_t *totals = reinterpret_cast<uint32_t *>(ws + L.totals);
-    hipLaunchKernelGGL(order_scan_kernel, dim3(kOrderBins / 1024), dim3(1024), 0, st, bins, totals);
-    hipLaunchKernelGGL(order_place_kernel, dim3(ib), dim3(kBlock), 0, st, (const uint32_t *)keys, n_items, bins, (const uint32_t *)totals, perm, inv);
+    uint32_t *status = reinterpret_cast<uint32_t *>(ws + L.status);
+    hipLaunchKernelGGL(order_scan_kernel, dim3(kOrderBins / 1024), dim3(1024), 0, st, bins, totals, status);
+    hipLaunchKernelGGL(order_place_kernel, dim3(ib), dim3(kBlock), 0, st, (const uint32_t *)keys, n_items, bins, (const uint32_t *)totals, perm, inv, status);
     *perm_out = perm;
     *excl_pos_out = nullptr;
     if (excl_nnz > 0) {

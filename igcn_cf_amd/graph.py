@@ -259,6 +259,7 @@ def graph_rank_nodes_from_adjacency(dataset, ranking_metric):
 # -11 %, Yelp-like -16 %, Gowalla-like -26 %, d = 32 +-1 %; thresholds 96...160 within 2 % of each other, 64 and below lose
 # (8 partial rows per cut row).  None = the plain long-row plan.
 CLOSING_AT = 0.25              # where a phase's closing segments are dealt: this fraction into the phase's rows (xcd_plan / CsrMatrix._build_plan)
+MIN_CLOSING_GAP = 8            # rows that must lie between a list's other segments and its closing ones for the plan to be foldable in the launch
 XCD_PLAN = {'threshold': 112}
 XCD_PLAN_FEATURES = XCD_PLAN   # INMO's template-feature matrix F and its transposed view: -1...-3 % (profiles/r03m_*); None = plain plan
 N_XCD = 8                  # lists of the XCD plan = XCDs of an MI355X (igcn_spmm_csr_f32: xcd_off has N_XCD + 1 entries)
@@ -287,6 +288,7 @@ def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assi
     Returns (long_rows int32 [n_long, 4], segments int32 [n_seg, 6] — the byte layouts of igcn_long_row /
     igcn_row_segment —, row_order int32, xcd_off int64 [N_XCD + 1], load float64 [N_XCD]) on that device."""
     NL = int(n_lists or N_XCD)        # lists of the plan (developer A/Bs cut fewer slices; the kernel always walks N_XCD)
+    xcd_plan.last_foldable = list_order == 'segments_first'          # (read by CsrMatrix._build_plan right after the call)
     dev = rowptr.device
     i64 = dict(dtype=torch.int64, device=dev)
     n_rows = rowptr.shape[0] - 1
@@ -415,6 +417,11 @@ def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assi
                 # full-length segments with a fold behind them end AFTER the list's last short rows: +12 us of tail (profiles/r05c_*)
                 cl = is_late[sx - n_rows]
                 at = int(rx.shape[0] * closing_at)
+                if bool(cl.any()) and at < MIN_CLOSING_GAP:
+                    # too few rows to put between a row's closing segment and the other segments: a wave could meet a closing segment
+                    # and one of its siblings in the SAME visit (up to 4 entries), or before the siblings' waves have started — such a
+                    # plan is never folded (the launch keeps the second kernel, whatever "spmm_fold" says)
+                    xcd_plan.last_foldable = False
                 lists[x] += [sx[~cl], rx[:at], sx[cl], rx[at:]]
             elif list_order == 'rows_first':
                 lists[x] += [rx, sx]
@@ -537,7 +544,7 @@ class CsrMatrix:
             self.long_rows = lr.contiguous().view(torch.uint8).reshape(-1) if self.n_long else None
             self.segments = sg.contiguous().view(torch.uint8).reshape(-1) if self.n_long else None
             self.row_order, self.xcd_off, self.xcd_load = order, xcd_off, load
-            self.closing_segments = cfg.get('list_order', 'segments_first') == 'segments_first' and self.n_long > 0
+            self.closing_segments = bool(xcd_plan.last_foldable) and self.n_long > 0
             return
         L = _lib.lib()
         n_long, n_seg = C.c_int64(0), C.c_int64(0)
@@ -568,13 +575,16 @@ class CsrMatrix:
             closing = sg['long_index'] < 0 if self.n_long else np.zeros(0, dtype=bool)      # (bit 31: the row's closing segment)
             pieces = []
             bounds = list(self.order_blocks)
+            foldable = True
             for lo, hi in zip(bounds[:-1], bounds[1:]):
                 in_block = (seg_row >= lo) & (seg_row < hi)
                 rows = lo + np.argsort(-lens[lo:hi], kind='stable')
                 # the block's segments first, its closing segments (they add their rows up, igcn_hip.h) CLOSING_AT into its rows
                 at = int(len(rows) * CLOSING_AT)
+                if at < MIN_CLOSING_GAP and bool((in_block & closing).any()):
+                    foldable = False              # (see xcd_plan: a closing segment next to its siblings — the launch keeps the second kernel)
                 pieces += [n_rows + np.flatnonzero(in_block & ~closing), rows[:at], n_rows + np.flatnonzero(in_block & closing), rows[at:]]
-            self.closing_segments = self.n_long > 0
+            self.closing_segments = self.n_long > 0 and foldable
             order = np.concatenate(pieces).astype(np.int32)
             assert order.shape[0] == n_rows + self.n_segments
             self.row_order = torch.from_numpy(order).to(self.device)

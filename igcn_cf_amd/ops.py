@@ -684,6 +684,9 @@ def set_fast_fallback(inside):
     _lib.set_tuning('topk_fast_fallback', None if inside else 0)
 
 
+FAST_WORKSPACE_FILL = None        # test hook: a byte value the two-stage call's workspace is filled with before the call (None: left as allocated)
+
+
 def _score_topk_fast(L, user_rows, item_rows, k, user_ids, excl_rowptr, excl_col, banned, B, n_items, d):
     dev = item_rows.device
     excl_rows = excl_rowptr.numel() - 1 if excl_rowptr is not None else 0
@@ -692,6 +695,8 @@ def _score_topk_fast(L, user_rows, item_rows, k, user_ids, excl_rowptr, excl_col
     if ws_bytes < 0:
         raise _lib.IgcnError('unsupported two-stage top-k shape: batch=%d n_items=%d d=%d k=%d' % (B, n_items, d, k))
     ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
+    if FAST_WORKSPACE_FILL is not None:                      # tests: the call must not rely on what the workspace held before
+        ws.fill_(FAST_WORKSPACE_FILL)
     ws_ptr = (ws.data_ptr() + 255) // 256 * 256
     out_idx = torch.empty((B, k), dtype=torch.int64, device=dev)
     out_val = torch.empty((B, k), dtype=torch.float32, device=dev)

@@ -52,7 +52,8 @@ const char *igcn_error_string(int code);
  * bound take a streaming filter over all items first), "topk_fast_warm" (tiles of the
  * candidate sweep's warm-up pass, 0: none; default 128, taken where the item rows at its end are still half as long as the first), "topk_fast_mode" (candidate sweep of
  * igcn_score_topk_fast_f32: 3 = one fp16 plane each side, the default; 2 = two fp16 user planes; 1 = two bf16 planes each side,
- * d = 64 only); value < 0 restores the library
+ * d = 64 only), "topk_fast_poison" (TEST ONLY, 1: igcn_score_topk_fast_f32 does not clear its order build's counting bins — the
+ * build must notice and take the id order); value < 0 restores the library
  * default.  Results never depend on them (tests/test_spmm_gpu.py::test_launch_shape_does_not_change_results).
  * Process-wide: not to be changed while another thread launches (a launch reads its knobs once, at entry; the SpMM takes
  * its three per call instead — igcn_spmm_args.tune_*).  Returns IGCN_E_RANGE for an unknown name. */

@@ -778,6 +778,34 @@ def test_split_lists_invalidate_themselves(golden):
         assert clone.csr('test')[0][w + 1] == clone.csr('test')[0][w] and len(ds.test_data[w]) > 0
 
 
+def test_a_plan_whose_closing_segments_sit_next_to_their_siblings_is_never_folded():
+    """The in-launch fold (opt-in "spmm_fold") lets a cut row's CLOSING segment wait for the row's other segments, which the dealing
+    order must hand out earlier — graph.py puts CLOSING_AT of the phase's rows between them.  In a phase (or an XCD list) with fewer
+    than MIN_CLOSING_GAP rows to put there, a closing segment and a sibling could share one visit of a multirow wave: such
+    a plan reports closing_segments = False, so that no launch on it sets IGCN_SPMM_CLOSING_SEGMENTS and the second kernel adds the
+    rows up.  Built on the host (no GPU): the plain plan through the library's host entry points."""
+    from igcn_cf_amd.graph import MIN_CLOSING_GAP, CsrMatrix
+
+    def csr(lens, n_cols, blocks):
+        rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        col = np.concatenate([np.arange(l, dtype=np.int32) % n_cols for l in lens])
+        return CsrMatrix(rowptr, col, None, (len(lens), n_cols), 'cpu', long_threshold=8, segment_len=8, order_blocks=blocks)
+    # a phase of 3 rows, one of them cut: no room between the closing segment and its siblings
+    few = csr([40, 2, 3], 64, [0, 3])
+    assert few.n_long == 1 and few.n_segments == 5 and few.closing_segments is False
+    # the same cut row among 64 rows: CLOSING_AT * 64 = 16 rows lie between
+    many = csr([40] + [3] * 63, 64, [0, 64])
+    assert many.n_long == 1 and many.closing_segments is True
+    order = many.row_order.numpy()
+    closing_at = int(np.flatnonzero(order == 64 + 4)[0])                    # the row's last segment
+    assert closing_at - 4 >= MIN_CLOSING_GAP and sorted(order[:4].tolist()) == [64, 65, 66, 67]
+    # two phases, the second one tiny and cut: the whole matrix is not folded
+    two = csr([40] + [3] * 63 + [40, 1], 64, [0, 64, 66])
+    assert two.n_long == 2 and two.closing_segments is False
+    # no cut row at all: nothing to fold
+    assert csr([3] * 10, 64, [0, 10]).closing_segments is False
+
+
 @pytest.mark.parametrize('threshold', [3, 8, 1000])
 def test_xcd_plan_covers_every_nonzero_once(golden, threshold):
     """graph.xcd_plan (what igcn_spmm_csr_f32's xcd_off / row_order take): every row that is not cut and every segment

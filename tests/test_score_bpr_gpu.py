@@ -501,6 +501,39 @@ def test_two_stage_sweep_order_and_early_exit_do_not_change_the_lists(d):
         _lib.set_tuning('topk_fast_give_up', None)
 
 
+@pytest.mark.parametrize('d', [64, 128])
+def test_two_stage_call_does_not_rely_on_what_its_workspace_held_and_survives_unzeroed_bins(d):
+    """Two properties of igcn_score_topk_fast_f32's workspace.  (1) The call clears what it needs itself: with the workspace filled
+    with 0x5A / 0xFF bytes before the call the lists are the fp32 sweep's, bit for bit.  (2) The order build's counting bins must
+    arrive zeroed — round 4's captured memset node once left them unzeroed, a GPU fault then, a silently wrong permutation behind
+    round 5's bounds guard.  With the test-only knob "topk_fast_poison" the call leaves the bins as the workspace held
+    them (garbage): the build notices that its counts no longer add up to n_items, every workgroup falls back to the identity
+    order, the tile bounds stop any early exit — the SAME lists come back (a slower sweep), trained-like norms, masks and all."""
+    from igcn_cf_amd import _lib, ops
+    from igcn_cf_amd.ops import score_topk
+    rng = np.random.default_rng(23)
+    n_users, n_items, k = 900, 30011, 20
+    U = (rng.standard_normal((n_users, d)) * 0.1 * np.exp(rng.standard_normal((n_users, 1)))).astype(np.float32)
+    I = (rng.standard_normal((n_items, d)) * 0.1 * np.exp(1.2 * rng.standard_normal((n_items, 1)))).astype(np.float32)
+    ex = [sorted(rng.choice(n_items, size=int(rng.integers(0, 40)), replace=False).tolist()) for _ in range(n_users)]
+    rowptr = np.zeros(n_users + 1, dtype=np.int64)
+    np.cumsum([len(x) for x in ex], out=rowptr[1:])
+    col = np.array([i for x in ex for i in x], dtype=np.int32)
+    kw = dict(excl_rowptr=_dev(rowptr), excl_col=_dev(col))
+    ref = score_topk(_dev(U), _dev(I), k, mode='exact', **kw)
+    try:
+        for fill, poison in ((0x5A, None), (0xFF, None), (0x5A, 1), (0x01, 1), (0xFF, 1)):
+            ops.FAST_WORKSPACE_FILL = fill
+            _lib.set_tuning('topk_fast_poison', poison)
+            got = score_topk(_dev(U), _dev(I), k, mode='fast', **kw)
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (fill, poison)
+    finally:
+        ops.FAST_WORKSPACE_FILL = None
+        _lib.set_tuning('topk_fast_poison', None)
+    got = score_topk(_dev(U), _dev(I), k, mode='fast', **kw)
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+
+
 def test_fused_eval_metrics_match_the_reference_formulas(golden):
     """igcn_eval_metrics (one pass over the recommended lists) against calculate_metrics' numpy restatement — which the
     reference-produced fixtures pin bit for bit (test_hit_matrix_and_metrics_golden) — on the golden recommendations and on
