@@ -171,7 +171,7 @@ ROOFLINE_TAIL = ('gathered_row_GBps', 'probe_peak_GBps', 'traffic_over_algorithm
                  'hbm_stream_copy_GBps', 'rank', 'world', 'local_spmm_ms_per_step', 'exposed_exchange_ms_per_step',
                  'exchanged_bytes_per_rank_per_pass', 'exchange_floor')
 # flat scalars, most important first: the line is cut from the END of this list if it ever outgrows the budget
-FLAT_STDOUT = ('eval_users_per_s', 'eval_ms', 'eval_users_per_s_fp32_sweep', 'eval_mfma_TFLOPs_fp32_sweep', 'eval_mfma_frac',
+FLAT_STDOUT = ('side_legs', 'eval_users_per_s', 'eval_ms', 'eval_users_per_s_fp32_sweep', 'eval_mfma_TFLOPs_fp32_sweep', 'eval_mfma_frac',
                'eval_scoring_ms_fp32_sweep', 'eval_scoring_ms_two_stage', 'eval_ms_after_2_epochs', 'train_step_ms',
                'hbm_bound_kernel', 'hbm_bound_ms', 'hbm_bound_counter_GBps', 'hbm_bound_counter_frac', 'hbm_bound_algorithmic_GBps',
                'hbm_bound_algorithmic_frac', 'hbm_bound_item_block_ms', 'hbm_bound_item_block_GBps', 'hbm_bound_item_block_frac',
@@ -304,6 +304,43 @@ def spawn_ranks(args, json_fd):
     if line is not None:
         os.write(json_fd, line.encode())
     return rc
+
+
+class SideLegGuard:
+    """N > 1 only.  When the headline has been measured, the side legs behind it run code that no multi-GPU node has ever run (RCCL
+    over xGMI; rounds 1-6 had one-GPU boxes).  Whatever happens in them — an exception on one rank, a collective that never completes
+    — the line with the headline must still come out, with exit status 0: every rank arms a timer of the same length behind the same
+    barrier; when it fires, or when a leg raises on this rank, rank 0 prints the line from what has been collected so far (with
+    `side_legs` saying what happened) and the rank leaves with os._exit(0) — the others follow when their own timers fire.
+    IGCN_BENCH_SIDE_LEG_BUDGET: seconds (default 300; the legs take ~30 s at N = 8 by the builder's estimate)."""
+
+    def __init__(self, rank, emit):
+        import threading
+        self.rank, self.emit = rank, emit
+        self.seconds = float(os.environ.get('IGCN_BENCH_SIDE_LEG_BUDGET', '300'))
+        self.lock, self.done = threading.Lock(), False
+        self.timer = threading.Timer(self.seconds, self.fire, args=('side legs did not finish within %g s: headline only' % self.seconds,))
+        self.timer.daemon = True
+
+    def arm(self):
+        self.timer.start()
+
+    def fire(self, why):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+        try:
+            sys.stderr.write('bench.py rank %d: %s\n' % (self.rank, why))
+            if self.rank == 0:
+                self.emit(why)
+        finally:
+            os._exit(0)
+
+    def disarm(self):
+        with self.lock:
+            self.done = True
+        self.timer.cancel()
 
 
 def main():
@@ -541,39 +578,62 @@ def main():
     out.update({k: v for k, v in sharded_checks.items() if not isinstance(v, list)})
     extras = {}
     stream_probe = None if sharded else st
-    if sharded and not args.no_extras:
-        extras = sharded_side_measurements(ds, device, d, K, rank, world, rowptr, col, val, emb_host, barrier_sync, job_max)
-    if not sharded and not args.no_extras:
-        extras = side_measurements(ds, device, d, K)
-        extras['propagation_uniform_random_graph'] = uniform_graph_pass(device, args.preset, d, K)
-    if not sharded and not args.no_hbm_leg:
-        del csr, x0
-        torch.cuda.empty_cache()
-        extras['roofline_hbm_bound'] = hbm_bound_leg(device, stream_probe=stream_probe)
-        torch.cuda.empty_cache()
-    if not args.no_config5:
-        # BASELINE config 5 across the ranks of this job (N = 1: the whole graph on the one GPU)
+
+    def emit(side_legs=None):
+        """The ONE line (rank 0), from what has been collected: at the end of the run, or by the side-leg guard."""
+        extras['gather_roof'] = g
+        if sharded_checks:
+            extras['nnz_per_rank'] = sharded_checks['nnz_per_rank']
+        out['extras'] = extras
+        if side_legs:
+            out['side_legs'] = side_legs
+        lift_flat(out, extras)
+        sys.stdout.flush()
+        if rank == 0:
+            write_sidecar(out)                                            # (stdout still points at stderr here)
+        os.dup2(json_fd, 1)
+        if rank == 0:
+            print(stdout_line(out), flush=True)
+
+    guard = None
+    if sharded:
+        barrier_sync()
+        guard = SideLegGuard(rank, emit)
+        guard.arm()
+    try:
+        if sharded and not args.no_extras:
+            extras.update(sharded_side_measurements(ds, device, d, K, rank, world, rowptr, col, val, emb_host, barrier_sync, job_max))
+        if not sharded and not args.no_extras:
+            extras.update(side_measurements(ds, device, d, K))
+            extras['propagation_uniform_random_graph'] = uniform_graph_pass(device, args.preset, d, K)
+        if not sharded and not args.no_hbm_leg:
+            del csr, x0
+            torch.cuda.empty_cache()
+            extras['roofline_hbm_bound'] = hbm_bound_leg(device, stream_probe=stream_probe)
+            torch.cuda.empty_cache()
+        if not args.no_config5:
+            # BASELINE config 5 across the ranks of this job (N = 1: the whole graph on the one GPU)
+            if sharded:
+                del prop, eu, ei
+            torch.cuda.empty_cache()
+            extras['config5_sharded'] = config5_sharded_leg(device, rank, world, rehearsal, barrier_sync, job_max)
         if sharded:
-            del prop, eu, ei
-        torch.cuda.empty_cache()
-        extras['config5_sharded'] = config5_sharded_leg(device, rank, world, rehearsal, barrier_sync, job_max)
-    extras['gather_roof'] = g
-    if sharded_checks:
-        extras['nnz_per_rank'] = sharded_checks['nnz_per_rank']
-    out['extras'] = extras
-    lift_flat(out, extras)
+            barrier_sync()                                                # every rank is through its legs
+    except BaseException as e:                                            # noqa: BLE001 (N > 1: the headline must still come out)
+        if guard is None or isinstance(e, (KeyboardInterrupt, SystemExit)):
+            raise
+        import traceback
+        traceback.print_exc()
+        guard.fire('a side leg raised on rank %d: %s — headline and the legs before it only' % (rank, repr(e)[:200]))
+    if guard is not None:
+        guard.disarm()
 
     if not sharded and rank == 0 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(rowptr, col, val, emb_host.numpy(), K, nnz, ds.n_users)
 
     if sharded:
         dist.destroy_process_group()
-    sys.stdout.flush()
-    if rank == 0:
-        write_sidecar(out)                                                # (stdout still points at stderr here)
-    os.dup2(json_fd, 1)
-    if rank == 0:
-        print(stdout_line(out), flush=True)
+    emit()
 
 
 def sharded_side_measurements(ds, device, d, K, rank, world, rowptr, col, val, emb_host, barrier_sync, job_max):

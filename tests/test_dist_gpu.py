@@ -421,3 +421,25 @@ def test_config5_reduced_eight_ranks_as_threads_against_the_unsharded_hip_pass()
     nnzs = [r[1] for r in res]
     assert sum(nnzs) == nnz and max(nnzs) / (sum(nnzs) / world) < 1.02
     assert len({r[2][1] for r in res}) > 1                                        # unequal item row counts
+
+
+def test_bench_side_legs_can_never_cost_the_headline_of_a_multi_gpu_run():
+    """At N > 1 the side legs behind the headline run code no multi-GPU node has run yet.  bench.SideLegGuard: every rank arms a
+    timer behind a common barrier; when it fires (here: a budget of half a second, far less than the legs take) rank 0 prints the
+    line from what it has — the headline, its roofline, the run's own parity check — with `side_legs` saying so, and every rank
+    leaves with status 0: the launcher reports success and stdout holds exactly one parseable line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IGCN_BENCH_ONE_GPU='1', IGCN_BENCH_SIDE_LEG_BUDGET='0.5')
+    env.pop('WORLD_SIZE', None), env.pop('RANK', None), env.pop('LOCAL_RANK', None)
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'],
+                       env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 8000
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['value'] > 0 and out['ms_per_step'] > 0
+    assert 'did not finish' in out['side_legs'] and 'config5_pass_ms' not in out
+    assert out['sample_rel_err_vs_unsharded'] < 1e-4 and out['roofline']['achieved'] > 0
