@@ -165,7 +165,7 @@ STDOUT_BUDGET = 7000
 SIDECAR = os.path.join('gpurun_out', 'bench_extras.json')
 CONTRACT_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
                  'dtype', 'data')
-CONFIG_KEYS = ('workload', 'preset', 'nnz', 'd', 'n_layers', 'parallelism', 'rehearsal', 'timing_note')
+CONFIG_KEYS = ('workload', 'preset', 'nnz', 'd', 'n_layers', 'parallelism', 'rehearsal', 'scaling_note', 'timing_note')
 # numeric companions of the roofline behind its 24-key head (no strings but kernel / bound / unit)
 ROOFLINE_TAIL = ('gathered_row_GBps', 'probe_peak_GBps', 'traffic_over_algorithmic', 'steady_state_ms_per_step', 'steady_state_edges_per_s',
                  'hbm_stream_copy_GBps', 'rank', 'world', 'local_spmm_ms_per_step', 'exposed_exchange_ms_per_step',
@@ -508,6 +508,10 @@ def main():
         out['config']['parallelism_note'] = parallelism_note
     if sharded and rehearsal:
         out['config']['rehearsal'] = True                # all ranks on ONE GPU over gloo: a code-path run, its timings mean nothing
+    if sharded:
+        # said in the line itself (round-5 review): at this size the exchange, not the SpMM, decides
+        out['config']['scaling_note'] = ('strong scaling of a 0.33 ms pass: %d collectives of a 52.8 MB operand decide; expect efficiency well '
+                                         'below 1 (column_sharded_* = no-exchange companion)' % K)          # (< 160 characters)
 
     # ---- roofline of the dominant kernel (per launch, this rank) ----------------------------------
     b_alg = local_nnz * (8 + 4 * d) + local_rows * (4 * d + 4)
