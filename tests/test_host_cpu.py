@@ -60,6 +60,23 @@ def test_the_struct_of_the_spmm_entry_point_is_laid_out_as_the_binding_declares_
     assert L.igcn_spmm_csr_f32_args(C.byref(a), None) == -4
 
 
+def test_the_plain_c_caller_compiles_and_links_against_the_library(tmp_path):
+    """tests/c_caller/spmm_caller.c (run on the GPU by tests/test_spmm_gpu.py): as C99 with -Wall -Werror it compiles against
+    include/igcn_hip.h and links against the built library — every symbol it uses is exported with C linkage."""
+    import shutil
+    import subprocess
+    from igcn_cf_amd import _lib
+    rocm = os.environ.get('ROCM_PATH', '/opt/rocm')
+    if shutil.which('gcc') is None or not os.path.exists(os.path.join(rocm, 'include', 'hip', 'hip_runtime_api.h')):
+        pytest.skip('no gcc / HIP runtime headers here')
+    lib_dir = os.path.dirname(_lib.LIB_PATH)
+    cmd = ['gcc', '-std=c99', '-Wall', '-Werror', '-D__HIP_PLATFORM_AMD__', '-I', os.path.join(ROOT, 'include'), '-I', os.path.join(rocm, 'include'),
+           os.path.join(ROOT, 'tests', 'c_caller', 'spmm_caller.c'), '-L', lib_dir, '-l:libigcn_hip.so', '-L', os.path.join(rocm, 'lib'),
+           '-lamdhip64', '-lm', '-o', str(tmp_path / 'spmm_caller')]
+    b = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert b.returncode == 0, b.stdout.decode()[-3000:]
+
+
 def test_library_is_loaded_behind_torch_in_a_fresh_process():
     """torch's wheel bundles a HIP runtime with the SONAME of the one the library is linked against: whichever is loaded first
     serves the process.  Loaded before torch, the library ended up on a second runtime and its first launch on the GPU box failed

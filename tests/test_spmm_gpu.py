@@ -511,6 +511,31 @@ def test_struct_entry_point_the_minimal_binding_fills_eight_fields():
     assert _lib.SpmmArgs.rowptr.offset == 8 and _lib.SpmmArgs.d.offset == 64 and C.sizeof(_lib.SpmmArgs) % 8 == 0
 
 
+def test_a_plain_c_program_drives_the_library(tmp_path):
+    """tests/c_caller/spmm_caller.c: a C program — no Python, no torch in its process — that includes include/igcn_hip.h, links
+    libigcn_hip.so, fills the eight required fields of a zeroed igcn_spmm_args and compares Y = M X with a host loop, then the
+    positional form (same bits) and the refusals.  The boundary as a cgo / JNI / plain C binding would use it."""
+    import os
+    import shutil
+    import subprocess
+    from igcn_cf_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rocm = os.environ.get('ROCM_PATH', '/opt/rocm')
+    if shutil.which('gcc') is None or not os.path.exists(os.path.join(rocm, 'include', 'hip', 'hip_runtime_api.h')):
+        pytest.skip('no gcc / HIP runtime headers on this box')
+    exe = str(tmp_path / 'spmm_caller')
+    lib_dir = os.path.dirname(_lib.LIB_PATH)
+    # gcc, C99: the header and the caller are plain C; the HIP runtime is linked for hipMalloc / hipMemcpy only
+    cmd = ['gcc', '-std=c99', '-Wall', '-Werror', '-D__HIP_PLATFORM_AMD__', '-I', os.path.join(root, 'include'), '-I', os.path.join(rocm, 'include'),
+           os.path.join(root, 'tests', 'c_caller', 'spmm_caller.c'), '-L', lib_dir, '-l:libigcn_hip.so', '-L', os.path.join(rocm, 'lib'),
+           '-lamdhip64', '-lm', '-Wl,-rpath,' + lib_dir, '-Wl,-rpath,' + os.path.join(rocm, 'lib'), '-o', exe]
+    b = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert b.returncode == 0, b.stdout.decode()[-3000:]
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and out.strip().endswith('ok'), out[-2000:]
+
+
 def test_per_call_launch_knobs_keep_concurrent_streams_apart():
     """igcn_set_tuning is process-wide; the SpMM's three result-neutral knobs can instead ride in the call (igcn_spmm_args.tune_* /
     ops.spmm(tune=...)).  Launches on several streams and threads at once, each with its own grid / rows-per-wave / fold choice and
