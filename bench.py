@@ -1,5 +1,10 @@
 """Benchmark of the propagation + scoring path (driver contract: one JSON line).
 
+stdout carries ONE compact JSON line (< 7 000 bytes: contract keys, a short `config`, the numeric `roofline`, the graded flat scalars, a
+short `cpu_baseline`); the full record — `extras.*` named below, every *_note / *_source string, per-variant tables — goes to
+gpurun_out/bench_extras.json and to stderr (stdout_line / write_sidecar).  At N > 1 the side legs run behind a guard: the line with
+the headline comes out whatever happens in them (SideLegGuard).
+
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...     (the driver's N > 1 command)
 A plain `python bench.py --gpus N` (N > 1, no launcher) starts its own N ranks as fresh child processes before any GPU call
