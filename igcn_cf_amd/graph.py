@@ -266,7 +266,7 @@ N_XCD = 8                  # lists of the XCD plan = XCDs of an MI355X (igcn_spm
 
 
 def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assign='affinity', list_order='segments_first', n_lists=None,
-             closing_at=CLOSING_AT, late_every=0):
+             closing_at=CLOSING_AT, late_every=0, cold_rows=0):
     """The XCD plan of a CSR matrix: the work of one SpMM launch cut into N_XCD lists, one per XCD, such that a list
     gathers as much as possible from ONE slice of the operand — a slice (1/8 of the operand's rows) fits an XCD's 4 MiB
     L2 where the whole operand does not, and the eight L2s are private (igcn_hip.h: xcd_off).
@@ -337,6 +337,19 @@ def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assi
         cnt = torch.bincount((row_e[w_e] - lo) * NL + sl[w_e], minlength=(hi - lo) * NL).reshape(hi - lo, NL)
         cnt = cnt[~cut[lo:hi]]
         best, pref = cnt.max(dim=1)
+        if cold_rows:
+            # developer A/B (round 6): prefer the list that holds most of the row's COLD columns — the `cold_rows` most-gathered
+            # operand rows of the block are in every XCD's L2 whatever list gathers them, so only the others can gain from being
+            # gathered by their slice's XCD; a row without cold columns keeps the plain preference
+            per_col = torch.bincount(c - cmin)
+            if per_col.shape[0] > cold_rows:
+                hot_min = torch.sort(per_col, descending=True).values[cold_rows - 1]
+                cold_e = w_e & (per_col[c - cmin] < hot_min)
+                ccnt = torch.bincount((row_e[cold_e] - lo) * NL + sl[cold_e], minlength=(hi - lo) * NL).reshape(hi - lo, NL)
+                ccnt = ccnt[~cut[lo:hi]]
+                cbest, cpref = ccnt.max(dim=1)
+                pref = torch.where(cbest > 0, cpref, pref)
+                best = torch.where(cbest > 0, cnt.gather(1, cpref[:, None])[:, 0], best)
         per_block.append((whole, pref, best.to(torch.float64) / torch.clamp(lens[whole], min=1).to(torch.float64)))
     if seg_parts:
         seg_start, seg_len, seg_row, seg_xcd = (torch.cat([p[j] for p in seg_parts]) for j in range(4))
@@ -539,7 +552,7 @@ class CsrMatrix:
             lr, sg, order, xcd_off, load = xcd_plan(self.rowptr, self.col, list(self.order_blocks), thr,
                                                     self.segment_len, cfg.get('row_cost', 4), cfg.get('assign', 'affinity'),
                                                     cfg.get('list_order', 'segments_first'), closing_at=cfg.get('closing_at', CLOSING_AT),
-                                                    late_every=cfg.get('late_every', 0))
+                                                    late_every=cfg.get('late_every', 0), cold_rows=cfg.get('cold_rows', 0))
             self.n_long, self.n_segments = int(lr.shape[0]), int(sg.shape[0])
             self.long_rows = lr.contiguous().view(torch.uint8).reshape(-1) if self.n_long else None
             self.segments = sg.contiguous().view(torch.uint8).reshape(-1) if self.n_long else None
