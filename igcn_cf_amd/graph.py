@@ -266,7 +266,7 @@ N_XCD = 8                  # lists of the XCD plan = XCDs of an MI355X (igcn_spm
 
 
 def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assign='affinity', list_order='segments_first', n_lists=None,
-             closing_at=CLOSING_AT, late_every=0, cold_rows=0):
+             closing_at=CLOSING_AT, late_every=0, cold_rows=0, info=None):
     """The XCD plan of a CSR matrix: the work of one SpMM launch cut into N_XCD lists, one per XCD, such that a list
     gathers as much as possible from ONE slice of the operand — a slice (1/8 of the operand's rows) fits an XCD's 4 MiB
     L2 where the whole operand does not, and the eight L2s are private (igcn_hip.h: xcd_off).
@@ -286,9 +286,13 @@ def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assi
     rowptr int64 [n_rows + 1], col int32/int64 [nnz]: torch tensors on ANY device — the plan is built where the matrix
     lives (in HBM for the device builders: the inductive update rebuilds the graph on a live model).
     Returns (long_rows int32 [n_long, 4], segments int32 [n_seg, 6] — the byte layouts of igcn_long_row /
-    igcn_row_segment —, row_order int32, xcd_off int64 [N_XCD + 1], load float64 [N_XCD]) on that device."""
+    igcn_row_segment —, row_order int32, xcd_off int64 [N_XCD + 1], load float64 [N_XCD]) on that device.
+    info (a dict, optional): receives 'foldable' — False when some list has fewer than MIN_CLOSING_GAP rows to put between a cut
+    row's closing segment and its other segments (such a plan is never added up inside the launch)."""
     NL = int(n_lists or N_XCD)        # lists of the plan (developer A/Bs cut fewer slices; the kernel always walks N_XCD)
-    xcd_plan.last_foldable = list_order == 'segments_first'          # (read by CsrMatrix._build_plan right after the call)
+    if info is None:
+        info = {}
+    info['foldable'] = list_order == 'segments_first'     # (out-parameter: may this plan's cut rows be added up inside the launch?)
     dev = rowptr.device
     i64 = dict(dtype=torch.int64, device=dev)
     n_rows = rowptr.shape[0] - 1
@@ -434,7 +438,7 @@ def xcd_plan(rowptr, col, blocks, slice_threshold, segment_len, row_cost=4, assi
                     # too few rows to put between a row's closing segment and the other segments: a wave could meet a closing segment
                     # and one of its siblings in the SAME visit (up to 4 entries), or before the siblings' waves have started — such a
                     # plan is never folded (the launch keeps the second kernel, whatever "spmm_fold" says)
-                    xcd_plan.last_foldable = False
+                    info['foldable'] = False
                 lists[x] += [sx[~cl], rx[:at], sx[cl], rx[at:]]
             elif list_order == 'rows_first':
                 lists[x] += [rx, sx]
@@ -549,15 +553,16 @@ class CsrMatrix:
             thr = cfg['threshold']
             self.long_threshold = int(min(thr)) if isinstance(thr, (list, tuple)) else int(thr)
             self.segment_len = min(self.segment_len, int(cfg.get('segment_len', self.long_threshold)))
+            info = {}
             lr, sg, order, xcd_off, load = xcd_plan(self.rowptr, self.col, list(self.order_blocks), thr,
                                                     self.segment_len, cfg.get('row_cost', 4), cfg.get('assign', 'affinity'),
                                                     cfg.get('list_order', 'segments_first'), closing_at=cfg.get('closing_at', CLOSING_AT),
-                                                    late_every=cfg.get('late_every', 0), cold_rows=cfg.get('cold_rows', 0))
+                                                    late_every=cfg.get('late_every', 0), cold_rows=cfg.get('cold_rows', 0), info=info)
             self.n_long, self.n_segments = int(lr.shape[0]), int(sg.shape[0])
             self.long_rows = lr.contiguous().view(torch.uint8).reshape(-1) if self.n_long else None
             self.segments = sg.contiguous().view(torch.uint8).reshape(-1) if self.n_long else None
             self.row_order, self.xcd_off, self.xcd_load = order, xcd_off, load
-            self.closing_segments = bool(xcd_plan.last_foldable) and self.n_long > 0
+            self.closing_segments = bool(info['foldable']) and self.n_long > 0
             return
         L = _lib.lib()
         n_long, n_seg = C.c_int64(0), C.c_int64(0)
