@@ -821,6 +821,14 @@ def test_a_plan_whose_closing_segments_sit_next_to_their_siblings_is_never_folde
     assert two.n_long == 2 and two.closing_segments is False
     # no cut row at all: nothing to fold
     assert csr([3] * 10, 64, [0, 10]).closing_segments is False
+    # the XCD plan decides list by list (graph.xcd_plan, info['foldable'])
+    def xcd(lens, n_cols, blocks):
+        rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        col = np.concatenate([np.sort(np.arange(l, dtype=np.int32) * 7 % n_cols) for l in lens])
+        return CsrMatrix(rowptr, col, None, (len(lens), n_cols), 'cpu', order_blocks=blocks, xcd_plan={'threshold': 16})
+    assert xcd([60, 2, 3], 64, [0, 3]).closing_segments is False
+    roomy = xcd([60] + [3] * 600, 64, [0, 601])
+    assert roomy.n_long == 1 and roomy.closing_segments is True
 
 
 @pytest.mark.parametrize('threshold', [3, 8, 1000])
