@@ -293,6 +293,28 @@ def test_the_bench_sidecar_holds_what_stdout_dropped(tmp_path, monkeypatch, caps
     assert bench.write_sidecar(full) is None
 
 
+def test_the_side_leg_guard_prints_the_line_and_leaves_with_status_zero():
+    """bench.SideLegGuard (N > 1 runs): when its budget runs out — or a leg raises and the rank calls fire() — rank 0 emits the line
+    from what it has and the process leaves with status 0 while its main thread is still stuck; disarmed in time, nothing happens.
+    Run in child processes (the guard ends its process with os._exit)."""
+    import subprocess
+    code = ("import os, sys, time; sys.path.insert(0, %r); os.environ['IGCN_BENCH_SIDE_LEG_BUDGET'] = '0.3'; import bench\n"
+            "g = bench.SideLegGuard(int(sys.argv[1]), lambda why: print('LINE ' + why, flush=True)); g.arm()\n"
+            "if sys.argv[2] == 'disarm':\n    g.disarm(); time.sleep(0.6); print('survived', flush=True); sys.exit(3)\n"
+            "if sys.argv[2] == 'raise':\n    g.fire('a side leg raised on rank 0: boom')\n"
+            "time.sleep(30); sys.exit(7)\n" % ROOT)
+    def run(rank, mode):
+        return subprocess.run([sys.executable, '-c', code, str(rank), mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    p = run(0, 'hang')
+    assert p.returncode == 0 and p.stdout.decode().startswith('LINE side legs did not finish within 0.3 s')
+    p = run(1, 'hang')                                                 # other ranks leave quietly
+    assert p.returncode == 0 and not p.stdout.strip() and b'did not finish' in p.stderr
+    p = run(0, 'raise')
+    assert p.returncode == 0 and p.stdout.decode().startswith('LINE a side leg raised on rank 0: boom')
+    p = run(0, 'disarm')
+    assert p.returncode == 3 and p.stdout.decode().strip() == 'survived'
+
+
 def test_bench_launcher_refuses_without_enough_gpus_before_starting_anything():
     """`python bench.py --gpus N` (N > 1, no launcher) becomes the launcher of its own ranks — but with fewer than N visible GPUs
     and no rehearsal switch it must say so and stop: rc != 0, nothing on stdout (the driver parses stdout as ONE JSON line), no
