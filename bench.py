@@ -458,23 +458,6 @@ def main():
     dev_ms = e0.elapsed_time(e1)
 
     sharded_checks = {}
-    if sharded:
-        # Parity and balance of THIS run (untimed): every rank's owned rows of the sharded pass against the unsharded single-GPU
-        # HIP pass over the same graph and table (max over ranks, relative to the largest entry), and the nonzeros per rank.
-        csr_full = CsrMatrix(rowptr, col, val, (n, n), device, order_blocks=[0, ds.n_users, n], xcd_plan=XCD_PLAN)
-        ref = ops.propagate_mean(csr_full, emb_host.to(device), K)
-        ru, ri = step()
-        scale = float(ref.abs().max())
-        err = max(float((ru[:uhi - ulo] - ref[ulo:uhi]).abs().max()) if uhi > ulo else 0.0,
-                  float((ri[:ihi - ilo] - ref[ds.n_users + ilo: ds.n_users + ihi]).abs().max()) if ihi > ilo else 0.0) / scale
-        t = torch.tensor([err, float(prop.local_nnz)], dtype=torch.float64, device=device)
-        every = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(every, t)
-        per_rank_nnz = [float(e[1]) for e in every]
-        sharded_checks = {'sample_rel_err_vs_unsharded': max(float(e[0]) for e in every),
-                          'nnz_balance_max_over_mean': max(per_rank_nnz) / (sum(per_rank_nnz) / world),
-                          'nnz_per_rank': [int(v) for v in per_rank_nnz]}
-        del csr_full, ref
     # The same pass at steady clocks, beside the contract's figure (never `value`): an idle MI355X needs ~60-90 of these 0.34 ms
     # passes to reach its working clocks (profiles/r05i_warmup_and_clocks.txt), more than a `--warmup 5` gives it.
     steady_ms = None
@@ -584,7 +567,6 @@ def main():
         roof['exchanged_bytes_per_rank_per_pass'] = K * (world - 1) * L.block * d * 4
         roof['exchange_floor'] = 'unmeasured: %d collectives per pass x this node\'s RCCL all-gather latency (never timed on > 1 GPU)' % K
     out['roofline'] = roof
-    out.update({k: v for k, v in sharded_checks.items() if not isinstance(v, list)})
     extras = {}
     stream_probe = None if sharded else st
 
@@ -604,12 +586,33 @@ def main():
         if rank == 0:
             print(stdout_line(out), flush=True)
 
+
+    def check_sharded_pass():
+        """Parity and balance of THIS run (untimed): every rank's owned rows of the sharded pass against the unsharded single-GPU HIP
+        pass over the same graph and table (max over ranks, relative to the largest entry), and the nonzeros per rank."""
+        csr_full = CsrMatrix(rowptr, col, val, (n, n), device, order_blocks=[0, ds.n_users, n], xcd_plan=XCD_PLAN)
+        ref = ops.propagate_mean(csr_full, emb_host.to(device), K)
+        ru, ri = step()
+        scale = float(ref.abs().max())
+        err = max(float((ru[:uhi - ulo] - ref[ulo:uhi]).abs().max()) if uhi > ulo else 0.0,
+                  float((ri[:ihi - ilo] - ref[ds.n_users + ilo: ds.n_users + ihi]).abs().max()) if ihi > ilo else 0.0) / scale
+        t = torch.tensor([err, float(prop.local_nnz)], dtype=torch.float64, device=device)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank_nnz = [float(e[1]) for e in every]
+        sharded_checks.update({'sample_rel_err_vs_unsharded': max(float(e[0]) for e in every),
+                               'nnz_balance_max_over_mean': max(per_rank_nnz) / (sum(per_rank_nnz) / world),
+                               'nnz_per_rank': [int(v) for v in per_rank_nnz]})
+        out.update({k: v for k, v in sharded_checks.items() if not isinstance(v, list)})
+
     guard = None
     if sharded:
         barrier_sync()
         guard = SideLegGuard(rank, emit)
         guard.arm()
     try:
+        if sharded:
+            check_sharded_pass()                                          # (behind the guard too: it holds a collective)
         if sharded and not args.no_extras:
             extras.update(sharded_side_measurements(ds, device, d, K, rank, world, rowptr, col, val, emb_host, barrier_sync, job_max))
         if not sharded and not args.no_extras:

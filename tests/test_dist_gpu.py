@@ -442,4 +442,5 @@ def test_bench_side_legs_can_never_cost_the_headline_of_a_multi_gpu_run():
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['value'] > 0 and out['ms_per_step'] > 0
     assert 'did not finish' in out['side_legs'] and 'config5_pass_ms' not in out
-    assert out['sample_rel_err_vs_unsharded'] < 1e-4 and out['roofline']['achieved'] > 0
+    # (the run's own parity check sits behind the guard too — it holds a collective —, so it may or may not have made it)
+    assert out.get('sample_rel_err_vs_unsharded', 0.0) < 1e-4 and out['roofline']['achieved'] > 0
